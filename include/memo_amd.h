@@ -1,0 +1,137 @@
+/*
+ * memo_amd.h -- C ABI of the MI355X-native MEMO windowed k-mer query path.
+ *
+ * The reference (StephenHwang/MEMO) is pure Python and has no FFI/plugin layer;
+ * the seam this library replaces is function-level, inside
+ * /root/reference/src/memo_query.py:main (lines 89-105):
+ *
+ *     genome_mems_arr = filter_pq(in_file, record, qs, qe + k)           # :100
+ *     mem_arr, rec    = memo_init(genome_mems_arr, k, qs, qe, N, memb)   # :103
+ *     rec             = memo_query(mem_arr, rec, memb)                   # :104
+ *     print_res(rec, out_file, memb)                                     # :105
+ *
+ * Every entry point below names the reference lines it stands in for.  Plain C
+ * types only: pointers, sizes, an opaque handle.  No torch / C++ types, no
+ * exceptions across the boundary.  All functions return MEMO_OK (0) or a
+ * negative code; memo_last_error() gives the message (thread-local).
+ *
+ * Row semantics: an index row (start s, end e, annot a) with
+ * e >= s marks the k-mers starting at p, max(e-(k-1), qs) <= p < min(s, qe), as
+ * ABSENT for order / genome a.  Rows must be sorted by start (they are in every
+ * index dap_to_bed.py writes); memo_index_finalize() checks that and sorts on the
+ * device when it does not hold.
+ *
+ * Result encodings
+ *   conservation  uint16 out[L], L = qe - qs:  smallest order a of any row
+ *                 covering p, num_docs if none  (= np.argmax(rec, axis=1), :70)
+ *   membership    uint32 out[L * W], W = ceil(num_docs / 32): genome g of
+ *                 position p is bit (g & 31) of word p*W + (g >> 5); 1 = k-mer
+ *                 present (= rec[p, g], :51 / :68); bits >= num_docs are 0
+ */
+#ifndef MEMO_AMD_H
+#define MEMO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MEMO_OK 0
+#define MEMO_EINVAL (-1)    /* bad argument; also: a row that writes has an annot outside the
+                               result columns -- the reference's IndexError (NumPy) / UB (Numba) */
+#define MEMO_EHIP (-2)      /* HIP runtime error */
+#define MEMO_ENOTREADY (-3) /* index not finalized */
+#define MEMO_EUNSORTED (-4) /* rows not sorted by start and sorting was disabled */
+#define MEMO_ELONGROW (-5)  /* a row has end < start: not a MEMO overlap row (dap_to_bed.py:93-98
+                               only emits end >= start); unsupported */
+
+typedef struct memo_index memo_index_t; /* one chromosome's rows, resident in HBM */
+
+typedef struct memo_index_info {
+    uint64_t rows;          /* m */
+    int64_t min_start;      /* valid after finalize */
+    int64_t max_start;
+    int32_t device;
+    int32_t bucket_shift;   /* bucket b starts at pivot position b << bucket_shift */
+    uint64_t buckets;
+    int32_t was_sorted;     /* 1 if the rows arrived start-sorted */
+    int32_t finalized;
+    uint64_t device_bytes;  /* HBM held by this index (columns + padding + bucket table) */
+} memo_index_info_t;
+
+const char *memo_last_error(void);
+int memo_device_count(void);
+const char *memo_version(void);
+
+/* ---- index lifecycle ---------------------------------------------------------------
+ * Stands in for the arrays filter_pq returns (memo_query.py:28-36) and memo_init
+ * re-types (:45), but kept as three int64 columns (exactly what the Parquet file
+ * stores, parquet_compress_bed.py:21-26) and kept RESIDENT so that many windows can be
+ * queried against one upload.  The library owns the device memory; the caller owns
+ * every host buffer and nothing is retained after a call returns. */
+int memo_index_create(uint64_t rows, int32_t device, memo_index_t **out);
+/* copy host columns (pageable or pinned) into the index; blocking */
+int memo_index_upload(memo_index_t *ix, const int64_t *start, const int64_t *end,
+                      const int64_t *annot, uint64_t rows);
+/* device pointers of the three columns, for callers that fill them on the device
+ * (synthetic generator, another kernel); each holds `rows` int64 */
+int memo_index_columns(memo_index_t *ix, int64_t **d_start, int64_t **d_end, int64_t **d_annot);
+/* check start-sortedness and end >= start, sort by start on the device if needed
+ * (allow_sort != 0), build the start-bucket table.  bucket_shift <= 0 picks the default. */
+int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_sort);
+int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);
+void memo_index_destroy(memo_index_t *ix);
+
+/* ---- the hot path: memo_init + memo_query + reduction (memo_query.py:42-63, :70) ----
+ * d_out is a DEVICE pointer (16-byte aligned) in the index's device; the launch is
+ * asynchronous on `stream` (a hipStream_t, NULL = default stream).  The window may be
+ * any [qs, qe); rows outside (qs, qe + k) are ignored exactly as filter_pq ignores them
+ * (:25-27 with :100).  An annot outside the result columns on a row that writes sets a
+ * sticky device flag that memo_query_check() reports as MEMO_EINVAL. */
+int memo_query_conservation_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,
+                                int32_t num_docs, uint16_t *d_out, void *stream);
+int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,
+                              int32_t num_docs, uint32_t *d_out, void *stream);
+/* synchronise `stream`, return and clear the sticky error of earlier queries */
+int memo_query_check(memo_index_t *ix, void *stream);
+
+/* ---- one-shot host form: the drop-in for memo_query.py:103-104 + :70 ------------------
+ * Host pointers in and out; uploads, finalizes, queries, downloads, frees.  `device`
+ * is a HIP device ordinal. */
+int memo_conservation(const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows,
+                      int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint16_t *out,
+                      int32_t device);
+int memo_membership(const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows,
+                    int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint32_t *out_bits,
+                    int32_t device);
+
+/* ---- raw device buffers, for hosts that do not bring a device allocator (the CLI) ------ */
+int memo_dev_malloc(int32_t device, size_t bytes, void **out);
+int memo_dev_free(int32_t device, void *p);
+/* copy device -> host on `stream` and wait for it */
+int memo_dev_download(int32_t device, void *host, const void *dev, size_t bytes, void *stream);
+
+/* ---- print_res (memo_query.py:65-71), host side ----------------------------------------
+ * Byte-identical text: conservation = decimal + '\n' per position (a single '\n' when
+ * L == 0); membership = num_docs '0'/'1' separated by ' ' per line.  Return the number
+ * of bytes the text needs; it is written only if it fits in cap. */
+size_t memo_emit_conservation(const uint16_t *vec, int64_t L, char *buf, size_t cap);
+size_t memo_emit_membership(const uint32_t *bits, int64_t L, int32_t num_docs, char *buf, size_t cap);
+
+/* ---- synthetic pangenome index (BASELINE.json configs 2-5) -------------------
+ * Fills rows [0, rows) of the index with global rows row_begin + i of the generator
+ *   start = 1 + floor(i * den / num), end = start + mix(seed, 2i) % 60,
+ *   annot = 1 + mix(seed, 2i+1) % (num_docs - 1)
+ * on the device (no host copy).  Same generator as oracle_synth_rows. */
+int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t den,
+                    int32_t num_docs, uint64_t seed);
+
+/* ---- tuning knobs (process-wide; also read once from MEMO_TILE_W / MEMO_VARIANT) ------ */
+int memo_set_tuning(int32_t tile_w, int32_t variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEMO_AMD_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of the C ABI declared in include/memo_amd.h.
+
+There is NO fallback: if libmemo_amd.so is missing or a HIP call fails, this raises.
+The CPU restatement under oracle/ is test infrastructure and is never imported here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libmemo_amd.so")
+
+MEMO_OK, MEMO_EINVAL, MEMO_EHIP, MEMO_ENOTREADY, MEMO_EUNSORTED, MEMO_ELONGROW = 0, -1, -2, -3, -4, -5
+
+
+class MemoError(RuntimeError):
+    """A C-ABI call returned a negative code (message from memo_last_error())."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"memo_amd error {code}: {msg}")
+        self.code = code
+
+
+class MemoIndexError(MemoError, IndexError):
+    """The reference raises IndexError here (annot column outside the result matrix)."""
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("rows", C.c_uint64), ("min_start", C.c_int64), ("max_start", C.c_int64),
+                ("device", C.c_int32), ("bucket_shift", C.c_int32), ("buckets", C.c_uint64),
+                ("was_sorted", C.c_int32), ("finalized", C.c_int32), ("device_bytes", C.c_uint64)]
+
+
+# every symbol include/memo_amd.h declares: name -> (restype, argtypes)
+_P, _I32, _I64, _U64, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
+SYMBOLS = {
+    "memo_last_error": (C.c_char_p, []),
+    "memo_device_count": (C.c_int, []),
+    "memo_version": (C.c_char_p, []),
+    "memo_index_create": (C.c_int, [_U64, _I32, C.POINTER(_P)]),
+    "memo_index_upload": (C.c_int, [_P, _P, _P, _P, _U64]),
+    "memo_index_columns": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "memo_index_finalize": (C.c_int, [_P, _I32, _I32]),
+    "memo_index_get_info": (C.c_int, [_P, C.POINTER(IndexInfo)]),
+    "memo_index_destroy": (None, [_P]),
+    "memo_query_conservation_dev": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P]),
+    "memo_query_membership_dev": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P]),
+    "memo_query_check": (C.c_int, [_P, _P]),
+    "memo_conservation": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _I32]),
+    "memo_membership": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _I32]),
+    "memo_dev_malloc": (C.c_int, [_I32, _SZ, C.POINTER(_P)]),
+    "memo_dev_free": (C.c_int, [_I32, _P]),
+    "memo_dev_download": (C.c_int, [_I32, _P, _P, _SZ, _P]),
+    "memo_emit_conservation": (_SZ, [_P, _I64, _P, _SZ]),
+    "memo_emit_membership": (_SZ, [_P, _I64, _I32, _P, _SZ]),
+    "memo_synth_fill": (C.c_int, [_P, _U64, _U64, _U64, _I32, _U64]),
+    "memo_set_tuning": (C.c_int, [_I32, _I32]),
+}
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "-s", "clean"])
+    subprocess.check_call(["make", "-C", src, "-s"])
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` or `make -C memo_amd/csrc` -- there is no CPU fallback")
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)        # AttributeError if the library does not export it
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        msg = lib().memo_last_error().decode(errors="replace")
+        if rc == MEMO_EINVAL and "IndexError" in msg:
+            raise MemoIndexError(rc, msg)
+        raise MemoError(rc, msg)
+    return rc

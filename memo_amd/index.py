@@ -1,0 +1,161 @@
+"""DeviceIndex: one chromosome of a MEMO index resident in HBM, and the sweep launches.
+
+Counterpart of the arrays /root/reference/src/memo_query.py passes between filter_pq,
+memo_init and memo_query (lines 28-36, 45-55): three int64 columns (start, end, annot).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _col(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.int64:
+        # filter_pq builds np.uint (memo_query.py:28-35) and memo_init re-types to int64 (:45)
+        a = a.astype(np.int64) if a.dtype != np.uint64 else a.view(np.int64)
+    return a
+
+
+def _ptr(x):
+    """device pointer of a torch tensor / raw int address."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+def words(num_docs):
+    return (num_docs + 31) // 32
+
+
+class DeviceIndex:
+    def __init__(self, rows, device=0):
+        self._h = C.c_void_p()
+        self.rows = int(rows)
+        self.device = int(device)
+        check(lib().memo_index_create(self.rows, self.device, C.byref(self._h)))
+
+    @classmethod
+    def from_host(cls, start, end, annot, device=0, bucket_shift=0, allow_sort=True):
+        s, e, o = _col(start), _col(end), _col(annot)
+        if not (len(s) == len(e) == len(o)):
+            raise ValueError("columns differ in length")
+        ix = cls(len(s), device)
+        check(lib().memo_index_upload(ix._h, s.ctypes.data, e.ctypes.data, o.ctypes.data, len(s)))
+        ix.finalize(bucket_shift, allow_sort)
+        return ix
+
+    @classmethod
+    def synthetic(cls, rows, row_begin, num, den, num_docs, seed=0x4D454D4F, device=0, bucket_shift=0):
+        ix = cls(rows, device)
+        check(lib().memo_synth_fill(ix._h, row_begin, num, den, num_docs, seed))
+        ix.finalize(bucket_shift, False)
+        return ix
+
+    def columns(self):
+        s, e, o = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib().memo_index_columns(self._h, C.byref(s), C.byref(e), C.byref(o)))
+        return s.value, e.value, o.value
+
+    def finalize(self, bucket_shift=0, allow_sort=True):
+        check(lib().memo_index_finalize(self._h, bucket_shift, 1 if allow_sort else 0))
+        return self
+
+    def info(self):
+        inf = _lib.IndexInfo()
+        check(lib().memo_index_get_info(self._h, C.byref(inf)))
+        return {k: getattr(inf, k) for k, _ in inf._fields_}
+
+    # ---- asynchronous launches on device buffers (torch tensors or raw addresses) ----
+    def conservation_dev(self, qs, qe, k, num_docs, out, stream=None):
+        check(lib().memo_query_conservation_dev(self._h, qs, qe, k, num_docs, _ptr(out), _ptr(stream)))
+
+    def membership_dev(self, qs, qe, k, num_docs, out, stream=None):
+        check(lib().memo_query_membership_dev(self._h, qs, qe, k, num_docs, _ptr(out), _ptr(stream)))
+
+    def check(self, stream=None):
+        check(lib().memo_query_check(self._h, _ptr(stream)))
+
+    # ---- blocking host-result forms ----
+    def _run(self, fn, qs, qe, k, num_docs, out):
+        nbytes = out.nbytes
+        d = C.c_void_p()
+        check(lib().memo_dev_malloc(self.device, nbytes, C.byref(d)))
+        try:
+            check(fn(self._h, qs, qe, k, num_docs, d, None))
+            self.check()
+            check(lib().memo_dev_download(self.device, out.ctypes.data, d, nbytes, None))
+        finally:
+            lib().memo_dev_free(self.device, d)
+        return out
+
+    def conservation(self, qs, qe, k, num_docs):
+        out = np.empty(max(qe - qs, 0), np.uint16)
+        return self._run(lib().memo_query_conservation_dev, qs, qe, k, num_docs, out)
+
+    def membership(self, qs, qe, k, num_docs):
+        out = np.empty((max(qe - qs, 0), words(num_docs)), np.uint32)
+        return self._run(lib().memo_query_membership_dev, qs, qe, k, num_docs, out)
+
+    def close(self):
+        if self._h:
+            lib().memo_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+# ---- one-shot host API: memo_init + memo_query + reduction on host arrays ----
+def conservation(start, end, annot, qs, qe, k, num_docs, device=0):
+    s, e, o = _col(start), _col(end), _col(annot)
+    out = np.empty(max(qe - qs, 0), np.uint16)
+    check(lib().memo_conservation(s.ctypes.data, e.ctypes.data, o.ctypes.data, len(s), qs, qe, k,
+                                  num_docs, out.ctypes.data, device))
+    return out
+
+
+def membership(start, end, annot, qs, qe, k, num_docs, device=0):
+    s, e, o = _col(start), _col(end), _col(annot)
+    out = np.empty((max(qe - qs, 0), words(num_docs)), np.uint32)
+    check(lib().memo_membership(s.ctypes.data, e.ctypes.data, o.ctypes.data, len(s), qs, qe, k,
+                                num_docs, out.ctypes.data, device))
+    return out
+
+
+# ---- print_res text (memo_query.py:65-71) ----
+def emit_conservation(vec):
+    vec = np.ascontiguousarray(vec, np.uint16)
+    need = lib().memo_emit_conservation(vec.ctypes.data, len(vec), None, 0)
+    buf = C.create_string_buffer(need)
+    lib().memo_emit_conservation(vec.ctypes.data, len(vec), buf, need)
+    return buf.raw[:need]
+
+
+def emit_membership(bits, num_docs):
+    bits = np.ascontiguousarray(bits, np.uint32)
+    L = bits.shape[0] if bits.ndim == 2 else len(bits) // max(words(num_docs), 1)
+    need = lib().memo_emit_membership(bits.ctypes.data, L, num_docs, None, 0)
+    buf = C.create_string_buffer(max(need, 1))
+    lib().memo_emit_membership(bits.ctypes.data, L, num_docs, buf, need)
+    return buf.raw[:need]
+
+
+def bits_to_matrix(bits, num_docs):
+    """uint32 [L, W] -> uint8 [L, N], the reference's rec.astype('byte') (memo_query.py:68)."""
+    bits = np.asarray(bits, np.uint32).reshape(-1, max(words(num_docs), 1))
+    g = np.arange(num_docs)
+    return ((bits[:, g >> 5] >> (g & 31).astype(np.uint32)) & 1).astype(np.uint8)

@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Host side of `memo query` -- same command line, same function names and argument
+meaning as the reference's src/memo_query.py, with the NumPy/Numba work replaced by
+the HIP sweep behind include/memo_amd.h.
+
+  reference (src/memo_query.py)            here
+  ---------------------------------------  ------------------------------------------------
+  filter_pq            :19-36              filter_pq      Arrow region slice -> SoA int64
+  memo_init            :42-55              memo_init      upload + finalize a DeviceIndex,
+                                                          describe the result buffer
+  memo_query (@jit)    :57-63              memo_query     launch the sweep kernel, download
+  print_res            :65-71              print_res      byte-identical text
+  parse_arguments/main :76-105             parse_arguments / main
+
+Run:  memo_query.py -b bed.parquet -r chr:start-end -k K -n N -o out.txt [-m]
+The GPU is chosen with the MEMO_DEVICE environment variable (default 0), so the flag set
+stays the reference's.
+"""
+import argparse
+import os
+
+import numpy as np
+import pyarrow.dataset as ds
+
+from .index import DeviceIndex, emit_conservation, emit_membership, words
+
+
+class RegionRows:
+    """Rows of one region as three int64 columns (what the Parquet file stores,
+    parquet_compress_bed.py:21-26).  ``as_array()`` gives the reference's uint64 [M, 3]."""
+
+    def __init__(self, start, end, annot):
+        self.start, self.end, self.annot = start, end, annot
+
+    def __len__(self):
+        return len(self.start)
+
+    def as_array(self):
+        return np.stack([self.start, self.end, self.annot], axis=1).astype(np.uint64)
+
+
+def _columns(table):
+    return [np.ascontiguousarray(table.column(c).to_numpy(), dtype=np.int64) for c in ("f1", "f2", "f3")]
+
+
+def filter_pq(in_file, query_record, query_start, query_end, spanning_rows=False):
+    """Rows of `query_record` with query_start < f1 < query_end  (memo_query.py:25-27; main
+    passes query_end + k, :100).  Row groups are pruned by the f0/f1 statistics the index
+    writer leaves in the file; columns come back as Arrow buffers, no pandas, no AoS copy.
+
+    The reference also fetches rows with f1 <= query_start < f2 (:22-24).  memo_init drops
+    every one of them (their start clips to 0, so casted_end < start cannot hold, :46-49);
+    they are read only when spanning_rows=True, which reproduces the reference's return
+    value row for row (spanning rows first)."""
+    pq_ds = ds.dataset(in_file, format="parquet")
+    rec = ds.field("f0") == query_record
+    inside = pq_ds.to_table(filter=rec & (ds.field("f1") > query_start) & (ds.field("f1") < query_end),
+                            columns=["f1", "f2", "f3"])
+    cols = _columns(inside)
+    if spanning_rows:
+        span = pq_ds.to_table(filter=rec & (ds.field("f1") <= query_start) & (ds.field("f2") > query_start),
+                              columns=["f1", "f2", "f3"])
+        cols = [np.concatenate([a, b]) for a, b in zip(_columns(span), cols)]
+    return RegionRows(*cols)
+
+
+class QueryResult:
+    """Counterpart of the reference's `rec` matrix, kept in reduced form:
+    conservation -> uint16 [L] (= argmax over columns, :70); membership -> uint32 [L, W] bits."""
+
+    def __init__(self, true_start, true_end, k, num_docs, membership_query):
+        self.true_start, self.true_end, self.k = true_start, true_end, k
+        self.num_docs, self.membership_query = num_docs, membership_query
+        self.values = None
+
+    @property
+    def true_len(self):
+        return max(self.true_end - self.true_start, 0)
+
+
+def _device():
+    return int(os.environ.get("MEMO_DEVICE", "0"))
+
+
+def memo_init(mem_arr, k, true_start, true_end, num_docs, membership_query):
+    """Put the rows in HBM (validated, start-bucketed) and describe the result.
+    Recentring, the k-1 shadow cast, clipping and the casted_end < start filter of
+    memo_query.py:45-49 happen inside the sweep kernel, per tile."""
+    if isinstance(mem_arr, RegionRows):
+        s, e, o = mem_arr.start, mem_arr.end, mem_arr.annot
+    else:                                     # the reference's [M, 3] array
+        arr = np.asarray(mem_arr)
+        s, e, o = (np.ascontiguousarray(arr[:, i]) for i in range(3))
+    index = DeviceIndex.from_host(s, e, o, device=_device())
+    return index, QueryResult(true_start, true_end, k, num_docs, membership_query)
+
+
+def memo_query(mem_arr, rec, membership_query):
+    """Run the conservation (min order) or membership (per-genome bit) sweep."""
+    if membership_query:
+        rec.values = mem_arr.membership(rec.true_start, rec.true_end, rec.k, rec.num_docs)
+    else:
+        rec.values = mem_arr.conservation(rec.true_start, rec.true_end, rec.k, rec.num_docs)
+    return rec
+
+
+def print_res(rec, out_file, membership_query):
+    """Same bytes as memo_query.py:65-71."""
+    text = emit_membership(rec.values, rec.num_docs) if membership_query else emit_conservation(rec.values)
+    with open(out_file, "wb") as fh:
+        fh.write(text)
+
+
+################################################################################
+
+def parse_arguments(argv=None):
+    parser = argparse.ArgumentParser(description="Extract and query overlap MEMs for k-mer presence/absence.")
+    parser.add_argument('-b', '--pq_bed_file', dest='in_file', help='parquet bed file', required=True)
+    parser.add_argument('-o', '--out_file', dest='out_file', help='output file', required=True)
+    parser.add_argument('-n', '--ndocs', dest='num_docs', help='total number of genomes in the pangenome', required=True)
+    parser.add_argument('-k', '--kmer_size', dest='k', help='k-mer size', required=True)
+    parser.add_argument('-r', '--genome_region', dest='genome_region', help='genome region, formatted as chr:start-end', required=True)
+    parser.add_argument('-m', '--membership_query', dest='membership_query', action='store_true', default=False,
+                        help='Perform membership query instead of conservation query')
+    return parser.parse_args(argv)
+
+
+def main(args):
+    membership_query = args.membership_query
+    num_docs, k = int(args.num_docs), int(args.k)
+    query_record, start_end = args.genome_region.split(':')      # exactly one ':' and one '-'
+    query_start, query_end = map(int, start_end.split('-'))
+    rows = filter_pq(args.in_file, query_record, query_start, query_end + k)
+    mem_arr, rec = memo_init(rows, k, query_start, query_end, num_docs, membership_query)
+    try:
+        rec = memo_query(mem_arr, rec, membership_query)
+    finally:
+        mem_arr.close()
+    print_res(rec, args.out_file, membership_query)
+
+
+if __name__ == "__main__":
+    main(parse_arguments())

@@ -1,0 +1,49 @@
+"""Synthetic pangenome workloads (BASELINE.json configs 2-5; DESIGN.md "Synthetic workload").
+
+Row i of the generator:  start = 1 + floor(i*den/num)   (num/den = rows per pivot position)
+                         end   = start + mix(seed, 2i) % 60
+                         annot = 1 + mix(seed, 2i+1) % (num_docs - 1)
+The rows are produced on the device (memo_synth_fill); oracle_synth_rows is the CPU twin
+used by the tests.  Index-addressable, so every shard generates exactly its own rows.
+"""
+from fractions import Fraction
+
+from .index import DeviceIndex
+
+SEED = 0x4D454D4F  # "MEMO"
+
+# name -> (num_docs, pivot length, density = rows per genome-position)
+CONFIGS = {
+    "c2": dict(num_docs=10, pivot=10_000_000, density=Fraction(5, 100)),     # ~5 M rows
+    "c3": dict(num_docs=100, pivot=100_000_000, density=Fraction(5, 100)),   # ~500 M rows
+    "c4": dict(num_docs=100, pivot=100_000_000, density=Fraction(5, 100)),   # membership on c3
+    "c5": dict(num_docs=500, pivot=3_000_000_000, density=Fraction(5, 100)),  # HPRC scale
+}
+
+
+def rows_per_position(num_docs, density=Fraction(5, 100)):
+    f = Fraction(density) * num_docs
+    return f.numerator, f.denominator
+
+
+def first_row_at_or_after(x, num, den):
+    """smallest i with start_i >= x, start_i = 1 + floor(i*den/num)."""
+    if x <= 1:
+        return 0
+    return -((-(x - 1) * num) // den)          # ceil((x-1)*num/den)
+
+
+def shard_rows(qs, qe, k, num, den, pivot):
+    """global row range [r0, r1) of the rows a window [qs, qe) can see: qs < start < qe + k
+    (memo_query.py:25-27 with :100), clipped to the pivot's total row count."""
+    total = first_row_at_or_after(pivot, num, den)     # rows with start < pivot length
+    r0 = min(first_row_at_or_after(qs + 1, num, den), total)
+    r1 = min(first_row_at_or_after(qe + k, num, den), total)
+    return r0, max(r1, r0)
+
+
+def device_index(qs, qe, k, num_docs, pivot, density=Fraction(5, 100), device=0, seed=SEED):
+    """DeviceIndex holding exactly the rows window [qs, qe) needs (generated in HBM)."""
+    num, den = rows_per_position(num_docs, density)
+    r0, r1 = shard_rows(qs, qe, k, num, den, pivot)
+    return DeviceIndex.synthetic(r1 - r0, r0, num, den, num_docs, seed=seed, device=device), (r0, r1)

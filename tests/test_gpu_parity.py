@@ -1,0 +1,246 @@
+"""Parity of the HIP path with the oracle and with the committed golden vectors.
+Everything here calls through the C ABI (memo_amd._lib) and needs a real MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def memo():
+    import memo_amd
+    from memo_amd import _lib
+    assert _lib.lib().memo_device_count() > 0, "no HIP device: the product has no CPU fallback"
+    return memo_amd
+
+
+def _cons(memo, rows, qs, qe, k, n):
+    return memo.conservation(*rows, qs, qe, k, n)
+
+
+# ---------------------------------------------------------------------------------------
+# golden vectors (the reference's own output), through the one-shot host ABI
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c", G.cases(raises=False), ids=lambda c: c["name"])
+def test_golden_one_shot(c, memo):
+    from memo_amd.index import bits_to_matrix
+    rec, qs, qe = G.region(c)
+    z = G.load(c)
+    chrom = G.index_columns(c["index"], rec)              # whole chromosome, unfiltered
+    ref = z["rows"].astype(np.int64).reshape(-1, 3)
+    filtered = tuple(np.ascontiguousarray(ref[:, i]) for i in range(3))   # what filter_pq returned
+    order = np.argsort(filtered[0], kind="stable")
+    filtered = tuple(col[order] for col in filtered)
+    for rows in (chrom, filtered):
+        if c["membership"]:
+            got = memo.membership(*rows, qs, qe, c["k"], c["n"])
+            assert np.array_equal(bits_to_matrix(got, c["n"]), G.expected_matrix(c, z))
+            text = memo.emit_membership(got, c["n"])
+        else:
+            got = memo.conservation(*rows, qs, qe, c["k"], c["n"])
+            assert np.array_equal(got.astype(np.int64), z["vec"])
+            text = memo.emit_conservation(got)
+        assert G.sha(text) == c["sha256"]
+
+
+@pytest.mark.parametrize("c", G.cases(raises=True), ids=lambda c: c["name"])
+def test_golden_index_error(c, memo):
+    rec, qs, qe = G.region(c)
+    rows = G.index_columns(c["index"], rec)
+    fn = memo.membership if c["membership"] else memo.conservation
+    with pytest.raises(IndexError):                    # the reference's error (memo_query.py:62)
+        fn(*rows, qs, qe, c["k"], c["n"])
+
+
+# ---------------------------------------------------------------------------------------
+# CLI-level: memo_query.main writes the reference's bytes
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c", [c for c in G.cases(raises=False) if c["name"].startswith("ex_")] +
+                         G.cases(raises=False)[20::17], ids=lambda c: c["name"])
+def test_cli_bytes(c, memo, tmp_path):
+    from memo_amd import memo_query as mq
+    out = tmp_path / "out.txt"
+    argv = ["-b", os.path.join(G.GOLD, c["index"]), "-k", str(c["k"]), "-n", str(c["n"]),
+            "-r", c["region"], "-o", str(out)] + (["-m"] if c["membership"] else [])
+    mq.main(mq.parse_arguments(argv))
+    data = out.read_bytes()
+    assert G.sha(data) == c["sha256"]
+
+
+# ---------------------------------------------------------------------------------------
+# resident index vs oracle: many windows, every tile width, k sweep
+# ---------------------------------------------------------------------------------------
+def _random_index(rng, n_rows, length, n_docs, maxlen):
+    s = np.sort(rng.integers(1, length, n_rows)).astype(np.int64)
+    e = s + rng.integers(0, maxlen, n_rows)
+    o = rng.integers(1, n_docs, n_rows).astype(np.int64)
+    return s, e, o
+
+
+@pytest.mark.parametrize("tile_w", [0, 256, 512, 1024, 2048, 4096])
+def test_resident_index_windows(tile_w, memo, oracle):
+    from memo_amd import _lib
+    rng = np.random.default_rng(tile_w + 7)
+    n_docs, length = 70, 60_000
+    s, e, o = _random_index(rng, 250_000, length, n_docs, 140)
+    _lib.check(_lib.lib().memo_set_tuning(tile_w, 0))
+    try:
+        with memo.DeviceIndex.from_host(s, e, o) as ix:
+            assert ix.info()["was_sorted"] == 1
+            for k in (2, 3, 4, 5, 8, 9, 16, 17, 21, 31, 32, 33, 64, 65, 101, 129, 300):
+                qs = int(rng.integers(0, length // 2))
+                qe = int(rng.integers(qs + 1, length + 200))
+                want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                got = ix.conservation(qs, qe, k, n_docs)
+                assert np.array_equal(got, want), (k, qs, qe)
+                if k in (3, 31, 101):
+                    qe = min(qe, qs + 9000)
+                    want = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                    assert np.array_equal(ix.membership(qs, qe, k, n_docs), want), (k, qs, qe)
+    finally:
+        _lib.check(_lib.lib().memo_set_tuning(0, 0))
+
+
+def test_ragged_density_and_edges(memo, oracle):
+    """clumped starts, empty stretches, window beyond the last row, window before the first."""
+    rng = np.random.default_rng(99)
+    parts = [rng.integers(1, 50, 4000), rng.integers(5000, 5003, 3000), rng.integers(20000, 90000, 500),
+             np.full(2000, 123456)]
+    s = np.sort(np.concatenate(parts)).astype(np.int64)
+    e = s + rng.integers(0, 70, len(s))
+    o = rng.integers(1, 9, len(s)).astype(np.int64)
+    with memo.DeviceIndex.from_host(s, e, o) as ix:
+        for qs, qe in ((0, 130000), (0, 1), (49, 5003), (4990, 5010), (123400, 123500), (123456, 123460),
+                       (200000, 200100), (5, 5), (7, 3), (122880, 124928), (1023, 1025)):
+            for k in (1, 2, 31, 64):
+                want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, 9, literal=False)
+                assert np.array_equal(ix.conservation(qs, qe, k, 9), want), (qs, qe, k)
+                want = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, 9, literal=False)
+                assert np.array_equal(ix.membership(qs, qe, k, 9), want), (qs, qe, k)
+
+
+def test_empty_index_and_empty_window(memo):
+    z = np.zeros(0, np.int64)
+    assert np.array_equal(memo.conservation(z, z, z, 10, 20, 31, 5), np.full(10, 5, np.uint16))
+    assert memo.conservation(z, z, z, 10, 10, 31, 5).size == 0
+    m = memo.membership(z, z, z, 0, 3, 31, 40)
+    assert m.shape == (3, 2) and np.all(m[:, 0] == 0xFFFFFFFF) and np.all(m[:, 1] == 0xFF)
+
+
+def test_num_docs_word_boundaries(memo, oracle):
+    rng = np.random.default_rng(5)
+    for n_docs in (2, 31, 32, 33, 64, 65, 200, 500):
+        s, e, o = _random_index(rng, 20000, 3000, n_docs, 60)
+        want = oracle.membership(s, e, o, 100, 2900, 31, n_docs, literal=False)
+        assert np.array_equal(memo.membership(s, e, o, 100, 2900, 31, n_docs), want), n_docs
+        want = oracle.conservation(s, e, o, 100, 2900, 31, n_docs, literal=False)
+        assert np.array_equal(memo.conservation(s, e, o, 100, 2900, 31, n_docs), want), n_docs
+
+
+def test_annot_edge_values(memo, oracle):
+    """order 0, order == N (the sentinel column), negative order (NumPy wraps), order > N (IndexError)."""
+    s = np.array([10, 20, 30, 40], np.int64)
+    e = s + 2
+    for o, ok in (([0, 5, 4, 3], True), ([5, 5, 5, 5], True), ([-1, -6, 2, 1], True), ([1, 6, 1, 1], False),
+                  ([1, -7, 1, 1], False)):
+        o = np.array(o, np.int64)
+        if ok:
+            assert np.array_equal(memo.conservation(s, e, o, 0, 50, 8, 5), oracle.conservation(s, e, o, 0, 50, 8, 5))
+        else:
+            with pytest.raises(IndexError):
+                memo.conservation(s, e, o, 0, 50, 8, 5)
+            with pytest.raises(IndexError):
+                oracle.conservation(s, e, o, 0, 50, 8, 5)
+    # the offending row is outside the window / does not write: no error, as in the reference
+    o = np.array([1, 99, 1, 1], np.int64)
+    assert np.array_equal(memo.conservation(s, e, o, 25, 50, 8, 5), oracle.conservation(s, e, o, 25, 50, 8, 5))
+
+
+def test_unsorted_rows_are_sorted_on_device(memo, oracle):
+    from memo_amd import _lib
+    rng = np.random.default_rng(11)
+    s, e, o = _random_index(rng, 50000, 20000, 12, 80)
+    perm = rng.permutation(len(s))
+    want = oracle.conservation(s, e, o, 0, 20000, 31, 12, literal=False)
+    with memo.DeviceIndex.from_host(s[perm], e[perm], o[perm]) as ix:
+        assert ix.info()["was_sorted"] == 0
+        assert np.array_equal(ix.conservation(0, 20000, 31, 12), want)
+    with pytest.raises(memo.MemoError) as ei:
+        memo.DeviceIndex.from_host(s[perm], e[perm], o[perm], allow_sort=False)
+    assert ei.value.code == _lib.MEMO_EUNSORTED
+
+
+def test_end_before_start_is_rejected(memo):
+    from memo_amd import _lib
+    with pytest.raises(memo.MemoError) as ei:
+        memo.conservation([5, 9], [7, 8], [1, 1], 0, 20, 3, 5)
+    assert ei.value.code == _lib.MEMO_ELONGROW
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE configs on the synthetic pangenome
+# ---------------------------------------------------------------------------------------
+def test_config2_full_window(memo, oracle):
+    """config 2: 10 genomes x 10 Mbp, ~5 M rows, k=31 -- whole window against the oracle."""
+    from memo_amd import synth
+    n, L, k = 10, 10_000_000, 31
+    ix, (r0, r1) = synth.device_index(0, L, k, n, L)
+    num, den = synth.rows_per_position(n)
+    s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, n)
+    with ix:
+        got = ix.conservation(0, L, k, n)
+        assert np.array_equal(got, oracle.conservation(s, e, o, 0, L, k, n, literal=False))
+        sub = ix.conservation(1_234_567, 2_345_678, k, n)
+        assert np.array_equal(sub, got[1_234_567:2_345_678])
+        for kk in (21, 101):
+            assert np.array_equal(ix.conservation(0, 2_000_000, kk, n),
+                                  oracle.conservation(s, e, o, 0, 2_000_000, kk, n, literal=False))
+        m = ix.membership(0, 3_000_000, k, n)
+        assert np.array_equal(m, oracle.membership(s, e, o, 0, 3_000_000, k, n, literal=False))
+
+
+@pytest.mark.parametrize("membership", [False, True])
+def test_config3_full_size_properties(membership, memo, oracle):
+    """configs 3/4: 100 genomes x 100 Mbp, 500 M rows (12 GB in HBM).  The full result is
+    checked on sampled sub-windows against the oracle (rows regenerated per sub-window) and
+    through the split-window property (any sub-window query == slice of the full query)."""
+    import ctypes as C
+    from memo_amd import synth, _lib
+    n, L, k = 100, 100_000_000, 31
+    num, den = synth.rows_per_position(n)
+    ix, (r0, r1) = synth.device_index(0, L, k, n, L)
+    W = (n + 31) // 32
+    with ix:
+        assert ix.info()["rows"] == r1 - r0 and abs((r1 - r0) - 500_000_000) < 1000
+        full = np.empty((L, W), np.uint32) if membership else np.empty(L, np.uint16)
+        d = C.c_void_p()
+        _lib.check(_lib.lib().memo_dev_malloc(0, full.nbytes, C.byref(d)))
+        try:
+            if membership:
+                ix.membership_dev(0, L, k, n, d.value)
+            else:
+                ix.conservation_dev(0, L, k, n, d.value)
+            ix.check()
+            _lib.check(_lib.lib().memo_dev_download(0, full.ctypes.data, d, full.nbytes, None))
+        finally:
+            _lib.lib().memo_dev_free(0, d)
+        rng = np.random.default_rng(3)
+        starts = [0, L - 300_000] + [int(x) for x in rng.integers(0, L - 300_000, 6)]
+        for a in starts:
+            b = a + 300_000
+            sr0, sr1 = synth.shard_rows(a, b, k, num, den, L)
+            s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
+            if membership:
+                want = oracle.membership(s, e, o, a, b, k, n, literal=False)
+                sub = ix.membership(a + 17, b - 5, k, n)
+            else:
+                want = oracle.conservation(s, e, o, a, b, k, n, literal=False)
+                sub = ix.conservation(a + 17, b - 5, k, n)
+            assert np.array_equal(full[a:b], want), a
+            assert np.array_equal(sub, full[a + 17:b - 5]), a
+        if not membership:
+            assert full.min() >= 1 and full.max() == n

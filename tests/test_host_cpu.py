@@ -1,0 +1,105 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the
+header declares, the text emitters and the Parquet region slice match the golden vectors.
+No compute call is made here (there is no GPU in this tier)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import golden_util as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def memo():
+    import memo_amd
+    memo_amd.build()
+    memo_amd.lib()
+    return memo_amd
+
+
+def test_library_exports_every_declared_symbol(memo):
+    from memo_amd import _lib
+    header = open(os.path.join(ROOT, "include", "memo_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)          # declarations only, not comments
+    declared = set(re.findall(r"\b(memo_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name)
+    assert b"gfx950" in L.memo_version()
+
+
+def test_no_gpu_fails_loudly(memo):
+    from memo_amd import _lib
+    if _lib.lib().memo_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(memo.MemoError) as ei:
+        memo.conservation([1], [2], [1], 0, 10, 3, 5)
+    assert ei.value.code == _lib.MEMO_EHIP
+
+
+def test_product_never_imports_oracle():
+    for dp, _, fs in os.walk(os.path.join(ROOT, "memo_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libmemo_oracle" not in txt, f
+
+
+@pytest.mark.parametrize("c", G.cases(raises=False), ids=lambda c: c["name"])
+def test_emitters_match_reference_text(c, memo):
+    z = G.load(c)
+    if c["membership"]:
+        m = G.expected_matrix(c, z)
+        W = (c["n"] + 31) // 32
+        bits = np.zeros((m.shape[0], W), np.uint32)
+        for g in range(c["n"]):
+            bits[:, g >> 5] |= m[:, g].astype(np.uint32) << np.uint32(g & 31)
+        text = memo.emit_membership(bits, c["n"])
+        from memo_amd.index import bits_to_matrix
+        assert np.array_equal(bits_to_matrix(bits, c["n"]), m)
+    else:
+        text = memo.emit_conservation(z["vec"].astype(np.uint16))
+    assert G.sha(text) == c["sha256"]
+    if "out" in c:
+        assert text == G.out_bytes(c)
+
+
+@pytest.mark.parametrize("c", G.cases(raises=False)[::7], ids=lambda c: c["name"])
+def test_filter_pq_matches_reference_rows(c, memo):
+    from memo_amd import memo_query as mq
+    rec, qs, qe = G.region(c)
+    z = G.load(c)
+    path = os.path.join(G.GOLD, c["index"])
+    rows = mq.filter_pq(path, rec, qs, qe + c["k"], spanning_rows=True)
+    assert np.array_equal(rows.as_array(), z["rows"].reshape(-1, 3))
+    live = mq.filter_pq(path, rec, qs, qe + c["k"])
+    ref = z["rows"].reshape(-1, 3).astype(np.int64)
+    keep = ref[:, 0] > qs
+    assert np.array_equal(live.as_array().astype(np.int64), ref[keep])
+
+
+def test_cli_argument_surface(memo):
+    from memo_amd import memo_query as mq
+    a = mq.parse_arguments(["-b", "x.parquet", "-o", "o.txt", "-n", "5", "-k", "31", "-r", "chr1:0-10"])
+    assert (a.in_file, a.out_file, a.num_docs, a.k, a.genome_region, a.membership_query) == \
+        ("x.parquet", "o.txt", "5", "31", "chr1:0-10", False)
+    assert mq.parse_arguments(["-m", "-b", "x", "-o", "o", "-n", "5", "-k", "3", "-r", "c:1-2"]).membership_query
+    with pytest.raises(SystemExit):
+        mq.parse_arguments(["-b", "x.parquet"])          # -o -n -k -r are required (memo_query.py:79-83)
+
+
+def test_synth_shard_rows_match_oracle(oracle):
+    from memo_amd import synth
+    for num_docs, qs, qe, k in ((10, 0, 5000, 31), (10, 1234, 7777, 21), (100, 300, 900, 101), (7, 5, 6, 3)):
+        num, den = synth.rows_per_position(num_docs)
+        pivot = 10_000
+        r0, r1 = synth.shard_rows(qs, qe, k, num, den, pivot)
+        total = synth.first_row_at_or_after(pivot, num, den)
+        s, _, _ = oracle.synth_rows(0, total, num, den, num_docs)
+        want = np.nonzero((s > qs) & (s < qe + k))[0]
+        assert (r0, r1) == ((int(want[0]), int(want[-1]) + 1) if len(want) else (r0, r0))
