@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--cpu-sample", type=int, default=30_000_000,
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000,
                     help="positions of the window the 1-core CPU baseline is timed on (0 = skip)")
     return ap.parse_args()
 

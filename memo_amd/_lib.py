@@ -25,6 +25,10 @@ class MemoIndexError(MemoError, IndexError):
     """The reference raises IndexError here (annot column outside the result matrix)."""
 
 
+class MemoValueError(MemoError, ValueError):
+    """The reference raises ValueError here (window end before window start)."""
+
+
 class IndexInfo(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("min_start", C.c_int64), ("max_start", C.c_int64),
                 ("device", C.c_int32), ("bucket_shift", C.c_int32), ("buckets", C.c_uint64),
@@ -90,5 +94,7 @@ def check(rc):
         msg = lib().memo_last_error().decode(errors="replace")
         if rc == MEMO_EINVAL and "IndexError" in msg:
             raise MemoIndexError(rc, msg)
+        if rc == MEMO_EINVAL and "ValueError" in msg:
+            raise MemoValueError(rc, msg)
         raise MemoError(rc, msg)
     return rc

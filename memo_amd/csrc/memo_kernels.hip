@@ -499,6 +499,8 @@ int check_query_args(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, in
     if (qs <= -kCoordLimit || qe >= kCoordLimit || qs >= kCoordLimit || qe <= -kCoordLimit)
         return fail(MEMO_EINVAL, "window coordinates out of range");
     if (k >= (1 << 30) || k <= -(1 << 30)) return fail(MEMO_EINVAL, "k out of range");
+    if (qe < qs)  // np.zeros([true_len, ...]) with true_len < 0 (memo_query.py:51,53)
+        return fail(MEMO_EINVAL, "ValueError: negative dimensions are not allowed (window end < start)");
     if (qe > qs && !d_out) return fail(MEMO_EINVAL, "output pointer is NULL");
     if (qe > qs && ((uintptr_t)d_out & 15)) return fail(MEMO_EINVAL, "output must be 16-byte aligned");
     if (qe - qs > ((int64_t)1 << 40)) return fail(MEMO_EINVAL, "window longer than 2^40");
@@ -784,7 +786,8 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
     do {
         if ((rc = memo_index_upload(ix, start, end, annot, rows))) break;
         if ((rc = memo_index_finalize(ix, 0, 1))) break;
-        const int64_t L = qe > qs ? qe - qs : 0;
+        if (qe < qs) { rc = fail(MEMO_EINVAL, "ValueError: negative dimensions are not allowed (window end < start)"); break; }
+        const int64_t L = qe - qs;
         if (L > 0 && !out) { rc = fail(MEMO_EINVAL, "output pointer is NULL"); break; }
         const size_t bytes = membership ? (size_t)L * ((num_docs + 31) / 32) * 4 : (size_t)L * 2;
         DeviceGuard guard(device);

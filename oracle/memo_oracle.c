@@ -39,6 +39,7 @@
 #define ORACLE_OK 0
 #define ORACLE_EINDEX (-1) /* the reference raises IndexError (NumPy) / is UB (Numba) */
 #define ORACLE_ENOMEM (-2)
+#define ORACLE_EVALUE (-3) /* qe < qs: np.zeros([negative, ..]) raises ValueError (:51/:53) */
 
 static inline int64_t clip64(int64_t v, int64_t lo, int64_t hi) {
     return v < lo ? lo : (v > hi ? hi : v);
@@ -93,7 +94,8 @@ static int literal_fill(const int64_t *s, const int64_t *e, const int64_t *o, ui
 int oracle_literal_conservation(const int64_t *s, const int64_t *e, const int64_t *o, uint64_t m,
                                 int64_t qs, int64_t qe, int64_t k, int64_t N, uint16_t *out) {
     int64_t L = qe - qs;
-    if (L <= 0) return ORACLE_OK;
+    if (L < 0) return ORACLE_EVALUE;
+    if (L == 0) return ORACLE_OK;
     int64_t nc = N + 1;
     uint8_t *rec = (uint8_t *)calloc((size_t)L * (size_t)nc, 1);
     if (!rec) return ORACLE_ENOMEM;
@@ -113,7 +115,8 @@ int oracle_literal_conservation(const int64_t *s, const int64_t *e, const int64_
 int oracle_literal_membership(const int64_t *s, const int64_t *e, const int64_t *o, uint64_t m,
                               int64_t qs, int64_t qe, int64_t k, int64_t N, uint32_t *out) {
     int64_t L = qe - qs;
-    if (L <= 0) return ORACLE_OK;
+    if (L < 0) return ORACLE_EVALUE;
+    if (L == 0) return ORACLE_OK;
     int64_t W = (N + 31) / 32;
     uint8_t *rec = (uint8_t *)malloc((size_t)L * (size_t)N);
     if (!rec) return ORACLE_ENOMEM;
@@ -139,6 +142,7 @@ int oracle_literal_membership(const int64_t *s, const int64_t *e, const int64_t 
 int oracle_closed_conservation(const int64_t *s, const int64_t *e, const int64_t *o, uint64_t m,
                                int64_t qs, int64_t qe, int64_t k, int64_t N, uint16_t *out) {
     int64_t L = qe - qs, nc = N + 1;
+    if (L < 0) return ORACLE_EVALUE;
     for (int64_t p = 0; p < L; p++) out[p] = (uint16_t)N;
     for (uint64_t i = 0; i < m; i++) {
         int64_t hi = clip64(s[i] - qs, 0, L), lo = clip64(e[i] - qs - (k - 1), 0, L);
@@ -155,6 +159,7 @@ int oracle_closed_conservation(const int64_t *s, const int64_t *e, const int64_t
 int oracle_closed_membership(const int64_t *s, const int64_t *e, const int64_t *o, uint64_t m,
                              int64_t qs, int64_t qe, int64_t k, int64_t N, uint32_t *out) {
     int64_t L = qe - qs, W = (N + 31) / 32;
+    if (L < 0) return ORACLE_EVALUE;
     for (int64_t p = 0; p < L; p++)
         for (int64_t w = 0; w < W; w++) {
             int64_t left = N - 32 * w;

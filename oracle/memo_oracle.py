@@ -85,6 +85,8 @@ def _run(fn, s, e, o, qs, qe, k, n_docs, out):
     rc = fn(s, e, o, len(s), qs, qe, k, n_docs, out)
     if rc == -1:
         raise OracleIndexError("order column outside the result matrix")
+    if rc == -3:
+        raise ValueError("negative dimensions are not allowed")     # np.zeros([qe - qs, ...])
     if rc != 0:
         raise MemoryError("oracle: cannot allocate the L x N matrix")
     return out
@@ -134,6 +136,8 @@ def fnv1a(arr):
 def _covered_pairs(s, e, o, qs, qe, k, ncols):
     """(position, column) pairs written by memo_query.py:61-62 after :45-49."""
     L = qe - qs
+    if L < 0:
+        raise ValueError("negative dimensions are not allowed")
     s = np.asarray(s, np.int64)
     e = np.asarray(e, np.int64)
     o = np.asarray(o, np.int64)
