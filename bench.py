@@ -10,7 +10,8 @@ k = 31, conservation.  A "step" is one query of the whole window: one launch of
 sweep_conservation_kernel over the rows resident in HBM, result left in HBM.  Weak scaling:
 every rank owns its own 10^8-position window of an N x 10^8 pivot and generates exactly the
 rows that window sees (index-addressable generator, memo_amd/synth.py); for N > 1 the result
-slices are gathered to rank 0 over RCCL inside the timed region.
+slices are gathered to rank 0 over RCCL inside the timed region (as bytes, uint8 per position
+when num_docs <= 255; two result buffers so that gather i overlaps sweep i+1).
 
 One JSON line on stdout (rank 0).  `roofline` prices the sweep kernel alone from HIP events
 recorded on the launch stream; `cpu_baseline` is the oracle's literal port of the
@@ -51,6 +52,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--wide", action="store_true", help="keep uint16 results for N > 1 (default: uint8 when num_docs <= 255)")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000,
                     help="positions of the window the 1-core CPU baseline is timed on (0 = skip)")
     return ap.parse_args()
@@ -97,32 +99,55 @@ def main():
     ix, (r0, r1) = synth.device_index(qs, qe, k, num_docs, pivot, device=local)
     rows = r1 - r0
     W = (num_docs + 31) // 32
+    # result element: membership = W uint32 words; conservation = uint16, or uint8 when the
+    # values fit and the slices have to cross xGMI (halves the gather)
+    narrow = (not membership) and world > 1 and num_docs <= 255 and not args.wide
     if membership:
-        out = torch.empty((L, W), dtype=torch.int32, device=dev)
-        b_out = 4 * W
+        shape, dtype, b_out = (L, W), torch.int32, 4 * W
+    elif narrow:
+        shape, dtype, b_out = (L,), torch.uint8, 1
     else:
-        out = torch.empty(L, dtype=torch.int16, device=dev)      # uint16 payload
-        b_out = 2
-    gathered = None
-    if world > 1 and rank == 0:
-        gathered = [torch.empty_like(out) for _ in range(world)]
-
+        shape, dtype, b_out = (L,), torch.int16, 2          # uint16 payload
+    # two result buffers: the gather of step i (RCCL stream) overlaps the sweep of step i+1
+    nbuf = 2 if world > 1 else 1
+    outs = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(nbuf)]
+    wires = [o.view(torch.uint8).reshape(-1) for o in outs]      # RCCL has no 16-bit integer type
+    roots = [[torch.empty_like(wires[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
+             for _ in range(nbuf)]
+    pending = [None] * nbuf
     stream = torch.cuda.current_stream()
 
-    def launch():
+    def launch(out):
         if membership:
             ix.membership_dev(qs, qe, k, num_docs, out, stream.cuda_stream)
+        elif narrow:
+            ix.conservation_u8_dev(qs, qe, k, num_docs, out, stream.cuda_stream)
         else:
             ix.conservation_dev(qs, qe, k, num_docs, out, stream.cuda_stream)
 
-    def step():
-        launch()
-        if world > 1:                      # result slices -> root over xGMI (RCCL send/recv)
-            dist.gather(out, gathered, dst=0)
+    def step(i, ev=None):
+        b = i % nbuf
+        if pending[b] is not None:         # buffer b is free once its previous gather is done
+            pending[b].wait()
+            pending[b] = None
+        if ev:
+            ev[0].record(stream)
+        launch(outs[b])
+        if ev:
+            ev[1].record(stream)
+        if world > 1:                      # result slices -> rank 0 over xGMI (RCCL send/recv)
+            pending[b] = dist.gather(wires[b], roots[b], dst=0, async_op=True)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    def drain():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
     ix.check(stream.cuda_stream)           # raises if the kernel flagged a bad row
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -132,12 +157,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record(stream)
-        launch()
-        ev[i][1].record(stream)
-        if world > 1:
-            dist.gather(out, gathered, dst=0)
-    torch.cuda.synchronize()
+        step(i, ev[i])
+    drain()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -147,6 +168,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kern_ms = float(t[0]), float(t[1])
     ix.check(stream.cuda_stream)
+    out = outs[(args.steps - 1) % nbuf]
 
     if rank == 0:
         b_alg = 24 * rows + b_out * L                  # 3 x int64 per row + output
@@ -164,7 +186,9 @@ def main():
                                    f"{'membership' if membership else 'conservation'}",
                        "num_docs": num_docs, "window_per_gpu": L, "rows_per_gpu": rows, "k": k,
                        "query": "membership" if membership else "conservation",
-                       "sharding": f"window split into {world} contiguous sub-windows, RCCL gather to rank 0"
+                       "result_bytes_per_position": b_out,
+                       "sharding": f"window split into {world} contiguous sub-windows, slices gathered to rank 0 "
+                                   f"over RCCL (double-buffered: gather i overlaps sweep i+1)"
                                    if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -181,6 +205,21 @@ def main():
                 h = out[:S].cpu().numpy()
                 return h.view(np.uint32) if membership else h.view(np.uint16)
             res["cpu_baseline"] = cpu_baseline(args, num_docs, L, k, membership, gpu_slice)
+        if world > 1:
+            # the gathered slice of the LAST rank, checked against the oracle on a small sample
+            from oracle import memo_oracle as oracle        # checker only
+            S, g = 200_000, world - 1
+            num, den = synth.rows_per_position(num_docs)
+            a = g * L
+            sr0, sr1 = synth.shard_rows(a, a + S, k, num, den, pivot)
+            s_, e_, o_ = oracle.synth_rows(sr0, sr1 - sr0, num, den, num_docs)
+            got = roots[(args.steps - 1) % nbuf][g].view(dtype).reshape(shape)[:S].cpu().numpy()
+            if membership:
+                ok = np.array_equal(got.view(np.uint32), oracle.membership(s_, e_, o_, a, a + S, k, num_docs, literal=False))
+            else:
+                want = oracle.conservation(s_, e_, o_, a, a + S, k, num_docs, literal=False)
+                ok = np.array_equal(got.view(np.uint8 if narrow else np.uint16).astype(np.uint16), want)
+            res["gather_parity_sample"] = {"rank": g, "positions": S, "equal_to_oracle": bool(ok)}
         print(json.dumps(res), flush=True)
     ix.close()
     if world > 1:

@@ -94,6 +94,10 @@ int memo_query_conservation_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_
                                 int32_t num_docs, uint16_t *d_out, void *stream);
 int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,
                               int32_t num_docs, uint32_t *d_out, void *stream);
+/* same values as memo_query_conservation_dev, one byte per position; needs num_docs <= 255.
+ * Halves the bytes each rank sends in the multi-GPU gather (memo_amd/shard.py). */
+int memo_query_conservation_u8_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,
+                                   int32_t num_docs, uint8_t *d_out, void *stream);
 /* synchronise `stream`, return and clear the sticky error of earlier queries */
 int memo_query_check(memo_index_t *ix, void *stream);
 

@@ -49,6 +49,7 @@ SYMBOLS = {
     "memo_index_destroy": (None, [_P]),
     "memo_query_conservation_dev": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P]),
     "memo_query_membership_dev": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P]),
+    "memo_query_conservation_u8_dev": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P]),
     "memo_query_check": (C.c_int, [_P, _P]),
     "memo_conservation": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _I32]),
     "memo_membership": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _I32]),

@@ -170,7 +170,7 @@ __device__ __forceinline__ void cons_row(uint32_t *lds, const SweepArgs &A, int6
     }
 }
 
-template <int W, int U>
+template <int W, int U, typename OutT>
 __global__ __launch_bounds__(kWave) void sweep_conservation_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
@@ -244,23 +244,28 @@ __global__ __launch_bounds__(kWave) void sweep_conservation_kernel(const SweepAr
         __syncthreads();
     }
 
-    // write level 0 as uint16, in 16-byte pieces aligned in the OUTPUT (the tile grid is
-    // aligned in pivot coordinates, the output starts at qs)
-    uint16_t *out = static_cast<uint16_t *>(A.out);
+    // write level 0 as OutT (uint16, or uint8 when num_docs <= 255), in 16-byte pieces aligned
+    // in the OUTPUT (the tile grid is aligned in pivot coordinates, the output starts at qs)
+    constexpr int PER = 16 / (int)sizeof(OutT);  // positions per 16-byte store
+    OutT *out = static_cast<OutT *>(A.out);
     const int64_t ob = a - A.qs;  // output index of tile position 0
     const int64_t o_lo = ob + x_lo, o_hi = ob + x_hi;
-    for (int64_t g = (o_lo & ~(int64_t)7) + 8 * lane; g < o_hi; g += 8 * kWave) {
+    for (int64_t g = (o_lo & ~(int64_t)(PER - 1)) + PER * lane; g < o_hi; g += PER * kWave) {
         const int x = (int)(g - ob);
-        if (g >= o_lo && g + 8 <= o_hi) {
-            uint4 pk;
-            pk.x = lds[x + 0] | (lds[x + 1] << 16);
-            pk.y = lds[x + 2] | (lds[x + 3] << 16);
-            pk.z = lds[x + 4] | (lds[x + 5] << 16);
-            pk.w = lds[x + 6] | (lds[x + 7] << 16);
-            *reinterpret_cast<uint4 *>(out + g) = pk;
+        if (g >= o_lo && g + PER <= o_hi) {
+            uint32_t pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (sizeof(OutT) == 2)
+                    pk[q] = lds[x + 2 * q] | (lds[x + 2 * q + 1] << 16);
+                else
+                    pk[q] = lds[x + 4 * q] | (lds[x + 4 * q + 1] << 8) | (lds[x + 4 * q + 2] << 16) |
+                            (lds[x + 4 * q + 3] << 24);
+            }
+            *reinterpret_cast<uint4 *>(out + g) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         } else {
-            for (int i = 0; i < 8; ++i)
-                if (g + i >= o_lo && g + i < o_hi) out[g + i] = (uint16_t)lds[x + i];
+            for (int i = 0; i < PER; ++i)
+                if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)lds[x + i];
         }
     }
 }
@@ -345,7 +350,8 @@ __global__ __launch_bounds__(kWave) void sweep_membership_kernel(const SweepArgs
 }
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
-__global__ void fill_conservation_kernel(uint16_t *out, int64_t n, uint16_t v) {
+template <typename OutT>
+__global__ void fill_conservation_kernel(OutT *out, int64_t n, OutT v) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
         out[i] = v;
@@ -454,7 +460,7 @@ Window make_window(int64_t qs, int64_t qe, int w) {
     return win;
 }
 
-template <int W, int U>
+template <int W, int U, typename OutT>
 int launch_cons(SweepArgs &A, hipStream_t st) {
     const Window win = make_window(A.qs, A.qe, W);
     if (win.tiles_per_xcd * 8 * kWave >= ((int64_t)1 << 32))
@@ -464,9 +470,9 @@ int launch_cons(SweepArgs &A, hipStream_t st) {
     A.tiles_per_xcd = win.tiles_per_xcd;
     const size_t lds = (size_t)A.nlev * W * sizeof(uint32_t);
     if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sweep_conservation_kernel<W, U>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sweep_conservation_kernel<W, U, OutT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((sweep_conservation_kernel<W, U>), dim3((unsigned)(win.tiles_per_xcd * 8)),
+    hipLaunchKernelGGL((sweep_conservation_kernel<W, U, OutT>), dim3((unsigned)(win.tiles_per_xcd * 8)),
                        dim3(kWave), lds, st, A);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
@@ -524,6 +530,41 @@ void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32
 }
 
 }  // namespace
+
+template <typename OutT>
+static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
+                              OutT *d_out, void *stream) {
+    read_env_once();
+    int rc = check_query_args(ix, qs, qe, k, num_docs, d_out, false);
+    if (rc) return rc;
+    if (sizeof(OutT) == 1 && num_docs > 255)
+        return fail(MEMO_EINVAL, "uint8 results need num_docs <= 255, got %d", num_docs);
+    if (qe <= qs) return MEMO_OK;
+    DeviceGuard guard(ix->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (k <= 1 || ix->rows == 0) {
+        hipLaunchKernelGGL((fill_conservation_kernel<OutT>), dim3(2048), dim3(256), 0, st, d_out,
+                           qe - qs, (OutT)num_docs);
+        HIP_TRY(hipGetLastError());
+        return MEMO_OK;
+    }
+    SweepArgs A;
+    fill_args(ix, A, qs, qe, k, d_out);
+    A.ncols = num_docs + 1;
+    A.nlev = floor_log2((uint32_t)(k - 1)) + 1;
+    int w = g_tile_w;
+    if (w == 0) w = A.nlev <= 8 ? 1024 : (A.nlev <= 16 ? 512 : 256);
+    while ((size_t)A.nlev * w * 4 > 128 * 1024 && w > 256) w >>= 1;
+    if ((size_t)A.nlev * w * 4 > 160 * 1024) return fail(MEMO_EINVAL, "k too large for the LDS tile");
+    switch (w) {
+        case 256: return launch_cons<256, 4, OutT>(A, st);
+        case 512: return launch_cons<512, 4, OutT>(A, st);
+        case 1024: return launch_cons<1024, 4, OutT>(A, st);
+        case 2048: return launch_cons<2048, 4, OutT>(A, st);
+        case 4096: return launch_cons<4096, 4, OutT>(A, st);
+    }
+    return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+}
 
 // ==========================================================================================
 // C ABI
@@ -691,34 +732,12 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
 
 int memo_query_conservation_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,
                                 int32_t num_docs, uint16_t *d_out, void *stream) {
-    read_env_once();
-    int rc = check_query_args(ix, qs, qe, k, num_docs, d_out, false);
-    if (rc) return rc;
-    if (qe <= qs) return MEMO_OK;
-    DeviceGuard guard(ix->device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (k <= 1 || ix->rows == 0) {
-        hipLaunchKernelGGL(fill_conservation_kernel, dim3(2048), dim3(256), 0, st, d_out, qe - qs,
-                           (uint16_t)num_docs);
-        HIP_TRY(hipGetLastError());
-        return MEMO_OK;
-    }
-    SweepArgs A;
-    fill_args(ix, A, qs, qe, k, d_out);
-    A.ncols = num_docs + 1;
-    A.nlev = floor_log2((uint32_t)(k - 1)) + 1;
-    int w = g_tile_w;
-    if (w == 0) w = A.nlev <= 8 ? 1024 : (A.nlev <= 16 ? 512 : 256);
-    while ((size_t)A.nlev * w * 4 > 128 * 1024 && w > 256) w >>= 1;
-    if ((size_t)A.nlev * w * 4 > 160 * 1024) return fail(MEMO_EINVAL, "k too large for the LDS tile");
-    switch (w) {
-        case 256: return launch_cons<256, 4>(A, st);
-        case 512: return launch_cons<512, 4>(A, st);
-        case 1024: return launch_cons<1024, 4>(A, st);
-        case 2048: return launch_cons<2048, 4>(A, st);
-        case 4096: return launch_cons<4096, 4>(A, st);
-    }
-    return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+    return query_conservation<uint16_t>(ix, qs, qe, k, num_docs, d_out, stream);
+}
+
+int memo_query_conservation_u8_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,
+                                   int32_t num_docs, uint8_t *d_out, void *stream) {
+    return query_conservation<uint8_t>(ix, qs, qe, k, num_docs, d_out, stream);
 }
 
 int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,

@@ -74,6 +74,9 @@ class DeviceIndex:
     def conservation_dev(self, qs, qe, k, num_docs, out, stream=None):
         check(lib().memo_query_conservation_dev(self._h, qs, qe, k, num_docs, _ptr(out), _ptr(stream)))
 
+    def conservation_u8_dev(self, qs, qe, k, num_docs, out, stream=None):
+        check(lib().memo_query_conservation_u8_dev(self._h, qs, qe, k, num_docs, _ptr(out), _ptr(stream)))
+
     def membership_dev(self, qs, qe, k, num_docs, out, stream=None):
         check(lib().memo_query_membership_dev(self._h, qs, qe, k, num_docs, _ptr(out), _ptr(stream)))
 
@@ -93,9 +96,10 @@ class DeviceIndex:
             lib().memo_dev_free(self.device, d)
         return out
 
-    def conservation(self, qs, qe, k, num_docs):
-        out = np.empty(max(qe - qs, 0), np.uint16)
-        return self._run(lib().memo_query_conservation_dev, qs, qe, k, num_docs, out)
+    def conservation(self, qs, qe, k, num_docs, dtype=np.uint16):
+        out = np.empty(max(qe - qs, 0), dtype)
+        fn = lib().memo_query_conservation_dev if out.itemsize == 2 else lib().memo_query_conservation_u8_dev
+        return self._run(fn, qs, qe, k, num_docs, out)
 
     def membership(self, qs, qe, k, num_docs):
         out = np.empty((max(qe - qs, 0), words(num_docs)), np.uint32)

@@ -1,0 +1,58 @@
+"""Window sharding across ranks (one process per GPU) and the gather of result slices.
+
+The reference is single-process; this is new.  It rests on one
+property of the path: position p is influenced only by rows with
+p < start <= p + k - 1, so a window [qs, qe) can be cut into contiguous sub-windows and each
+sub-window queried on its own with the rows  a < start < b + k  -- the reference's own
+filter (memo_query.py:25-27 with :100) applied to the sub-window.  No exchange during the
+sweep; one gather of disjoint slices to the root at the end (RCCL over xGMI on GPUs:
+every peer has a direct link to the root, so the G-1 sends run concurrently).
+"""
+import numpy as np
+
+ALIGN = 8      # positions; keeps every uint16 slice 16-byte aligned in the gathered buffer
+
+
+def split_window(qs, qe, world, align=ALIGN):
+    """[(a_g, b_g)] for g in range(world): contiguous, equal length `per` (a multiple of
+    `align`) except the tail; ranks past the end get empty windows (a == b)."""
+    L = max(qe - qs, 0)
+    per = -(-L // world)
+    per = -(-per // align) * align if per else 0
+    cuts = [min(qs + g * per, qe) for g in range(world + 1)]
+    return [(cuts[g], cuts[g + 1]) for g in range(world)], per
+
+
+def rows_for_window(start_sorted, a, b, k):
+    """index range [i0, i1) of the rows a sub-window sees: a < start < b + k."""
+    i0 = int(np.searchsorted(start_sorted, a, side="right"))
+    i1 = int(np.searchsorted(start_sorted, b + k, side="left"))
+    return i0, max(i1, i0)
+
+
+def gather_slices(local, per, lengths, rank, world, dist, dst=0):
+    """local: this rank's slice, first dim padded to `per`.  Returns on dst the concatenation
+    of the first lengths[g] entries of every slice (torch tensor), None elsewhere."""
+    import torch
+    if world == 1:
+        return local[:lengths[0]]
+    # slices travel as bytes: neither RCCL nor gloo carries 16-bit integers
+    wire = local.contiguous().view(torch.uint8).reshape(-1)
+    bufs = [torch.empty_like(wire) for _ in range(world)] if rank == dst else None
+    dist.gather(wire, bufs, dst=dst)
+    if rank != dst:
+        return None
+    parts = [bufs[g].view(local.dtype).reshape(local.shape)[:lengths[g]] for g in range(world)]
+    return torch.cat(parts, dim=0)
+
+
+def sharded_query(sweep, qs, qe, k, rank, world, dist, alloc, dst=0):
+    """Run `sweep(a, b, out)` on this rank's sub-window [a, b) of [qs, qe), writing into
+    out[:b-a] (out = alloc(per)), then gather.  Returns (result on dst | None, (a, b))."""
+    wins, per = split_window(qs, qe, world)
+    a, b = wins[rank]
+    out = alloc(per)
+    if b > a:
+        sweep(a, b, out)
+    res = gather_slices(out, per, [w[1] - w[0] for w in wins], rank, world, dist, dst)
+    return res, (a, b)
