@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--wide", action="store_true", help="keep uint16 results for N > 1 (default: uint8 when num_docs <= 255)")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="also run the read-once calibration kernel (for the FETCH_SIZE PMC pass)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the gather path even with one rank (validation)")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000,
                     help="positions of the window the 1-core CPU baseline is timed on (0 = skip)")
     return ap.parse_args()
@@ -82,6 +86,11 @@ def cpu_baseline(args, num_docs, L, k, membership, gpu_result_slice):
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line.  RCCL and the HIP runtime sometimes print banners
+    # on fd 1, so fd 1 is pointed at stderr for the run and the line goes to the saved fd.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -89,8 +98,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    multi = world > 1 or args.force_dist
+    if multi:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     num_docs, L, membership = WORKLOADS[args.workload]
     k = args.k
@@ -101,7 +116,7 @@ def main():
     W = (num_docs + 31) // 32
     # result element: membership = W uint32 words; conservation = uint16, or uint8 when the
     # values fit and the slices have to cross xGMI (halves the gather)
-    narrow = (not membership) and world > 1 and num_docs <= 255 and not args.wide
+    narrow = (not membership) and multi and num_docs <= 255 and not args.wide
     if membership:
         shape, dtype, b_out = (L, W), torch.int32, 4 * W
     elif narrow:
@@ -109,10 +124,10 @@ def main():
     else:
         shape, dtype, b_out = (L,), torch.int16, 2          # uint16 payload
     # two result buffers: the gather of step i (RCCL stream) overlaps the sweep of step i+1
-    nbuf = 2 if world > 1 else 1
+    nbuf = 2 if multi else 1
     outs = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(nbuf)]
     wires = [o.view(torch.uint8).reshape(-1) for o in outs]      # RCCL has no 16-bit integer type
-    roots = [[torch.empty_like(wires[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
+    roots = [[torch.empty_like(wires[0]) for _ in range(world)] if (multi and rank == 0) else None
              for _ in range(nbuf)]
     pending = [None] * nbuf
     stream = torch.cuda.current_stream()
@@ -135,7 +150,7 @@ def main():
         launch(outs[b])
         if ev:
             ev[1].record(stream)
-        if world > 1:                      # result slices -> rank 0 over xGMI (RCCL send/recv)
+        if multi:                          # result slices -> rank 0 over xGMI (RCCL send/recv)
             pending[b] = dist.gather(wires[b], roots[b], dst=0, async_op=True)
 
     def drain():
@@ -145,6 +160,8 @@ def main():
                 pending[b] = None
         torch.cuda.synchronize()
 
+    if args.calibrate:
+        ix.debug_stream_rows(stream.cuda_stream)
     for i in range(args.warmup):
         step(i)
     drain()
@@ -152,18 +169,18 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, ev[i])
     drain()
-    if world > 1:
+    if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if world > 1:
+    if multi:
         t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kern_ms = float(t[0]), float(t[1])
@@ -205,7 +222,7 @@ def main():
                 h = out[:S].cpu().numpy()
                 return h.view(np.uint32) if membership else h.view(np.uint16)
             res["cpu_baseline"] = cpu_baseline(args, num_docs, L, k, membership, gpu_slice)
-        if world > 1:
+        if multi:
             # the gathered slice of the LAST rank, checked against the oracle on a small sample
             from oracle import memo_oracle as oracle        # checker only
             S, g = 200_000, world - 1
@@ -220,9 +237,9 @@ def main():
                 want = oracle.conservation(s_, e_, o_, a, a + S, k, num_docs, literal=False)
                 ok = np.array_equal(got.view(np.uint8 if narrow else np.uint16).astype(np.uint16), want)
             res["gather_parity_sample"] = {"rank": g, "positions": S, "equal_to_oracle": bool(ok)}
-        print(json.dumps(res), flush=True)
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     ix.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

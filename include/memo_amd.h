@@ -132,8 +132,15 @@ size_t memo_emit_membership(const uint32_t *bits, int64_t L, int32_t num_docs, c
 int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t den,
                     int32_t num_docs, uint64_t seed);
 
-/* ---- tuning knobs (process-wide; also read once from MEMO_TILE_W / MEMO_VARIANT) ------ */
-int memo_set_tuning(int32_t tile_w, int32_t variant);
+/* ---- tuning knobs (process-wide; also read once from the environment: MEMO_TILE_W,
+ * MEMO_WAVES, MEMO_MEMB_ALGO).  0 = let the library choose.  tile_w: positions per tile
+ * (256..4096); waves: 1 or 4 waves share a tile; membership_algo: 1 = direct scatter,
+ * 2 = doubling.  Results never depend on these. */
+int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo);
+
+/* profiling aid: one pass that reads the three columns exactly once (24 B/row) with the
+ * sweep's access shape, to calibrate the FETCH_SIZE counter on a known byte count */
+int memo_debug_stream_rows(memo_index_t *ix, void *stream);
 
 #ifdef __cplusplus
 }

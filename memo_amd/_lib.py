@@ -59,7 +59,8 @@ SYMBOLS = {
     "memo_emit_conservation": (_SZ, [_P, _I64, _P, _SZ]),
     "memo_emit_membership": (_SZ, [_P, _I64, _I32, _P, _SZ]),
     "memo_synth_fill": (C.c_int, [_P, _U64, _U64, _U64, _I32, _U64]),
-    "memo_set_tuning": (C.c_int, [_I32, _I32]),
+    "memo_debug_stream_rows": (C.c_int, [_P, _P]),
+    "memo_set_tuning": (C.c_int, [_I32, _I32, _I32]),
 }
 
 

@@ -72,7 +72,6 @@ struct DeviceGuard {  // the caller (e.g. torch) keeps its own notion of the cur
     }
 };
 
-constexpr int kWave = 64;
 constexpr uint64_t kPadRows = 4096;           // sentinel rows behind the last real row
 constexpr int64_t kSentinel = INT64_MAX / 4;  // start/end of a padding row: clips to "empty"
 constexpr int kDefaultBucketShift = 5;        // 32 pivot positions per bucket
@@ -116,7 +115,8 @@ struct SweepArgs {
     int bshift;
     int km1;    // k - 1 (>= 1 here; k <= 1 never reaches a sweep kernel)
     int ncols;  // result columns: num_docs + 1 (conservation) / num_docs (membership)
-    int nlev;   // conservation: floor(log2(k-1)) + 1;  membership: words per position
+    int nlev;   // doubling levels: floor(log2(k-1)) + 1
+    int nwords; // membership: 32-bit words per position
 };
 
 // blockIdx -> tile.  Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the XCD
@@ -148,56 +148,37 @@ __device__ __forceinline__ int clamp_to_tile(int64_t v, int lo, int hi) {
 }
 
 // ------------------------------------------------------------------------------------------
-// conservation: doubling scatter + top-down fold
+// shared pieces of the sweep kernels.  T = threads per workgroup (64 = one wave owns the tile;
+// 256 = four waves share it and meet at workgroup barriers between the phases).
 // ------------------------------------------------------------------------------------------
+struct Tile {
+    int64_t a;     // pivot position of tile slot 0
+    int x_lo, x_hi;  // slots of the tile that lie inside the window
+    uint64_t r0, r1;  // row slice
+};
+
 template <int W>
-__device__ __forceinline__ void cons_row(uint32_t *lds, const SweepArgs &A, int64_t a, int x_lo,
-                                         int x_hi, int64_t s, int64_t e, int64_t o) {
-    // memo_query.py:46-48 restricted to the tile: recentre, shadow-cast by k-1, clip
-    const int h = clamp_to_tile(s - a, x_lo, x_hi);
-    const int c = clamp_to_tile(e - a - A.km1, x_lo, x_hi);
-    const int len = h - c;  // :49  keep rows with casted_end < start
-    if (len > 0) {
-        int64_t col = o < 0 ? o + A.ncols : o;  // NumPy/Numba negative-index wrap
-        if ((uint64_t)col >= (uint64_t)A.ncols) {
-            atomicOr(A.status, kStatusBadAnnot);  // reference: IndexError / UB
-        } else {
-            const int j = 31 - __clz(len);
-            uint32_t *lv = lds + j * W;
-            atomicMin(lv + c, (uint32_t)col);                // block [c, c + 2^j)
-            atomicMin(lv + (h - (1 << j)), (uint32_t)col);   // block [h - 2^j, h)
-        }
-    }
+__device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t) {
+    const int64_t tile = tile_of_block(A);
+    if (tile >= A.ntiles) return false;
+    t.a = A.tile0 + tile * W;
+    t.x_lo = (int)(A.qs > t.a ? A.qs - t.a : 0);
+    t.x_hi = (int)(A.qe - t.a < W ? A.qe - t.a : W);
+    row_slice(A, t.a, t.a + t.x_hi, t.r0, t.r1);
+    return true;
 }
 
-template <int W, int U, typename OutT>
-__global__ __launch_bounds__(kWave) void sweep_conservation_kernel(const SweepArgs A) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int lane = threadIdx.x;
-    const int64_t tile = tile_of_block(A);
-    if (tile >= A.ntiles) return;
-    const int64_t a = A.tile0 + tile * W;
-    const int x_lo = (int)(A.qs > a ? A.qs - a : 0);
-    const int x_hi = (int)(A.qe - a < W ? A.qe - a : W);
-
-    // every level starts at the sentinel column N (memo_query.py:53-54)
-    {
-        const uint32_t sent = (uint32_t)(A.ncols - 1);
-        const uint4 sv = make_uint4(sent, sent, sent, sent);
-        uint4 *p = reinterpret_cast<uint4 *>(lds);
-        for (int i = lane; i < A.nlev * (W / 4); i += kWave) p[i] = sv;
-    }
-    uint64_t r0, r1;
-    row_slice(A, a, a + x_hi, r0, r1);
-    __syncthreads();
-
-    // stream the row slice: 2 rows per lane per column per load (16 B / lane, 1 KiB / wave)
-    for (uint64_t base = (r0 & ~(uint64_t)15) + 2 * lane; base < r1; base += 2 * kWave * U) {
+// stream the row slice: 2 rows per lane per column per load (16 B / lane, 1 KiB / wave),
+// U loads of each column in flight per lane; f(start, end, annot) sees every row once
+template <int T, int U, typename F>
+__device__ __forceinline__ void for_each_row(const SweepArgs &A, const Tile &t, F f) {
+    const int tid = threadIdx.x;
+    for (uint64_t base = (t.r0 & ~(uint64_t)15) + 2 * tid; base < t.r1; base += 2 * T * U) {
         longlong2 S[U], E[U], O[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint64_t idx = base + (uint64_t)u * 2 * kWave;
-            if (idx < r1) {
+            const uint64_t idx = base + (uint64_t)u * 2 * T;
+            if (idx < t.r1) {
                 S[u] = *reinterpret_cast<const longlong2 *>(A.s + idx);
                 E[u] = *reinterpret_cast<const longlong2 *>(A.e + idx);
                 O[u] = *reinterpret_cast<const longlong2 *>(A.o + idx);
@@ -209,10 +190,63 @@ __global__ __launch_bounds__(kWave) void sweep_conservation_kernel(const SweepAr
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            cons_row<W>(lds, A, a, x_lo, x_hi, S[u].x, E[u].x, O[u].x);
-            cons_row<W>(lds, A, a, x_lo, x_hi, S[u].y, E[u].y, O[u].y);
+            f(S[u].x, E[u].x, O[u].x);
+            f(S[u].y, E[u].y, O[u].y);
         }
     }
+}
+
+// memo_query.py:46-49 restricted to the tile: recentre, shadow-cast by k-1, clip, keep rows
+// with casted_end < start; then the column check of :62 (NumPy/Numba wrap a negative index
+// once; anything else outside the matrix is the reference's IndexError / UB)
+__device__ __forceinline__ bool clip_row(const SweepArgs &A, const Tile &t, int64_t s, int64_t e,
+                                         int64_t o, int &c, int &h, int &col) {
+    h = clamp_to_tile(s - t.a, t.x_lo, t.x_hi);
+    c = clamp_to_tile(e - t.a - A.km1, t.x_lo, t.x_hi);
+    if (h <= c) return false;
+    const int64_t cc = o < 0 ? o + A.ncols : o;
+    if ((uint64_t)cc >= (uint64_t)A.ncols) {
+        atomicOr(A.status, kStatusBadAnnot);
+        return false;
+    }
+    col = (int)cc;
+    return true;
+}
+
+__device__ __forceinline__ uint32_t full_word(int ncols, int w) {  // genomes 32w .. 32w+31 that exist
+    const int left = ncols - 32 * w;
+    return left >= 32 ? 0xFFFFFFFFu : (left <= 0 ? 0u : ((1u << left) - 1u));
+}
+
+// ------------------------------------------------------------------------------------------
+// conservation: doubling scatter + top-down fold
+// ------------------------------------------------------------------------------------------
+template <int W, int U, int T, typename OutT>
+__global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    Tile t;
+    if (!locate_tile<W>(A, t)) return;
+
+    // every level starts at the sentinel column N (memo_query.py:53-54)
+    {
+        const uint32_t sent = (uint32_t)(A.ncols - 1);
+        const uint4 sv = make_uint4(sent, sent, sent, sent);
+        uint4 *p = reinterpret_cast<uint4 *>(lds);
+        for (int i = tid; i < A.nlev * (W / 4); i += T) p[i] = sv;
+    }
+    __syncthreads();
+
+    // the clipped interval [c, h) is the union of two blocks of 2^j, j = floor(log2(h - c))
+    for_each_row<T, U>(A, t, [&](int64_t s, int64_t e, int64_t o) {
+        int c, h, col;
+        if (clip_row(A, t, s, e, o, c, h, col)) {
+            const int j = 31 - __clz(h - c);
+            uint32_t *lv = lds + j * W;
+            atomicMin(lv + c, (uint32_t)col);               // block [c, c + 2^j)
+            atomicMin(lv + (h - (1 << j)), (uint32_t)col);  // block [h - 2^j, h)
+        }
+    });
     __syncthreads();
 
     // fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1)
@@ -220,19 +254,19 @@ __global__ __launch_bounds__(kWave) void sweep_conservation_kernel(const SweepAr
         const int half = 1 << (j - 1);
         const uint32_t *hi = lds + j * W;
         uint32_t *lo = lds + (j - 1) * W;
-        for (int x = 4 * lane; x < W; x += 4 * kWave) {
+        for (int x = 4 * tid; x < W; x += 4 * T) {
             const uint4 v = *reinterpret_cast<const uint4 *>(hi + x);
             uint4 u;
             if (half >= 4) {
                 u = x >= half ? *reinterpret_cast<const uint4 *>(hi + x - half)
                               : make_uint4(~0u, ~0u, ~0u, ~0u);
             } else if (half == 2) {
-                const uint2 t = x >= 2 ? *reinterpret_cast<const uint2 *>(hi + x - 2)
+                const uint2 q = x >= 2 ? *reinterpret_cast<const uint2 *>(hi + x - 2)
                                        : make_uint2(~0u, ~0u);
-                u = make_uint4(t.x, t.y, v.x, v.y);
+                u = make_uint4(q.x, q.y, v.x, v.y);
             } else {
-                const uint32_t t = x >= 1 ? hi[x - 1] : ~0u;
-                u = make_uint4(t, v.x, v.y, v.z);
+                const uint32_t q = x >= 1 ? hi[x - 1] : ~0u;
+                u = make_uint4(q, v.x, v.y, v.z);
             }
             uint4 w = *reinterpret_cast<const uint4 *>(lo + x);
             w.x = min(w.x, min(v.x, u.x));
@@ -248,9 +282,9 @@ __global__ __launch_bounds__(kWave) void sweep_conservation_kernel(const SweepAr
     // in the OUTPUT (the tile grid is aligned in pivot coordinates, the output starts at qs)
     constexpr int PER = 16 / (int)sizeof(OutT);  // positions per 16-byte store
     OutT *out = static_cast<OutT *>(A.out);
-    const int64_t ob = a - A.qs;  // output index of tile position 0
-    const int64_t o_lo = ob + x_lo, o_hi = ob + x_hi;
-    for (int64_t g = (o_lo & ~(int64_t)(PER - 1)) + PER * lane; g < o_hi; g += PER * kWave) {
+    const int64_t ob = t.a - A.qs;  // output index of tile slot 0
+    const int64_t o_lo = ob + t.x_lo, o_hi = ob + t.x_hi;
+    for (int64_t g = (o_lo & ~(int64_t)(PER - 1)) + PER * tid; g < o_hi; g += PER * T) {
         const int x = (int)(g - ob);
         if (g >= o_lo && g + PER <= o_hi) {
             uint32_t pk[4];
@@ -271,82 +305,96 @@ __global__ __launch_bounds__(kWave) void sweep_conservation_kernel(const SweepAr
 }
 
 // ------------------------------------------------------------------------------------------
-// membership: one LDS and-atomic per covered (position, genome) bit
+// membership.  Result word w of position x:  full_word(w) & ~absent[x][w].
+//   DOUBLING = false: one ds_or per covered (position, genome) bit into absent[x][w].
+//   DOUBLING = true : the same two-blocks-per-row scatter and top-down fold as conservation,
+//                     on cells of nw words (or instead of min); nlev * W * nw words of LDS.
 // ------------------------------------------------------------------------------------------
-template <int W>
-__device__ __forceinline__ void memb_row(uint32_t *lds, const SweepArgs &A, int64_t a, int x_lo,
-                                         int x_hi, int64_t s, int64_t e, int64_t o) {
-    const int h = clamp_to_tile(s - a, x_lo, x_hi);
-    const int c = clamp_to_tile(e - a - A.km1, x_lo, x_hi);
-    if (h > c) {
-        int64_t col = o < 0 ? o + A.ncols : o;
-        if ((uint64_t)col >= (uint64_t)A.ncols) {
-            atomicOr(A.status, kStatusBadAnnot);
+template <int T>
+__device__ __forceinline__ void store_membership(const SweepArgs &A, const Tile &t,
+                                                 const uint32_t *absent, int nw) {
+    // slots [x_lo, x_hi) are one contiguous run of words in LDS and in the output
+    uint32_t *out = static_cast<uint32_t *>(A.out);
+    const int tid = threadIdx.x;
+    const int64_t ob = (t.a - A.qs) * nw;  // output word of LDS word 0
+    const int64_t o_lo = ob + (int64_t)t.x_lo * nw, o_hi = ob + (int64_t)t.x_hi * nw;
+    for (int64_t g = (o_lo & ~(int64_t)3) + 4 * tid; g < o_hi; g += 4 * T) {
+        const int x = (int)(g - ob);
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = g + i >= o_lo && g + i < o_hi;
+            v[i] = in ? (full_word(A.ncols, (x + i) % nw) & ~absent[x + i]) : 0u;
+        }
+        if (g >= o_lo && g + 4 <= o_hi) {
+            *reinterpret_cast<uint4 *>(out + g) = make_uint4(v[0], v[1], v[2], v[3]);
         } else {
-            const int nw = A.nlev;
-            uint32_t *cell = lds + c * nw + ((int)col >> 5);
-            const uint32_t keep = ~(1u << ((int)col & 31));
-            for (int x = c; x < h; ++x, cell += nw) atomicAnd(cell, keep);  // rec[c:h, a] = False
+            for (int i = 0; i < 4; ++i)
+                if (g + i >= o_lo && g + i < o_hi) out[g + i] = v[i];
         }
     }
 }
 
-template <int W, int U>
-__global__ __launch_bounds__(kWave) void sweep_membership_kernel(const SweepArgs A) {
+template <int W, int U, int T, bool DOUBLING>
+__global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int lane = threadIdx.x;
-    const int64_t tile = tile_of_block(A);
-    if (tile >= A.ntiles) return;
-    const int64_t a = A.tile0 + tile * W;
-    const int x_lo = (int)(A.qs > a ? A.qs - a : 0);
-    const int x_hi = (int)(A.qe - a < W ? A.qe - a : W);
-    const int nw = A.nlev;
+    const int tid = threadIdx.x;
+    Tile t;
+    if (!locate_tile<W>(A, t)) return;
+    const int nw = A.nwords;
+    const int nlev = DOUBLING ? A.nlev : 1;
+    const int plane = W * nw;  // words per level
 
-    // rec = ones([L, N])  (memo_query.py:51); bits >= N stay 0
-    for (int i = lane; i < W * nw; i += kWave) {
-        const int left = A.ncols - 32 * (i % nw);
-        lds[i] = left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u);
+    {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        uint4 *p = reinterpret_cast<uint4 *>(lds);
+        for (int i = tid; i < nlev * plane / 4; i += T) p[i] = z;
     }
-    uint64_t r0, r1;
-    row_slice(A, a, a + x_hi, r0, r1);
     __syncthreads();
 
-    for (uint64_t base = (r0 & ~(uint64_t)15) + 2 * lane; base < r1; base += 2 * kWave * U) {
-        longlong2 S[U], E[U], O[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t idx = base + (uint64_t)u * 2 * kWave;
-            if (idx < r1) {
-                S[u] = *reinterpret_cast<const longlong2 *>(A.s + idx);
-                E[u] = *reinterpret_cast<const longlong2 *>(A.e + idx);
-                O[u] = *reinterpret_cast<const longlong2 *>(A.o + idx);
+    for_each_row<T, U>(A, t, [&](int64_t s, int64_t e, int64_t o) {
+        int c, h, col;
+        if (clip_row(A, t, s, e, o, c, h, col)) {
+            const uint32_t bit = 1u << (col & 31);
+            const int word = col >> 5;
+            if (DOUBLING) {
+                const int j = 31 - __clz(h - c);
+                uint32_t *lv = lds + j * plane + word;
+                atomicOr(lv + c * nw, bit);
+                atomicOr(lv + (h - (1 << j)) * nw, bit);
             } else {
-                S[u] = make_longlong2(kSentinel, kSentinel);
-                E[u] = S[u];
-                O[u] = make_longlong2(0, 0);
+                uint32_t *cell = lds + c * nw + word;
+                for (int x = c; x < h; ++x, cell += nw) atomicOr(cell, bit);  // rec[c:h, a] = False
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            memb_row<W>(lds, A, a, x_lo, x_hi, S[u].x, E[u].x, O[u].x);
-            memb_row<W>(lds, A, a, x_lo, x_hi, S[u].y, E[u].y, O[u].y);
-        }
-    }
+    });
     __syncthreads();
 
-    // positions [x_lo, x_hi) are one contiguous run of words in LDS and in the output
-    uint32_t *out = static_cast<uint32_t *>(A.out);
-    const int64_t ob = (a - A.qs) * nw;  // output word of LDS word 0
-    const int64_t o_lo = ob + (int64_t)x_lo * nw, o_hi = ob + (int64_t)x_hi * nw;
-    for (int64_t g = (o_lo & ~(int64_t)3) + 4 * lane; g < o_hi; g += 4 * kWave) {
-        const int x = (int)(g - ob);
-        if (g >= o_lo && g + 4 <= o_hi) {
-            *reinterpret_cast<uint4 *>(out + g) = make_uint4(lds[x], lds[x + 1], lds[x + 2], lds[x + 3]);
-        } else {
-            for (int i = 0; i < 4; ++i)
-                if (g + i >= o_lo && g + i < o_hi) out[g + i] = lds[x + i];
+    if (DOUBLING) {
+        for (int j = nlev - 1; j >= 1; --j) {
+            const int shift = (1 << (j - 1)) * nw;  // half a block, in words
+            const uint32_t *hi = lds + j * plane;
+            uint32_t *lo = lds + (j - 1) * plane;
+            if ((shift & 3) == 0) {
+                for (int i = 4 * tid; i < plane; i += 4 * T) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(hi + i);
+                    const uint4 u = i >= shift ? *reinterpret_cast<const uint4 *>(hi + i - shift)
+                                               : make_uint4(0u, 0u, 0u, 0u);
+                    uint4 w = *reinterpret_cast<const uint4 *>(lo + i);
+                    w.x |= v.x | u.x;
+                    w.y |= v.y | u.y;
+                    w.z |= v.z | u.z;
+                    w.w |= v.w | u.w;
+                    *reinterpret_cast<uint4 *>(lo + i) = w;
+                }
+            } else {
+                for (int i = tid; i < plane; i += T)
+                    lo[i] |= hi[i] | (i >= shift ? hi[i - shift] : 0u);
+            }
+            __syncthreads();
         }
     }
+    store_membership<T>(A, t, lds, nw);
 }
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
@@ -410,6 +458,22 @@ __global__ void bucket_table_kernel(const int64_t *s, uint64_t rows, int64_t *bo
     boff[b] = (int64_t)lo;
 }
 
+// PMC calibration: reads every row of the three columns exactly once with the sweep's own
+// access shape (16 B per lane, 1 KiB per wave-instruction) and nothing else, so that
+// FETCH_SIZE can be checked against a known byte count (24 B x padded rows) in the same run.
+__global__ void stream_rows_kernel(const int64_t *s, const int64_t *e, const int64_t *o,
+                                   uint64_t rows, unsigned long long *sink) {
+    long long acc = 0;
+    for (uint64_t i = 2 * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x); i < rows;
+         i += 2 * (uint64_t)gridDim.x * blockDim.x) {
+        const longlong2 a = *reinterpret_cast<const longlong2 *>(s + i);
+        const longlong2 b = *reinterpret_cast<const longlong2 *>(e + i);
+        const longlong2 c = *reinterpret_cast<const longlong2 *>(o + i);
+        acc += a.x ^ a.y ^ b.x ^ b.y ^ c.x ^ c.y;
+    }
+    if (acc == 0x7fffffffffffffffll) atomicAdd(sink, 1ull);  // keeps the loads alive
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t x) {
     uint64_t z = seed + (x + 1) * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -433,67 +497,76 @@ __global__ void synth_rows_kernel(int64_t *s, int64_t *e, int64_t *o, uint64_t r
 // ------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------
-int g_tile_w = 0;    // 0 = choose per query
-int g_variant = 0;   // reserved for kernel A/B
+int g_tile_w = 0;     // 0 = choose per query
+int g_waves = 0;      // waves per tile: 0 = choose, 1 or 4
+int g_memb_algo = 0;  // membership: 0 = choose, 1 = direct scatter, 2 = doubling
 bool g_env_read = false;
 
 void read_env_once() {
     if (g_env_read) return;
     g_env_read = true;
     if (const char *v = getenv("MEMO_TILE_W")) g_tile_w = atoi(v);
-    if (const char *v = getenv("MEMO_VARIANT")) g_variant = atoi(v);
+    if (const char *v = getenv("MEMO_WAVES")) g_waves = atoi(v);
+    if (const char *v = getenv("MEMO_MEMB_ALGO")) g_memb_algo = atoi(v);
 }
 
 int floor_log2(uint32_t v) { return 31 - __builtin_clz(v); }
 
-struct Window {
-    int64_t tile0, ntiles, tiles_per_xcd;
-};
+using SweepKernel = void (*)(const SweepArgs);
 
-Window make_window(int64_t qs, int64_t qe, int w) {
-    Window win;
-    // floor to a multiple of w (w is a power of two; >> on a negative int64 is arithmetic)
+// tiles are aligned in pivot coordinates: tile 0 starts at floor(qs / w) * w
+int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st) {
     const int sh = floor_log2((uint32_t)w);
-    win.tile0 = (qs >> sh) << sh;
-    win.ntiles = ((qe - win.tile0) + w - 1) >> sh;
-    win.tiles_per_xcd = (win.ntiles + 7) / 8;
-    return win;
-}
-
-template <int W, int U, typename OutT>
-int launch_cons(SweepArgs &A, hipStream_t st) {
-    const Window win = make_window(A.qs, A.qe, W);
-    if (win.tiles_per_xcd * 8 * kWave >= ((int64_t)1 << 32))
-        return fail(MEMO_EINVAL, "window too long for one launch at tile width %d", W);
-    A.tile0 = win.tile0;
-    A.ntiles = win.ntiles;
-    A.tiles_per_xcd = win.tiles_per_xcd;
-    const size_t lds = (size_t)A.nlev * W * sizeof(uint32_t);
+    A.tile0 = (A.qs >> sh) << sh;  // >> on a negative int64 is arithmetic: floor
+    A.ntiles = ((A.qe - A.tile0) + w - 1) >> sh;
+    A.tiles_per_xcd = (A.ntiles + 7) / 8;
+    if (A.tiles_per_xcd * 8 * threads >= ((int64_t)1 << 32))
+        return fail(MEMO_EINVAL, "window too long for one launch at tile width %d", w);
+    if (lds > 160 * 1024) return fail(MEMO_EINVAL, "tile needs %zu bytes of LDS (> 160 KiB)", lds);
     if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sweep_conservation_kernel<W, U, OutT>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((sweep_conservation_kernel<W, U, OutT>), dim3((unsigned)(win.tiles_per_xcd * 8)),
-                       dim3(kWave), lds, st, A);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(threads), lds, st, A);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }
 
-template <int W, int U>
-int launch_memb(SweepArgs &A, hipStream_t st) {
-    const Window win = make_window(A.qs, A.qe, W);
-    if (win.tiles_per_xcd * 8 * kWave >= ((int64_t)1 << 32))
-        return fail(MEMO_EINVAL, "window too long for one launch at tile width %d", W);
-    A.tile0 = win.tile0;
-    A.ntiles = win.ntiles;
-    A.tiles_per_xcd = win.tiles_per_xcd;
-    const size_t lds = (size_t)A.nlev * W * sizeof(uint32_t);
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sweep_membership_kernel<W, U>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((sweep_membership_kernel<W, U>), dim3((unsigned)(win.tiles_per_xcd * 8)),
-                       dim3(kWave), lds, st, A);
-    HIP_TRY(hipGetLastError());
-    return MEMO_OK;
+constexpr int kU = 4;  // loads of each column in flight per lane
+
+template <typename OutT>
+SweepKernel cons_kernel(int w, int waves) {
+#define MEMO_CASE(WW)                                                                   \
+    case WW:                                                                            \
+        return waves == 4 ? (SweepKernel)sweep_conservation_kernel<WW, kU, 256, OutT>   \
+                          : (SweepKernel)sweep_conservation_kernel<WW, kU, 64, OutT>;
+    switch (w) {
+        MEMO_CASE(256)
+        MEMO_CASE(512)
+        MEMO_CASE(1024)
+        MEMO_CASE(2048)
+        MEMO_CASE(4096)
+    }
+#undef MEMO_CASE
+    return nullptr;
+}
+
+SweepKernel memb_kernel(int w, int waves, bool doubling) {
+#define MEMO_CASE(WW)                                                                              \
+    case WW:                                                                                       \
+        if (doubling)                                                                              \
+            return waves == 4 ? (SweepKernel)sweep_membership_kernel<WW, kU, 256, true>            \
+                              : (SweepKernel)sweep_membership_kernel<WW, kU, 64, true>;            \
+        return waves == 4 ? (SweepKernel)sweep_membership_kernel<WW, kU, 256, false>               \
+                          : (SweepKernel)sweep_membership_kernel<WW, kU, 64, false>;
+    switch (w) {
+        MEMO_CASE(256)
+        MEMO_CASE(512)
+        MEMO_CASE(1024)
+        MEMO_CASE(2048)
+        MEMO_CASE(4096)
+    }
+#undef MEMO_CASE
+    return nullptr;
 }
 
 int check_query_args(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
@@ -552,18 +625,21 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     fill_args(ix, A, qs, qe, k, d_out);
     A.ncols = num_docs + 1;
     A.nlev = floor_log2((uint32_t)(k - 1)) + 1;
-    int w = g_tile_w;
-    if (w == 0) w = A.nlev <= 8 ? 1024 : (A.nlev <= 16 ? 512 : 256);
-    while ((size_t)A.nlev * w * 4 > 128 * 1024 && w > 256) w >>= 1;
-    if ((size_t)A.nlev * w * 4 > 160 * 1024) return fail(MEMO_EINVAL, "k too large for the LDS tile");
-    switch (w) {
-        case 256: return launch_cons<256, 4, OutT>(A, st);
-        case 512: return launch_cons<512, 4, OutT>(A, st);
-        case 1024: return launch_cons<1024, 4, OutT>(A, st);
-        case 2048: return launch_cons<2048, 4, OutT>(A, st);
-        case 4096: return launch_cons<4096, 4, OutT>(A, st);
+    A.nwords = 0;
+    // Tile shape (interleaved A/B on one device, profiles/r01_ab_*.txt): four waves sharing a
+    // 4096-position tile beat one wave per 1024 positions by 1-3 % at k <= 32 and by 10 % at
+    // k = 101 (fewer k-1 row halos per position); short windows want many small tiles instead.
+    int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
+    if (!w) {
+        w = 4096;
+        while ((size_t)A.nlev * w * 4 > 80 * 1024 && w > 256) w >>= 1;
+        while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
     }
-    return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+    if (!waves) waves = w >= 2048 ? 4 : 1;
+    while ((size_t)A.nlev * w * 4 > 160 * 1024 && w > 256) w >>= 1;
+    SweepKernel kern = cons_kernel<OutT>(w, waves);
+    if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+    return launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * w * 4, st);
 }
 
 // ==========================================================================================
@@ -581,13 +657,16 @@ int memo_device_count(void) {
     return n;
 }
 
-int memo_set_tuning(int32_t tile_w, int32_t variant) {
+int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo) {
     read_env_once();
     if (tile_w != 0 && tile_w != 256 && tile_w != 512 && tile_w != 1024 && tile_w != 2048 &&
         tile_w != 4096)
         return fail(MEMO_EINVAL, "tile_w must be 0, 256, 512, 1024, 2048 or 4096");
+    if (waves != 0 && waves != 1 && waves != 4) return fail(MEMO_EINVAL, "waves must be 0, 1 or 4");
+    if (membership_algo < 0 || membership_algo > 2) return fail(MEMO_EINVAL, "membership_algo must be 0, 1 or 2");
     g_tile_w = tile_w;
-    g_variant = variant;
+    g_waves = waves;
+    g_memb_algo = membership_algo;
     return MEMO_OK;
 }
 
@@ -758,22 +837,24 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     SweepArgs A;
     fill_args(ix, A, qs, qe, k, d_out);
     A.ncols = num_docs;
-    A.nlev = nw;
-    int w = g_tile_w;
-    if (w == 0) {
-        w = 1024;
-        while ((size_t)nw * w * 4 > 20 * 1024 && w > 256) w >>= 1;
+    A.nlev = floor_log2((uint32_t)(k - 1)) + 1;
+    A.nwords = nw;
+    // doubling needs nlev * nw words per position; four waves share one tile so that the tile
+    // stays wide (the k-1 row halo is re-read once per tile).  Direct scatter otherwise.
+    const size_t per_pos_doubling = (size_t)A.nlev * nw * 4;
+    const bool doubling = g_memb_algo ? g_memb_algo == 2 : per_pos_doubling * 256 <= 40 * 1024;
+    const size_t per_pos = doubling ? per_pos_doubling : (size_t)nw * 4;
+    int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
+    if (!waves) waves = doubling ? 4 : 1;
+    if (!w) {  // config 4 (A/B, profiles/r01_ab_c4.txt): doubling, 512 positions x 4 waves, 40 KiB
+        w = 4096;
+        while (per_pos * w > (waves == 4 ? 40u : 20u) * 1024 && w > 256) w >>= 1;
+        while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
     }
-    while ((size_t)nw * w * 4 > 128 * 1024 && w > 256) w >>= 1;
-    if ((size_t)nw * w * 4 > 160 * 1024) return fail(MEMO_EINVAL, "num_docs too large for the LDS tile");
-    switch (w) {
-        case 256: return launch_memb<256, 4>(A, st);
-        case 512: return launch_memb<512, 4>(A, st);
-        case 1024: return launch_memb<1024, 4>(A, st);
-        case 2048: return launch_memb<2048, 4>(A, st);
-        case 4096: return launch_memb<4096, 4>(A, st);
-    }
-    return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+    while (per_pos * w > 160 * 1024 && w > 256) w >>= 1;
+    SweepKernel kern = memb_kernel(w, waves, doubling);
+    if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+    return launch_tiles(kern, A, w, 64 * waves, per_pos * w, st);
 }
 
 int memo_query_check(memo_index_t *ix, void *stream) {
@@ -855,6 +936,16 @@ int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t
         HIP_TRY(hipDeviceSynchronize());
     }
     ix->finalized = 0;
+    return MEMO_OK;
+}
+
+int memo_debug_stream_rows(memo_index_t *ix, void *stream) {
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    DeviceGuard guard(ix->device);
+    hipLaunchKernelGGL(stream_rows_kernel, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       ix->s, ix->e, ix->o, ix->rows & ~(uint64_t)1,
+                       reinterpret_cast<unsigned long long *>(ix->d_scratch));
+    HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }
 

@@ -80,6 +80,9 @@ class DeviceIndex:
     def membership_dev(self, qs, qe, k, num_docs, out, stream=None):
         check(lib().memo_query_membership_dev(self._h, qs, qe, k, num_docs, _ptr(out), _ptr(stream)))
 
+    def debug_stream_rows(self, stream=None):
+        check(lib().memo_debug_stream_rows(self._h, _ptr(stream)))
+
     def check(self, stream=None):
         check(lib().memo_query_check(self._h, _ptr(stream)))
 

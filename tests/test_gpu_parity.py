@@ -81,13 +81,18 @@ def _random_index(rng, n_rows, length, n_docs, maxlen):
     return s, e, o
 
 
-@pytest.mark.parametrize("tile_w", [0, 256, 512, 1024, 2048, 4096])
-def test_resident_index_windows(tile_w, memo, oracle):
+TUNINGS = [(0, 0, 0)] + [(w, wv, al) for w in (256, 512, 1024, 2048, 4096) for wv, al in ((1, 1), (4, 2))] + \
+    [(512, 1, 2), (1024, 4, 1)]
+
+
+@pytest.mark.parametrize("tile_w,waves,algo", TUNINGS)
+def test_resident_index_windows(tile_w, waves, algo, memo, oracle):
+    """every tile width x {1, 4} waves per tile x membership {direct, doubling}"""
     from memo_amd import _lib
-    rng = np.random.default_rng(tile_w + 7)
+    rng = np.random.default_rng(tile_w + 7 + waves)
     n_docs, length = 70, 60_000
     s, e, o = _random_index(rng, 250_000, length, n_docs, 140)
-    _lib.check(_lib.lib().memo_set_tuning(tile_w, 0))
+    _lib.check(_lib.lib().memo_set_tuning(tile_w, waves, algo))
     try:
         with memo.DeviceIndex.from_host(s, e, o) as ix:
             assert ix.info()["was_sorted"] == 1
@@ -102,7 +107,7 @@ def test_resident_index_windows(tile_w, memo, oracle):
                     want = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
                     assert np.array_equal(ix.membership(qs, qe, k, n_docs), want), (k, qs, qe)
     finally:
-        _lib.check(_lib.lib().memo_set_tuning(0, 0))
+        _lib.check(_lib.lib().memo_set_tuning(0, 0, 0))
 
 
 def test_ragged_density_and_edges(memo, oracle):

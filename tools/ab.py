@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of kernel tunings in ONE process on ONE device (box-to-box spread
+on this pool is larger than most tuning effects).  GPU box only.
+
+  python tools/ab.py --workload c3 --k 31 --rounds 12 "0,0,0" "1024,1,0" "4096,4,0"
+each variant = tile_w,waves,membership_algo  (memo_set_tuning)
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from memo_amd import _lib, synth  # noqa: E402
+from bench import WORKLOADS  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--rounds", type=int, default=12)
+    ap.add_argument("--u8", action="store_true")
+    ap.add_argument("variants", nargs="+")
+    a = ap.parse_args()
+    num_docs, L, membership = WORKLOADS[a.workload]
+    ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L)
+    W = (num_docs + 31) // 32
+    out = torch.empty((L, W) if membership else (L,), dtype=torch.int32 if membership else torch.int16, device="cuda")
+    st = torch.cuda.current_stream()
+    variants = [tuple(int(x) for x in v.split(",")) for v in a.variants]
+    times = {v: [] for v in variants}
+
+    def launch():
+        if membership:
+            ix.membership_dev(0, L, a.k, num_docs, out, st.cuda_stream)
+        elif a.u8:
+            ix.conservation_u8_dev(0, L, a.k, num_docs, out, st.cuda_stream)
+        else:
+            ix.conservation_dev(0, L, a.k, num_docs, out, st.cuda_stream)
+
+    for r in range(a.rounds + 1):
+        for v in variants:
+            _lib.check(_lib.lib().memo_set_tuning(*v))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            launch()
+            e1.record(st)
+            torch.cuda.synchronize()
+            if r:                                   # round 0 = warm-up
+                times[v].append(e0.elapsed_time(e1))
+    ix.check()
+    b_alg = 24 * (r1 - r0) + (4 * W if membership else (1 if a.u8 else 2)) * L
+    for v in variants:
+        t = np.array(times[v])
+        print(json.dumps({"variant": v, "workload": a.workload, "k": a.k, "ms_median": float(np.median(t)),
+                          "ms_min": float(t.min()), "ms_max": float(t.max()),
+                          "frac_of_8TBs": b_alg / (float(np.median(t)) * 1e-3) / 8e12}))
+
+
+if __name__ == "__main__":
+    main()
