@@ -71,6 +71,27 @@ def test_cli_bytes(c, memo, tmp_path):
     assert G.sha(data) == c["sha256"]
 
 
+def test_memo_front_end_subprocess(memo, tmp_path):
+    """`memo query ...` as a user runs it: banner on stdout, the reference's bytes in -o."""
+    import subprocess
+    import sys
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "memo")
+    for name in ("ex_cons_k3_0_20", "ex_memb_k3_0_20", "ex_cons_k31_full"):
+        c = next(x for x in G.cases() if x["name"] == name)
+        out = tmp_path / (name + ".txt")
+        argv = [sys.executable, exe, "query", "-b", os.path.join(G.GOLD, c["index"]), "-n", str(c["n"]),
+                "-r", c["region"], "-o", str(out)] + ([] if c["k"] == 31 else ["-k", str(c["k"])]) + \
+               (["-m"] if c["membership"] else [])
+        r = subprocess.run(argv, capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == (b"MEMO - membership query\n" if c["membership"] else b"MEMO - conservation query\n")
+        assert out.read_bytes() == G.out_bytes(c)
+    c = next(x for x in G.cases() if x["name"] == "ex_cons_n_too_small")
+    r = subprocess.run([sys.executable, exe, "query", "-b", os.path.join(G.GOLD, c["index"]), "-k", "3", "-n", "2",
+                        "-r", c["region"], "-o", str(tmp_path / "x.txt")], capture_output=True)
+    assert r.returncode != 0 and b"IndexError" in r.stderr
+
+
 # ---------------------------------------------------------------------------------------
 # resident index vs oracle: many windows, every tile width, k sweep
 # ---------------------------------------------------------------------------------------

@@ -103,3 +103,20 @@ def test_synth_shard_rows_match_oracle(oracle):
         s, _, _ = oracle.synth_rows(0, total, num, den, num_docs)
         want = np.nonzero((s > qs) & (s < qe + k))[0]
         assert (r0, r1) == ((int(want[0]), int(want[-1]) + 1) if len(want) else (r0, r0))
+
+
+def test_cli_front_end_usage_bytes():
+    """bin/memo prints the reference dispatcher's usage text and exits 0 (src/memo:4-20,
+    src/query.sh:14-33); fixtures captured from the reference's bash scripts."""
+    import subprocess
+    import sys
+    exe = os.path.join(ROOT, "bin", "memo")
+    for argv, fixture in (([], "memo_usage.txt"), (["-h"], "memo_usage.txt"), (["query"], "memo_query_usage.txt"),
+                          (["query", "-h"], "memo_query_usage.txt"), (["bogus"], "memo_bogus.txt")):
+        r = subprocess.run([sys.executable, exe] + argv, capture_output=True)
+        assert r.returncode == 0
+        assert r.stdout == open(os.path.join(G.GOLD, "cli", fixture), "rb").read(), argv
+    r = subprocess.run([sys.executable, exe, "query", "-x"], capture_output=True)
+    assert r.returncode == 0 and r.stdout == open(os.path.join(G.GOLD, "cli", "memo_query_usage.txt"), "rb").read()
+    r = subprocess.run([sys.executable, exe, "query", "-b", "x.parquet"], capture_output=True)
+    assert r.returncode == 2 and r.stdout == b"MEMO - conservation query\n"      # argparse: required flags

@@ -233,6 +233,13 @@ def main():
                             qe = qs + 120_000 // n
                         run_case(manifest, f"{name}_{tag}_k{k}_c{ci}w{wi}", pq, k, n,
                                  f"{cname}:{qs}-{qe}", memb, work)
+    # --- stdout of the reference's bash front end (usage banners; exit status 0 in all three)
+    import subprocess
+    os.makedirs(os.path.join(GOLD, "cli"))
+    for fname, argv in (("memo_usage.txt", []), ("memo_query_usage.txt", ["query"]), ("memo_bogus.txt", ["bogus"])):
+        r = subprocess.run(["bash", os.path.join(REF, "src", "memo")] + argv, capture_output=True)
+        assert r.returncode == 0
+        open(os.path.join(GOLD, "cli", fname), "wb").write(r.stdout)
     json.dump(manifest, open(os.path.join(GOLD, "manifest.json"), "w"), indent=0)
     shutil.rmtree(work)
     tot = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(GOLD) for f in fs)
