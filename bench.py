@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--wide", action="store_true", help="keep uint16 results for N > 1 (default: uint8 when num_docs <= 255)")
+    ap.add_argument("--rows", default="packed", choices=["packed", "wide"],
+                    help="row format the timed sweep reads: packed (memo_index_pack, 4-6 B/row) or the "
+                         "int64 columns as uploaded (24 B/row); at N=1 the other one is timed too")
     ap.add_argument("--calibrate", action="store_true",
                     help="also run the read-once calibration kernel (for the FETCH_SIZE PMC pass)")
     ap.add_argument("--force-dist", action="store_true",
@@ -111,8 +114,17 @@ def main():
     k = args.k
     pivot = L * world
     qs, qe = rank * L, (rank + 1) * L
-    ix, (r0, r1) = synth.device_index(qs, qe, k, num_docs, pivot, device=local)
+    from memo_amd import _lib
+    ix, (r0, r1) = synth.device_index(qs, qe, k, num_docs, pivot, device=local, pack="keep")
     rows = r1 - r0
+    packed_fmt = ix.info()["packed_format"]
+    if k - 1 > 255:
+        args.rows = "wide"                  # packed rows answer k <= 256 only
+
+    def use_rows(which):
+        _lib.check(_lib.lib().memo_set_row_source(1 if which == "wide" else 0))
+        return 24 if which == "wide" else packed_fmt
+    row_bytes = use_rows(args.rows)
     W = (num_docs + 31) // 32
     # result element: membership = W uint32 words; conservation = uint16, or uint8 when the
     # values fit and the slices have to cross xGMI (halves the gather)
@@ -187,8 +199,32 @@ def main():
     ix.check(stream.cuda_stream)
     out = outs[(args.steps - 1) % nbuf]
 
+    def kernel_name(which):
+        rows_t = "WideRows" if which == "wide" else f"PackedRows<{'true' if packed_fmt == 6 else 'false'}>"
+        return ("sweep_membership_kernel<" if membership else "sweep_conservation_kernel<") + rows_t + ", ...>"
+
+    other = None
+    if not multi and k - 1 <= 255:          # the same query on the other row format, for the record
+        which = "wide" if args.rows == "packed" else "packed"
+        ob = use_rows(which)
+        for i in range(args.warmup):
+            launch(outs[0])
+        e2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a_, b_ in e2:
+            a_.record(stream)
+            launch(outs[0])
+            b_.record(stream)
+        torch.cuda.synchronize()
+        ms2 = float(np.mean([a_.elapsed_time(b_) for a_, b_ in e2]))
+        alg2 = ob * rows + b_out * L
+        other = {"rows": which, "row_bytes": ob, "kernel": kernel_name(which), "kernel_ms": ms2,
+                 "query_positions_per_s": L / (ms2 * 1e-3), "algorithmic_bytes": alg2,
+                 "achieved_GBs": alg2 / (ms2 * 1e-3) / 1e9, "frac": alg2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        use_rows(args.rows)
+
     if rank == 0:
-        b_alg = 24 * rows + b_out * L                  # 3 x int64 per row + output
+        # bytes of the row layout the timed kernel reads + the result it writes
+        b_alg = row_bytes * rows + b_out * L
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         res = {
             "metric": "query-positions/sec (chr window, k=%d)" % k,
@@ -197,26 +233,30 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int64", "data": "synthetic",
+            "dtype": "int64" if args.rows == "wide" else "u32", "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.workload[1:]}: synthetic {num_docs}-genome index, "
                                    f"{L} positions/GPU window, {rows} rows/GPU, k={k}, "
                                    f"{'membership' if membership else 'conservation'}",
                        "num_docs": num_docs, "window_per_gpu": L, "rows_per_gpu": rows, "k": k,
                        "query": "membership" if membership else "conservation",
-                       "result_bytes_per_position": b_out,
+                       "row_format": "3 x int64 per row as uploaded (24 B)" if args.rows == "wide" else
+                                     f"packed {packed_fmt} B/row built once per index by memo_index_pack",
+                       "row_bytes": row_bytes, "result_bytes_per_position": b_out,
                        "sharding": f"window split into {world} contiguous sub-windows, slices gathered to rank 0 "
                                    f"over RCCL (double-buffered: gather i overlaps sweep i+1)"
                                    if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sweep_membership_kernel" if membership else "sweep_conservation_kernel",
+                         "kernel": kernel_name(args.rows),
                          "kernel_ms": kern_ms, "algorithmic_bytes": b_alg},
         }
         prof = os.path.join(ROOT, "profiles", "traffic.json")    # PMC passes are separate runs
         if os.path.exists(prof):
-            tj = json.load(open(prof)).get(args.workload)
+            tj = json.load(open(prof)).get(f"{args.workload}_{args.rows}")
             if tj:
                 res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+        if other:
+            res["other_row_format"] = other
         if world == 1 and args.cpu_sample > 0:
             def gpu_slice(S):
                 h = out[:S].cpu().numpy()

@@ -59,6 +59,8 @@ typedef struct memo_index_info {
     int32_t was_sorted;     /* 1 if the rows arrived start-sorted */
     int32_t finalized;
     uint64_t device_bytes;  /* HBM held by this index (columns + padding + bucket table) */
+    int32_t packed_format;  /* 0 = none, 4 = 4 B/row, 6 = 6 B/row (memo_index_pack) */
+    int32_t has_wide;       /* 1 while the three int64 columns are resident */
 } memo_index_info_t;
 
 const char *memo_last_error(void);
@@ -81,6 +83,15 @@ int memo_index_columns(memo_index_t *ix, int64_t **d_start, int64_t **d_end, int
 /* check start-sortedness and end >= start, sort by start on the device if needed
  * (allow_sort != 0), build the start-bucket table.  bucket_shift <= 0 picks the default. */
 int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_sort);
+/* Build the query-time row format: one 32-bit word per row
+ *     start mod 2^16 | min(end - start, 255) << 16 | annot << 24
+ * (4 B/row; when some annot > 255 the annot moves to a separate uint16 column, 6 B/row).
+ * Exact for every query with k <= 256: inside a tile's row slice starts span far less than 2^16
+ * positions, and an overlap of >= 255 never writes when k - 1 <= 255.  Queries then read the packed
+ * rows (6x / 4x fewer bytes); k > 256 keeps using the int64 columns.  keep_wide == 0 frees the int64
+ * columns (an HPRC-scale shard is 37 GB packed against 225 GB as int64); such an index answers
+ * k <= 256 only and cannot be re-uploaded.  Needs 0 <= annot <= 65535 on every row. */
+int memo_index_pack(memo_index_t *ix, int32_t keep_wide);
 int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);
 void memo_index_destroy(memo_index_t *ix);
 
@@ -137,6 +148,9 @@ int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t
  * (256..4096); waves: 1 or 4 waves share a tile; membership_algo: 1 = direct scatter,
  * 2 = doubling.  Results never depend on these. */
 int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo);
+/* 0 = queries read the packed rows when the index has them (default); 1 = always the int64
+ * columns (also MEMO_ROWS=wide).  For A/B measurements; results are identical. */
+int memo_set_row_source(int32_t source);
 
 /* profiling aid: one pass that reads the three columns exactly once (24 B/row) with the
  * sweep's access shape, to calibrate the FETCH_SIZE counter on a known byte count */

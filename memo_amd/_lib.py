@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libmemo_amd.so")
+SO_PATH = os.environ.get("MEMO_AMD_LIB") or os.path.join(_HERE, "libmemo_amd.so")   # override: A/B of builds
 
 MEMO_OK, MEMO_EINVAL, MEMO_EHIP, MEMO_ENOTREADY, MEMO_EUNSORTED, MEMO_ELONGROW = 0, -1, -2, -3, -4, -5
 
@@ -32,7 +32,8 @@ class MemoValueError(MemoError, ValueError):
 class IndexInfo(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("min_start", C.c_int64), ("max_start", C.c_int64),
                 ("device", C.c_int32), ("bucket_shift", C.c_int32), ("buckets", C.c_uint64),
-                ("was_sorted", C.c_int32), ("finalized", C.c_int32), ("device_bytes", C.c_uint64)]
+                ("was_sorted", C.c_int32), ("finalized", C.c_int32), ("device_bytes", C.c_uint64),
+                ("packed_format", C.c_int32), ("has_wide", C.c_int32)]
 
 
 # every symbol include/memo_amd.h declares: name -> (restype, argtypes)
@@ -45,6 +46,7 @@ SYMBOLS = {
     "memo_index_upload": (C.c_int, [_P, _P, _P, _P, _U64]),
     "memo_index_columns": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "memo_index_finalize": (C.c_int, [_P, _I32, _I32]),
+    "memo_index_pack": (C.c_int, [_P, _I32]),
     "memo_index_get_info": (C.c_int, [_P, C.POINTER(IndexInfo)]),
     "memo_index_destroy": (None, [_P]),
     "memo_query_conservation_dev": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P]),
@@ -60,6 +62,7 @@ SYMBOLS = {
     "memo_emit_membership": (_SZ, [_P, _I64, _I32, _P, _SZ]),
     "memo_synth_fill": (C.c_int, [_P, _U64, _U64, _U64, _I32, _U64]),
     "memo_debug_stream_rows": (C.c_int, [_P, _P]),
+    "memo_set_row_source": (C.c_int, [_I32]),
     "memo_set_tuning": (C.c_int, [_I32, _I32, _I32]),
 }
 

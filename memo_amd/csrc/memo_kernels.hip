@@ -92,6 +92,11 @@ struct memo_index {
     int64_t min_s = 0, max_s = -1;
     int finalized = 0;
     int was_sorted = 0;
+    // packed rows (memo_index_pack): word = start & 0xFFFF | min(end - start, 255) << 16 | annot8 << 24
+    uint32_t *pk = nullptr;
+    uint16_t *pa = nullptr;    // format 6 only: 16-bit annot per row (the word's top byte is 0)
+    int packed_fmt = 0;        // 0 = none, 4 = word only (annot <= 255), 6 = word + 16-bit annot
+    int has_wide = 1;          // the three int64 columns are still resident
     int *d_status = nullptr;   // sticky flags set by the sweep kernels
     uint64_t *d_scratch = nullptr;  // finalize(): [0] unsorted pairs, [1] rows with end < start
 };
@@ -103,6 +108,8 @@ namespace {
 // ------------------------------------------------------------------------------------------
 struct SweepArgs {
     const int64_t *s, *e, *o;
+    const uint32_t *pk;
+    const uint16_t *pa;
     const int64_t *boff;
     int64_t nb;
     uint64_t rows;
@@ -168,42 +175,12 @@ __device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t) {
     return true;
 }
 
-// stream the row slice: 2 rows per lane per column per load (16 B / lane, 1 KiB / wave),
-// U loads of each column in flight per lane; f(start, end, annot) sees every row once
-template <int T, int U, typename F>
-__device__ __forceinline__ void for_each_row(const SweepArgs &A, const Tile &t, F f) {
-    const int tid = threadIdx.x;
-    for (uint64_t base = (t.r0 & ~(uint64_t)15) + 2 * tid; base < t.r1; base += 2 * T * U) {
-        longlong2 S[U], E[U], O[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t idx = base + (uint64_t)u * 2 * T;
-            if (idx < t.r1) {
-                S[u] = *reinterpret_cast<const longlong2 *>(A.s + idx);
-                E[u] = *reinterpret_cast<const longlong2 *>(A.e + idx);
-                O[u] = *reinterpret_cast<const longlong2 *>(A.o + idx);
-            } else {
-                S[u] = make_longlong2(kSentinel, kSentinel);
-                E[u] = S[u];
-                O[u] = make_longlong2(0, 0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            f(S[u].x, E[u].x, O[u].x);
-            f(S[u].y, E[u].y, O[u].y);
-        }
-    }
-}
-
-// memo_query.py:46-49 restricted to the tile: recentre, shadow-cast by k-1, clip, keep rows
-// with casted_end < start; then the column check of :62 (NumPy/Numba wrap a negative index
-// once; anything else outside the matrix is the reference's IndexError / UB)
-__device__ __forceinline__ bool clip_row(const SweepArgs &A, const Tile &t, int64_t s, int64_t e,
-                                         int64_t o, int &c, int &h, int &col) {
-    h = clamp_to_tile(s - t.a, t.x_lo, t.x_hi);
-    c = clamp_to_tile(e - t.a - A.km1, t.x_lo, t.x_hi);
-    if (h <= c) return false;
+// Row sources.  Each streams the tile's row slice once and hands f(c, h, col) the rows that
+// write: [c, h) = the row's interval clipped to the tile (memo_query.py:46-49: recentre,
+// shadow-cast by k-1, clip, keep casted_end < start), col = its column after the index check
+// of :62 (NumPy/Numba wrap a negative index once; anything else outside the matrix is the
+// reference's IndexError / UB and sets the sticky status flag).
+__device__ __forceinline__ bool check_col(const SweepArgs &A, int64_t o, int &col) {
     const int64_t cc = o < 0 ? o + A.ncols : o;
     if ((uint64_t)cc >= (uint64_t)A.ncols) {
         atomicOr(A.status, kStatusBadAnnot);
@@ -213,6 +190,92 @@ __device__ __forceinline__ bool clip_row(const SweepArgs &A, const Tile &t, int6
     return true;
 }
 
+// the Parquet columns as they are: 3 x int64 per row.  2 rows per lane per column per load
+// (16 B / lane, 1 KiB / wave), U loads of each column in flight per lane.
+struct WideRows {
+    template <int T, int U, typename F>
+    static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, F f) {
+        const int tid = threadIdx.x;
+        auto one = [&](int64_t s, int64_t e, int64_t o) {
+            const int h = clamp_to_tile(s - t.a, t.x_lo, t.x_hi);
+            const int c = clamp_to_tile(e - t.a - A.km1, t.x_lo, t.x_hi);
+            int col;
+            if (h > c && check_col(A, o, col)) f(c, h, col);
+        };
+        for (uint64_t base = (t.r0 & ~(uint64_t)15) + 2 * tid; base < t.r1; base += 2 * T * U) {
+            longlong2 S[U], E[U], O[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t idx = base + (uint64_t)u * 2 * T;
+                if (idx < t.r1) {
+                    S[u] = *reinterpret_cast<const longlong2 *>(A.s + idx);
+                    E[u] = *reinterpret_cast<const longlong2 *>(A.e + idx);
+                    O[u] = *reinterpret_cast<const longlong2 *>(A.o + idx);
+                } else {
+                    S[u] = make_longlong2(kSentinel, kSentinel);
+                    E[u] = S[u];
+                    O[u] = make_longlong2(0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                one(S[u].x, E[u].x, O[u].x);
+                one(S[u].y, E[u].y, O[u].y);
+            }
+        }
+    }
+};
+
+// packed rows (memo_index_pack): one 32-bit word per row -- start mod 2^16, min(end - start,
+// 255), annot (8 bits; ANNOT16: in a second 16-bit column).  Inside a row slice every start
+// lies in [a, a + W + k + 32), far less than 2^16 from the tile start, so the low 16 bits
+// give the tile-relative start exactly; rows outside [r0, r1) are masked by index.  Exact
+// for k - 1 <= 255: a saturated length clips to "does not write" just as the true one does.
+// 4 rows per lane per load (16 B / lane).
+template <bool ANNOT16>
+struct PackedRows {
+    template <int T, int U, typename F>
+    static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, F f) {
+        const int tid = threadIdx.x;
+        const uint32_t a16 = (uint32_t)t.a & 0xFFFFu;
+        auto one = [&](uint64_t idx, uint32_t w, uint32_t annot) {
+            if (idx < t.r0 || idx >= t.r1) return;
+            const int d = (int)(((w & 0xFFFFu) - a16) & 0xFFFFu);       // start - a
+            const int h = min(max(d, t.x_lo), t.x_hi);
+            const int c = min(max(d + (int)((w >> 16) & 0xFFu) - A.km1, t.x_lo), t.x_hi);
+            if (h > c) {
+                if (annot >= (uint32_t)A.ncols)
+                    atomicOr(A.status, kStatusBadAnnot);
+                else
+                    f(c, h, (int)annot);
+            }
+        };
+        for (uint64_t base = (t.r0 & ~(uint64_t)31) + 4 * tid; base < t.r1; base += 4 * T * U) {
+            uint4 V[U];
+            uint2 N[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t idx = base + (uint64_t)u * 4 * T;
+                if (idx < t.r1) {
+                    V[u] = *reinterpret_cast<const uint4 *>(A.pk + idx);
+                    if (ANNOT16) N[u] = *reinterpret_cast<const uint2 *>(A.pa + idx);
+                } else {
+                    V[u] = make_uint4(0u, 0u, 0u, 0u);
+                    N[u] = make_uint2(0u, 0u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t idx = base + (uint64_t)u * 4 * T;
+                one(idx + 0, V[u].x, ANNOT16 ? (N[u].x & 0xFFFFu) : (V[u].x >> 24));
+                one(idx + 1, V[u].y, ANNOT16 ? (N[u].x >> 16) : (V[u].y >> 24));
+                one(idx + 2, V[u].z, ANNOT16 ? (N[u].y & 0xFFFFu) : (V[u].z >> 24));
+                one(idx + 3, V[u].w, ANNOT16 ? (N[u].y >> 16) : (V[u].w >> 24));
+            }
+        }
+    }
+};
+
 __device__ __forceinline__ uint32_t full_word(int ncols, int w) {  // genomes 32w .. 32w+31 that exist
     const int left = ncols - 32 * w;
     return left >= 32 ? 0xFFFFFFFFu : (left <= 0 ? 0u : ((1u << left) - 1u));
@@ -221,7 +284,7 @@ __device__ __forceinline__ uint32_t full_word(int ncols, int w) {  // genomes 32
 // ------------------------------------------------------------------------------------------
 // conservation: doubling scatter + top-down fold
 // ------------------------------------------------------------------------------------------
-template <int W, int U, int T, typename OutT>
+template <typename Rows, int W, int U, int T, typename OutT>
 __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
@@ -238,14 +301,11 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
     __syncthreads();
 
     // the clipped interval [c, h) is the union of two blocks of 2^j, j = floor(log2(h - c))
-    for_each_row<T, U>(A, t, [&](int64_t s, int64_t e, int64_t o) {
-        int c, h, col;
-        if (clip_row(A, t, s, e, o, c, h, col)) {
-            const int j = 31 - __clz(h - c);
-            uint32_t *lv = lds + j * W;
-            atomicMin(lv + c, (uint32_t)col);               // block [c, c + 2^j)
-            atomicMin(lv + (h - (1 << j)), (uint32_t)col);  // block [h - 2^j, h)
-        }
+    Rows::template for_each<T, U>(A, t, [&](int c, int h, int col) {
+        const int j = 31 - __clz(h - c);
+        uint32_t *lv = lds + j * W;
+        atomicMin(lv + c, (uint32_t)col);               // block [c, c + 2^j)
+        atomicMin(lv + (h - (1 << j)), (uint32_t)col);  // block [h - 2^j, h)
     });
     __syncthreads();
 
@@ -335,7 +395,7 @@ __device__ __forceinline__ void store_membership(const SweepArgs &A, const Tile 
     }
 }
 
-template <int W, int U, int T, bool DOUBLING>
+template <typename Rows, int W, int U, int T, bool DOUBLING>
 __global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
@@ -352,20 +412,17 @@ __global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) 
     }
     __syncthreads();
 
-    for_each_row<T, U>(A, t, [&](int64_t s, int64_t e, int64_t o) {
-        int c, h, col;
-        if (clip_row(A, t, s, e, o, c, h, col)) {
-            const uint32_t bit = 1u << (col & 31);
-            const int word = col >> 5;
-            if (DOUBLING) {
-                const int j = 31 - __clz(h - c);
-                uint32_t *lv = lds + j * plane + word;
-                atomicOr(lv + c * nw, bit);
-                atomicOr(lv + (h - (1 << j)) * nw, bit);
-            } else {
-                uint32_t *cell = lds + c * nw + word;
-                for (int x = c; x < h; ++x, cell += nw) atomicOr(cell, bit);  // rec[c:h, a] = False
-            }
+    Rows::template for_each<T, U>(A, t, [&](int c, int h, int col) {
+        const uint32_t bit = 1u << (col & 31);
+        const int word = col >> 5;
+        if (DOUBLING) {
+            const int j = 31 - __clz(h - c);
+            uint32_t *lv = lds + j * plane + word;
+            atomicOr(lv + c * nw, bit);
+            atomicOr(lv + (h - (1 << j)) * nw, bit);
+        } else {
+            uint32_t *cell = lds + c * nw + word;
+            for (int x = c; x < h; ++x, cell += nw) atomicOr(cell, bit);  // rec[c:h, a] = False
         }
     });
     __syncthreads();
@@ -440,6 +497,34 @@ __global__ void pad_rows_kernel(int64_t *s, int64_t *e, int64_t *o, uint64_t row
     }
 }
 
+// memo_index_pack: annot range census, then one word (+ optional 16-bit annot) per row
+__global__ void annot_census_kernel(const int64_t *o, uint64_t rows, uint64_t *scratch) {
+    uint64_t outside = 0, over8 = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < rows;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const int64_t v = o[i];
+        if (v < 0 || v > 65535) ++outside;
+        if (v > 255) ++over8;
+    }
+    if (outside) atomicAdd((unsigned long long *)&scratch[3], (unsigned long long)outside);
+    if (over8) atomicAdd((unsigned long long *)&scratch[4], (unsigned long long)over8);
+}
+
+__global__ void pack_rows_kernel(const int64_t *s, const int64_t *e, const int64_t *o, uint64_t rows,
+                                 uint64_t padded, uint32_t *pk, uint16_t *pa) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < padded;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w = 0, a = 0;
+        if (i < rows) {
+            const int64_t len = e[i] - s[i];  // >= 0 (finalize checked end >= start)
+            w = ((uint32_t)s[i] & 0xFFFFu) | ((uint32_t)(len > 255 ? 255 : len) << 16);
+            a = (uint32_t)o[i];
+        }
+        if (pa) pa[i] = (uint16_t)a; else w |= a << 24;
+        pk[i] = w;
+    }
+}
+
 // boff[b] = lower_bound(start, b << shift); the last bucket is pinned to `rows`
 __global__ void bucket_table_kernel(const int64_t *s, uint64_t rows, int64_t *boff, uint64_t nb,
                                     int shift) {
@@ -500,6 +585,7 @@ __global__ void synth_rows_kernel(int64_t *s, int64_t *e, int64_t *o, uint64_t r
 int g_tile_w = 0;     // 0 = choose per query
 int g_waves = 0;      // waves per tile: 0 = choose, 1 or 4
 int g_memb_algo = 0;  // membership: 0 = choose, 1 = direct scatter, 2 = doubling
+int g_force_wide = 0; // 1 = read the int64 columns even when packed rows exist
 bool g_env_read = false;
 
 void read_env_once() {
@@ -508,6 +594,7 @@ void read_env_once() {
     if (const char *v = getenv("MEMO_TILE_W")) g_tile_w = atoi(v);
     if (const char *v = getenv("MEMO_WAVES")) g_waves = atoi(v);
     if (const char *v = getenv("MEMO_MEMB_ALGO")) g_memb_algo = atoi(v);
+    if (const char *v = getenv("MEMO_ROWS")) g_force_wide = strcmp(v, "wide") == 0;
 }
 
 int floor_log2(uint32_t v) { return 31 - __builtin_clz(v); }
@@ -531,14 +618,17 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
     return MEMO_OK;
 }
 
-constexpr int kU = 4;  // loads of each column in flight per lane
+#ifndef MEMO_KU
+#define MEMO_KU 4
+#endif
+constexpr int kU = MEMO_KU;  // loads of each column in flight per lane
 
-template <typename OutT>
+template <typename Rows, typename OutT>
 SweepKernel cons_kernel(int w, int waves) {
-#define MEMO_CASE(WW)                                                                   \
-    case WW:                                                                            \
-        return waves == 4 ? (SweepKernel)sweep_conservation_kernel<WW, kU, 256, OutT>   \
-                          : (SweepKernel)sweep_conservation_kernel<WW, kU, 64, OutT>;
+#define MEMO_CASE(WW)                                                                         \
+    case WW:                                                                                  \
+        return waves == 4 ? (SweepKernel)sweep_conservation_kernel<Rows, WW, kU, 256, OutT>   \
+                          : (SweepKernel)sweep_conservation_kernel<Rows, WW, kU, 64, OutT>;
     switch (w) {
         MEMO_CASE(256)
         MEMO_CASE(512)
@@ -550,14 +640,15 @@ SweepKernel cons_kernel(int w, int waves) {
     return nullptr;
 }
 
+template <typename Rows>
 SweepKernel memb_kernel(int w, int waves, bool doubling) {
 #define MEMO_CASE(WW)                                                                              \
     case WW:                                                                                       \
         if (doubling)                                                                              \
-            return waves == 4 ? (SweepKernel)sweep_membership_kernel<WW, kU, 256, true>            \
-                              : (SweepKernel)sweep_membership_kernel<WW, kU, 64, true>;            \
-        return waves == 4 ? (SweepKernel)sweep_membership_kernel<WW, kU, 256, false>               \
-                          : (SweepKernel)sweep_membership_kernel<WW, kU, 64, false>;
+            return waves == 4 ? (SweepKernel)sweep_membership_kernel<Rows, WW, kU, 256, true>      \
+                              : (SweepKernel)sweep_membership_kernel<Rows, WW, kU, 64, true>;      \
+        return waves == 4 ? (SweepKernel)sweep_membership_kernel<Rows, WW, kU, 256, false>         \
+                          : (SweepKernel)sweep_membership_kernel<Rows, WW, kU, 64, false>;
     switch (w) {
         MEMO_CASE(256)
         MEMO_CASE(512)
@@ -567,6 +658,16 @@ SweepKernel memb_kernel(int w, int waves, bool doubling) {
     }
 #undef MEMO_CASE
     return nullptr;
+}
+
+// which row source a query reads: packed when the index has it and k - 1 <= 255 (MEMO_ROWS=wide
+// forces the int64 columns), else the int64 columns
+int pick_rows(const memo_index *ix, int32_t k, int &fmt) {
+    fmt = 0;
+    if (ix->packed_fmt && k - 1 <= 255 && !(g_force_wide && ix->has_wide)) fmt = ix->packed_fmt;
+    if (!fmt && !ix->has_wide)
+        return fail(MEMO_EINVAL, "k = %d needs the int64 columns, which this index dropped when it was packed", k);
+    return MEMO_OK;
 }
 
 int check_query_args(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
@@ -591,6 +692,8 @@ void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32
     A.s = ix->s;
     A.e = ix->e;
     A.o = ix->o;
+    A.pk = ix->pk;
+    A.pa = ix->pa;
     A.boff = ix->boff;
     A.nb = (int64_t)ix->nb;
     A.rows = ix->rows;
@@ -626,18 +729,26 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     A.ncols = num_docs + 1;
     A.nlev = floor_log2((uint32_t)(k - 1)) + 1;
     A.nwords = 0;
-    // Tile shape (interleaved A/B on one device, profiles/r01_ab_*.txt): four waves sharing a
-    // 4096-position tile beat one wave per 1024 positions by 1-3 % at k <= 32 and by 10 % at
-    // k = 101 (fewer k-1 row halos per position); short windows want many small tiles instead.
+    int fmt;
+    if ((rc = pick_rows(ix, k, fmt))) return rc;
+    // Tile shape, from interleaved A/B on one device (profiles/r01_ab_*.txt).
+    //  int64 rows (HBM-bound): four waves share a 4096-position tile -- fewest k-1 row halos per
+    //    position; 1-3 % over one wave per 1024 positions at k <= 32, 10 % at k = 101.
+    //  packed rows (4-6x fewer bytes; latency/issue-bound): what matters is waves per CU, so the
+    //    tile gets ~20 KiB of LDS: 8 workgroups of 4 waves per CU (k = 31: 1024 positions).
+    // Short windows want many small tiles either way.
     int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
     if (!w) {
+        const size_t budget = fmt ? 20 * 1024 : 80 * 1024;
         w = 4096;
-        while ((size_t)A.nlev * w * 4 > 80 * 1024 && w > 256) w >>= 1;
+        while ((size_t)A.nlev * w * 4 > budget && w > 256) w >>= 1;
         while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
     }
-    if (!waves) waves = w >= 2048 ? 4 : 1;
+    if (!waves) waves = w >= (fmt ? 512 : 2048) ? 4 : 1;
     while ((size_t)A.nlev * w * 4 > 160 * 1024 && w > 256) w >>= 1;
-    SweepKernel kern = cons_kernel<OutT>(w, waves);
+    SweepKernel kern = fmt == 4   ? cons_kernel<PackedRows<false>, OutT>(w, waves)
+                       : fmt == 6 ? cons_kernel<PackedRows<true>, OutT>(w, waves)
+                                  : cons_kernel<WideRows, OutT>(w, waves);
     if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
     return launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * w * 4, st);
 }
@@ -657,6 +768,13 @@ int memo_device_count(void) {
     return n;
 }
 
+int memo_set_row_source(int32_t source) {
+    read_env_once();
+    if (source != 0 && source != 1) return fail(MEMO_EINVAL, "source must be 0 (packed when present) or 1 (int64 columns)");
+    g_force_wide = source;
+    return MEMO_OK;
+}
+
 int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo) {
     read_env_once();
     if (tile_w != 0 && tile_w != 256 && tile_w != 512 && tile_w != 1024 && tile_w != 2048 &&
@@ -668,6 +786,14 @@ int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo) {
     g_waves = waves;
     g_memb_algo = membership_algo;
     return MEMO_OK;
+}
+
+static void drop_packed(memo_index *ix) {  // the rows are about to change
+    (void)hipFree(ix->pk);
+    (void)hipFree(ix->pa);
+    ix->pk = nullptr;
+    ix->pa = nullptr;
+    ix->packed_fmt = 0;
 }
 
 int memo_index_create(uint64_t rows, int32_t device, memo_index_t **out) {
@@ -706,6 +832,8 @@ void memo_index_destroy(memo_index_t *ix) {
     (void)hipFree(ix->e);
     (void)hipFree(ix->o);
     (void)hipFree(ix->boff);
+    (void)hipFree(ix->pk);
+    (void)hipFree(ix->pa);
     (void)hipFree(ix->d_status);
     (void)hipFree(ix->d_scratch);
     delete ix;
@@ -717,7 +845,9 @@ int memo_index_upload(memo_index_t *ix, const int64_t *start, const int64_t *end
     if (rows != ix->rows) return fail(MEMO_EINVAL, "upload of %llu rows into an index of %llu",
                                       (unsigned long long)rows, (unsigned long long)ix->rows);
     if (rows && (!start || !end || !annot)) return fail(MEMO_EINVAL, "column pointer is NULL");
+    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns of this index were dropped by memo_index_pack");
     DeviceGuard guard(ix->device);
+    drop_packed(ix);
     if (rows) {
         HIP_TRY(hipMemcpy(ix->s, start, rows * sizeof(int64_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ix->e, end, rows * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -729,6 +859,11 @@ int memo_index_upload(memo_index_t *ix, const int64_t *start, const int64_t *end
 
 int memo_index_columns(memo_index_t *ix, int64_t **d_start, int64_t **d_end, int64_t **d_annot) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns of this index were dropped by memo_index_pack");
+    {
+        DeviceGuard guard(ix->device);
+        drop_packed(ix);
+    }
     if (d_start) *d_start = ix->s;
     if (d_end) *d_end = ix->e;
     if (d_annot) *d_annot = ix->o;
@@ -738,6 +873,7 @@ int memo_index_columns(memo_index_t *ix, int64_t **d_start, int64_t **d_end, int
 
 int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_sort) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns of this index were dropped by memo_index_pack");
     if (bucket_shift <= 0) bucket_shift = kDefaultBucketShift;
     if (bucket_shift > 8) return fail(MEMO_EINVAL, "bucket_shift must be <= 8 (tile width 256)");
     DeviceGuard guard(ix->device);
@@ -795,6 +931,43 @@ int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_so
     return MEMO_OK;
 }
 
+int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (!ix->finalized) return fail(MEMO_ENOTREADY, "index not finalized");
+    if (!ix->has_wide) return ix->packed_fmt ? MEMO_OK : fail(MEMO_EINVAL, "nothing to pack");
+    if (ix->rows && ix->min_s < 0) return fail(MEMO_EINVAL, "rows with a negative start cannot be packed");
+    DeviceGuard guard(ix->device);
+    hipStream_t st = nullptr;
+    drop_packed(ix);
+    uint64_t h[8] = {0};
+    if (ix->rows) {
+        HIP_TRY(hipMemsetAsync(ix->d_scratch, 0, 64, st));
+        const unsigned grid = (unsigned)(ix->rows / 256 + 1 < 4096 ? ix->rows / 256 + 1 : 4096);
+        hipLaunchKernelGGL(annot_census_kernel, dim3(grid), dim3(256), 0, st, ix->o, ix->rows, ix->d_scratch);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(h, ix->d_scratch, 64, hipMemcpyDeviceToHost));
+        if (h[3])
+            return fail(MEMO_EINVAL, "%llu rows have an annot outside [0, 65535]: cannot be packed",
+                        (unsigned long long)h[3]);
+    }
+    const int fmt = h[4] ? 6 : 4;
+    HIP_TRY(hipMalloc(&ix->pk, ix->padded * sizeof(uint32_t)));
+    if (fmt == 6) HIP_TRY(hipMalloc(&ix->pa, ix->padded * sizeof(uint16_t)));
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(4096), dim3(256), 0, st, ix->s, ix->e, ix->o, ix->rows,
+                       ix->padded, ix->pk, ix->pa);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    ix->packed_fmt = fmt;
+    if (!keep_wide) {
+        (void)hipFree(ix->s);
+        (void)hipFree(ix->e);
+        (void)hipFree(ix->o);
+        ix->s = ix->e = ix->o = nullptr;
+        ix->has_wide = 0;
+    }
+    return MEMO_OK;
+}
+
 int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     if (!ix || !info) return fail(MEMO_EINVAL, "NULL argument");
     info->rows = ix->rows;
@@ -805,7 +978,10 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     info->buckets = ix->nb;
     info->was_sorted = ix->was_sorted;
     info->finalized = ix->finalized;
-    info->device_bytes = ix->padded * 3 * sizeof(int64_t) + ix->nb * sizeof(int64_t) + 128;
+    info->packed_format = ix->packed_fmt;
+    info->has_wide = ix->has_wide;
+    info->device_bytes = (ix->has_wide ? ix->padded * 3 * sizeof(int64_t) : 0) + ix->nb * sizeof(int64_t) + 128 +
+                         (ix->pk ? ix->padded * 4 : 0) + (ix->pa ? ix->padded * 2 : 0);
     return MEMO_OK;
 }
 
@@ -841,18 +1017,23 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     A.nwords = nw;
     // doubling needs nlev * nw words per position; four waves share one tile so that the tile
     // stays wide (the k-1 row halo is re-read once per tile).  Direct scatter otherwise.
+    int fmt;
+    if ((rc = pick_rows(ix, k, fmt))) return rc;
     const size_t per_pos_doubling = (size_t)A.nlev * nw * 4;
     const bool doubling = g_memb_algo ? g_memb_algo == 2 : per_pos_doubling * 256 <= 40 * 1024;
     const size_t per_pos = doubling ? per_pos_doubling : (size_t)nw * 4;
     int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
     if (!waves) waves = doubling ? 4 : 1;
-    if (!w) {  // config 4 (A/B, profiles/r01_ab_c4.txt): doubling, 512 positions x 4 waves, 40 KiB
+    if (!w) {  // config 4 A/B: int64 rows 512 positions x 4 waves (40 KiB); packed rows 256 x 4 (20 KiB)
+        const size_t budget = (waves == 4 ? (fmt ? 20u : 40u) : 20u) * 1024;
         w = 4096;
-        while (per_pos * w > (waves == 4 ? 40u : 20u) * 1024 && w > 256) w >>= 1;
+        while (per_pos * w > budget && w > 256) w >>= 1;
         while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
     }
     while (per_pos * w > 160 * 1024 && w > 256) w >>= 1;
-    SweepKernel kern = memb_kernel(w, waves, doubling);
+    SweepKernel kern = fmt == 4   ? memb_kernel<PackedRows<false>>(w, waves, doubling)
+                       : fmt == 6 ? memb_kernel<PackedRows<true>>(w, waves, doubling)
+                                  : memb_kernel<WideRows>(w, waves, doubling);
     if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
     return launch_tiles(kern, A, w, 64 * waves, per_pos * w, st);
 }
@@ -928,7 +1109,9 @@ int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t
                     int32_t num_docs, uint64_t seed) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
     if (num == 0 || den == 0 || num_docs < 2) return fail(MEMO_EINVAL, "bad generator parameters");
+    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns were dropped");
     DeviceGuard guard(ix->device);
+    drop_packed(ix);
     if (ix->rows) {
         hipLaunchKernelGGL(synth_rows_kernel, dim3(4096), dim3(256), 0, nullptr, ix->s, ix->e, ix->o,
                            ix->rows, row_begin, num, den, (uint64_t)(num_docs - 1), seed);
@@ -941,6 +1124,7 @@ int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t
 
 int memo_debug_stream_rows(memo_index_t *ix, void *stream) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns were dropped");
     DeviceGuard guard(ix->device);
     hipLaunchKernelGGL(stream_rows_kernel, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream),
                        ix->s, ix->e, ix->o, ix->rows & ~(uint64_t)1,

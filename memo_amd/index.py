@@ -65,6 +65,11 @@ class DeviceIndex:
         check(lib().memo_index_finalize(self._h, bucket_shift, 1 if allow_sort else 0))
         return self
 
+    def pack(self, keep_wide=True):
+        """build the 4/6-byte-per-row query format (memo_index_pack)"""
+        check(lib().memo_index_pack(self._h, 1 if keep_wide else 0))
+        return self
+
     def info(self):
         inf = _lib.IndexInfo()
         check(lib().memo_index_get_info(self._h, C.byref(inf)))

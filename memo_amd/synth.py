@@ -42,8 +42,12 @@ def shard_rows(qs, qe, k, num, den, pivot):
     return r0, max(r1, r0)
 
 
-def device_index(qs, qe, k, num_docs, pivot, density=Fraction(5, 100), device=0, seed=SEED):
-    """DeviceIndex holding exactly the rows window [qs, qe) needs (generated in HBM)."""
+def device_index(qs, qe, k, num_docs, pivot, density=Fraction(5, 100), device=0, seed=SEED, pack=None):
+    """DeviceIndex holding exactly the rows window [qs, qe) needs (generated in HBM).
+    pack: None = int64 columns only; "keep" = also the packed rows; "only" = packed rows only."""
     num, den = rows_per_position(num_docs, density)
     r0, r1 = shard_rows(qs, qe, k, num, den, pivot)
-    return DeviceIndex.synthetic(r1 - r0, r0, num, den, num_docs, seed=seed, device=device), (r0, r1)
+    ix = DeviceIndex.synthetic(r1 - r0, r0, num, den, num_docs, seed=seed, device=device)
+    if pack:
+        ix.pack(keep_wide=(pack == "keep"))
+    return ix, (r0, r1)

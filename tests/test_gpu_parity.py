@@ -131,6 +131,44 @@ def test_resident_index_windows(tile_w, waves, algo, memo, oracle):
         _lib.check(_lib.lib().memo_set_tuning(0, 0, 0))
 
 
+@pytest.mark.parametrize("n_docs,keep_wide", [(70, True), (70, False), (256, True), (257, True), (500, False)])
+def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle):
+    """memo_index_pack: 4 B/row (annot <= 255) and 6 B/row formats, every tile shape, k up to 256;
+    k > 256 falls back to the int64 columns, or is refused when they were dropped."""
+    from memo_amd import _lib
+    rng = np.random.default_rng(n_docs)
+    length = 150_000                                    # > 2^16: the 16-bit start wraps inside the index
+    s, e, o = _random_index(rng, 400_000, length, n_docs, 300)
+    e[::7] = s[::7] + rng.integers(250, 5000, len(s[::7]))        # overlaps that saturate the 8-bit length
+    with memo.DeviceIndex.from_host(s, e, o) as ix:
+        ix.pack(keep_wide=keep_wide)
+        inf = ix.info()
+        assert inf["packed_format"] == (4 if n_docs <= 256 else 6) and inf["has_wide"] == int(keep_wide)
+        try:
+            for tile_w, waves, algo in [(0, 0, 0), (256, 1, 1), (512, 4, 2), (1024, 1, 2), (2048, 4, 1), (4096, 4, 0)]:
+                _lib.check(_lib.lib().memo_set_tuning(tile_w, waves, algo))
+                for k in (2, 3, 17, 31, 32, 101, 255, 256):
+                    qs = int(rng.integers(0, length // 2))
+                    qe = int(rng.integers(qs + 1, length + 100))
+                    want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                    assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (k, qs, qe, tile_w)
+                    if k in (3, 31, 256):
+                        qe = min(qe, qs + 6000)
+                        want = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                        assert np.array_equal(ix.membership(qs, qe, k, n_docs), want), (k, qs, qe, tile_w)
+        finally:
+            _lib.check(_lib.lib().memo_set_tuning(0, 0, 0))
+        if keep_wide:
+            want = oracle.conservation(*oracle.filter_rows(s, e, o, 100, 9000, 300), 100, 9000, 300, n_docs, literal=False)
+            assert np.array_equal(ix.conservation(100, 9000, 300, n_docs), want)
+        else:
+            with pytest.raises(memo.MemoError):
+                ix.conservation(100, 9000, 300, n_docs)
+        # num_docs too small for a row that writes: still the reference's IndexError
+        with pytest.raises(IndexError):
+            ix.conservation(0, length, 31, 3)
+
+
 def test_ragged_density_and_edges(memo, oracle):
     """clumped starts, empty stretches, window beyond the last row, window before the first."""
     rng = np.random.default_rng(99)

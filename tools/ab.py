@@ -24,10 +24,11 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--u8", action="store_true")
+    ap.add_argument("--pack", default=None, choices=[None, "keep", "only"])
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     num_docs, L, membership = WORKLOADS[a.workload]
-    ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L)
+    ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L, pack=a.pack)
     W = (num_docs + 31) // 32
     out = torch.empty((L, W) if membership else (L,), dtype=torch.int32 if membership else torch.int16, device="cuda")
     st = torch.cuda.current_stream()
@@ -53,10 +54,11 @@ def main():
             if r:                                   # round 0 = warm-up
                 times[v].append(e0.elapsed_time(e1))
     ix.check()
-    b_alg = 24 * (r1 - r0) + (4 * W if membership else (1 if a.u8 else 2)) * L
+    brow = 24 if not a.pack else ix.info()['packed_format']
+    b_alg = brow * (r1 - r0) + (4 * W if membership else (1 if a.u8 else 2)) * L
     for v in variants:
         t = np.array(times[v])
-        print(json.dumps({"variant": v, "workload": a.workload, "k": a.k, "ms_median": float(np.median(t)),
+        print(json.dumps({"variant": v, "workload": a.workload, "k": a.k, "row_bytes": brow, "ms_median": float(np.median(t)),
                           "ms_min": float(t.min()), "ms_max": float(t.max()),
                           "frac_of_8TBs": b_alg / (float(np.median(t)) * 1e-3) / 8e12}))
 

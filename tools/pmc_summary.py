@@ -44,7 +44,7 @@ def main():
            "hbm_read_bytes_per_launch": fetch, "hbm_write_bytes_per_launch": write,
            "hbm_bytes_per_launch": fetch + write}
     cal = {}
-    for name, bytes_per_row in (("stream_rows_kernel", 24), ("check_rows_kernel", 16)):
+    for name, bytes_per_row in (("stream_rows_kernel", 24), ("check_rows_kernel", 16), ("pack_rows_kernel", 24)):
         v, n = mean(fr, name)
         if v:
             cal[name] = {"FETCH_SIZE_KiB_raw": v, "bytes_per_row_known": bytes_per_row}
