@@ -1157,46 +1157,4 @@ int memo_dev_download(int32_t device, void *host, const void *dev, size_t bytes,
     return MEMO_OK;
 }
 
-// ---- print_res (memo_query.py:65-71) -----------------------------------------------------
-size_t memo_emit_conservation(const uint16_t *vec, int64_t L, char *buf, size_t cap) {
-    if (L <= 0) {  // print(*[], sep='\n') still writes the newline
-        if (cap >= 1 && buf) buf[0] = '\n';
-        return 1;
-    }
-    size_t need = 0;
-    for (int64_t i = 0; i < L; ++i) {
-        const unsigned v = vec[i];
-        need += v < 10 ? 2 : v < 100 ? 3 : v < 1000 ? 4 : v < 10000 ? 5 : 6;
-    }
-    if (need > cap || !buf) return need;
-    char *p = buf;
-    for (int64_t i = 0; i < L; ++i) {
-        unsigned v = vec[i];
-        char tmp[6];
-        int n = 0;
-        do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-        while (n) *p++ = tmp[--n];
-        *p++ = '\n';
-    }
-    return need;
-}
-
-size_t memo_emit_membership(const uint32_t *bits, int64_t L, int32_t num_docs, char *buf, size_t cap) {
-    if (L <= 0) return 0;
-    const size_t per_line = num_docs > 0 ? (size_t)2 * num_docs : 1;
-    const size_t need = per_line * (size_t)L;
-    if (need > cap || !buf) return need;
-    const int nw = (num_docs + 31) / 32;
-    char *p = buf;
-    for (int64_t i = 0; i < L; ++i) {
-        const uint32_t *row = bits + i * nw;
-        for (int g = 0; g < num_docs; ++g) {
-            *p++ = (char)('0' + ((row[g >> 5] >> (g & 31)) & 1u));
-            *p++ = ' ';
-        }
-        if (num_docs > 0) p[-1] = '\n'; else *p++ = '\n';
-    }
-    return need;
-}
-
 }  // extern "C"

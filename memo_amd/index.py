@@ -149,21 +149,30 @@ def membership(start, end, annot, qs, qe, k, num_docs, device=0):
 
 
 # ---- print_res text (memo_query.py:65-71) ----
-def emit_conservation(vec):
+def emit_conservation_buffer(vec):
+    """the text as a uint8 array (no extra copies; write it with fh.write(memoryview(buf)))"""
     vec = np.ascontiguousarray(vec, np.uint16)
     need = lib().memo_emit_conservation(vec.ctypes.data, len(vec), None, 0)
-    buf = C.create_string_buffer(need)
-    lib().memo_emit_conservation(vec.ctypes.data, len(vec), buf, need)
-    return buf.raw[:need]
+    buf = np.empty(need, np.uint8)
+    lib().memo_emit_conservation(vec.ctypes.data, len(vec), buf.ctypes.data, need)
+    return buf
 
 
-def emit_membership(bits, num_docs):
+def emit_membership_buffer(bits, num_docs):
     bits = np.ascontiguousarray(bits, np.uint32)
     L = bits.shape[0] if bits.ndim == 2 else len(bits) // max(words(num_docs), 1)
     need = lib().memo_emit_membership(bits.ctypes.data, L, num_docs, None, 0)
-    buf = C.create_string_buffer(max(need, 1))
-    lib().memo_emit_membership(bits.ctypes.data, L, num_docs, buf, need)
-    return buf.raw[:need]
+    buf = np.empty(need, np.uint8)
+    lib().memo_emit_membership(bits.ctypes.data, L, num_docs, buf.ctypes.data, need)
+    return buf
+
+
+def emit_conservation(vec):
+    return emit_conservation_buffer(vec).tobytes()
+
+
+def emit_membership(bits, num_docs):
+    return emit_membership_buffer(bits, num_docs).tobytes()
 
 
 def bits_to_matrix(bits, num_docs):

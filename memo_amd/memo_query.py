@@ -22,7 +22,7 @@ import os
 import numpy as np
 import pyarrow.dataset as ds
 
-from .index import DeviceIndex, emit_conservation, emit_membership, words
+from .index import DeviceIndex, emit_conservation_buffer, emit_membership_buffer, words
 
 
 class RegionRows:
@@ -106,9 +106,10 @@ def memo_query(mem_arr, rec, membership_query):
 
 def print_res(rec, out_file, membership_query):
     """Same bytes as memo_query.py:65-71."""
-    text = emit_membership(rec.values, rec.num_docs) if membership_query else emit_conservation(rec.values)
+    text = emit_membership_buffer(rec.values, rec.num_docs) if membership_query else \
+        emit_conservation_buffer(rec.values)
     with open(out_file, "wb") as fh:
-        fh.write(text)
+        fh.write(memoryview(text))
 
 
 ################################################################################
