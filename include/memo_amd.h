@@ -77,6 +77,12 @@ int memo_index_create(uint64_t rows, int32_t device, memo_index_t **out);
 /* copy host columns (pageable or pinned) into the index; blocking */
 int memo_index_upload(memo_index_t *ix, const int64_t *start, const int64_t *end,
                       const int64_t *annot, uint64_t rows);
+/* streaming form of the same: copy `rows` host rows to row_offset .. row_offset + rows, so that
+ * a region slice can be uploaded row group by row group while the next one is decoded; create
+ * the index with an upper bound and memo_index_truncate() it to the rows actually written */
+int memo_index_upload_rows(memo_index_t *ix, uint64_t row_offset, const int64_t *start,
+                           const int64_t *end, const int64_t *annot, uint64_t rows);
+int memo_index_truncate(memo_index_t *ix, uint64_t rows);
 /* device pointers of the three columns, for callers that fill them on the device
  * (synthetic generator, another kernel); each holds `rows` int64 */
 int memo_index_columns(memo_index_t *ix, int64_t **d_start, int64_t **d_end, int64_t **d_annot);

@@ -44,6 +44,8 @@ SYMBOLS = {
     "memo_version": (C.c_char_p, []),
     "memo_index_create": (C.c_int, [_U64, _I32, C.POINTER(_P)]),
     "memo_index_upload": (C.c_int, [_P, _P, _P, _P, _U64]),
+    "memo_index_upload_rows": (C.c_int, [_P, _U64, _P, _P, _P, _U64]),
+    "memo_index_truncate": (C.c_int, [_P, _U64]),
     "memo_index_columns": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "memo_index_finalize": (C.c_int, [_P, _I32, _I32]),
     "memo_index_pack": (C.c_int, [_P, _I32]),

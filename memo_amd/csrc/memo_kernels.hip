@@ -857,6 +857,39 @@ int memo_index_upload(memo_index_t *ix, const int64_t *start, const int64_t *end
     return MEMO_OK;
 }
 
+int memo_index_upload_rows(memo_index_t *ix, uint64_t row_offset, const int64_t *start,
+                           const int64_t *end, const int64_t *annot, uint64_t rows) {
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (row_offset > ix->rows || rows > ix->rows - row_offset)
+        return fail(MEMO_EINVAL, "rows [%llu, +%llu) do not fit an index of %llu rows",
+                    (unsigned long long)row_offset, (unsigned long long)rows, (unsigned long long)ix->rows);
+    if (rows && (!start || !end || !annot)) return fail(MEMO_EINVAL, "column pointer is NULL");
+    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns of this index were dropped by memo_index_pack");
+    DeviceGuard guard(ix->device);
+    drop_packed(ix);
+    if (rows) {
+        HIP_TRY(hipMemcpy(ix->s + row_offset, start, rows * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ix->e + row_offset, end, rows * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ix->o + row_offset, annot, rows * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    ix->finalized = 0;
+    return MEMO_OK;
+}
+
+int memo_index_truncate(memo_index_t *ix, uint64_t rows) {
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (rows > ix->rows) return fail(MEMO_EINVAL, "cannot grow an index (%llu > %llu rows)",
+                                     (unsigned long long)rows, (unsigned long long)ix->rows);
+    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns of this index were dropped by memo_index_pack");
+    {
+        DeviceGuard guard(ix->device);
+        drop_packed(ix);
+    }
+    ix->rows = rows;  // `padded` keeps the allocated size; finalize() rewrites the sentinel rows behind `rows`
+    ix->finalized = 0;
+    return MEMO_OK;
+}
+
 int memo_index_columns(memo_index_t *ix, int64_t **d_start, int64_t **d_end, int64_t **d_annot) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
     if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns of this index were dropped by memo_index_pack");

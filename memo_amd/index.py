@@ -49,6 +49,14 @@ class DeviceIndex:
         ix.finalize(bucket_shift, allow_sort)
         return ix
 
+    def upload_rows(self, offset, start, end, annot):
+        s, e, o = _col(start), _col(end), _col(annot)
+        check(lib().memo_index_upload_rows(self._h, offset, s.ctypes.data, e.ctypes.data, o.ctypes.data, len(s)))
+
+    def truncate(self, rows):
+        check(lib().memo_index_truncate(self._h, rows))
+        self.rows = int(rows)
+
     @classmethod
     def synthetic(cls, rows, row_begin, num, den, num_docs, seed=0x4D454D4F, device=0, bucket_shift=0):
         ix = cls(rows, device)

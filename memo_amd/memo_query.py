@@ -64,6 +64,65 @@ def filter_pq(in_file, query_record, query_start, query_end, spanning_rows=False
     return RegionRows(*cols)
 
 
+def region_chunks(in_file, query_record, query_start, query_end):
+    """(upper bound on rows, iterator of (start, end, annot) chunks) for the rows of
+    `query_record` with query_start < f1 < query_end in ONE Parquet file.  Row groups are selected
+    by their f0 / f1 min-max statistics and decoded one at a time, one ahead of the consumer."""
+    import concurrent.futures as cf
+    import pyarrow.compute as pc
+    import pyarrow.parquet as pq
+    pf = pq.ParquetFile(in_file)
+    md = pf.metadata
+    names = [md.schema.column(i).name for i in range(md.num_columns)]
+    i0, i1 = names.index("f0"), names.index("f1")
+    groups, bound = [], 0
+    for g in range(md.num_row_groups):
+        rg = md.row_group(g)
+        s0, s1 = rg.column(i0).statistics, rg.column(i1).statistics
+        if s0 is not None and s0.has_min_max and not (s0.min <= query_record <= s0.max):
+            continue
+        if s1 is not None and s1.has_min_max and not (s1.max > query_start and s1.min < query_end):
+            continue
+        groups.append(g)
+        bound += rg.num_rows
+
+    def load(g):
+        t = pf.read_row_group(g, columns=["f0", "f1", "f2", "f3"])
+        f1 = t.column("f1")
+        keep = pc.and_(pc.equal(t.column("f0"), query_record),
+                       pc.and_(pc.greater(f1, query_start), pc.less(f1, query_end)))
+        return _columns(t.filter(keep))
+
+    def chunks():
+        with cf.ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(load, groups[0]) if groups else None
+            for n in range(len(groups)):
+                cols = nxt.result()
+                nxt = pool.submit(load, groups[n + 1]) if n + 1 < len(groups) else None
+                if len(cols[0]):
+                    yield cols
+    return bound, chunks()
+
+
+def region_index(in_file, query_record, query_start, query_end, device=None):
+    """filter_pq + the upload half of memo_init in one streaming pass: the rows go from the
+    Parquet file straight into a finalized DeviceIndex, row group by row group (the next one is
+    decoded by Arrow while the current one is copied to the GPU); the host never holds more than
+    two row groups.  Anything that is not a single Parquet file goes through filter_pq."""
+    device = _device() if device is None else device
+    if not os.path.isfile(in_file):
+        rows = filter_pq(in_file, query_record, query_start, query_end)
+        return DeviceIndex.from_host(rows.start, rows.end, rows.annot, device=device)
+    bound, chunks = region_chunks(in_file, query_record, query_start, query_end)
+    index = DeviceIndex(bound, device)
+    written = 0
+    for cols in chunks:
+        index.upload_rows(written, *cols)
+        written += len(cols[0])
+    index.truncate(written)
+    return index.finalize()
+
+
 class QueryResult:
     """Counterpart of the reference's `rec` matrix, kept in reduced form:
     conservation -> uint16 [L] (= argmax over columns, :70); membership -> uint32 [L, W] bits."""
@@ -86,6 +145,8 @@ def memo_init(mem_arr, k, true_start, true_end, num_docs, membership_query):
     """Put the rows in HBM (validated, start-bucketed) and describe the result.
     Recentring, the k-1 shadow cast, clipping and the casted_end < start filter of
     memo_query.py:45-49 happen inside the sweep kernel, per tile."""
+    if isinstance(mem_arr, DeviceIndex):      # region_index() already put the rows in HBM
+        return mem_arr, QueryResult(true_start, true_end, k, num_docs, membership_query)
     if isinstance(mem_arr, RegionRows):
         s, e, o = mem_arr.start, mem_arr.end, mem_arr.annot
     else:                                     # the reference's [M, 3] array
@@ -127,17 +188,27 @@ def parse_arguments(argv=None):
 
 
 def main(args):
+    import sys
+    import time
     membership_query = args.membership_query
     num_docs, k = int(args.num_docs), int(args.k)
     query_record, start_end = args.genome_region.split(':')      # exactly one ':' and one '-'
     query_start, query_end = map(int, start_end.split('-'))
-    rows = filter_pq(args.in_file, query_record, query_start, query_end + k)
+    t = [time.perf_counter()]
+    rows = region_index(args.in_file, query_record, query_start, query_end + k)     # filter_pq, :100
+    t.append(time.perf_counter())
     mem_arr, rec = memo_init(rows, k, query_start, query_end, num_docs, membership_query)
     try:
         rec = memo_query(mem_arr, rec, membership_query)
     finally:
         mem_arr.close()
+    t.append(time.perf_counter())
     print_res(rec, args.out_file, membership_query)
+    t.append(time.perf_counter())
+    if os.environ.get("MEMO_TIMING"):          # stderr only: stdout stays the reference's
+        sys.stderr.write("memo_query timing: region slice+upload %.3f s, sweep+download %.3f s, text+write %.3f s "
+                         "(%d rows, %d positions)\n" % (t[1] - t[0], t[2] - t[1], t[3] - t[2], mem_arr.rows,
+                                                       max(query_end - query_start, 0)))
 
 
 if __name__ == "__main__":

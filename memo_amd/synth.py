@@ -51,3 +51,38 @@ def device_index(qs, qe, k, num_docs, pivot, density=Fraction(5, 100), device=0,
     if pack:
         ix.pack(keep_wide=(pack == "keep"))
     return ix, (r0, r1)
+
+
+def host_rows(row_begin, count, num, den, num_docs, seed=SEED):
+    """the same rows as memo_synth_fill / oracle_synth_rows, generated with NumPy on the host
+    (used to write synthetic Parquet indexes for end-to-end CLI runs)."""
+    import numpy as np
+    M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def mix(x):
+        with np.errstate(over="ignore"):
+            z = (np.uint64(seed) + (x + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)) & M64
+            z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M64
+            z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M64
+            return z ^ (z >> np.uint64(31))
+    i = np.arange(row_begin, row_begin + count, dtype=np.uint64)
+    start = (np.uint64(1) + (i * np.uint64(den)) // np.uint64(num)).astype(np.int64)
+    end = start + (mix(np.uint64(2) * i) % np.uint64(60)).astype(np.int64)
+    annot = (np.uint64(1) + mix(np.uint64(2) * i + np.uint64(1)) % np.uint64(num_docs - 1)).astype(np.int64)
+    return start, end, annot
+
+
+def write_parquet(path, num_docs, pivot, record="chr1", density=Fraction(5, 100), seed=SEED, chunk=4_000_000):
+    """a synthetic index in the reference's on-disk format (f0 utf8, f1..f3 int64, ZSTD;
+    parquet_compress_bed.py:19-38), written chunk by chunk."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    num, den = rows_per_position(num_docs, density)
+    total = first_row_at_or_after(pivot, num, den)
+    schema = pa.schema([("f0", pa.utf8()), ("f1", pa.int64()), ("f2", pa.int64()), ("f3", pa.int64())])
+    with pq.ParquetWriter(path, schema, compression="ZSTD") as w:
+        for b in range(0, total, chunk):
+            n = min(chunk, total - b)
+            s, e, a = host_rows(b, n, num, den, num_docs, seed)
+            w.write_table(pa.table({"f0": pa.array([record] * n, pa.utf8()), "f1": s, "f2": e, "f3": a}, schema=schema))
+    return total

@@ -120,3 +120,43 @@ def test_cli_front_end_usage_bytes():
     assert r.returncode == 0 and r.stdout == open(os.path.join(G.GOLD, "cli", "memo_query_usage.txt"), "rb").read()
     r = subprocess.run([sys.executable, exe, "query", "-b", "x.parquet"], capture_output=True)
     assert r.returncode == 2 and r.stdout == b"MEMO - conservation query\n"      # argparse: required flags
+
+
+def test_region_chunks_equal_filter_pq(memo, tmp_path):
+    """the streaming region slice (row groups pruned by statistics) returns filter_pq's rows"""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from memo_amd import memo_query as mq
+    rng = np.random.default_rng(8)
+    tabs = []
+    for name, n in (("chrA", 7000), ("chrB", 12000), ("chrC", 300)):
+        s = np.sort(rng.integers(1, 50_000, n))
+        tabs.append(pa.table({"f0": pa.array([name] * n, pa.utf8()), "f1": s, "f2": s + rng.integers(0, 60, n),
+                              "f3": rng.integers(1, 9, n)}))
+    path = str(tmp_path / "multi_rg.parquet")
+    pq.write_table(pa.concat_tables(tabs), path, row_group_size=1000, compression="ZSTD")
+    assert pq.ParquetFile(path).metadata.num_row_groups >= 19
+    for rec, qs, qe in (("chrB", 10_000, 20_031), ("chrA", 0, 50_031), ("chrC", 49_000, 60_000), ("chrB", 70_000, 70_100),
+                        ("nochr", 0, 1000), ("chrA", 25_000, 25_001)):
+        want = mq.filter_pq(path, rec, qs, qe)
+        bound, chunks = mq.region_chunks(path, rec, qs, qe)
+        got = list(chunks)
+        cat = [np.concatenate([c[i] for c in got]) if got else np.zeros(0, np.int64) for i in range(3)]
+        assert np.array_equal(cat[0], want.start) and np.array_equal(cat[1], want.end) and np.array_equal(cat[2], want.annot)
+        assert len(want) <= bound
+        if rec == "chrB" and qs == 10_000:
+            assert bound < 12_000                      # pruning really skipped row groups
+    for c in G.cases(raises=False)[::23]:
+        rec, qs, qe = G.region(c)
+        want = mq.filter_pq(os.path.join(G.GOLD, c["index"]), rec, qs, qe + c["k"])
+        _, chunks = mq.region_chunks(os.path.join(G.GOLD, c["index"]), rec, qs, qe + c["k"])
+        got = list(chunks)
+        assert sum(len(x[0]) for x in got) == len(want)
+
+
+def test_synth_host_rows_equal_oracle(oracle):
+    from memo_amd import synth
+    for rb, n, num, den, nd in ((0, 5000, 5, 1, 100), (123456789, 3000, 1, 2, 10), (7_000_000_000, 2000, 25, 1, 500)):
+        got = synth.host_rows(rb, n, num, den, nd)
+        want = oracle.synth_rows(rb, n, num, den, nd)
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""End-to-end `memo query` timing on a synthetic Parquet index (GPU box).
+  python tools/cli_timing.py --num-docs 100 --pivot 20000000 --out gpurun_out/cli"""
+import argparse
+import hashlib
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from memo_amd import synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--num-docs", type=int, default=100)
+ap.add_argument("--pivot", type=int, default=20_000_000)
+ap.add_argument("--out", default="/tmp/cli_timing")
+a = ap.parse_args()
+os.makedirs(a.out, exist_ok=True)
+pq_path = os.path.join(a.out, f"synth_n{a.num_docs}_{a.pivot}.parquet")
+t = time.time()
+rows = synth.write_parquet(pq_path, a.num_docs, a.pivot)
+print(f"wrote {rows} rows, {os.path.getsize(pq_path) / 1e6:.0f} MB parquet in {time.time() - t:.1f} s", flush=True)
+exe = os.path.join(ROOT, "bin", "memo")
+for region, memb in ((f"chr1:0-{a.pivot}", False), (f"chr1:{a.pivot // 4}-{a.pivot // 2}", False),
+                     (f"chr1:0-{min(a.pivot, 2_000_000)}", True)):
+    out = os.path.join(a.out, "out.txt")
+    argv = [sys.executable, exe, "query", "-b", pq_path, "-n", str(a.num_docs), "-r", region, "-o", out] + (["-m"] if memb else [])
+    t = time.time()
+    r = subprocess.run(argv, capture_output=True, env=dict(os.environ, MEMO_TIMING="1"))
+    wall = time.time() - t
+    sz = os.path.getsize(out) if os.path.exists(out) else -1
+    print(f"{region} {'membership' if memb else 'conservation'}: wall {wall:.2f} s, rc {r.returncode}, output {sz / 1e6:.0f} MB")
+    print("   ", r.stderr.decode().strip().splitlines()[-1] if r.stderr else "")
