@@ -67,7 +67,8 @@ def filter_pq(in_file, query_record, query_start, query_end, spanning_rows=False
 def region_chunks(in_file, query_record, query_start, query_end):
     """(upper bound on rows, iterator of (start, end, annot) chunks) for the rows of
     `query_record` with query_start < f1 < query_end in ONE Parquet file.  Row groups are selected
-    by their f0 / f1 min-max statistics and decoded one at a time, one ahead of the consumer."""
+    by their f0 / f1 min-max statistics and decoded by a small thread pool, a bounded window ahead
+    of the consumer, in file order."""
     import concurrent.futures as cf
     import pyarrow.compute as pc
     import pyarrow.parquet as pq
@@ -86,19 +87,28 @@ def region_chunks(in_file, query_record, query_start, query_end):
         groups.append(g)
         bound += rg.num_rows
 
+    import threading
+    tls = threading.local()
+
     def load(g):
-        t = pf.read_row_group(g, columns=["f0", "f1", "f2", "f3"])
+        if not hasattr(tls, "pf"):              # one reader per decode thread: a ParquetFile's
+            tls.pf = pq.ParquetFile(in_file)    # read cache is not safe to share
+        t = tls.pf.read_row_group(g, columns=["f0", "f1", "f2", "f3"])
         f1 = t.column("f1")
         keep = pc.and_(pc.equal(t.column("f0"), query_record),
                        pc.and_(pc.greater(f1, query_start), pc.less(f1, query_end)))
         return _columns(t.filter(keep))
 
     def chunks():
-        with cf.ThreadPoolExecutor(max_workers=1) as pool:
-            nxt = pool.submit(load, groups[0]) if groups else None
+        # row groups decode in parallel (Arrow releases the GIL), a bounded window ahead of the
+        # consumer, and are handed over in file order so that the rows stay start-sorted
+        depth = max(1, min(int(os.environ.get("MEMO_DECODE_THREADS", "8")), os.cpu_count() or 1))
+        with cf.ThreadPoolExecutor(max_workers=depth) as pool:
+            window = [pool.submit(load, g) for g in groups[:depth]]
             for n in range(len(groups)):
-                cols = nxt.result()
-                nxt = pool.submit(load, groups[n + 1]) if n + 1 < len(groups) else None
+                cols = window.pop(0).result()
+                if n + depth < len(groups):
+                    window.append(pool.submit(load, groups[n + depth]))
                 if len(cols[0]):
                     yield cols
     return bound, chunks()

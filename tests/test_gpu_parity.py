@@ -92,6 +92,26 @@ def test_memo_front_end_subprocess(memo, tmp_path):
     assert r.returncode != 0 and b"IndexError" in r.stderr
 
 
+def test_region_index_streams_row_groups(memo, oracle, tmp_path):
+    """Parquet -> DeviceIndex row group by row group (memo_index_upload_rows + _truncate)"""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from memo_amd import memo_query as mq
+    rng = np.random.default_rng(21)
+    n = 30_000
+    s = np.sort(rng.integers(1, 40_000, n))
+    e = s + rng.integers(0, 70, n)
+    o = rng.integers(1, 12, n)
+    path = str(tmp_path / "rg.parquet")
+    pq.write_table(pa.table({"f0": pa.array(["chrZ"] * n, pa.utf8()), "f1": s, "f2": e, "f3": o}), path,
+                   row_group_size=2048, compression="ZSTD")
+    for qs, qe, k in ((0, 40_000, 31), (12_345, 23_456, 31), (39_990, 40_100, 5), (50_000, 50_010, 31)):
+        with mq.region_index(path, "chrZ", qs, qe + k) as ix:
+            want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, 12, literal=False)
+            assert np.array_equal(ix.conservation(qs, qe, k, 12), want)
+            assert ix.info()["rows"] == int(((s > qs) & (s < qe + k)).sum())
+
+
 # ---------------------------------------------------------------------------------------
 # resident index vs oracle: many windows, every tile width, k sweep
 # ---------------------------------------------------------------------------------------
