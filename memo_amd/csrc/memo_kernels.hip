@@ -96,6 +96,7 @@ struct memo_index {
     uint32_t *pk = nullptr;
     uint16_t *pa = nullptr;    // format 6 only: 16-bit annot per row (the word's top byte is 0)
     int packed_fmt = 0;        // 0 = none, 4 = word only (annot <= 255), 6 = word + 16-bit annot
+    uint64_t max_annot = 0;    // largest annot of the packed rows
     int has_wide = 1;          // the three int64 columns are still resident
     int *d_status = nullptr;   // sticky flags set by the sweep kernels
     uint64_t *d_scratch = nullptr;  // finalize(): [0] unsorted pairs, [1] rows with end < start
@@ -158,6 +159,13 @@ __device__ __forceinline__ int clamp_to_tile(int64_t v, int lo, int hi) {
 // shared pieces of the sweep kernels.  T = threads per workgroup (64 = one wave owns the tile;
 // 256 = four waves share it and meet at workgroup barriers between the phases).
 // ------------------------------------------------------------------------------------------
+// Level arrays of the conservation sweep are W + kLevelSkew words apart: rows that hit the same
+// position on different levels then fall into different LDS banks.
+#ifndef MEMO_SKEW
+#define MEMO_SKEW 0
+#endif
+constexpr int kLevelSkew = MEMO_SKEW;
+
 struct Tile {
     int64_t a;     // pivot position of tile slot 0
     int x_lo, x_hi;  // slots of the tile that lie inside the window
@@ -202,15 +210,19 @@ struct WideRows {
             int col;
             if (h > c && check_col(A, o, col)) f(c, h, col);
         };
-        for (uint64_t base = (t.r0 & ~(uint64_t)15) + 2 * tid; base < t.r1; base += 2 * T * U) {
+        // 32-bit row numbers relative to the 128-byte-aligned start of the slice
+        const uint64_t base0 = t.r0 & ~(uint64_t)15;
+        const uint32_t end = (uint32_t)(t.r1 - base0);
+        const int64_t *ps = A.s + base0, *pe = A.e + base0, *po = A.o + base0;
+        for (uint32_t rel = 2 * tid; rel < end; rel += 2 * T * U) {
             longlong2 S[U], E[U], O[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint64_t idx = base + (uint64_t)u * 2 * T;
-                if (idx < t.r1) {
-                    S[u] = *reinterpret_cast<const longlong2 *>(A.s + idx);
-                    E[u] = *reinterpret_cast<const longlong2 *>(A.e + idx);
-                    O[u] = *reinterpret_cast<const longlong2 *>(A.o + idx);
+                const uint32_t r = rel + (uint32_t)u * 2 * T;
+                if (r < end) {
+                    S[u] = *reinterpret_cast<const longlong2 *>(ps + r);
+                    E[u] = *reinterpret_cast<const longlong2 *>(pe + r);
+                    O[u] = *reinterpret_cast<const longlong2 *>(po + r);
                 } else {
                     S[u] = make_longlong2(kSentinel, kSentinel);
                     E[u] = S[u];
@@ -219,6 +231,8 @@ struct WideRows {
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                // wave-uniform: nothing of this wave's load is inside the slice
+                if ((uint32_t)__builtin_amdgcn_readfirstlane(rel + (uint32_t)u * 2 * T) >= end) break;
                 one(S[u].x, E[u].x, O[u].x);
                 one(S[u].y, E[u].y, O[u].y);
             }
@@ -232,47 +246,83 @@ struct WideRows {
 // give the tile-relative start exactly; rows outside [r0, r1) are masked by index.  Exact
 // for k - 1 <= 255: a saturated length clips to "does not write" just as the true one does.
 // 4 rows per lane per load (16 B / lane).
-template <bool ANNOT16>
+// clamp(v, lo, hi) for lo <= hi in one instruction; hi is wave-uniform (one SGPR operand is all a
+// gfx9 VALU instruction may read), lo is a VGPR pinned by pin_vgpr() so that it is not
+// re-materialised from its SGPR before every use
+__device__ __forceinline__ int med3(int v, int lo, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "s"(hi));
+    return r;
+}
+
+__device__ __forceinline__ int pin_vgpr(int uniform) {
+    int r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(uniform));
+    return r;
+}
+
+// CHECKED = false is chosen by the host when the largest annot of the index (known since
+// memo_index_pack) is inside the result matrix, so that no row can raise the reference's
+// IndexError; the column test then leaves the loop.
+template <bool ANNOT16, bool CHECKED>
 struct PackedRows {
     template <int T, int U, typename F>
     static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, F f) {
         const int tid = threadIdx.x;
         const uint32_t a16 = (uint32_t)t.a & 0xFFFFu;
-        auto one = [&](uint64_t idx, uint32_t w, uint32_t annot) {
-            if (idx < t.r0 || idx >= t.r1) return;
-            const int d = (int)(((w & 0xFFFFu) - a16) & 0xFFFFu);       // start - a
-            const int h = min(max(d, t.x_lo), t.x_hi);
-            const int c = min(max(d + (int)((w >> 16) & 0xFFu) - A.km1, t.x_lo), t.x_hi);
-            if (h > c) {
-                if (annot >= (uint32_t)A.ncols)
-                    atomicOr(A.status, kStatusBadAnnot);
-                else
-                    f(c, h, (int)annot);
+        // 32-bit row numbers relative to the 128-byte-aligned start of the slice
+        const uint64_t base0 = t.r0 & ~(uint64_t)31;
+        const uint32_t first = (uint32_t)(t.r0 - base0), end = (uint32_t)(t.r1 - base0);
+        const uint32_t *pk = A.pk + base0;
+        const uint16_t *pa = ANNOT16 ? A.pa + base0 : nullptr;
+        const int x_lo = pin_vgpr(t.x_lo), x_hi = t.x_hi, km1 = A.km1;
+        const uint32_t ncols = (uint32_t)A.ncols;
+        // a row that cannot write: start == a, overlap 255 >= k - 1  ->  c >= h
+        const uint32_t dead = a16 | 0x00FF0000u;
+        uint32_t bad = 0;
+        auto one = [&](uint32_t w, uint32_t annot) {
+            const int d = (int)((w - a16) & 0xFFFFu);  // start - a
+            int h = med3(d, x_lo, x_hi);
+            const int c = med3(d + (int)__builtin_amdgcn_ubfe(w, 16, 8) - km1, x_lo, x_hi);
+            if (CHECKED && annot >= ncols) {
+                bad |= (uint32_t)(h > c);
+                h = c;
             }
+            f(c, h, (int)annot);  // f writes iff h > c
         };
-        for (uint64_t base = (t.r0 & ~(uint64_t)31) + 4 * tid; base < t.r1; base += 4 * T * U) {
+        for (uint32_t rel = 4 * tid; rel < end; rel += 4 * T * U) {
             uint4 V[U];
             uint2 N[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint64_t idx = base + (uint64_t)u * 4 * T;
-                if (idx < t.r1) {
-                    V[u] = *reinterpret_cast<const uint4 *>(A.pk + idx);
-                    if (ANNOT16) N[u] = *reinterpret_cast<const uint2 *>(A.pa + idx);
+                const uint32_t r = rel + (uint32_t)u * 4 * T;
+                if (r < end) {
+                    V[u] = *reinterpret_cast<const uint4 *>(pk + r);
+                    if (ANNOT16) N[u] = *reinterpret_cast<const uint2 *>(pa + r);
                 } else {
-                    V[u] = make_uint4(0u, 0u, 0u, 0u);
+                    V[u] = make_uint4(dead, dead, dead, dead);
                     N[u] = make_uint2(0u, 0u);
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint64_t idx = base + (uint64_t)u * 4 * T;
-                one(idx + 0, V[u].x, ANNOT16 ? (N[u].x & 0xFFFFu) : (V[u].x >> 24));
-                one(idx + 1, V[u].y, ANNOT16 ? (N[u].x >> 16) : (V[u].y >> 24));
-                one(idx + 2, V[u].z, ANNOT16 ? (N[u].y & 0xFFFFu) : (V[u].z >> 24));
-                one(idx + 3, V[u].w, ANNOT16 ? (N[u].y >> 16) : (V[u].w >> 24));
+                const uint32_t r = rel + (uint32_t)u * 4 * T;
+                // wave-uniform: only a load that straddles an end of the slice masks rows by number
+                const uint32_t wave_lo = __builtin_amdgcn_readfirstlane(r) & ~(uint32_t)255;
+                if (wave_lo >= end) break;  // nothing of this wave's load is inside the slice
+                if (!(wave_lo >= first && wave_lo + 256 <= end)) {
+                    V[u].x = (r + 0 >= first && r + 0 < end) ? V[u].x : dead;
+                    V[u].y = (r + 1 >= first && r + 1 < end) ? V[u].y : dead;
+                    V[u].z = (r + 2 >= first && r + 2 < end) ? V[u].z : dead;
+                    V[u].w = (r + 3 >= first && r + 3 < end) ? V[u].w : dead;
+                }
+                one(V[u].x, ANNOT16 ? (N[u].x & 0xFFFFu) : (V[u].x >> 24));
+                one(V[u].y, ANNOT16 ? (N[u].x >> 16) : (V[u].y >> 24));
+                one(V[u].z, ANNOT16 ? (N[u].y & 0xFFFFu) : (V[u].z >> 24));
+                one(V[u].w, ANNOT16 ? (N[u].y >> 16) : (V[u].w >> 24));
             }
         }
+        if (CHECKED && bad) atomicOr(A.status, kStatusBadAnnot);
     }
 };
 
@@ -288,6 +338,7 @@ template <typename Rows, int W, int U, int T, typename OutT>
 __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
+    constexpr int LS = W + kLevelSkew;  // words between level arrays
     Tile t;
     if (!locate_tile<W>(A, t)) return;
 
@@ -296,24 +347,26 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
         const uint32_t sent = (uint32_t)(A.ncols - 1);
         const uint4 sv = make_uint4(sent, sent, sent, sent);
         uint4 *p = reinterpret_cast<uint4 *>(lds);
-        for (int i = tid; i < A.nlev * (W / 4); i += T) p[i] = sv;
+        for (int i = tid; i < A.nlev * (LS / 4); i += T) p[i] = sv;
     }
     __syncthreads();
 
     // the clipped interval [c, h) is the union of two blocks of 2^j, j = floor(log2(h - c))
     Rows::template for_each<T, U>(A, t, [&](int c, int h, int col) {
-        const int j = 31 - __clz(h - c);
-        uint32_t *lv = lds + j * W;
-        atomicMin(lv + c, (uint32_t)col);               // block [c, c + 2^j)
-        atomicMin(lv + (h - (1 << j)), (uint32_t)col);  // block [h - 2^j, h)
+        if (h > c) {
+            const int j = 31 - __builtin_clz((unsigned)(h - c));  // h - c >= 1
+            uint32_t *lv = lds + j * LS;
+            atomicMin(lv + c, (uint32_t)col);               // block [c, c + 2^j)
+            atomicMin(lv + (h - (1 << j)), (uint32_t)col);  // block [h - 2^j, h)
+        }
     });
     __syncthreads();
 
     // fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1)
     for (int j = A.nlev - 1; j >= 1; --j) {
         const int half = 1 << (j - 1);
-        const uint32_t *hi = lds + j * W;
-        uint32_t *lo = lds + (j - 1) * W;
+        const uint32_t *hi = lds + j * LS;
+        uint32_t *lo = lds + (j - 1) * LS;
         for (int x = 4 * tid; x < W; x += 4 * T) {
             const uint4 v = *reinterpret_cast<const uint4 *>(hi + x);
             uint4 u;
@@ -413,10 +466,11 @@ __global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) 
     __syncthreads();
 
     Rows::template for_each<T, U>(A, t, [&](int c, int h, int col) {
+        if (h <= c) return;
         const uint32_t bit = 1u << (col & 31);
         const int word = col >> 5;
         if (DOUBLING) {
-            const int j = 31 - __clz(h - c);
+            const int j = 31 - __builtin_clz((unsigned)(h - c));  // h - c >= 1
             uint32_t *lv = lds + j * plane + word;
             atomicOr(lv + c * nw, bit);
             atomicOr(lv + (h - (1 << j)) * nw, bit);
@@ -499,15 +553,17 @@ __global__ void pad_rows_kernel(int64_t *s, int64_t *e, int64_t *o, uint64_t row
 
 // memo_index_pack: annot range census, then one word (+ optional 16-bit annot) per row
 __global__ void annot_census_kernel(const int64_t *o, uint64_t rows, uint64_t *scratch) {
-    uint64_t outside = 0, over8 = 0;
+    uint64_t outside = 0, over8 = 0, top = 0;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < rows;
          i += (uint64_t)gridDim.x * blockDim.x) {
         const int64_t v = o[i];
         if (v < 0 || v > 65535) ++outside;
+        else if ((uint64_t)v > top) top = (uint64_t)v;
         if (v > 255) ++over8;
     }
     if (outside) atomicAdd((unsigned long long *)&scratch[3], (unsigned long long)outside);
     if (over8) atomicAdd((unsigned long long *)&scratch[4], (unsigned long long)over8);
+    if (top) atomicMax((unsigned long long *)&scratch[5], (unsigned long long)top);
 }
 
 __global__ void pack_rows_kernel(const int64_t *s, const int64_t *e, const int64_t *o, uint64_t rows,
@@ -746,11 +802,14 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     }
     if (!waves) waves = w >= (fmt ? 512 : 2048) ? 4 : 1;
     while ((size_t)A.nlev * w * 4 > 160 * 1024 && w > 256) w >>= 1;
-    SweepKernel kern = fmt == 4   ? cons_kernel<PackedRows<false>, OutT>(w, waves)
-                       : fmt == 6 ? cons_kernel<PackedRows<true>, OutT>(w, waves)
+    const bool checked = ix->max_annot >= (uint64_t)A.ncols;  // some row could be outside the matrix
+    SweepKernel kern = fmt == 4   ? (checked ? cons_kernel<PackedRows<false, true>, OutT>(w, waves)
+                                             : cons_kernel<PackedRows<false, false>, OutT>(w, waves))
+                       : fmt == 6 ? (checked ? cons_kernel<PackedRows<true, true>, OutT>(w, waves)
+                                             : cons_kernel<PackedRows<true, false>, OutT>(w, waves))
                                   : cons_kernel<WideRows, OutT>(w, waves);
     if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-    return launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * w * 4, st);
+    return launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * (w + kLevelSkew) * 4, st);
 }
 
 // ==========================================================================================
@@ -984,6 +1043,7 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
                         (unsigned long long)h[3]);
     }
     const int fmt = h[4] ? 6 : 4;
+    ix->max_annot = h[5];
     HIP_TRY(hipMalloc(&ix->pk, ix->padded * sizeof(uint32_t)));
     if (fmt == 6) HIP_TRY(hipMalloc(&ix->pa, ix->padded * sizeof(uint16_t)));
     hipLaunchKernelGGL(pack_rows_kernel, dim3(4096), dim3(256), 0, st, ix->s, ix->e, ix->o, ix->rows,
@@ -1064,8 +1124,11 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
     }
     while (per_pos * w > 160 * 1024 && w > 256) w >>= 1;
-    SweepKernel kern = fmt == 4   ? memb_kernel<PackedRows<false>>(w, waves, doubling)
-                       : fmt == 6 ? memb_kernel<PackedRows<true>>(w, waves, doubling)
+    const bool checked = ix->max_annot >= (uint64_t)A.ncols;
+    SweepKernel kern = fmt == 4   ? (checked ? memb_kernel<PackedRows<false, true>>(w, waves, doubling)
+                                             : memb_kernel<PackedRows<false, false>>(w, waves, doubling))
+                       : fmt == 6 ? (checked ? memb_kernel<PackedRows<true, true>>(w, waves, doubling)
+                                             : memb_kernel<PackedRows<true, false>>(w, waves, doubling))
                                   : memb_kernel<WideRows>(w, waves, doubling);
     if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
     return launch_tiles(kern, A, w, 64 * waves, per_pos * w, st);
