@@ -200,7 +200,7 @@ def main():
     out = outs[(args.steps - 1) % nbuf]
 
     def kernel_name(which):
-        rows_t = "WideRows" if which == "wide" else f"PackedRows<{'true' if packed_fmt == 6 else 'false'}>"
+        rows_t = "WideRows" if which == "wide" else f"PackedRows<{'true' if packed_fmt == 6 else 'false'}, false>"
         return ("sweep_membership_kernel<" if membership else "sweep_conservation_kernel<") + rows_t + ", ...>"
 
     other = None

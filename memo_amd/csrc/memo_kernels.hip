@@ -159,6 +159,10 @@ __device__ __forceinline__ int clamp_to_tile(int64_t v, int lo, int hi) {
 // shared pieces of the sweep kernels.  T = threads per workgroup (64 = one wave owns the tile;
 // 256 = four waves share it and meet at workgroup barriers between the phases).
 // ------------------------------------------------------------------------------------------
+#ifndef MEMO_KU
+#define MEMO_KU 4
+#endif
+
 // Level arrays of the conservation sweep are W + kLevelSkew words apart: rows that hit the same
 // position on different levels then fall into different LDS banks.
 #ifndef MEMO_SKEW
@@ -201,6 +205,7 @@ __device__ __forceinline__ bool check_col(const SweepArgs &A, int64_t o, int &co
 // the Parquet columns as they are: 3 x int64 per row.  2 rows per lane per column per load
 // (16 B / lane, 1 KiB / wave), U loads of each column in flight per lane.
 struct WideRows {
+    static constexpr int kLoads = MEMO_KU;  // loads of each column in flight per lane
     template <int T, int U, typename F>
     static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, F f) {
         const int tid = threadIdx.x;
@@ -266,6 +271,7 @@ __device__ __forceinline__ int pin_vgpr(int uniform) {
 // IndexError; the column test then leaves the loop.
 template <bool ANNOT16, bool CHECKED>
 struct PackedRows {
+    static constexpr int kLoads = 2 * MEMO_KU;  // A/B: 8 x 16 B in flight per lane, 5 % over 4
     template <int T, int U, typename F>
     static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, F f) {
         const int tid = threadIdx.x;
@@ -674,17 +680,13 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
     return MEMO_OK;
 }
 
-#ifndef MEMO_KU
-#define MEMO_KU 4
-#endif
-constexpr int kU = MEMO_KU;  // loads of each column in flight per lane
 
 template <typename Rows, typename OutT>
 SweepKernel cons_kernel(int w, int waves) {
 #define MEMO_CASE(WW)                                                                         \
     case WW:                                                                                  \
-        return waves == 4 ? (SweepKernel)sweep_conservation_kernel<Rows, WW, kU, 256, OutT>   \
-                          : (SweepKernel)sweep_conservation_kernel<Rows, WW, kU, 64, OutT>;
+        return waves == 4 ? (SweepKernel)sweep_conservation_kernel<Rows, WW, Rows::kLoads, 256, OutT>   \
+                          : (SweepKernel)sweep_conservation_kernel<Rows, WW, Rows::kLoads, 64, OutT>;
     switch (w) {
         MEMO_CASE(256)
         MEMO_CASE(512)
@@ -701,10 +703,10 @@ SweepKernel memb_kernel(int w, int waves, bool doubling) {
 #define MEMO_CASE(WW)                                                                              \
     case WW:                                                                                       \
         if (doubling)                                                                              \
-            return waves == 4 ? (SweepKernel)sweep_membership_kernel<Rows, WW, kU, 256, true>      \
-                              : (SweepKernel)sweep_membership_kernel<Rows, WW, kU, 64, true>;      \
-        return waves == 4 ? (SweepKernel)sweep_membership_kernel<Rows, WW, kU, 256, false>         \
-                          : (SweepKernel)sweep_membership_kernel<Rows, WW, kU, 64, false>;
+            return waves == 4 ? (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 256, true>      \
+                              : (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 64, true>;      \
+        return waves == 4 ? (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 256, false>         \
+                          : (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 64, false>;
     switch (w) {
         MEMO_CASE(256)
         MEMO_CASE(512)
@@ -790,12 +792,13 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // Tile shape, from interleaved A/B on one device (profiles/r01_ab_*.txt).
     //  int64 rows (HBM-bound): four waves share a 4096-position tile -- fewest k-1 row halos per
     //    position; 1-3 % over one wave per 1024 positions at k <= 32, 10 % at k = 101.
-    //  packed rows (4-6x fewer bytes; latency/issue-bound): what matters is waves per CU, so the
-    //    tile gets ~20 KiB of LDS: 8 workgroups of 4 waves per CU (k = 31: 1024 positions).
+    //  packed rows (4-6x fewer bytes; LDS-atomic / issue-bound): waves per CU matter, but so does
+    //    the k-1 halo: 1024 positions x 4 waves wins at k = 31 (20 KiB, 8 workgroups per CU) and at
+    //    k = 101 (28 KiB) over 512 or 2048 positions.
     // Short windows want many small tiles either way.
     int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
     if (!w) {
-        const size_t budget = fmt ? 20 * 1024 : 80 * 1024;
+        const size_t budget = fmt ? 32 * 1024 : 80 * 1024;
         w = 4096;
         while ((size_t)A.nlev * w * 4 > budget && w > 256) w >>= 1;
         while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
