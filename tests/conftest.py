@@ -17,3 +17,8 @@ def oracle():
     from oracle import memo_oracle
     memo_oracle.lib()
     return memo_oracle
+
+
+@pytest.fixture(scope="session")
+def oracle_mod(oracle):
+    return oracle
