@@ -131,7 +131,8 @@ int memo_membership(const int64_t *start, const int64_t *end, const int64_t *ann
 /* ---- raw device buffers, for hosts that do not bring a device allocator (the CLI) ------ */
 int memo_dev_malloc(int32_t device, size_t bytes, void **out);
 int memo_dev_free(int32_t device, void *p);
-/* copy device -> host on `stream` and wait for it */
+/* copy host -> device / device -> host on `stream` and wait for it */
+int memo_dev_upload(int32_t device, void *dev, const void *host, size_t bytes, void *stream);
 int memo_dev_download(int32_t device, void *host, const void *dev, size_t bytes, void *stream);
 
 /* ---- print_res (memo_query.py:65-71), host side ----------------------------------------
@@ -140,6 +141,14 @@ int memo_dev_download(int32_t device, void *host, const void *dev, size_t bytes,
  * of bytes the text needs; it is written only if it fits in cap. */
 size_t memo_emit_conservation(const uint16_t *vec, int64_t L, char *buf, size_t cap);
 size_t memo_emit_membership(const uint32_t *bits, int64_t L, int32_t num_docs, char *buf, size_t cap);
+
+/* ---- `memo view` binning: the per-bin histogram of plot_conservation.py:52-56 ------------------
+ * d_vec: conservation result on `device` (L values); edges: nbins + 1 HOST values, the reference's
+ * list(map(int, np.linspace(0, L, nbins + 1))); counts: HOST array [nbins][num_docs + 1] of uint64,
+ * counts[b][v] = number of positions p in [edges[b], edges[b+1]) with d_vec[p] == v.
+ * Blocking (synchronises `stream`). */
+int memo_bin_conservation_dev(const uint16_t *d_vec, int64_t L, const int64_t *edges, int32_t nbins,
+                              int32_t num_docs, uint64_t *counts, int32_t device, void *stream);
 
 /* ---- synthetic pangenome index (BASELINE.json configs 2-5) -------------------
  * Fills rows [0, rows) of the index with global rows row_begin + i of the generator

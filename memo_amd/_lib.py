@@ -59,9 +59,11 @@ SYMBOLS = {
     "memo_membership": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _I32]),
     "memo_dev_malloc": (C.c_int, [_I32, _SZ, C.POINTER(_P)]),
     "memo_dev_free": (C.c_int, [_I32, _P]),
+    "memo_dev_upload": (C.c_int, [_I32, _P, _P, _SZ, _P]),
     "memo_dev_download": (C.c_int, [_I32, _P, _P, _SZ, _P]),
     "memo_emit_conservation": (_SZ, [_P, _I64, _P, _SZ]),
     "memo_emit_membership": (_SZ, [_P, _I64, _I32, _P, _SZ]),
+    "memo_bin_conservation_dev": (C.c_int, [_P, _I64, _P, _I32, _I32, _P, _I32, _P]),
     "memo_synth_fill": (C.c_int, [_P, _U64, _U64, _U64, _I32, _U64]),
     "memo_debug_stream_rows": (C.c_int, [_P, _P]),
     "memo_set_row_source": (C.c_int, [_I32]),

@@ -605,6 +605,35 @@ __global__ void bucket_table_kernel(const int64_t *s, uint64_t rows, int64_t *bo
     boff[b] = (int64_t)lo;
 }
 
+// `memo view` binning (plot_conservation.py:52-56): counts[b][v] = #{p in [edge[b], edge[b+1]) : vec[p] == v}
+// for v in 0..num_docs.  One workgroup per (bin, slice of the bin); LDS histogram when it fits.
+template <bool LDS_HIST>
+__global__ __launch_bounds__(256) void bin_conservation_kernel(const uint16_t *vec, const int64_t *edges,
+                                                               int ncols, int slices,
+                                                               unsigned long long *counts) {
+    extern __shared__ uint32_t hist[];
+    const int b = blockIdx.x / slices, sl = blockIdx.x % slices;
+    const int64_t lo = edges[b], hi = edges[b + 1];
+    const int64_t per = (hi - lo + slices - 1) / slices;
+    const int64_t p0 = lo + sl * per, p1 = p0 + per < hi ? p0 + per : hi;
+    if (LDS_HIST) {
+        for (int i = threadIdx.x; i < ncols; i += 256) hist[i] = 0;
+        __syncthreads();
+    }
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int v = vec[p];
+        if (v < ncols) {
+            if (LDS_HIST) atomicAdd(&hist[v], 1u);
+            else atomicAdd(&counts[(int64_t)b * ncols + v], 1ull);
+        }
+    }
+    if (LDS_HIST) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < ncols; i += 256)
+            if (hist[i]) atomicAdd(&counts[(int64_t)b * ncols + i], (unsigned long long)hist[i]);
+    }
+}
+
 // PMC calibration: reads every row of the three columns exactly once with the sweep's own
 // access shape (16 B per lane, 1 KiB per wave-instruction) and nothing else, so that
 // FETCH_SIZE can be checked against a known byte count (24 B x padded rows) in the same run.
@@ -1221,6 +1250,46 @@ int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t
     return MEMO_OK;
 }
 
+int memo_bin_conservation_dev(const uint16_t *d_vec, int64_t L, const int64_t *edges, int32_t nbins,
+                              int32_t num_docs, uint64_t *counts, int32_t device, void *stream) {
+    if (nbins < 1 || num_docs < 1 || num_docs > 65534 || !edges || !counts || (L > 0 && !d_vec))
+        return fail(MEMO_EINVAL, "bad binning arguments");
+    for (int i = 0; i < nbins; ++i)
+        if (edges[i] < 0 || edges[i] > edges[i + 1] || edges[i + 1] > L)
+            return fail(MEMO_EINVAL, "bin edges must be non-decreasing inside [0, L]");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(MEMO_EHIP, "cannot select HIP device %d", device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ncols = num_docs + 1;
+    const size_t cbytes = (size_t)nbins * ncols * sizeof(uint64_t);
+    int64_t *d_edges = nullptr;
+    unsigned long long *d_counts = nullptr;
+    int rc = MEMO_OK;
+    hipError_t err = hipMalloc(&d_edges, (size_t)(nbins + 1) * sizeof(int64_t));
+    if (err == hipSuccess) err = hipMalloc(&d_counts, cbytes);
+    if (err == hipSuccess) err = hipMemcpyAsync(d_edges, edges, (size_t)(nbins + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (err == hipSuccess) err = hipMemsetAsync(d_counts, 0, cbytes, st);
+    if (err == hipSuccess) {
+        // enough workgroups to fill the chip, at least one per bin
+        int slices = (int)((2048 + nbins - 1) / nbins);
+        const int64_t longest = (L + nbins - 1) / nbins;
+        while (slices > 1 && longest / slices < 4096) --slices;
+        if ((size_t)ncols * 4 <= 48 * 1024)
+            hipLaunchKernelGGL(bin_conservation_kernel<true>, dim3((unsigned)(nbins * slices)), dim3(256),
+                               (size_t)ncols * 4, st, d_vec, d_edges, ncols, slices, d_counts);
+        else
+            hipLaunchKernelGGL(bin_conservation_kernel<false>, dim3((unsigned)(nbins * slices)), dim3(256), 0, st,
+                               d_vec, d_edges, ncols, slices, d_counts);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpyAsync(counts, d_counts, cbytes, hipMemcpyDeviceToHost, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err != hipSuccess) rc = fail(MEMO_EHIP, "binning failed: %s", hipGetErrorString(err));
+    (void)hipFree(d_edges);
+    (void)hipFree(d_counts);
+    return rc;
+}
+
 int memo_debug_stream_rows(memo_index_t *ix, void *stream) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
     if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns were dropped");
@@ -1245,6 +1314,14 @@ int memo_dev_malloc(int32_t device, size_t bytes, void **out) {
 int memo_dev_free(int32_t device, void *p) {
     DeviceGuard guard(device);
     HIP_TRY(hipFree(p));
+    return MEMO_OK;
+}
+
+int memo_dev_upload(int32_t device, void *dev, const void *host, size_t bytes, void *stream) {
+    DeviceGuard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bytes) HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return MEMO_OK;
 }
 

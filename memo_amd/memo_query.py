@@ -197,9 +197,62 @@ def parse_arguments(argv=None):
     return parser.parse_args(argv)
 
 
+def _main_sharded(args):
+    """`memo query` under torch.distributed.run: one process per GPU, the window cut into
+    contiguous sub-windows (memo_amd/shard.py), every rank slices + sweeps its own, result slices
+    gathered to rank 0 over RCCL, rank 0 writes the file.  Same bytes as the single-GPU run."""
+    import torch
+    import torch.distributed as dist
+    from . import shard
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    membership_query = args.membership_query
+    num_docs, k = int(args.num_docs), int(args.k)
+    query_record, start_end = args.genome_region.split(':')
+    query_start, query_end = map(int, start_end.split('-'))
+    if query_end < query_start:
+        raise ValueError("negative dimensions are not allowed")          # np.zeros of memo_init
+    stream = torch.cuda.current_stream()
+    held = []
+
+    def alloc(per):
+        return torch.empty((per, words(num_docs)) if membership_query else (per,),
+                           dtype=torch.int32 if membership_query else torch.int16, device=dev)
+
+    def sweep(a, b, out):
+        ix = region_index(args.in_file, query_record, a, b + k, device=local)
+        held.append(ix)
+        if membership_query:
+            ix.membership_dev(a, b, k, num_docs, out, stream.cuda_stream)
+        else:
+            ix.conservation_dev(a, b, k, num_docs, out, stream.cuda_stream)
+        ix.check(stream.cuda_stream)
+
+    try:
+        res, _ = shard.sharded_query(sweep, query_start, query_end, k, rank, world, dist, alloc)
+    finally:
+        for ix in held:
+            ix.close()
+    if rank == 0:
+        rec = QueryResult(query_start, query_end, k, num_docs, membership_query)
+        host = res.cpu().numpy()
+        rec.values = host.view(np.uint32) if membership_query else host.view(np.uint16)
+        print_res(rec, args.out_file, membership_query)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main(args):
     import sys
     import time
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("MEMO_FORCE_SHARDED"):
+        return _main_sharded(args)
     membership_query = args.membership_query
     num_docs, k = int(args.num_docs), int(args.k)
     query_record, start_end = args.genome_region.split(':')      # exactly one ':' and one '-'

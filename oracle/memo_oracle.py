@@ -177,3 +177,23 @@ def bits_to_matrix(bits, n_docs):
     bits = np.asarray(bits, np.uint32)
     g = np.arange(n_docs)
     return ((bits[:, g >> 5] >> (g & 31).astype(np.uint32)) & 1).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------
+# `memo view` preprocessing (plot_conservation.py:46-65), restated with NumPy
+# ---------------------------------------------------------------------------
+def view_table(vec, n_docs, n_bins):
+    """(bin, No. Genomes, value) rows as the reference's melted DataFrame holds them."""
+    vec = np.asarray(vec, np.int64)
+    edges = [int(x) for x in np.linspace(0, len(vec), n_bins + 1)]          # :52
+    value = np.zeros((n_bins, n_docs + 1))
+    for b, (lo, hi) in enumerate(zip(edges[:-1], edges[1:])):
+        if hi == lo:
+            raise ZeroDivisionError("division by zero")                      # :56, empty Counter
+        seg = vec[lo:hi]
+        for order in range(n_docs + 1):
+            value[b, order] = int((seg == order).sum()) / (hi - lo)
+    keep = np.arange(n_docs)                                                 # :65 drops order n_docs
+    return {"bin": np.tile(np.arange(n_bins, dtype=np.int64), n_docs),
+            "No. Genomes": np.repeat(keep.astype(np.float64), n_bins),
+            "value": value[:, :n_docs].T.reshape(-1)}

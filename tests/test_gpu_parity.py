@@ -335,3 +335,54 @@ def test_config3_full_size_properties(membership, memo, oracle):
             assert np.array_equal(sub, full[a + 17:b - 5]), a
         if not membership:
             assert full.min() >= 1 and full.max() == n
+
+
+# ---------------------------------------------------------------------------------------
+# `memo view` binning on the device (plot_conservation.py:46-65)
+# ---------------------------------------------------------------------------------------
+def test_view_binning_matches_reference(memo, oracle):
+    import json
+    from memo_amd import view
+    for c in json.load(open(os.path.join(G.GOLD, "view", "manifest.json"))):
+        z = np.load(os.path.join(G.GOLD, "view", c["name"] + ".npz"))
+        if "raises" in c:
+            with pytest.raises(ZeroDivisionError):
+                view.preprocess_data(z["vec"], c["n_docs"], c["n_bins"])
+            continue
+        got = view.preprocess_data(z["vec"], c["n_docs"], c["n_bins"])
+        assert np.array_equal(got["bin"], z["bin"]) and np.array_equal(got["No. Genomes"], z["genomes"])
+        assert np.array_equal(got["value"], z["value"])      # float64, bit for bit
+    rng = np.random.default_rng(2)
+    for n_docs, n_bins, npos in ((100, 500, 3_000_000), (20000, 3, 100_000), (7, 1, 1)):
+        vec = rng.integers(0, n_docs + 1, npos).astype(np.uint16)
+        got = view.preprocess_data(vec, n_docs, n_bins)
+        want = oracle.view_table(vec, n_docs, n_bins) if n_docs < 1000 else None
+        if want:
+            assert np.array_equal(got["value"], want["value"])
+        counts, edges = view.bin_counts(vec, n_docs, n_bins)
+        assert counts.sum() == npos and np.array_equal(counts.sum(0), np.bincount(vec, minlength=n_docs + 1))
+
+
+def test_view_from_text_file(memo, tmp_path):
+    from memo_amd import view
+    vec = np.array([5, 5, 3, 4, 5, 2, 1, 2, 5, 5, 4, 4], np.uint16)
+    p = tmp_path / "c.txt"
+    p.write_bytes(memo.emit_conservation(vec))
+    t = view.preprocess_data(str(p), 5, 3)
+    assert np.allclose(t["value"].reshape(5, 3)[:, 0], [0, 0, 0, 0.25, 0.25])
+
+
+def test_cli_sharded_path_single_rank(memo, tmp_path):
+    """the torch.distributed form of `memo query` (RCCL initialised, shard + gather code path) with
+    one rank; N > 1 needs more GPUs than this box has and is covered on CPU by test_shard_gloo.py"""
+    import subprocess
+    import sys
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "memo")
+    for name in ("ex_cons_k3_0_20", "ex_memb_k3_0_20", "rnd_n40_cons_k31_c0w0"):
+        c = next(x for x in G.cases() if x["name"] == name)
+        out = tmp_path / (name + ".txt")
+        argv = [sys.executable, exe, "query", "-b", os.path.join(G.GOLD, c["index"]), "-n", str(c["n"]), "-k", str(c["k"]),
+                "-r", c["region"], "-o", str(out)] + (["-m"] if c["membership"] else [])
+        r = subprocess.run(argv, capture_output=True, env=dict(os.environ, MEMO_FORCE_SHARDED="1", MASTER_PORT="29541"))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert G.sha(out.read_bytes()) == c["sha256"]

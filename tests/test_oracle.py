@@ -78,3 +78,22 @@ def test_synth_rows_addressable(oracle):
     assert o.min() >= 1 and o.max() <= 99
     sh, _, _ = oracle.synth_rows(0, 100, 1, 2, 10)      # 0.5 rows per position
     assert np.array_equal(sh, 1 + 2 * np.arange(100))
+
+
+def _view_cases():
+    import json
+    import os
+    return json.load(open(os.path.join(G.GOLD, "view", "manifest.json")))
+
+
+@pytest.mark.parametrize("c", _view_cases(), ids=lambda c: c["name"])
+def test_view_table_matches_reference(c, oracle):
+    import os
+    z = np.load(os.path.join(G.GOLD, "view", c["name"] + ".npz"))
+    if "raises" in c:
+        with pytest.raises(ZeroDivisionError):
+            oracle.view_table(z["vec"], c["n_docs"], c["n_bins"])
+        return
+    got = oracle.view_table(z["vec"], c["n_docs"], c["n_bins"])
+    assert np.array_equal(got["bin"], z["bin"]) and np.array_equal(got["No. Genomes"], z["genomes"])
+    assert np.array_equal(got["value"], z["value"])          # float64, bit for bit

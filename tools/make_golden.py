@@ -233,6 +233,37 @@ def main():
                             qe = qs + 120_000 // n
                         run_case(manifest, f"{name}_{tag}_k{k}_c{ci}w{wi}", pq, k, n,
                                  f"{cname}:{qs}-{qe}", memb, work)
+    # --- `memo view` binning (plot_conservation.py:46-65): per-bin composition of a conservation
+    # vector; plotnine is absent here and only needed for drawing, so it is stubbed for the import
+    pn = types.ModuleType("plotnine")
+    for nm in ("ggplot aes theme themes element_blank element_line element_text geom_bar ggtitle xlab ylab "
+               "scale_y_continuous scale_fill_gradient").split():
+        setattr(pn, nm, None)
+    po = types.ModuleType("plotnine.options")
+    po.figure_size = None
+    sys.modules["plotnine"], sys.modules["plotnine.options"] = pn, po
+    import plot_conservation as ref_v
+    os.makedirs(os.path.join(GOLD, "view"))
+    vrng = np.random.default_rng(7)
+    view_cases = []
+    for vi, (npos, n_docs, n_bins) in enumerate([(20, 5, 4), (1000, 9, 7), (5000, 40, 500), (333, 3, 1), (7, 5, 10), (4096, 100, 64)]):
+        vec = vrng.integers(1, n_docs + 1, npos)
+        vec[vrng.random(npos) < 0.5] = n_docs
+        path = os.path.join(work, f"view{vi}.txt")
+        open(path, "w").write("".join(f"{v}\n" for v in vec))
+        try:
+            df = ref_v.preprocess_data(path, n_docs, n_bins)
+        except ZeroDivisionError:                 # an empty bin (more bins than positions)
+            np.savez_compressed(os.path.join(GOLD, "view", f"view{vi}.npz"), vec=vec.astype(np.uint16))
+            view_cases.append(dict(name=f"view{vi}", n_docs=n_docs, n_bins=n_bins, positions=npos,
+                                   raises="ZeroDivisionError"))
+            continue
+        np.savez_compressed(os.path.join(GOLD, "view", f"view{vi}.npz"), vec=vec.astype(np.uint16),
+                            bin=df["bin"].to_numpy(np.int64), genomes=df["No. Genomes"].to_numpy(np.float64),
+                            value=df["value"].to_numpy(np.float64))
+        view_cases.append(dict(name=f"view{vi}", n_docs=n_docs, n_bins=n_bins, positions=npos))
+    json.dump(view_cases, open(os.path.join(GOLD, "view", "manifest.json"), "w"))
+
     # --- stdout of the reference's bash front end (usage banners; exit status 0 in all three)
     import subprocess
     os.makedirs(os.path.join(GOLD, "cli"))
