@@ -514,6 +514,87 @@ __global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) 
     store_membership<T>(A, t, lds, nw);
 }
 
+// ------------------------------------------------------------------------------------------
+// membership, "runs" form: bit planes per GENOME instead of per position.
+//   absent[g][P] (P = position / 32) holds 32 positions of genome g per word, so a row's interval
+//   [c, h) is one run of bits: one ds_or_b32 when it stays inside a word, two when it straddles
+//   (more only for k - 1 > 32), and rows of different genomes never share a word.  No levels, no
+//   fold; 4 * W * nw bytes of LDS.  Each lane then transposes 32 genomes x 32 positions in
+//   registers (5 butterfly stages) into the position-major result words and stores them.
+// ------------------------------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ void transpose32_stage(uint32_t (&m)[32]) {
+    constexpr uint32_t mask = J == 16 ? 0x0000FFFFu : J == 8 ? 0x00FF00FFu : J == 4 ? 0x0F0F0F0Fu
+                              : J == 2 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        if ((k & J) == 0) {  // swap the high J-bit halves of m[k] with the low halves of m[k + J]
+            const uint32_t tt = ((m[k] >> J) ^ m[k + J]) & mask;
+            m[k] ^= tt << J;
+            m[k + J] ^= tt;
+        }
+    }
+}
+
+__device__ __forceinline__ void transpose32(uint32_t (&m)[32]) {  // m[j] bit i  <-  m[i] bit j
+    transpose32_stage<16>(m);
+    transpose32_stage<8>(m);
+    transpose32_stage<4>(m);
+    transpose32_stage<2>(m);
+    transpose32_stage<1>(m);
+}
+
+template <typename Rows, int W, int U, int T>
+__global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    constexpr int PW = W / 32;  // words per genome row
+    Tile t;
+    if (!locate_tile<W>(A, t)) return;
+    const int nw = A.nwords;
+    // genome g lives at g * PW + (g >> 5): the extra word per 32 genomes keeps the four lanes that
+    // read the same position word of different genome groups on different banks
+    const int total = 32 * nw * PW + nw;
+    for (int i = tid; i < total; i += T) lds[i] = 0;
+    __syncthreads();
+
+    Rows::template for_each<T, U>(A, t, [&](int c, int h, int col) {
+        if (h <= c) return;
+        uint32_t *row = lds + col * PW + (col >> 5);
+        const int w0 = c >> 5, w1 = (h - 1) >> 5;
+        const uint32_t first = 0xFFFFFFFFu << (c & 31), last = 0xFFFFFFFFu >> (31 - ((h - 1) & 31));
+        if (w0 == w1) {
+            atomicOr(row + w0, first & last);
+        } else {
+            atomicOr(row + w0, first);
+            for (int w = w0 + 1; w < w1; ++w) atomicOr(row + w, 0xFFFFFFFFu);
+            atomicOr(row + w1, last);
+        }
+    });
+    __syncthreads();
+
+    uint32_t *out = static_cast<uint32_t *>(A.out);
+    const int64_t ob = t.a - A.qs;  // output position of tile slot 0
+    for (int b = tid; b < nw * PW; b += T) {
+        const int G = b % nw, P = b / nw;  // genome group, position word
+        if (32 * P + 32 <= t.x_lo || 32 * P >= t.x_hi) continue;
+        uint32_t m[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) m[i] = lds[(32 * G + i) * PW + G + P];
+        transpose32(m);
+        const uint32_t full = full_word(A.ncols, G);
+        uint32_t *dst = out + (ob + 32 * P) * nw + G;
+        if (32 * P >= t.x_lo && 32 * P + 32 <= t.x_hi) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) dst[(int64_t)j * nw] = full & ~m[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (32 * P + j >= t.x_lo && 32 * P + j < t.x_hi) dst[(int64_t)j * nw] = full & ~m[j];
+        }
+    }
+}
+
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
 template <typename OutT>
 __global__ void fill_conservation_kernel(OutT *out, int64_t n, OutT v) {
@@ -747,6 +828,23 @@ SweepKernel memb_kernel(int w, int waves, bool doubling) {
     return nullptr;
 }
 
+template <typename Rows>
+SweepKernel memb_runs_kernel(int w, int waves) {
+#define MEMO_CASE(WW)                                                                                \
+    case WW:                                                                                         \
+        return waves == 4 ? (SweepKernel)sweep_membership_runs_kernel<Rows, WW, Rows::kLoads, 256>   \
+                          : (SweepKernel)sweep_membership_runs_kernel<Rows, WW, Rows::kLoads, 64>;
+    switch (w) {
+        MEMO_CASE(256)
+        MEMO_CASE(512)
+        MEMO_CASE(1024)
+        MEMO_CASE(2048)
+        MEMO_CASE(4096)
+    }
+#undef MEMO_CASE
+    return nullptr;
+}
+
 // which row source a query reads: packed when the index has it and k - 1 <= 255 (MEMO_ROWS=wide
 // forces the int64 columns), else the int64 columns
 int pick_rows(const memo_index *ix, int32_t k, int &fmt) {
@@ -872,7 +970,7 @@ int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo) {
         tile_w != 4096)
         return fail(MEMO_EINVAL, "tile_w must be 0, 256, 512, 1024, 2048 or 4096");
     if (waves != 0 && waves != 1 && waves != 4) return fail(MEMO_EINVAL, "waves must be 0, 1 or 4");
-    if (membership_algo < 0 || membership_algo > 2) return fail(MEMO_EINVAL, "membership_algo must be 0, 1 or 2");
+    if (membership_algo < 0 || membership_algo > 3) return fail(MEMO_EINVAL, "membership_algo must be 0..3");
     g_tile_w = tile_w;
     g_waves = waves;
     g_memb_algo = membership_algo;
@@ -1144,10 +1242,33 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // stays wide (the k-1 row halo is re-read once per tile).  Direct scatter otherwise.
     int fmt;
     if ((rc = pick_rows(ix, k, fmt))) return rc;
+    // algorithm: 3 = runs (bit planes per genome + register transpose), 2 = doubling, 1 = direct
     const size_t per_pos_doubling = (size_t)A.nlev * nw * 4;
-    const bool doubling = g_memb_algo ? g_memb_algo == 2 : per_pos_doubling * 256 <= 40 * 1024;
-    const size_t per_pos = doubling ? per_pos_doubling : (size_t)nw * 4;
+    int algo = g_memb_algo;
+    // A/B on config 4 (profiles/r01_membership_algorithms.txt): packed rows 0.87 ms runs vs 1.13 ms
+    // doubling; int64 rows (HBM-bound either way) 2.52 ms doubling vs 2.64 ms runs
+    if (!algo) algo = (fmt || per_pos_doubling * 256 > 40 * 1024) ? 3 : 2;
+    const bool checked = ix->max_annot >= (uint64_t)A.ncols;
     int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
+    if (algo == 3) {
+        if (!waves) waves = 4;
+        if (!w) {  // a lane transposes one 32 x 32 block: keep nw * W / 32 >= threads
+            w = 4096;
+            while ((size_t)nw * 4 * w > 32 * 1024 && w > 256) w >>= 1;
+            while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
+        }
+        while ((size_t)nw * 4 * w + (size_t)nw * 4 > 160 * 1024 && w > 256) w >>= 1;
+        const size_t lds = (size_t)nw * 4 * w + (size_t)nw * 4;
+        SweepKernel kern = fmt == 4   ? (checked ? memb_runs_kernel<PackedRows<false, true>>(w, waves)
+                                                 : memb_runs_kernel<PackedRows<false, false>>(w, waves))
+                           : fmt == 6 ? (checked ? memb_runs_kernel<PackedRows<true, true>>(w, waves)
+                                                 : memb_runs_kernel<PackedRows<true, false>>(w, waves))
+                                      : memb_runs_kernel<WideRows>(w, waves);
+        if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+        return launch_tiles(kern, A, w, 64 * waves, lds, st);
+    }
+    const bool doubling = algo == 2;
+    const size_t per_pos = doubling ? per_pos_doubling : (size_t)nw * 4;
     if (!waves) waves = doubling ? 4 : 1;
     if (!w) {  // config 4 A/B: int64 rows 512 positions x 4 waves (40 KiB); packed rows 256 x 4 (20 KiB)
         const size_t budget = (waves == 4 ? (fmt ? 20u : 40u) : 20u) * 1024;
@@ -1156,7 +1277,6 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
     }
     while (per_pos * w > 160 * 1024 && w > 256) w >>= 1;
-    const bool checked = ix->max_annot >= (uint64_t)A.ncols;
     SweepKernel kern = fmt == 4   ? (checked ? memb_kernel<PackedRows<false, true>>(w, waves, doubling)
                                              : memb_kernel<PackedRows<false, false>>(w, waves, doubling))
                        : fmt == 6 ? (checked ? memb_kernel<PackedRows<true, true>>(w, waves, doubling)
