@@ -15,11 +15,13 @@
  * exceptions across the boundary.  All functions return MEMO_OK (0) or a
  * negative code; memo_last_error() gives the message (thread-local).
  *
- * Row semantics: an index row (start s, end e, annot a) with
- * e >= s marks the k-mers starting at p, max(e-(k-1), qs) <= p < min(s, qe), as
- * ABSENT for order / genome a.  Rows must be sorted by start (they are in every
- * index dap_to_bed.py writes); memo_index_finalize() checks that and sorts on the
- * device when it does not hold.
+ * Row semantics: an index row (start s, end e, annot a) marks the
+ * k-mers starting at p, max(e-(k-1), qs) <= p < min(s, qe), as ABSENT for order / genome a.
+ * Rows must be sorted by start (they are in every index dap_to_bed.py writes);
+ * memo_index_finalize() checks that and sorts on the device when it does not hold.  Index
+ * rows have e >= s (dap_to_bed.py:93-98), which bounds a row's reach to k-1 positions; rows
+ * with e < s are legal input to memo_query.py and give the same results here, through a
+ * separate pass (they are set aside at finalize and applied after each sweep).
  *
  * Result encodings
  *   conservation  uint16 out[L], L = qe - qs:  smallest order a of any row
@@ -44,8 +46,8 @@ extern "C" {
 #define MEMO_EHIP (-2)      /* HIP runtime error */
 #define MEMO_ENOTREADY (-3) /* index not finalized */
 #define MEMO_EUNSORTED (-4) /* rows not sorted by start and sorting was disabled */
-#define MEMO_ELONGROW (-5)  /* a row has end < start: not a MEMO overlap row (dap_to_bed.py:93-98
-                               only emits end >= start); unsupported */
+#define MEMO_ELONGROW (-5)  /* more than 2^22 rows have end < start.  dap_to_bed.py:93-98 never emits
+                               such a row; a few are accepted and applied by a side pass */
 
 typedef struct memo_index memo_index_t; /* one chromosome's rows, resident in HBM */
 

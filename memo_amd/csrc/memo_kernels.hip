@@ -98,6 +98,10 @@ struct memo_index {
     int packed_fmt = 0;        // 0 = none, 4 = word only (annot <= 255), 6 = word + 16-bit annot
     uint64_t max_annot = 0;    // largest annot of the packed rows
     int has_wide = 1;          // the three int64 columns are still resident
+    // rows with end < start (never written by the reference's index builder, but legal input to
+    // memo_query.py): copied aside at finalize and applied by long_rows_kernel after each sweep
+    int64_t *ls = nullptr, *le = nullptr, *lo = nullptr;
+    uint64_t n_long = 0;
     int *d_status = nullptr;   // sticky flags set by the sweep kernels
     uint64_t *d_scratch = nullptr;  // finalize(): [0] unsorted pairs, [1] rows with end < start
 };
@@ -213,7 +217,8 @@ struct WideRows {
             const int h = clamp_to_tile(s - t.a, t.x_lo, t.x_hi);
             const int c = clamp_to_tile(e - t.a - A.km1, t.x_lo, t.x_hi);
             int col;
-            if (h > c && check_col(A, o, col)) f(c, h, col);
+            // end < start: the row may reach further left than k-1 positions; long_rows_kernel owns it
+            if (h > c && e >= s && check_col(A, o, col)) f(c, h, col);
         };
         // 32-bit row numbers relative to the 128-byte-aligned start of the slice
         const uint64_t base0 = t.r0 & ~(uint64_t)15;
@@ -638,6 +643,72 @@ __global__ void pad_rows_kernel(int64_t *s, int64_t *e, int64_t *o, uint64_t row
     }
 }
 
+// finalize: copy the rows with end < start aside (order is irrelevant: min / and commute)
+__global__ void collect_long_rows_kernel(const int64_t *s, const int64_t *e, const int64_t *o, uint64_t rows,
+                                         int64_t *ls, int64_t *le, int64_t *lo, unsigned long long *count) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < rows;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        if (e[i] < s[i]) {
+            const unsigned long long k = atomicAdd(count, 1ull);
+            ls[k] = s[i];
+            le[k] = e[i];
+            lo[k] = o[i];
+        }
+}
+
+// One workgroup per row with end < start: its interval [clip(e-qs-(k-1)), clip(s-qs)) can be any
+// length, so it is applied straight to the result in HBM, after the sweep, with atomics (rows may
+// overlap each other).  filter_pq keeps such a row iff qs < start < qe + k (memo_query.py:25-27).
+template <typename OutT>
+__global__ void long_rows_conservation_kernel(const int64_t *ls, const int64_t *le, const int64_t *lo,
+                                              int64_t qs, int64_t qe, int km1, int ncols, OutT *out,
+                                              int *status) {
+    const int64_t s = ls[blockIdx.x], e = le[blockIdx.x], o = lo[blockIdx.x];
+    if (!(s > qs && s < qe + km1 + 1)) return;
+    const int64_t L = qe - qs;
+    const int64_t hi = s - qs > L ? L : s - qs;
+    int64_t c = e - qs - km1;
+    c = c < 0 ? 0 : c;
+    if (c >= hi) return;
+    const int64_t cc = o < 0 ? o + ncols : o;
+    if ((uint64_t)cc >= (uint64_t)ncols) {
+        if (threadIdx.x == 0) atomicOr(status, kStatusBadAnnot);
+        return;
+    }
+    constexpr int PER = 4 / (int)sizeof(OutT);  // results per 32-bit word
+    uint32_t *words = reinterpret_cast<uint32_t *>(out);
+    for (int64_t p = c + threadIdx.x; p < hi; p += blockDim.x) {
+        uint32_t *wp = words + p / PER;
+        const int sh = (int)(p % PER) * 8 * (int)sizeof(OutT);
+        const uint32_t field = (sizeof(OutT) == 2 ? 0xFFFFu : 0xFFu) << sh;
+        uint32_t old = *wp;
+        while (((old & field) >> sh) > (uint32_t)cc) {  // out[p] = min(out[p], col), on the field only
+            const uint32_t seen = atomicCAS(wp, old, (old & ~field) | ((uint32_t)cc << sh));
+            if (seen == old) break;
+            old = seen;
+        }
+    }
+}
+
+__global__ void long_rows_membership_kernel(const int64_t *ls, const int64_t *le, const int64_t *lo,
+                                            int64_t qs, int64_t qe, int km1, int ncols, int nw,
+                                            uint32_t *out, int *status) {
+    const int64_t s = ls[blockIdx.x], e = le[blockIdx.x], o = lo[blockIdx.x];
+    if (!(s > qs && s < qe + km1 + 1)) return;
+    const int64_t L = qe - qs;
+    const int64_t hi = s - qs > L ? L : s - qs;
+    int64_t c = e - qs - km1;
+    c = c < 0 ? 0 : c;
+    if (c >= hi) return;
+    const int64_t cc = o < 0 ? o + ncols : o;
+    if ((uint64_t)cc >= (uint64_t)ncols) {
+        if (threadIdx.x == 0) atomicOr(status, kStatusBadAnnot);
+        return;
+    }
+    const uint32_t keep = ~(1u << (cc & 31));
+    for (int64_t p = c + threadIdx.x; p < hi; p += blockDim.x) atomicAnd(out + p * nw + (cc >> 5), keep);
+}
+
 // memo_index_pack: annot range census, then one word (+ optional 16-bit annot) per row
 __global__ void annot_census_kernel(const int64_t *o, uint64_t rows, uint64_t *scratch) {
     uint64_t outside = 0, over8 = 0, top = 0;
@@ -659,8 +730,9 @@ __global__ void pack_rows_kernel(const int64_t *s, const int64_t *e, const int64
          i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t w = 0, a = 0;
         if (i < rows) {
-            const int64_t len = e[i] - s[i];  // >= 0 (finalize checked end >= start)
-            w = ((uint32_t)s[i] & 0xFFFFu) | ((uint32_t)(len > 255 ? 255 : len) << 16);
+            const int64_t len = e[i] - s[i];
+            // end < start (handled by long_rows_kernel) packs as "never writes", like len >= 255
+            w = ((uint32_t)s[i] & 0xFFFFu) | ((uint32_t)(len > 255 || len < 0 ? 255 : len) << 16);
             a = (uint32_t)o[i];
         }
         if (pa) pa[i] = (uint16_t)a; else w |= a << 24;
@@ -893,6 +965,25 @@ void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32
 }  // namespace
 
 template <typename OutT>
+static int long_rows_conservation(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int ncols,
+                                  OutT *d_out, hipStream_t st) {
+    if (!ix->n_long) return MEMO_OK;
+    hipLaunchKernelGGL((long_rows_conservation_kernel<OutT>), dim3((unsigned)ix->n_long), dim3(256), 0, st,
+                       ix->ls, ix->le, ix->lo, qs, qe, k - 1, ncols, d_out, ix->d_status);
+    HIP_TRY(hipGetLastError());
+    return MEMO_OK;
+}
+
+static int long_rows_membership(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int ncols, int nw,
+                                uint32_t *d_out, hipStream_t st) {
+    if (!ix->n_long) return MEMO_OK;
+    hipLaunchKernelGGL(long_rows_membership_kernel, dim3((unsigned)ix->n_long), dim3(256), 0, st, ix->ls,
+                       ix->le, ix->lo, qs, qe, k - 1, ncols, nw, d_out, ix->d_status);
+    HIP_TRY(hipGetLastError());
+    return MEMO_OK;
+}
+
+template <typename OutT>
 static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
                               OutT *d_out, void *stream) {
     read_env_once();
@@ -907,7 +998,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         hipLaunchKernelGGL((fill_conservation_kernel<OutT>), dim3(2048), dim3(256), 0, st, d_out,
                            qe - qs, (OutT)num_docs);
         HIP_TRY(hipGetLastError());
-        return MEMO_OK;
+        return long_rows_conservation<OutT>(ix, qs, qe, k, num_docs + 1, d_out, st);
     }
     SweepArgs A;
     fill_args(ix, A, qs, qe, k, d_out);
@@ -939,7 +1030,8 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                              : cons_kernel<PackedRows<true, false>, OutT>(w, waves))
                                   : cons_kernel<WideRows, OutT>(w, waves);
     if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-    return launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * (w + kLevelSkew) * 4, st);
+    if ((rc = launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * (w + kLevelSkew) * 4, st))) return rc;
+    return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
 }
 
 // ==========================================================================================
@@ -1023,6 +1115,9 @@ void memo_index_destroy(memo_index_t *ix) {
     (void)hipFree(ix->boff);
     (void)hipFree(ix->pk);
     (void)hipFree(ix->pa);
+    (void)hipFree(ix->ls);
+    (void)hipFree(ix->le);
+    (void)hipFree(ix->lo);
     (void)hipFree(ix->d_status);
     (void)hipFree(ix->d_scratch);
     delete ix;
@@ -1117,9 +1212,25 @@ int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_so
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(h, ix->d_scratch, 24, hipMemcpyDeviceToHost));
         if (h[2]) return fail(MEMO_EINVAL, "%llu rows have coordinates beyond +-2^61", (unsigned long long)h[2]);
-        if (h[1])
-            return fail(MEMO_ELONGROW, "%llu rows have end < start: not a MEMO overlap index",
-                        (unsigned long long)h[1]);
+        (void)hipFree(ix->ls);
+        (void)hipFree(ix->le);
+        (void)hipFree(ix->lo);
+        ix->ls = ix->le = ix->lo = nullptr;
+        ix->n_long = 0;
+        if (h[1]) {  // rows with end < start: set aside for long_rows_kernel
+            if (h[1] > ((uint64_t)1 << 22))
+                return fail(MEMO_ELONGROW, "%llu rows have end < start: not a MEMO overlap index",
+                            (unsigned long long)h[1]);
+            HIP_TRY(hipMalloc(&ix->ls, h[1] * sizeof(int64_t)));
+            HIP_TRY(hipMalloc(&ix->le, h[1] * sizeof(int64_t)));
+            HIP_TRY(hipMalloc(&ix->lo, h[1] * sizeof(int64_t)));
+            HIP_TRY(hipMemsetAsync(ix->d_scratch + 6, 0, 8, st));
+            hipLaunchKernelGGL(collect_long_rows_kernel, dim3(grid), dim3(256), 0, st, ix->s, ix->e, ix->o, rows,
+                               ix->ls, ix->le, ix->lo, (unsigned long long *)(ix->d_scratch + 6));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));
+            ix->n_long = h[1];
+        }
         if (h[0]) {
             ix->was_sorted = 0;
             if (!allow_sort)
@@ -1231,7 +1342,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         hipLaunchKernelGGL(fill_membership_kernel, dim3(2048), dim3(256), 0, st, d_out,
                            (qe - qs) * nw, nw, num_docs);
         HIP_TRY(hipGetLastError());
-        return MEMO_OK;
+        return long_rows_membership(ix, qs, qe, k, num_docs, nw, d_out, st);
     }
     SweepArgs A;
     fill_args(ix, A, qs, qe, k, d_out);
@@ -1265,7 +1376,8 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                                  : memb_runs_kernel<PackedRows<true, false>>(w, waves))
                                       : memb_runs_kernel<WideRows>(w, waves);
         if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-        return launch_tiles(kern, A, w, 64 * waves, lds, st);
+        if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st))) return rc;
+        return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
     }
     const bool doubling = algo == 2;
     const size_t per_pos = doubling ? per_pos_doubling : (size_t)nw * 4;
@@ -1283,7 +1395,8 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                              : memb_kernel<PackedRows<true, false>>(w, waves, doubling))
                                   : memb_kernel<WideRows>(w, waves, doubling);
     if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-    return launch_tiles(kern, A, w, 64 * waves, per_pos * w, st);
+    if ((rc = launch_tiles(kern, A, w, 64 * waves, per_pos * w, st))) return rc;
+    return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
 }
 
 int memo_query_check(memo_index_t *ix, void *stream) {

@@ -233,6 +233,26 @@ def main():
                             qe = qs + 120_000 // n
                         run_case(manifest, f"{name}_{tag}_k{k}_c{ci}w{wi}", pq, k, n,
                                  f"{cname}:{qs}-{qe}", memb, work)
+    # --- rows with end < start: never written by dap_to_bed.py (:93-98) but legal input to
+    # memo_query.py, where they shade [end-(k-1), start) like any other row -- possibly far more
+    # than k-1 positions
+    rng2 = np.random.default_rng(0xBEEF)
+    lines = []
+    starts = np.sort(rng2.integers(1, 3000, size=4000))
+    for st_ in starts:
+        st_ = int(st_)
+        if rng2.random() < 0.08:
+            en = st_ - int(rng2.integers(1, 400))
+        else:
+            en = st_ + int(rng2.integers(0, 70))
+        lines.append(f"chrN\t{st_}\t{max(en, 0)}\t{int(rng2.integers(1, 12))}")
+    pqn = make_random_index(work, "rnd_negoverlap", "\n".join(lines) + "\n")
+    for memb in (False, True):
+        tag = "memb" if memb else "cons"
+        for k in (1, 2, 31, 101):
+            for wi, (qs, qe) in enumerate(((0, 3100), (700, 1900), (2900, 3300))):
+                run_case(manifest, f"rnd_negoverlap_{tag}_k{k}_w{wi}", pqn, k, 12, f"chrN:{qs}-{qe}", memb, work)
+
     # --- `memo view` binning (plot_conservation.py:46-65): per-bin composition of a conservation
     # vector; plotnine is absent here and only needed for drawing, so it is stubbed for the import
     pn = types.ModuleType("plotnine")
