@@ -255,6 +255,13 @@ def main():
             tj = json.load(open(prof)).get(f"{args.workload}_{args.rows}")
             if tj:
                 res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+        if multi:
+            # what the same run delivers when the result slices stay on their GPUs (no root):
+            # every rank's sweep time from its own HIP events, slowest rank counts
+            res["without_gather"] = {"value": L * world / (kern_ms * 1e-3), "unit": "query-positions/s",
+                                     "note": "aggregate of the per-rank sweeps alone (max kernel_ms over ranks); "
+                                             "`value` above includes delivering every slice to rank 0, which is "
+                                             f"bound by {b_out * L / 1e6:.0f} MB per peer link per step"}
         if other:
             res["other_row_format"] = other
         if world == 1 and args.cpu_sample > 0:

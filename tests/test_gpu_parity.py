@@ -407,3 +407,29 @@ def test_cli_sharded_path_single_rank(memo, tmp_path):
         r = subprocess.run(argv, capture_output=True, env=dict(os.environ, MEMO_FORCE_SHARDED="1", MASTER_PORT="29541"))
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert G.sha(out.read_bytes()) == c["sha256"]
+
+
+def test_more_than_2_pow_32_rows(memo, oracle):
+    """4.4e9 rows (106 GB of int64 columns + 18 GB packed in HBM): row numbers, byte offsets and
+    pivot coordinates beyond 32 bits; windows at both ends against the oracle."""
+    from memo_amd import synth
+    n, k = 20, 31                                   # 1 row per pivot position
+    pivot = 4_400_000_000
+    num, den = synth.rows_per_position(n)
+    ix, (r0, r1) = synth.device_index(0, pivot, k, n, pivot, pack="keep")
+    with ix:
+        assert r1 - r0 > 2 ** 32 and ix.info()["rows"] == r1 - r0 and ix.info()["packed_format"] == 4
+        from memo_amd import _lib
+        for source in (0, 1):                       # packed rows, then the int64 columns
+            _lib.check(_lib.lib().memo_set_row_source(source))
+            try:
+                for a in (0, 2 ** 32 - 70_000, pivot - 150_000):
+                    b = min(a + 140_001, pivot + 100)
+                    sr0, sr1 = synth.shard_rows(a, b, k, num, den, pivot)
+                    s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
+                    want = oracle.conservation(s, e, o, a, b, k, n, literal=False)
+                    assert np.array_equal(ix.conservation(a, b, k, n), want), (source, a)
+                    wantb = oracle.membership(s, e, o, a, a + 3000, k, n, literal=False)
+                    assert np.array_equal(ix.membership(a, a + 3000, k, n), wantb), (source, a)
+            finally:
+                _lib.check(_lib.lib().memo_set_row_source(0))
