@@ -191,6 +191,12 @@ __device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t) {
     return true;
 }
 
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() would
+// wait for vmcnt(0) first (cdna_hip_programming.md, "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Row sources.  Each streams the tile's row slice once and hands f(c, h, col) the rows that
 // write: [c, h) = the row's interval clipped to the tile (memo_query.py:46-49: recentre,
 // shadow-cast by k-1, clip, keep casted_end < start), col = its column after the index check
@@ -210,8 +216,12 @@ __device__ __forceinline__ bool check_col(const SweepArgs &A, int64_t o, int &co
 // (16 B / lane, 1 KiB / wave), U loads of each column in flight per lane.
 struct WideRows {
     static constexpr int kLoads = MEMO_KU;  // loads of each column in flight per lane
-    template <int T, int U, typename F>
-    static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, F f) {
+    // `between` runs once, in every thread, before any row is handed to f: the kernels clear their
+    // LDS tile there.  PackedRows issues its first batch of loads before it; here (ten batches per
+    // tile, HBM-bound) that ordering measured 5 % slower, so the tile is cleared first.
+    template <int T, int U, typename B, typename F>
+    static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, B between, F f) {
+        between();
         const int tid = threadIdx.x;
         auto one = [&](int64_t s, int64_t e, int64_t o) {
             const int h = clamp_to_tile(s - t.a, t.x_lo, t.x_hi);
@@ -277,8 +287,8 @@ __device__ __forceinline__ int pin_vgpr(int uniform) {
 template <bool ANNOT16, bool CHECKED>
 struct PackedRows {
     static constexpr int kLoads = 2 * MEMO_KU;  // A/B: 8 x 16 B in flight per lane, 5 % over 4
-    template <int T, int U, typename F>
-    static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, F f) {
+    template <int T, int U, typename B, typename F>
+    static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, B between, F f) {
         const int tid = threadIdx.x;
         const uint32_t a16 = (uint32_t)t.a & 0xFFFFu;
         // 32-bit row numbers relative to the 128-byte-aligned start of the slice
@@ -301,7 +311,8 @@ struct PackedRows {
             }
             f(c, h, (int)annot);  // f writes iff h > c
         };
-        for (uint32_t rel = 4 * tid; rel < end; rel += 4 * T * U) {
+        bool first_batch = true;
+        for (uint32_t rel = 4 * tid; first_batch || rel < end; rel += 4 * T * U) {
             uint4 V[U];
             uint2 N[U];
 #pragma unroll
@@ -314,6 +325,10 @@ struct PackedRows {
                     V[u] = make_uint4(dead, dead, dead, dead);
                     N[u] = make_uint2(0u, 0u);
                 }
+            }
+            if (first_batch) {
+                between();
+                first_batch = false;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -353,24 +368,24 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
     Tile t;
     if (!locate_tile<W>(A, t)) return;
 
-    // every level starts at the sentinel column N (memo_query.py:53-54)
-    {
-        const uint32_t sent = (uint32_t)(A.ncols - 1);
-        const uint4 sv = make_uint4(sent, sent, sent, sent);
-        uint4 *p = reinterpret_cast<uint4 *>(lds);
-        for (int i = tid; i < A.nlev * (LS / 4); i += T) p[i] = sv;
-    }
-    __syncthreads();
-
     // the clipped interval [c, h) is the union of two blocks of 2^j, j = floor(log2(h - c))
-    Rows::template for_each<T, U>(A, t, [&](int c, int h, int col) {
-        if (h > c) {
-            const int j = 31 - __builtin_clz((unsigned)(h - c));  // h - c >= 1
-            uint32_t *lv = lds + j * LS;
-            atomicMin(lv + c, (uint32_t)col);               // block [c, c + 2^j)
-            atomicMin(lv + (h - (1 << j)), (uint32_t)col);  // block [h - 2^j, h)
-        }
-    });
+    Rows::template for_each<T, U>(
+        A, t,
+        [&]() {  // every level starts at the sentinel column N (memo_query.py:53-54)
+            const uint32_t sent = (uint32_t)(A.ncols - 1);
+            const uint4 sv = make_uint4(sent, sent, sent, sent);
+            uint4 *p = reinterpret_cast<uint4 *>(lds);
+            for (int i = tid; i < A.nlev * (LS / 4); i += T) p[i] = sv;
+            lds_barrier();
+        },
+        [&](int c, int h, int col) {
+            if (h > c) {
+                const int j = 31 - __builtin_clz((unsigned)(h - c));  // h - c >= 1
+                uint32_t *lv = lds + j * LS;
+                atomicMin(lv + c, (uint32_t)col);               // block [c, c + 2^j)
+                atomicMin(lv + (h - (1 << j)), (uint32_t)col);  // block [h - 2^j, h)
+            }
+        });
     __syncthreads();
 
     // fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1)
@@ -469,14 +484,13 @@ __global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) 
     const int nlev = DOUBLING ? A.nlev : 1;
     const int plane = W * nw;  // words per level
 
-    {
+    auto clear_tile = [&]() {
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         uint4 *p = reinterpret_cast<uint4 *>(lds);
         for (int i = tid; i < nlev * plane / 4; i += T) p[i] = z;
-    }
-    __syncthreads();
-
-    Rows::template for_each<T, U>(A, t, [&](int c, int h, int col) {
+        lds_barrier();
+    };
+    Rows::template for_each<T, U>(A, t, clear_tile, [&](int c, int h, int col) {
         if (h <= c) return;
         const uint32_t bit = 1u << (col & 31);
         const int word = col >> 5;
@@ -560,10 +574,11 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
     // genome g lives at g * PW + (g >> 5): the extra word per 32 genomes keeps the four lanes that
     // read the same position word of different genome groups on different banks
     const int total = 32 * nw * PW + nw;
-    for (int i = tid; i < total; i += T) lds[i] = 0;
-    __syncthreads();
-
-    Rows::template for_each<T, U>(A, t, [&](int c, int h, int col) {
+    auto clear_tile = [&]() {
+        for (int i = tid; i < total; i += T) lds[i] = 0;
+        lds_barrier();
+    };
+    Rows::template for_each<T, U>(A, t, clear_tile, [&](int c, int h, int col) {
         if (h <= c) return;
         uint32_t *row = lds + col * PW + (col >> 5);
         const int w0 = c >> 5, w1 = (h - 1) >> 5;
