@@ -81,10 +81,31 @@ def cpu_baseline(args, num_docs, L, k, membership, gpu_result_slice):
     want = fn(s, e, o, 0, S, k, num_docs, literal=True)
     dt = time.perf_counter() - t0
     ok = bool(np.array_equal(want, gpu_result_slice(S)))
-    return {"value": S / dt, "unit": "query-positions/s", "cores": 1, "kind": "port",
+    base = {"value": S / dt, "unit": "query-positions/s", "cores": 1, "kind": "port",
             "sample": f"first {S} positions of the window ({r1 - r0} rows), literal bool-matrix "
                       f"port of memo_query.py:45-63,70 (oracle_literal_*), {dt:.1f} s",
             "parity_with_gpu_on_sample": ok}
+    # the strong CPU baseline of SURVEY.md 8(d)(ii): closed form (no L x N matrix), the window cut
+    # into one sub-window per thread (the same sharding rule the GPUs use), all in C (GIL released)
+    import concurrent.futures as cf
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    cuts = np.linspace(0, S, threads + 1).astype(np.int64)
+    fn2 = oracle.membership if membership else oracle.conservation
+
+    def part(i):
+        a, b = int(cuts[i]), int(cuts[i + 1])
+        i0 = int(np.searchsorted(s, a, side="right"))
+        i1 = int(np.searchsorted(s, b + k, side="left"))
+        return fn2(s[i0:i1], e[i0:i1], o[i0:i1], a, b, k, num_docs, literal=False)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(threads) as pool:
+        parts = list(pool.map(part, range(threads)))
+    dt2 = time.perf_counter() - t0
+    ok2 = bool(np.array_equal(np.concatenate(parts), want))
+    base["all_cores"] = {"value": S / dt2, "unit": "query-positions/s", "cores": threads, "kind": "port",
+                         "sample": f"same {S} positions, closed-form restatement (oracle_closed_*) on {threads} "
+                                   f"threads, one sub-window each, {dt2:.2f} s", "equal_to_literal_port": ok2}
+    return base
 
 
 def main():

@@ -86,6 +86,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        if not os.path.exists(SO_PATH) and not os.environ.get("MEMO_AMD_LIB"):
+            try:                                  # compile the real thing; never substitute for it
+                build()
+            except Exception:
+                pass
         if not os.path.exists(SO_PATH):
             raise ImportError(f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                               "g.build()'` or `make -C memo_amd/csrc` -- there is no CPU fallback")

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 def memo():
     import memo_amd
     from memo_amd import _lib
+    memo_amd.build()                     # make: a no-op when libmemo_amd.so is up to date
     assert _lib.lib().memo_device_count() > 0, "no HIP device: the product has no CPU fallback"
     return memo_amd
 
