@@ -1,0 +1,76 @@
+// memo_common.h -- shared by the translation units of libmemo_amd.so (not part of the public ABI).
+#ifndef MEMO_COMMON_H
+#define MEMO_COMMON_H
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "memo_amd.h"
+
+namespace memo {
+
+// error plumbing: every C-ABI function returns fail(code, ...) on error; the message is what
+// memo_last_error() hands out (thread-local, defined in memo_index.hip)
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+struct DeviceGuard {  // the caller (e.g. torch) keeps its own notion of the current device
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+constexpr uint64_t kPadRows = 4096;           // sentinel rows behind the last real row
+constexpr int64_t kSentinel = INT64_MAX / 4;  // start/end of a padding row: clips to "empty"
+constexpr int kDefaultBucketShift = 5;        // 32 pivot positions per bucket
+constexpr int64_t kCoordLimit = (int64_t)1 << 61;
+constexpr int kStatusBadAnnot = 1;            // sticky device flag: the reference's IndexError case
+
+}  // namespace memo
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t err__ = (expr);                                                             \
+        if (err__ != hipSuccess)                                                               \
+            return memo::fail(MEMO_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(err__),    \
+                              __FILE__, __LINE__);                                             \
+    } while (0)
+
+// one chromosome's rows, resident in HBM (the opaque memo_index_t of the ABI)
+struct memo_index {
+    int device = 0;
+    uint64_t rows = 0;
+    uint64_t padded = 0;
+    int64_t *s = nullptr, *e = nullptr, *o = nullptr;
+    int64_t *boff = nullptr;  // boff[b] = first row with start >= (b << bshift); boff[nb-1] == rows
+    uint64_t nb = 0;
+    int bshift = 0;
+    int64_t min_s = 0, max_s = -1;
+    int finalized = 0;
+    int was_sorted = 0;
+    // packed rows (memo_index_pack): word = start & 0xFFFF | min(end - start, 255) << 16 | annot8 << 24
+    uint32_t *pk = nullptr;
+    uint16_t *pa = nullptr;    // format 6 only: 16-bit annot per row (the word's top byte is 0)
+    int packed_fmt = 0;        // 0 = none, 4 = word only (annot <= 255), 6 = word + 16-bit annot
+    uint64_t max_annot = 0;    // largest annot of the packed rows
+    int has_wide = 1;          // the three int64 columns are still resident
+    // rows with end < start (never written by the reference's index builder, but legal input to
+    // memo_query.py): copied aside at finalize and applied by long_rows_kernel after each sweep
+    int64_t *ls = nullptr, *le = nullptr, *lo = nullptr;
+    uint64_t n_long = 0;
+    int *d_status = nullptr;   // sticky flags set by the sweep kernels
+    uint64_t *d_scratch = nullptr;  // finalize(): [0] unsorted pairs, [1] rows with end < start
+};
+
+#endif  // MEMO_COMMON_H

@@ -1,110 +1,26 @@
-// memo_kernels.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI of the MEMO windowed query path.
+// memo_sweep.hip -- the hot path: MI355X (gfx950 / CDNA4) sweep kernels and their launchers.
 //
-// Replaces /root/reference/src/memo_query.py:42-63 and :70 (memo_init + memo_query +
-// the argmax reduction of print_res).  See DESIGN.md for the algorithm; in short:
+// Replaces /root/reference/src/memo_query.py:42-63 and :70 (memo_init + memo_query + the argmax
+// reduction of print_res).  DESIGN.md section 3 has the algorithm; in short:
 //
-//   * one 64-lane wave owns one TILE of W consecutive pivot positions and is fully
-//     independent of every other wave (no inter-workgroup traffic, no barriers that
-//     span waves);
-//   * the rows that can touch the tile are a contiguous slice of the start-sorted
-//     columns, found with two loads from a bucket table built once per index;
-//   * rows are streamed from HBM with 16-byte-per-lane coalesced loads, each row is
-//     clipped to the tile and scattered into LDS;
-//       conservation: the clipped interval [c, h) is covered by two power-of-two
-//         blocks, one ds_min_u32 each into the level-log2 array; afterwards the levels
-//         are folded top-down (block of 2^j -> two blocks of 2^(j-1)) so that level 0
-//         holds min(order) per position.  min is idempotent and commutative, so the
-//         overlap of the two blocks and the arrival order of atomics cannot change a
-//         bit of the result.
-//       membership: one ds_and_b32 per covered (position, genome) bit.
-//   * the tile is written out with 16-byte stores.
+//   * a workgroup of one or four 64-lane waves owns one TILE of W consecutive pivot positions
+//     and never talks to another workgroup;
+//   * the rows that can touch the tile are a contiguous slice of the start-sorted index, found
+//     with two loads from a bucket table built once per index; they are streamed from HBM with
+//     16-byte-per-lane loads, either as the three int64 columns (WideRows) or as the packed
+//     4/6-byte rows of memo_index_pack (PackedRows);
+//   * conservation: each row's interval, clipped to the tile, is covered by two power-of-two
+//     blocks (one ds_min_u32 each into the level-log2 array); the levels are then folded
+//     top-down so that level 0 holds min(order) per position;
+//   * membership: per-genome bit planes (a row is one run of bits) + an in-register 32 x 32 bit
+//     transpose, or the doubling scheme on bit cells;
+//   * min / or are idempotent and commutative: overlapping blocks and the arrival order of the
+//     atomics cannot change a bit of the result.
 //
-// Integer work only (int64 compares, min, and): no MFMA.  Bound: HBM bandwidth.
-#include <hip/hip_runtime.h>
+// Integer work only: no MFMA.  Bound: HBM bandwidth (int64 rows), HBM + LDS atomics (packed rows).
+#include "memo_common.h"
 
-#include <climits>
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-
-#include "memo_amd.h"
-
-extern "C" int memo_sort_rows_by_start(int64_t *s, int64_t *e, int64_t *o, uint64_t rows,
-                                       uint64_t padded_rows, hipStream_t stream, char *err,
-                                       size_t errcap);
-
-namespace {
-
-// ------------------------------------------------------------------------------------------
-// error plumbing
-// ------------------------------------------------------------------------------------------
-thread_local char g_err[512] = "";
-
-int fail(int code, const char *fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                     \
-    do {                                                                                  \
-        hipError_t err__ = (expr);                                                        \
-        if (err__ != hipSuccess)                                                          \
-            return fail(MEMO_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(err__),     \
-                        __FILE__, __LINE__);                                              \
-    } while (0)
-
-struct DeviceGuard {  // the caller (e.g. torch) keeps its own notion of the current device
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
-    }
-    ~DeviceGuard() {
-        int cur = -1;
-        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
-    }
-};
-
-constexpr uint64_t kPadRows = 4096;           // sentinel rows behind the last real row
-constexpr int64_t kSentinel = INT64_MAX / 4;  // start/end of a padding row: clips to "empty"
-constexpr int kDefaultBucketShift = 5;        // 32 pivot positions per bucket
-constexpr int64_t kCoordLimit = (int64_t)1 << 61;
-
-constexpr int kStatusBadAnnot = 1;
-
-}  // namespace
-
-struct memo_index {
-    int device = 0;
-    uint64_t rows = 0;
-    uint64_t padded = 0;
-    int64_t *s = nullptr, *e = nullptr, *o = nullptr;
-    int64_t *boff = nullptr;  // boff[b] = first row with start >= (b << bshift); boff[nb-1] == rows
-    uint64_t nb = 0;
-    int bshift = 0;
-    int64_t min_s = 0, max_s = -1;
-    int finalized = 0;
-    int was_sorted = 0;
-    // packed rows (memo_index_pack): word = start & 0xFFFF | min(end - start, 255) << 16 | annot8 << 24
-    uint32_t *pk = nullptr;
-    uint16_t *pa = nullptr;    // format 6 only: 16-bit annot per row (the word's top byte is 0)
-    int packed_fmt = 0;        // 0 = none, 4 = word only (annot <= 255), 6 = word + 16-bit annot
-    uint64_t max_annot = 0;    // largest annot of the packed rows
-    int has_wide = 1;          // the three int64 columns are still resident
-    // rows with end < start (never written by the reference's index builder, but legal input to
-    // memo_query.py): copied aside at finalize and applied by long_rows_kernel after each sweep
-    int64_t *ls = nullptr, *le = nullptr, *lo = nullptr;
-    uint64_t n_long = 0;
-    int *d_status = nullptr;   // sticky flags set by the sweep kernels
-    uint64_t *d_scratch = nullptr;  // finalize(): [0] unsorted pairs, [1] rows with end < start
-};
+using namespace memo;
 
 namespace {
 
@@ -631,46 +547,6 @@ __global__ void fill_membership_kernel(uint32_t *out, int64_t n, int nw, int nco
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// index build: validation, padding, bucket table, synthetic rows
-// ------------------------------------------------------------------------------------------
-__global__ void check_rows_kernel(const int64_t *s, const int64_t *e, uint64_t rows,
-                                  uint64_t *scratch) {
-    uint64_t unsorted = 0, longrow = 0, wild = 0;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < rows;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        const int64_t si = s[i], ei = e[i];
-        if (i > 0 && s[i - 1] > si) ++unsorted;
-        if (ei < si) ++longrow;
-        if (si <= -kCoordLimit || si >= kCoordLimit || ei <= -kCoordLimit || ei >= kCoordLimit) ++wild;
-    }
-    if (unsorted) atomicAdd((unsigned long long *)&scratch[0], (unsigned long long)unsorted);
-    if (longrow) atomicAdd((unsigned long long *)&scratch[1], (unsigned long long)longrow);
-    if (wild) atomicAdd((unsigned long long *)&scratch[2], (unsigned long long)wild);
-}
-
-__global__ void pad_rows_kernel(int64_t *s, int64_t *e, int64_t *o, uint64_t rows, uint64_t padded) {
-    const uint64_t i = rows + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (i < padded) {
-        s[i] = kSentinel;
-        e[i] = kSentinel;
-        o[i] = 0;
-    }
-}
-
-// finalize: copy the rows with end < start aside (order is irrelevant: min / and commute)
-__global__ void collect_long_rows_kernel(const int64_t *s, const int64_t *e, const int64_t *o, uint64_t rows,
-                                         int64_t *ls, int64_t *le, int64_t *lo, unsigned long long *count) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < rows;
-         i += (uint64_t)gridDim.x * blockDim.x)
-        if (e[i] < s[i]) {
-            const unsigned long long k = atomicAdd(count, 1ull);
-            ls[k] = s[i];
-            le[k] = e[i];
-            lo[k] = o[i];
-        }
-}
-
 // One workgroup per row with end < start: its interval [clip(e-qs-(k-1)), clip(s-qs)) can be any
 // length, so it is applied straight to the result in HBM, after the sweep, with atomics (rows may
 // overlap each other).  filter_pq keeps such a row iff qs < start < qe + k (memo_query.py:25-27).
@@ -724,119 +600,6 @@ __global__ void long_rows_membership_kernel(const int64_t *ls, const int64_t *le
     for (int64_t p = c + threadIdx.x; p < hi; p += blockDim.x) atomicAnd(out + p * nw + (cc >> 5), keep);
 }
 
-// memo_index_pack: annot range census, then one word (+ optional 16-bit annot) per row
-__global__ void annot_census_kernel(const int64_t *o, uint64_t rows, uint64_t *scratch) {
-    uint64_t outside = 0, over8 = 0, top = 0;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < rows;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        const int64_t v = o[i];
-        if (v < 0 || v > 65535) ++outside;
-        else if ((uint64_t)v > top) top = (uint64_t)v;
-        if (v > 255) ++over8;
-    }
-    if (outside) atomicAdd((unsigned long long *)&scratch[3], (unsigned long long)outside);
-    if (over8) atomicAdd((unsigned long long *)&scratch[4], (unsigned long long)over8);
-    if (top) atomicMax((unsigned long long *)&scratch[5], (unsigned long long)top);
-}
-
-__global__ void pack_rows_kernel(const int64_t *s, const int64_t *e, const int64_t *o, uint64_t rows,
-                                 uint64_t padded, uint32_t *pk, uint16_t *pa) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < padded;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t w = 0, a = 0;
-        if (i < rows) {
-            const int64_t len = e[i] - s[i];
-            // end < start (handled by long_rows_kernel) packs as "never writes", like len >= 255
-            w = ((uint32_t)s[i] & 0xFFFFu) | ((uint32_t)(len > 255 || len < 0 ? 255 : len) << 16);
-            a = (uint32_t)o[i];
-        }
-        if (pa) pa[i] = (uint16_t)a; else w |= a << 24;
-        pk[i] = w;
-    }
-}
-
-// boff[b] = lower_bound(start, b << shift); the last bucket is pinned to `rows`
-__global__ void bucket_table_kernel(const int64_t *s, uint64_t rows, int64_t *boff, uint64_t nb,
-                                    int shift) {
-    const uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    if (b == nb - 1) {
-        boff[b] = (int64_t)rows;
-        return;
-    }
-    const int64_t key = (int64_t)(b << shift);
-    uint64_t lo = 0, hi = rows;
-    while (lo < hi) {
-        const uint64_t mid = lo + ((hi - lo) >> 1);
-        if (s[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    boff[b] = (int64_t)lo;
-}
-
-// `memo view` binning (plot_conservation.py:52-56): counts[b][v] = #{p in [edge[b], edge[b+1]) : vec[p] == v}
-// for v in 0..num_docs.  One workgroup per (bin, slice of the bin); LDS histogram when it fits.
-template <bool LDS_HIST>
-__global__ __launch_bounds__(256) void bin_conservation_kernel(const uint16_t *vec, const int64_t *edges,
-                                                               int ncols, int slices,
-                                                               unsigned long long *counts) {
-    extern __shared__ uint32_t hist[];
-    const int b = blockIdx.x / slices, sl = blockIdx.x % slices;
-    const int64_t lo = edges[b], hi = edges[b + 1];
-    const int64_t per = (hi - lo + slices - 1) / slices;
-    const int64_t p0 = lo + sl * per, p1 = p0 + per < hi ? p0 + per : hi;
-    if (LDS_HIST) {
-        for (int i = threadIdx.x; i < ncols; i += 256) hist[i] = 0;
-        __syncthreads();
-    }
-    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
-        const int v = vec[p];
-        if (v < ncols) {
-            if (LDS_HIST) atomicAdd(&hist[v], 1u);
-            else atomicAdd(&counts[(int64_t)b * ncols + v], 1ull);
-        }
-    }
-    if (LDS_HIST) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < ncols; i += 256)
-            if (hist[i]) atomicAdd(&counts[(int64_t)b * ncols + i], (unsigned long long)hist[i]);
-    }
-}
-
-// PMC calibration: reads every row of the three columns exactly once with the sweep's own
-// access shape (16 B per lane, 1 KiB per wave-instruction) and nothing else, so that
-// FETCH_SIZE can be checked against a known byte count (24 B x padded rows) in the same run.
-__global__ void stream_rows_kernel(const int64_t *s, const int64_t *e, const int64_t *o,
-                                   uint64_t rows, unsigned long long *sink) {
-    long long acc = 0;
-    for (uint64_t i = 2 * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x); i < rows;
-         i += 2 * (uint64_t)gridDim.x * blockDim.x) {
-        const longlong2 a = *reinterpret_cast<const longlong2 *>(s + i);
-        const longlong2 b = *reinterpret_cast<const longlong2 *>(e + i);
-        const longlong2 c = *reinterpret_cast<const longlong2 *>(o + i);
-        acc += a.x ^ a.y ^ b.x ^ b.y ^ c.x ^ c.y;
-    }
-    if (acc == 0x7fffffffffffffffll) atomicAdd(sink, 1ull);  // keeps the loads alive
-}
-
-__device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t x) {
-    uint64_t z = seed + (x + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
-__global__ void synth_rows_kernel(int64_t *s, int64_t *e, int64_t *o, uint64_t rows,
-                                  uint64_t row_begin, uint64_t num, uint64_t den, uint64_t nm1,
-                                  uint64_t seed) {
-    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < rows;
-         j += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t i = row_begin + j;
-        const int64_t st = 1 + (int64_t)((i * den) / num);
-        s[j] = st;
-        e[j] = st + (int64_t)(mix64(seed, 2 * i) % 60);
-        o[j] = 1 + (int64_t)(mix64(seed, 2 * i + 1) % nm1);
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // launch helpers
@@ -1049,20 +812,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
 }
 
-// ==========================================================================================
-// C ABI
-// ==========================================================================================
 extern "C" {
-
-const char *memo_last_error(void) { return g_err; }
-
-const char *memo_version(void) { return "memo_amd 0.1 (gfx950)"; }
-
-int memo_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
 
 int memo_set_row_source(int32_t source) {
     read_env_once();
@@ -1081,256 +831,6 @@ int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo) {
     g_tile_w = tile_w;
     g_waves = waves;
     g_memb_algo = membership_algo;
-    return MEMO_OK;
-}
-
-static void drop_packed(memo_index *ix) {  // the rows are about to change
-    (void)hipFree(ix->pk);
-    (void)hipFree(ix->pa);
-    ix->pk = nullptr;
-    ix->pa = nullptr;
-    ix->packed_fmt = 0;
-}
-
-int memo_index_create(uint64_t rows, int32_t device, memo_index_t **out) {
-    if (!out) return fail(MEMO_EINVAL, "out is NULL");
-    *out = nullptr;
-    if (rows > ((uint64_t)1 << 40)) return fail(MEMO_EINVAL, "too many rows");
-    int ndev = memo_device_count();
-    if (device < 0 || device >= ndev)
-        return fail(MEMO_EHIP, "HIP device %d not available (%d visible)", device, ndev);
-    DeviceGuard guard(device);
-    if (!guard.ok) return fail(MEMO_EHIP, "cannot select HIP device %d", device);
-    memo_index *ix = new (std::nothrow) memo_index();
-    if (!ix) return fail(MEMO_EHIP, "out of host memory");
-    ix->device = device;
-    ix->rows = rows;
-    ix->padded = ((rows + 15) & ~(uint64_t)15) + kPadRows;
-    const size_t bytes = ix->padded * sizeof(int64_t);
-    hipError_t err = hipMalloc(&ix->s, bytes);
-    if (err == hipSuccess) err = hipMalloc(&ix->e, bytes);
-    if (err == hipSuccess) err = hipMalloc(&ix->o, bytes);
-    if (err == hipSuccess) err = hipMalloc(&ix->d_status, 64);
-    if (err == hipSuccess) err = hipMalloc(&ix->d_scratch, 64);
-    if (err == hipSuccess) err = hipMemset(ix->d_status, 0, 64);
-    if (err != hipSuccess) {
-        memo_index_destroy(ix);
-        return fail(MEMO_EHIP, "hipMalloc of %zu bytes x3 failed: %s", bytes, hipGetErrorString(err));
-    }
-    *out = ix;
-    return MEMO_OK;
-}
-
-void memo_index_destroy(memo_index_t *ix) {
-    if (!ix) return;
-    DeviceGuard guard(ix->device);
-    (void)hipFree(ix->s);
-    (void)hipFree(ix->e);
-    (void)hipFree(ix->o);
-    (void)hipFree(ix->boff);
-    (void)hipFree(ix->pk);
-    (void)hipFree(ix->pa);
-    (void)hipFree(ix->ls);
-    (void)hipFree(ix->le);
-    (void)hipFree(ix->lo);
-    (void)hipFree(ix->d_status);
-    (void)hipFree(ix->d_scratch);
-    delete ix;
-}
-
-int memo_index_upload(memo_index_t *ix, const int64_t *start, const int64_t *end,
-                      const int64_t *annot, uint64_t rows) {
-    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
-    if (rows != ix->rows) return fail(MEMO_EINVAL, "upload of %llu rows into an index of %llu",
-                                      (unsigned long long)rows, (unsigned long long)ix->rows);
-    if (rows && (!start || !end || !annot)) return fail(MEMO_EINVAL, "column pointer is NULL");
-    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns of this index were dropped by memo_index_pack");
-    DeviceGuard guard(ix->device);
-    drop_packed(ix);
-    if (rows) {
-        HIP_TRY(hipMemcpy(ix->s, start, rows * sizeof(int64_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ix->e, end, rows * sizeof(int64_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ix->o, annot, rows * sizeof(int64_t), hipMemcpyHostToDevice));
-    }
-    ix->finalized = 0;
-    return MEMO_OK;
-}
-
-int memo_index_upload_rows(memo_index_t *ix, uint64_t row_offset, const int64_t *start,
-                           const int64_t *end, const int64_t *annot, uint64_t rows) {
-    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
-    if (row_offset > ix->rows || rows > ix->rows - row_offset)
-        return fail(MEMO_EINVAL, "rows [%llu, +%llu) do not fit an index of %llu rows",
-                    (unsigned long long)row_offset, (unsigned long long)rows, (unsigned long long)ix->rows);
-    if (rows && (!start || !end || !annot)) return fail(MEMO_EINVAL, "column pointer is NULL");
-    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns of this index were dropped by memo_index_pack");
-    DeviceGuard guard(ix->device);
-    drop_packed(ix);
-    if (rows) {
-        HIP_TRY(hipMemcpy(ix->s + row_offset, start, rows * sizeof(int64_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ix->e + row_offset, end, rows * sizeof(int64_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ix->o + row_offset, annot, rows * sizeof(int64_t), hipMemcpyHostToDevice));
-    }
-    ix->finalized = 0;
-    return MEMO_OK;
-}
-
-int memo_index_truncate(memo_index_t *ix, uint64_t rows) {
-    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
-    if (rows > ix->rows) return fail(MEMO_EINVAL, "cannot grow an index (%llu > %llu rows)",
-                                     (unsigned long long)rows, (unsigned long long)ix->rows);
-    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns of this index were dropped by memo_index_pack");
-    {
-        DeviceGuard guard(ix->device);
-        drop_packed(ix);
-    }
-    ix->rows = rows;  // `padded` keeps the allocated size; finalize() rewrites the sentinel rows behind `rows`
-    ix->finalized = 0;
-    return MEMO_OK;
-}
-
-int memo_index_columns(memo_index_t *ix, int64_t **d_start, int64_t **d_end, int64_t **d_annot) {
-    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
-    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns of this index were dropped by memo_index_pack");
-    {
-        DeviceGuard guard(ix->device);
-        drop_packed(ix);
-    }
-    if (d_start) *d_start = ix->s;
-    if (d_end) *d_end = ix->e;
-    if (d_annot) *d_annot = ix->o;
-    ix->finalized = 0;  // the caller may be about to rewrite the rows
-    return MEMO_OK;
-}
-
-int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_sort) {
-    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
-    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns of this index were dropped by memo_index_pack");
-    if (bucket_shift <= 0) bucket_shift = kDefaultBucketShift;
-    if (bucket_shift > 8) return fail(MEMO_EINVAL, "bucket_shift must be <= 8 (tile width 256)");
-    DeviceGuard guard(ix->device);
-    hipStream_t st = nullptr;
-    const uint64_t rows = ix->rows;
-    {
-        const uint64_t npad = ix->padded - rows;
-        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st,
-                           ix->s, ix->e, ix->o, rows, ix->padded);
-        HIP_TRY(hipGetLastError());
-    }
-    uint64_t h[8] = {0};
-    ix->was_sorted = 1;
-    if (rows) {
-        HIP_TRY(hipMemsetAsync(ix->d_scratch, 0, 64, st));
-        const unsigned grid = (unsigned)(rows / 256 + 1 < 4096 ? rows / 256 + 1 : 4096);
-        hipLaunchKernelGGL(check_rows_kernel, dim3(grid), dim3(256), 0, st, ix->s, ix->e, rows,
-                           ix->d_scratch);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpy(h, ix->d_scratch, 24, hipMemcpyDeviceToHost));
-        if (h[2]) return fail(MEMO_EINVAL, "%llu rows have coordinates beyond +-2^61", (unsigned long long)h[2]);
-        (void)hipFree(ix->ls);
-        (void)hipFree(ix->le);
-        (void)hipFree(ix->lo);
-        ix->ls = ix->le = ix->lo = nullptr;
-        ix->n_long = 0;
-        if (h[1]) {  // rows with end < start: set aside for long_rows_kernel
-            if (h[1] > ((uint64_t)1 << 22))
-                return fail(MEMO_ELONGROW, "%llu rows have end < start: not a MEMO overlap index",
-                            (unsigned long long)h[1]);
-            HIP_TRY(hipMalloc(&ix->ls, h[1] * sizeof(int64_t)));
-            HIP_TRY(hipMalloc(&ix->le, h[1] * sizeof(int64_t)));
-            HIP_TRY(hipMalloc(&ix->lo, h[1] * sizeof(int64_t)));
-            HIP_TRY(hipMemsetAsync(ix->d_scratch + 6, 0, 8, st));
-            hipLaunchKernelGGL(collect_long_rows_kernel, dim3(grid), dim3(256), 0, st, ix->s, ix->e, ix->o, rows,
-                               ix->ls, ix->le, ix->lo, (unsigned long long *)(ix->d_scratch + 6));
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(st));
-            ix->n_long = h[1];
-        }
-        if (h[0]) {
-            ix->was_sorted = 0;
-            if (!allow_sort)
-                return fail(MEMO_EUNSORTED, "rows are not sorted by start (%llu descents)",
-                            (unsigned long long)h[0]);
-            char msg[256] = "";
-            if (memo_sort_rows_by_start(ix->s, ix->e, ix->o, rows, ix->padded, st, msg, sizeof msg) != 0)
-                return fail(MEMO_EHIP, "device sort failed: %s", msg);
-        }
-        HIP_TRY(hipMemcpy(&ix->min_s, ix->s, sizeof(int64_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&ix->max_s, ix->s + (rows - 1), sizeof(int64_t), hipMemcpyDeviceToHost));
-    } else {
-        ix->min_s = 0;
-        ix->max_s = -1;
-    }
-    // buckets 0 .. ceil((max_s + 1) / width), plus one pinned to `rows`
-    const int64_t top = ix->max_s < 0 ? 0 : ix->max_s;
-    const uint64_t nb = (uint64_t)((top >> bucket_shift) + 3);
-    if (ix->boff) {
-        (void)hipFree(ix->boff);
-        ix->boff = nullptr;
-    }
-    HIP_TRY(hipMalloc(&ix->boff, nb * sizeof(int64_t)));
-    hipLaunchKernelGGL(bucket_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st,
-                       ix->s, rows, ix->boff, nb, bucket_shift);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-    ix->nb = nb;
-    ix->bshift = bucket_shift;
-    ix->finalized = 1;
-    return MEMO_OK;
-}
-
-int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
-    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
-    if (!ix->finalized) return fail(MEMO_ENOTREADY, "index not finalized");
-    if (!ix->has_wide) return ix->packed_fmt ? MEMO_OK : fail(MEMO_EINVAL, "nothing to pack");
-    if (ix->rows && ix->min_s < 0) return fail(MEMO_EINVAL, "rows with a negative start cannot be packed");
-    DeviceGuard guard(ix->device);
-    hipStream_t st = nullptr;
-    drop_packed(ix);
-    uint64_t h[8] = {0};
-    if (ix->rows) {
-        HIP_TRY(hipMemsetAsync(ix->d_scratch, 0, 64, st));
-        const unsigned grid = (unsigned)(ix->rows / 256 + 1 < 4096 ? ix->rows / 256 + 1 : 4096);
-        hipLaunchKernelGGL(annot_census_kernel, dim3(grid), dim3(256), 0, st, ix->o, ix->rows, ix->d_scratch);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpy(h, ix->d_scratch, 64, hipMemcpyDeviceToHost));
-        if (h[3])
-            return fail(MEMO_EINVAL, "%llu rows have an annot outside [0, 65535]: cannot be packed",
-                        (unsigned long long)h[3]);
-    }
-    const int fmt = h[4] ? 6 : 4;
-    ix->max_annot = h[5];
-    HIP_TRY(hipMalloc(&ix->pk, ix->padded * sizeof(uint32_t)));
-    if (fmt == 6) HIP_TRY(hipMalloc(&ix->pa, ix->padded * sizeof(uint16_t)));
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(4096), dim3(256), 0, st, ix->s, ix->e, ix->o, ix->rows,
-                       ix->padded, ix->pk, ix->pa);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-    ix->packed_fmt = fmt;
-    if (!keep_wide) {
-        (void)hipFree(ix->s);
-        (void)hipFree(ix->e);
-        (void)hipFree(ix->o);
-        ix->s = ix->e = ix->o = nullptr;
-        ix->has_wide = 0;
-    }
-    return MEMO_OK;
-}
-
-int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
-    if (!ix || !info) return fail(MEMO_EINVAL, "NULL argument");
-    info->rows = ix->rows;
-    info->min_start = ix->min_s;
-    info->max_start = ix->max_s;
-    info->device = ix->device;
-    info->bucket_shift = ix->bshift;
-    info->buckets = ix->nb;
-    info->was_sorted = ix->was_sorted;
-    info->finalized = ix->finalized;
-    info->packed_format = ix->packed_fmt;
-    info->has_wide = ix->has_wide;
-    info->device_bytes = (ix->has_wide ? ix->padded * 3 * sizeof(int64_t) : 0) + ix->nb * sizeof(int64_t) + 128 +
-                         (ix->pk ? ix->padded * 4 : 0) + (ix->pa ? ix->padded * 2 : 0);
     return MEMO_OK;
 }
 
@@ -1430,154 +930,6 @@ int memo_query_check(memo_index_t *ix, void *stream) {
                         "result matrix (num_docs too small?) -- the reference raises IndexError here");
         return fail(MEMO_EINVAL, "device status 0x%x", flags);
     }
-    return MEMO_OK;
-}
-
-static int one_shot(const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows,
-                    int64_t qs, int64_t qe, int32_t k, int32_t num_docs, void *out, int32_t device,
-                    bool membership) {
-    memo_index_t *ix = nullptr;
-    int rc = memo_index_create(rows, device, &ix);
-    if (rc) return rc;
-    void *d_out = nullptr;
-    do {
-        if ((rc = memo_index_upload(ix, start, end, annot, rows))) break;
-        if ((rc = memo_index_finalize(ix, 0, 1))) break;
-        if (qe < qs) { rc = fail(MEMO_EINVAL, "ValueError: negative dimensions are not allowed (window end < start)"); break; }
-        const int64_t L = qe - qs;
-        if (L > 0 && !out) { rc = fail(MEMO_EINVAL, "output pointer is NULL"); break; }
-        const size_t bytes = membership ? (size_t)L * ((num_docs + 31) / 32) * 4 : (size_t)L * 2;
-        DeviceGuard guard(device);
-        if (bytes) {
-            hipError_t err = hipMalloc(&d_out, bytes);
-            if (err != hipSuccess) { rc = fail(MEMO_EHIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(err)); break; }
-        }
-        rc = membership ? memo_query_membership_dev(ix, qs, qe, k, num_docs, (uint32_t *)d_out, nullptr)
-                        : memo_query_conservation_dev(ix, qs, qe, k, num_docs, (uint16_t *)d_out, nullptr);
-        if (rc) break;
-        if ((rc = memo_query_check(ix, nullptr))) break;
-        if (bytes) {
-            hipError_t err = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
-            if (err != hipSuccess) { rc = fail(MEMO_EHIP, "hipMemcpy D2H: %s", hipGetErrorString(err)); break; }
-        }
-    } while (0);
-    if (d_out) {
-        DeviceGuard guard(device);
-        (void)hipFree(d_out);
-    }
-    memo_index_destroy(ix);
-    return rc;
-}
-
-int memo_conservation(const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows,
-                      int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint16_t *out,
-                      int32_t device) {
-    return one_shot(start, end, annot, rows, qs, qe, k, num_docs, out, device, false);
-}
-
-int memo_membership(const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows,
-                    int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint32_t *out_bits,
-                    int32_t device) {
-    return one_shot(start, end, annot, rows, qs, qe, k, num_docs, out_bits, device, true);
-}
-
-int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t den,
-                    int32_t num_docs, uint64_t seed) {
-    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
-    if (num == 0 || den == 0 || num_docs < 2) return fail(MEMO_EINVAL, "bad generator parameters");
-    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns were dropped");
-    DeviceGuard guard(ix->device);
-    drop_packed(ix);
-    if (ix->rows) {
-        hipLaunchKernelGGL(synth_rows_kernel, dim3(4096), dim3(256), 0, nullptr, ix->s, ix->e, ix->o,
-                           ix->rows, row_begin, num, den, (uint64_t)(num_docs - 1), seed);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
-    }
-    ix->finalized = 0;
-    return MEMO_OK;
-}
-
-int memo_bin_conservation_dev(const uint16_t *d_vec, int64_t L, const int64_t *edges, int32_t nbins,
-                              int32_t num_docs, uint64_t *counts, int32_t device, void *stream) {
-    if (nbins < 1 || num_docs < 1 || num_docs > 65534 || !edges || !counts || (L > 0 && !d_vec))
-        return fail(MEMO_EINVAL, "bad binning arguments");
-    for (int i = 0; i < nbins; ++i)
-        if (edges[i] < 0 || edges[i] > edges[i + 1] || edges[i + 1] > L)
-            return fail(MEMO_EINVAL, "bin edges must be non-decreasing inside [0, L]");
-    DeviceGuard guard(device);
-    if (!guard.ok) return fail(MEMO_EHIP, "cannot select HIP device %d", device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int ncols = num_docs + 1;
-    const size_t cbytes = (size_t)nbins * ncols * sizeof(uint64_t);
-    int64_t *d_edges = nullptr;
-    unsigned long long *d_counts = nullptr;
-    int rc = MEMO_OK;
-    hipError_t err = hipMalloc(&d_edges, (size_t)(nbins + 1) * sizeof(int64_t));
-    if (err == hipSuccess) err = hipMalloc(&d_counts, cbytes);
-    if (err == hipSuccess) err = hipMemcpyAsync(d_edges, edges, (size_t)(nbins + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);
-    if (err == hipSuccess) err = hipMemsetAsync(d_counts, 0, cbytes, st);
-    if (err == hipSuccess) {
-        // enough workgroups to fill the chip, at least one per bin
-        int slices = (int)((2048 + nbins - 1) / nbins);
-        const int64_t longest = (L + nbins - 1) / nbins;
-        while (slices > 1 && longest / slices < 4096) --slices;
-        if ((size_t)ncols * 4 <= 48 * 1024)
-            hipLaunchKernelGGL(bin_conservation_kernel<true>, dim3((unsigned)(nbins * slices)), dim3(256),
-                               (size_t)ncols * 4, st, d_vec, d_edges, ncols, slices, d_counts);
-        else
-            hipLaunchKernelGGL(bin_conservation_kernel<false>, dim3((unsigned)(nbins * slices)), dim3(256), 0, st,
-                               d_vec, d_edges, ncols, slices, d_counts);
-        err = hipGetLastError();
-    }
-    if (err == hipSuccess) err = hipMemcpyAsync(counts, d_counts, cbytes, hipMemcpyDeviceToHost, st);
-    if (err == hipSuccess) err = hipStreamSynchronize(st);
-    if (err != hipSuccess) rc = fail(MEMO_EHIP, "binning failed: %s", hipGetErrorString(err));
-    (void)hipFree(d_edges);
-    (void)hipFree(d_counts);
-    return rc;
-}
-
-int memo_debug_stream_rows(memo_index_t *ix, void *stream) {
-    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
-    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns were dropped");
-    DeviceGuard guard(ix->device);
-    hipLaunchKernelGGL(stream_rows_kernel, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       ix->s, ix->e, ix->o, ix->rows & ~(uint64_t)1,
-                       reinterpret_cast<unsigned long long *>(ix->d_scratch));
-    HIP_TRY(hipGetLastError());
-    return MEMO_OK;
-}
-
-// ---- raw device buffers for hosts that do not bring their own allocator ---------------------
-int memo_dev_malloc(int32_t device, size_t bytes, void **out) {
-    if (!out) return fail(MEMO_EINVAL, "out is NULL");
-    *out = nullptr;
-    DeviceGuard guard(device);
-    if (!guard.ok) return fail(MEMO_EHIP, "cannot select HIP device %d", device);
-    HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
-    return MEMO_OK;
-}
-
-int memo_dev_free(int32_t device, void *p) {
-    DeviceGuard guard(device);
-    HIP_TRY(hipFree(p));
-    return MEMO_OK;
-}
-
-int memo_dev_upload(int32_t device, void *dev, const void *host, size_t bytes, void *stream) {
-    DeviceGuard guard(device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bytes) HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return MEMO_OK;
-}
-
-int memo_dev_download(int32_t device, void *host, const void *dev, size_t bytes, void *stream) {
-    DeviceGuard guard(device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bytes) HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
     return MEMO_OK;
 }
 
