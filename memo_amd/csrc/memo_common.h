@@ -36,6 +36,7 @@ constexpr int64_t kSentinel = INT64_MAX / 4;  // start/end of a padding row: cli
 constexpr int kDefaultBucketShift = 5;        // 32 pivot positions per bucket
 constexpr int64_t kCoordLimit = (int64_t)1 << 61;
 constexpr int kStatusBadAnnot = 1;            // sticky device flag: the reference's IndexError case
+constexpr int kStatusHugeSlice = 2;           // sticky device flag: >= 2^32 rows reach one tile
 
 }  // namespace memo
 

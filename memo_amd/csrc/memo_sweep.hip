@@ -33,7 +33,6 @@ struct SweepArgs {
     const uint16_t *pa;
     const int64_t *boff;
     int64_t nb;
-    uint64_t rows;
     int64_t qs, qe;
     int64_t tile0;          // pivot position of tile 0 (multiple of the tile width, <= qs)
     int64_t ntiles;
@@ -104,6 +103,10 @@ __device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t) {
     t.x_lo = (int)(A.qs > t.a ? A.qs - t.a : 0);
     t.x_hi = (int)(A.qe - t.a < W ? A.qe - t.a : W);
     row_slice(A, t.a, t.a + t.x_hi, t.r0, t.r1);
+    if (t.r1 - t.r0 >= 0xFFFF0000ull) {  // the row loops count a tile's rows in 32 bits
+        if (threadIdx.x == 0) atomicOr(A.status, kStatusHugeSlice);
+        return false;
+    }
     return true;
 }
 
@@ -176,12 +179,6 @@ struct WideRows {
     }
 };
 
-// packed rows (memo_index_pack): one 32-bit word per row -- start mod 2^16, min(end - start,
-// 255), annot (8 bits; ANNOT16: in a second 16-bit column).  Inside a row slice every start
-// lies in [a, a + W + k + 32), far less than 2^16 from the tile start, so the low 16 bits
-// give the tile-relative start exactly; rows outside [r0, r1) are masked by index.  Exact
-// for k - 1 <= 255: a saturated length clips to "does not write" just as the true one does.
-// 4 rows per lane per load (16 B / lane).
 // clamp(v, lo, hi) for lo <= hi in one instruction; hi is wave-uniform (one SGPR operand is all a
 // gfx9 VALU instruction may read), lo is a VGPR pinned by pin_vgpr() so that it is not
 // re-materialised from its SGPR before every use
@@ -197,6 +194,12 @@ __device__ __forceinline__ int pin_vgpr(int uniform) {
     return r;
 }
 
+// packed rows (memo_index_pack): one 32-bit word per row -- start mod 2^16, min(end - start,
+// 255), annot (8 bits; ANNOT16: in a second 16-bit column).  Inside a row slice every start
+// lies in [a, a + W + k + 32), far less than 2^16 from the tile start, so the low 16 bits
+// give the tile-relative start exactly; rows outside [r0, r1) are masked by index.  Exact
+// for k - 1 <= 255: a saturated length clips to "does not write" just as the true one does.
+// 4 rows per lane per load (16 B / lane).
 // CHECKED = false is chosen by the host when the largest annot of the index (known since
 // memo_index_pack) is inside the result matrix, so that no row can raise the reference's
 // IndexError; the column test then leaves the loop.
@@ -487,22 +490,24 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
     Tile t;
     if (!locate_tile<W>(A, t)) return;
     const int nw = A.nwords;
-    // genome g lives at g * PW + (g >> 5): the extra word per 32 genomes keeps the four lanes that
-    // read the same position word of different genome groups on different banks
-    const int total = 32 * nw * PW + nw;
+    // genome g lives at g * PITCH + (g >> 5) * skew.  PITCH is odd, so the scatter's bank is
+    // (genome + word) mod 32 -- with a pitch of PW (a multiple of 32) every genome would land on
+    // the banks of its position word alone.  In the transpose phase 32 lanes read word P of genome
+    // groups G = 0..nw-1 for 32 / nw consecutive P: skew = 32 / nw puts them on 32 different banks.
+    constexpr int PITCH = PW + 1;
+    const int skew = A.nlev;  // membership runs: the launcher passes the skew in nlev
+    const int total = 32 * nw * PITCH + nw * skew;
     auto clear_tile = [&]() {
         for (int i = tid; i < total; i += T) lds[i] = 0;
         lds_barrier();
     };
     Rows::template for_each<T, U>(A, t, clear_tile, [&](int c, int h, int col) {
         if (h <= c) return;
-        uint32_t *row = lds + col * PW + (col >> 5);
+        uint32_t *row = lds + col * PITCH + (col >> 5) * skew;
         const int w0 = c >> 5, w1 = (h - 1) >> 5;
         const uint32_t first = 0xFFFFFFFFu << (c & 31), last = 0xFFFFFFFFu >> (31 - ((h - 1) & 31));
-        if (w0 == w1) {
-            atomicOr(row + w0, first & last);
-        } else {
-            atomicOr(row + w0, first);
+        atomicOr(row + w0, w0 == w1 ? first & last : first);  // one instruction for both shapes
+        if (w1 > w0) {
             for (int w = w0 + 1; w < w1; ++w) atomicOr(row + w, 0xFFFFFFFFu);
             atomicOr(row + w1, last);
         }
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
         if (32 * P + 32 <= t.x_lo || 32 * P >= t.x_hi) continue;
         uint32_t m[32];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) m[i] = lds[(32 * G + i) * PW + G + P];
+        for (int i = 0; i < 32; ++i) m[i] = lds[(32 * G + i) * PITCH + G * skew + P];
         transpose32(m);
         const uint32_t full = full_word(A.ncols, G);
         uint32_t *dst = out + (ob + 32 * P) * nw + G;
@@ -640,7 +645,6 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
     return MEMO_OK;
 }
 
-
 template <typename Rows, typename OutT>
 SweepKernel cons_kernel(int w, int waves) {
 #define MEMO_CASE(WW)                                                                         \
@@ -706,7 +710,7 @@ int pick_rows(const memo_index *ix, int32_t k, int &fmt) {
 }
 
 int check_query_args(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
-                     const void *d_out, bool membership) {
+                     const void *d_out) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
     if (!ix->finalized) return fail(MEMO_ENOTREADY, "index not finalized");
     if (num_docs < 1 || num_docs > 65534)
@@ -719,7 +723,6 @@ int check_query_args(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, in
     if (qe > qs && !d_out) return fail(MEMO_EINVAL, "output pointer is NULL");
     if (qe > qs && ((uintptr_t)d_out & 15)) return fail(MEMO_EINVAL, "output must be 16-byte aligned");
     if (qe - qs > ((int64_t)1 << 40)) return fail(MEMO_EINVAL, "window longer than 2^40");
-    (void)membership;
     return MEMO_OK;
 }
 
@@ -731,7 +734,6 @@ void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32
     A.pa = ix->pa;
     A.boff = ix->boff;
     A.nb = (int64_t)ix->nb;
-    A.rows = ix->rows;
     A.qs = qs;
     A.qe = qe;
     A.out = d_out;
@@ -765,7 +767,7 @@ template <typename OutT>
 static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
                               OutT *d_out, void *stream) {
     read_env_once();
-    int rc = check_query_args(ix, qs, qe, k, num_docs, d_out, false);
+    int rc = check_query_args(ix, qs, qe, k, num_docs, d_out);
     if (rc) return rc;
     if (sizeof(OutT) == 1 && num_docs > 255)
         return fail(MEMO_EINVAL, "uint8 results need num_docs <= 255, got %d", num_docs);
@@ -847,7 +849,7 @@ int memo_query_conservation_u8_dev(memo_index_t *ix, int64_t qs, int64_t qe, int
 int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,
                               int32_t num_docs, uint32_t *d_out, void *stream) {
     read_env_once();
-    int rc = check_query_args(ix, qs, qe, k, num_docs, d_out, true);
+    int rc = check_query_args(ix, qs, qe, k, num_docs, d_out);
     if (rc) return rc;
     if (qe <= qs) return MEMO_OK;
     DeviceGuard guard(ix->device);
@@ -864,8 +866,6 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     A.ncols = num_docs;
     A.nlev = floor_log2((uint32_t)(k - 1)) + 1;
     A.nwords = nw;
-    // doubling needs nlev * nw words per position; four waves share one tile so that the tile
-    // stays wide (the k-1 row halo is re-read once per tile).  Direct scatter otherwise.
     int fmt;
     if ((rc = pick_rows(ix, k, fmt))) return rc;
     // algorithm: 3 = runs (bit planes per genome + register transpose), 2 = doubling, 1 = direct
@@ -883,8 +883,12 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             while ((size_t)nw * 4 * w > 32 * 1024 && w > 256) w >>= 1;
             while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
         }
-        while ((size_t)nw * 4 * w + (size_t)nw * 4 > 160 * 1024 && w > 256) w >>= 1;
-        const size_t lds = (size_t)nw * 4 * w + (size_t)nw * 4;
+        int skew = 1;
+        while (skew * 2 * nw <= 32) skew *= 2;  // largest power of two <= 32 / nw (1 when nw > 16)
+        A.nlev = skew;
+        auto lds_bytes = [&](int ww) { return ((size_t)32 * nw * (ww / 32 + 1) + (size_t)nw * skew) * 4; };
+        while (lds_bytes(w) > 160 * 1024 && w > 256) w >>= 1;
+        const size_t lds = lds_bytes(w);
         SweepKernel kern = fmt == 4   ? (checked ? memb_runs_kernel<PackedRows<false, true>>(w, waves)
                                                  : memb_runs_kernel<PackedRows<false, false>>(w, waves))
                            : fmt == 6 ? (checked ? memb_runs_kernel<PackedRows<true, true>>(w, waves)
@@ -924,6 +928,8 @@ int memo_query_check(memo_index_t *ix, void *stream) {
     if (flags) {
         HIP_TRY(hipMemsetAsync(ix->d_status, 0, sizeof(int), st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (flags & kStatusHugeSlice)
+            return fail(MEMO_EINVAL, "more than 2^32 index rows can reach one tile of the window: unsupported");
         if (flags & kStatusBadAnnot)
             return fail(MEMO_EINVAL,
                         "a row that covers the window has an order/genome column outside the "
