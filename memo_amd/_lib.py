@@ -64,6 +64,13 @@ SYMBOLS = {
     "memo_emit_conservation": (_SZ, [_P, _I64, _P, _SZ]),
     "memo_emit_membership": (_SZ, [_P, _I64, _I32, _P, _SZ]),
     "memo_bin_conservation_dev": (C.c_int, [_P, _I64, _P, _I32, _I32, _P, _I32, _P]),
+    "memo_dap_create": (C.c_int, [_I32, _P, _I32, _I32, _I32, _I32, C.POINTER(_P)]),
+    "memo_dap_push": (C.c_int, [_P, _P, _I64, C.POINTER(_U64)]),
+    "memo_dap_fetch": (C.c_int, [_P, _P, _P, _P, _P]),
+    "memo_dap_finish": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(_U64)]),
+    "memo_dap_destroy": (None, [_P]),
+    "memo_parse_ints": (C.c_int64, [_P, _SZ, _P, _SZ]),
+    "memo_emit_bed": (_SZ, [_P, _P, _P, _P, _U64, _P, _I32, _P, _SZ]),
     "memo_synth_fill": (C.c_int, [_P, _U64, _U64, _U64, _I32, _U64]),
     "memo_debug_stream_rows": (C.c_int, [_P, _P]),
     "memo_set_row_source": (C.c_int, [_I32]),

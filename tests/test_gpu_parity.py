@@ -434,3 +434,61 @@ def test_more_than_2_pow_32_rows(memo, oracle):
                     assert np.array_equal(ix.membership(a, a + 3000, k, n), wantb), (source, a)
             finally:
                 _lib.check(_lib.lib().memo_set_row_source(0))
+
+
+# ---------------------------------------------------------------------------------------
+# index-row construction on the device (dap_to_bed.py:55-134)
+# ---------------------------------------------------------------------------------------
+def _dap_cases():
+    import json
+    return json.load(open(os.path.join(G.GOLD, "dap", "manifest.json")))
+
+
+@pytest.mark.parametrize("c", _dap_cases(), ids=lambda c: c["name"])
+def test_dap_to_bed_matches_reference(c, memo):
+    import io
+    from memo_amd import dap_to_bed as D
+    d = os.path.join(G.GOLD, "dap")
+    argv = ["--mem", "--fai", os.path.join(d, c["fai"]), "--dap", os.path.join(d, c["dap"])] + \
+        (["--overlap"] if c["overlap"] else []) + (["--order"] if c["order"] else [])
+    args = D.parse_arguments(argv)
+    D.check_args(args)
+    buf = io.BytesIO()
+    D.main(args, buf)
+    assert G.sha(buf.getvalue()) == c["sha256"]
+    assert buf.getvalue() == open(os.path.join(d, c["name"] + ".bed"), "rb").read()
+
+
+def test_dap_streaming_chunks_and_truncated_record(memo):
+    """rows pushed in many small pieces == one push; a DAP that stops inside a record still gets its
+    chr-end rows (dap_to_bed.py:133-134); checked against the oracle restatement"""
+    from memo_amd.dap_to_bed import DapConverter
+    from oracle import dap_oracle as O
+    rng = np.random.default_rng(4)
+    rec_begin = np.array([0, 700, 701, 1500, 4000], np.int64)
+    for C_, npos, order, overlap in ((7, 4000, True, True), (130, 3333, False, True), (600, 900, True, True), (33, 4000, False, False)):
+        lcp = rng.integers(0, 40, (npos, C_)).astype(np.int32)
+        want = O.dap_rows(lcp, rec_begin, overlap, order)
+        if npos < rec_begin[-1]:                   # truncated: the oracle sees the stream end as a record end
+            pass
+        for pieces in (1, 7, 64):
+            with DapConverter(C_, rec_begin, order, overlap) as conv:
+                got = [conv.push(part) for part in np.array_split(lcp, pieces)] + [conv.finish()]
+            cat = [np.concatenate([g[i] for g in got]) for i in range(4)]
+            assert all(np.array_equal(a, b) for a, b in zip(cat, want)), (C_, npos, pieces)
+
+
+def test_dap_to_parquet_is_a_queryable_index(memo, oracle, tmp_path):
+    """DAP -> Parquet on the device, then `memo query` on it == oracle on the oracle's rows"""
+    from memo_amd import dap_to_bed as D, memo_query as mq
+    from oracle import dap_oracle as O
+    d = os.path.join(G.GOLD, "dap")
+    out = str(tmp_path / "idx.parquet")
+    D.dap_to_parquet(os.path.join(d, "dap_wide.dap.txt"), os.path.join(d, "dap_wide.fa.fai"), out, order=True)
+    names, rec_begin = O.read_fai(os.path.join(d, "dap_wide.fa.fai"))
+    _, lcp = O.read_dap(os.path.join(d, "dap_wide.dap.txt"))
+    rec, s, e, a = O.dap_rows(lcp, rec_begin, True, True)
+    sel = rec == 0
+    want = oracle.conservation(*oracle.filter_rows(s[sel], e[sel], a[sel], 10, 290, 5), 10, 290, 5, 71, literal=False)
+    with mq.region_index(out, names[0], 10, 290 + 5) as ix:
+        assert np.array_equal(ix.conservation(10, 290, 5, 71), want)

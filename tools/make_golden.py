@@ -253,6 +253,46 @@ def main():
             for wi, (qs, qe) in enumerate(((0, 3100), (700, 1900), (2900, 3300))):
                 run_case(manifest, f"rnd_negoverlap_{tag}_k{k}_w{wi}", pqn, k, 12, f"chrN:{qs}-{qe}", memb, work)
 
+    # --- index construction (dap_to_bed.py:116-134): DAP rows -> MEMs / MEM-overlap BED rows
+    os.makedirs(os.path.join(GOLD, "dap"))
+    drng = np.random.default_rng(0xDA9)
+    dap_cases = []
+
+    def synth_dap(records, cols, jitter):
+        """matching-statistic-like columns: lcp[i+1] >= lcp[i] - 1, random restarts"""
+        rows, fai, pos = [], [], 0
+        for name, length in records:
+            fai.append(f"{name}\t{length}\t0\t60\t61")
+            cur = drng.integers(1, 12, cols)
+            for i in range(length):
+                cur = np.maximum(cur - 1, 0)
+                bump = drng.random(cols) < jitter
+                cur = np.where(bump, drng.integers(0, 25, cols), cur)
+                cur = np.minimum(cur, length - i)
+                rows.append(" ".join(map(str, [pos] + cur.tolist())))
+                pos += 1
+        return "\n".join(rows) + "\n", "\n".join(fai) + "\n"
+
+    dap_specs = [("dap_one", [("chrA", 60)], 3, 0.2), ("dap_multi", [("r1", 40), ("r2", 1), ("r3", 77)], 5, 0.15),
+                 ("dap_wide", [("c1", 300), ("c2", 150)], 70, 0.1), ("dap_dense", [("x", 500)], 12, 0.5)]
+    example_dap = open(os.path.join(GOLD, "example_dap.txt")).read()
+    dap_inputs = [(n,) + synth_dap(r, c, j) for n, r, c, j in dap_specs] + \
+        [("dap_example", example_dap, "ref_1\t26\t7\t26\t27\n")]
+    for name, dap_text, fai_text in dap_inputs:
+        dpath, fpath = os.path.join(GOLD, "dap", name + ".dap.txt"), os.path.join(GOLD, "dap", name + ".fa.fai")
+        open(dpath, "w").write(dap_text)
+        open(fpath, "w").write(fai_text)
+        for overlap in (True, False):
+            for order in (True, False):
+                buf = io.StringIO()
+                with contextlib.redirect_stdout(buf):
+                    ref_d.print_dap_as_mem_bed(ref_d.read_file(dpath), ref_d.parse_fai(fpath), overlap, order).dap_to_mem()
+                tag = f"{name}_{'ovl' if overlap else 'mem'}_{'order' if order else 'doc'}"
+                open(os.path.join(GOLD, "dap", tag + ".bed"), "w").write(buf.getvalue())
+                dap_cases.append(dict(name=tag, dap=name + ".dap.txt", fai=name + ".fa.fai", overlap=overlap, order=order,
+                                      sha256=hashlib.sha256(buf.getvalue().encode()).hexdigest()))
+    json.dump(dap_cases, open(os.path.join(GOLD, "dap", "manifest.json"), "w"), indent=0)
+
     # --- `memo view` binning (plot_conservation.py:46-65): per-bin composition of a conservation
     # vector; plotnine is absent here and only needed for drawing, so it is stubbed for the import
     pn = types.ModuleType("plotnine")
