@@ -83,7 +83,7 @@ def build(force=False):
     src = os.path.join(_HERE, "csrc")
     if force:
         subprocess.check_call(["make", "-C", src, "-s", "clean"])
-    subprocess.check_call(["make", "-C", src, "-s"])
+    subprocess.check_call(["make", "-C", src, "-s", "-j", str(min(4, os.cpu_count() or 1))])
     return SO_PATH
 
 
