@@ -10,8 +10,9 @@ k = 31, conservation.  A "step" is one query of the whole window: one launch of
 sweep_conservation_kernel over the rows resident in HBM, result left in HBM.  Weak scaling:
 every rank owns its own 10^8-position window of an N x 10^8 pivot and generates exactly the
 rows that window sees (index-addressable generator, memo_amd/synth.py); for N > 1 the result
-slices are gathered to rank 0 over RCCL inside the timed region (as bytes, uint8 per position
-when num_docs <= 255; two result buffers so that gather i overlaps sweep i+1).
+slices are gathered to rank 0 over RCCL inside the timed region (as bytes; two result buffers so
+that gather i overlaps sweep i+1).  Conservation results are uint8 per position when num_docs <= 255
+(uint16 otherwise, or with --wide), at every N.
 
 One JSON line on stdout (rank 0).  `roofline` prices the sweep kernel alone from HIP events
 recorded on the launch stream; `cpu_baseline` is the oracle's literal port of the
@@ -52,7 +53,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--wide", action="store_true", help="keep uint16 results for N > 1 (default: uint8 when num_docs <= 255)")
+    ap.add_argument("--wide", action="store_true", help="uint16 conservation results even when num_docs <= 255")
     ap.add_argument("--rows", default="packed", choices=["packed", "wide"],
                     help="row format the timed sweep reads: packed (memo_index_pack, 4-6 B/row) or the "
                          "int64 columns as uploaded (24 B/row); at N=1 the other one is timed too")
@@ -147,9 +148,9 @@ def main():
         return 24 if which == "wide" else packed_fmt
     row_bytes = use_rows(args.rows)
     W = (num_docs + 31) // 32
-    # result element: membership = W uint32 words; conservation = uint16, or uint8 when the
-    # values fit and the slices have to cross xGMI (halves the gather)
-    narrow = (not membership) and multi and num_docs <= 255 and not args.wide
+    # result element: membership = W uint32 words; conservation = uint8 when num_docs <= 255 (the
+    # same at every N; it also halves what the slices put on xGMI), else uint16
+    narrow = (not membership) and num_docs <= 255 and not args.wide
     if membership:
         shape, dtype, b_out = (L, W), torch.int32, 4 * W
     elif narrow:
@@ -288,7 +289,9 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             def gpu_slice(S):
                 h = out[:S].cpu().numpy()
-                return h.view(np.uint32) if membership else h.view(np.uint16)
+                if membership:
+                    return h.view(np.uint32)
+                return h.view(np.uint8).astype(np.uint16) if narrow else h.view(np.uint16)
             res["cpu_baseline"] = cpu_baseline(args, num_docs, L, k, membership, gpu_slice)
         if multi:
             # the gathered slice of the LAST rank, checked against the oracle on a small sample

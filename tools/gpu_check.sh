@@ -1,17 +1,24 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): GPU parity tests, smoke, a bench line, and a rocprofv3 kernel trace.
-# Usage: tools/gpu_check.sh [tag]      outputs -> gpurun_out/<tag>/
-TAG=${1:-r01}
-OUT=gpurun_out/$TAG
-mkdir -p $OUT
-export TMPDIR=/tmp
-rocm-smi --showmeminfo vram 2>/dev/null | head -8 > $OUT/smi.txt
-free -g > $OUT/host_mem.txt; nproc >> $OUT/host_mem.txt
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 > $OUT/pytest_gpu.txt
-echo "pytest rc=$?" >> $OUT/pytest_gpu.txt
-tail -5 $OUT/pytest_gpu.txt
-timeout 300 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.txt
-timeout 600 python bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -3 $OUT/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o c3 -- python bench.py --steps 5 --warmup 1 --cpu-sample 0 > $OUT/prof_bench.json 2> $OUT/prof.err
-echo "rocprof rc=$?"; cat $OUT/prof_bench.json
-find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
+# GPU box: parity tests, smoke, bench (packed default) + rocprofv3 stats + PMC passes for both row formats.
+TAG=${1:-r01g}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > $OUT/pytest_gpu.txt; tail -2 $OUT/pytest_gpu.txt
+timeout 300 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json
+for rows in packed wide; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$rows -o c3 -- python bench.py --rows $rows --steps 10 --warmup 2 --cpu-sample 0 > $OUT/prof_$rows.json 2>> $OUT/prof.err
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$rows/pmc_$c -o c3 -- python bench.py --rows $rows --steps 3 --warmup 1 --cpu-sample 0 --calibrate > /dev/null 2>> $OUT/prof.err
+  done
+done
+head -6 $OUT/prof_packed/c3_kernel_stats.csv | cut -c1-200
+for wl in c2 c4 c5; do timeout 300 python bench.py --workload $wl --steps 10 --warmup 2 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.txt; done
+timeout 300 python bench.py --k 101 --steps 10 --warmup 2 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.txt
+timeout 300 python bench.py --k 21 --steps 10 --warmup 2 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.txt
+timeout 300 python bench.py --force-dist --steps 10 --warmup 2 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.txt
+python - <<PY
+import json
+for l in open("$OUT/workloads.txt"):
+    j=json.loads(l); r=j["roofline"]; o=j.get("other_row_format") or {}
+    print(j["config"]["workload"][:52], "k=%d"%j["config"]["k"], "| %s: %.3f ms frac %.3f val %.3g | other: %s %.3f ms frac %.3f"%(j["config"]["row_bytes"], r["kernel_ms"], r["frac"], j["value"], o.get("rows"), o.get("kernel_ms",0), o.get("frac",0)), j.get("gather_parity_sample",""))
+PY
+grep -v "amdgpu.ids\|socket.cpp" $OUT/bench.err | tail -5
