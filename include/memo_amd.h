@@ -194,10 +194,18 @@ int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo);
 /* 0 = queries read the packed rows when the index has them (default); 1 = always the int64
  * columns (also MEMO_ROWS=wide).  For A/B measurements; results are identical. */
 int memo_set_row_source(int32_t source);
+/* 0 = library's choice, 1 = one workgroup per tile, 2 = persistent workgroups (as many as stay
+ * resident; each walks a run of tiles and looks the next one up under the current one's work).
+ * Also MEMO_PERSIST.  Results are identical. */
+int memo_set_persistent(int32_t mode);
 
 /* profiling aid: one pass that reads the three columns exactly once (24 B/row) with the
  * sweep's access shape, to calibrate the FETCH_SIZE counter on a known byte count */
 int memo_debug_stream_rows(memo_index_t *ix, void *stream);
+/* profiling aid for -DMEMO_STAMPS builds of the conservation sweep: a device buffer of 8 uint64
+ * per workgroup that receives the cycles wave 0 spent in each phase (NULL = off; ignored by the
+ * product library, which contains no stamp) */
+int memo_debug_set_stamp_buffer(uint64_t *d_buffer);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,9 @@ SYMBOLS = {
     "memo_parse_ints": (C.c_int64, [_P, _SZ, _P, _SZ]),
     "memo_emit_bed": (_SZ, [_P, _P, _P, _P, _U64, _P, _I32, _P, _SZ]),
     "memo_synth_fill": (C.c_int, [_P, _U64, _U64, _U64, _I32, _U64]),
+    "memo_debug_set_stamp_buffer": (C.c_int, [_P]),
     "memo_debug_stream_rows": (C.c_int, [_P, _P]),
+    "memo_set_persistent": (C.c_int, [_I32]),
     "memo_set_row_source": (C.c_int, [_I32]),
     "memo_set_tuning": (C.c_int, [_I32, _I32, _I32]),
 }

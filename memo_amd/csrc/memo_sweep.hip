@@ -37,6 +37,7 @@ struct SweepArgs {
     int64_t tile0;          // pivot position of tile 0 (multiple of the tile width, <= qs)
     int64_t ntiles;
     int64_t tiles_per_xcd;  // ceil(ntiles / 8)
+    int64_t blocks_per_xcd; // workgroups per XCD group; < tiles_per_xcd when workgroups are persistent
     void *out;
     int *status;
     int bshift;
@@ -44,15 +45,33 @@ struct SweepArgs {
     int ncols;  // result columns: num_docs + 1 (conservation) / num_docs (membership)
     int nlev;   // doubling levels: floor(log2(k-1)) + 1
     int nwords; // membership: 32-bit words per position
+    unsigned long long *stamps;  // diagnostic builds (-DMEMO_STAMPS): per-phase cycle sums
 };
+
+// Diagnostic builds only (never in the product library): wave 0 of every workgroup stores the
+// shader cycles it spent in each phase of the conservation sweep to stamps[8 * block + phase]
+// (a buffer of its own, set with memo_debug_set_stamp_buffer; plain stores, no contention).
+#ifdef MEMO_STAMPS
+#define MEMO_STAMP(i)                                                                         \
+    do {                                                                                      \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();                        \
+        if (threadIdx.x == 0 && A.stamps) A.stamps[8ull * blockIdx.x + (i)] = now__ - stamp_t0; \
+        stamp_t0 = now__;                                                                     \
+    } while (0)
+#else
+#define MEMO_STAMP(i) do { } while (0)
+#endif
 
 // blockIdx -> tile.  Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the XCD
 // group), so give each group one contiguous run of tiles: neighbouring tiles share their
 // k-1 halo rows and the cache lines that straddle the tile boundary, and those then hit in
 // that XCD's L2 instead of being fetched twice.  Speed only -- results do not depend on it.
-__device__ __forceinline__ int64_t tile_of_block(const SweepArgs &A) {
+// A persistent workgroup (blocks_per_xcd < tiles_per_xcd) walks its XCD group's run with stride
+// blocks_per_xcd: `it` is its iteration.  Returns -1 past the end of the run.
+__device__ __forceinline__ int64_t tile_of_block(const SweepArgs &A, int it) {
     const int64_t b = blockIdx.x;
-    return (b & 7) * A.tiles_per_xcd + (b >> 3);
+    const int64_t j = (b >> 3) + (int64_t)it * A.blocks_per_xcd;
+    return j < A.tiles_per_xcd ? (b & 7) * A.tiles_per_xcd + j : -1;
 }
 
 // Row slice [r0, r1) that can touch positions [lo_abs, hi_abs) of a tile starting at a:
@@ -96,9 +115,9 @@ struct Tile {
 };
 
 template <int W>
-__device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t) {
-    const int64_t tile = tile_of_block(A);
-    if (tile >= A.ntiles) return false;
+__device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t, int it) {
+    const int64_t tile = tile_of_block(A, it);
+    if (tile < 0 || tile >= A.ntiles) return false;
     t.a = A.tile0 + tile * W;
     t.x_lo = (int)(A.qs > t.a ? A.qs - t.a : 0);
     t.x_hi = (int)(A.qe - t.a < W ? A.qe - t.a : W);
@@ -285,7 +304,16 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
     const int tid = threadIdx.x;
     constexpr int LS = W + kLevelSkew;  // words between level arrays
     Tile t;
-    if (!locate_tile<W>(A, t)) return;
+#ifdef MEMO_STAMPS
+    unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    bool have = locate_tile<W>(A, t, 0);
+    for (int it = 0; have; ++it) {
+    // a persistent workgroup looks its next tile up now: the two bucket-table loads (2-4k cycles
+    // when HBM is busy) then return under this tile's work instead of in front of the next one's
+    Tile t_next;
+    const bool have_next = locate_tile<W>(A, t_next, it + 1);
+    MEMO_STAMP(0);  // tile location (kernarg + two bucket-table loads)
 
     // the clipped interval [c, h) is the union of two blocks of 2^j, j = floor(log2(h - c))
     Rows::template for_each<T, U>(
@@ -296,6 +324,7 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
             uint4 *p = reinterpret_cast<uint4 *>(lds);
             for (int i = tid; i < A.nlev * (LS / 4); i += T) p[i] = sv;
             lds_barrier();
+            MEMO_STAMP(1);  // issue of the first loads + LDS clear + barrier
         },
         [&](int c, int h, int col) {
             if (h > c) {
@@ -305,7 +334,9 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
                 atomicMin(lv + (h - (1 << j)), (uint32_t)col);  // block [h - 2^j, h)
             }
         });
+    MEMO_STAMP(2);  // waiting for rows + scatter
     __syncthreads();
+    MEMO_STAMP(3);  // barrier after the scatter
 
     // fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1)
     for (int j = A.nlev - 1; j >= 1; --j) {
@@ -336,6 +367,7 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
         __syncthreads();
     }
 
+    MEMO_STAMP(4);  // fold
     // write level 0 as OutT (uint16, or uint8 when num_docs <= 255), in 16-byte pieces aligned
     // in the OUTPUT (the tile grid is aligned in pivot coordinates, the output starts at qs)
     constexpr int PER = 16 / (int)sizeof(OutT);  // positions per 16-byte store
@@ -360,7 +392,16 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
                 if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)lds[x + i];
         }
     }
+    MEMO_STAMP(5);  // store
+#ifdef MEMO_STAMPS
+    if (threadIdx.x == 0 && A.stamps && it == 0) A.stamps[8ull * blockIdx.x + 7] = 1;
+#endif
+    if (have_next) __syncthreads();  // the LDS tile is reused
+    t = t_next;
+    have = have_next;
+    }
 }
+
 
 // ------------------------------------------------------------------------------------------
 // membership.  Result word w of position x:  full_word(w) & ~absent[x][w].
@@ -398,10 +439,13 @@ __global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) 
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
     Tile t;
-    if (!locate_tile<W>(A, t)) return;
     const int nw = A.nwords;
     const int nlev = DOUBLING ? A.nlev : 1;
     const int plane = W * nw;  // words per level
+    bool have = locate_tile<W>(A, t, 0);
+    for (int it = 0; have; ++it) {
+    Tile t_next;  // persistent workgroups: next tile's bucket-table loads fly under this tile's work
+    const bool have_next = locate_tile<W>(A, t_next, it + 1);
 
     auto clear_tile = [&]() {
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -450,6 +494,10 @@ __global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) 
         }
     }
     store_membership<T>(A, t, lds, nw);
+    if (have_next) __syncthreads();  // the LDS tile is reused
+    t = t_next;
+    have = have_next;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -488,8 +536,11 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
     const int tid = threadIdx.x;
     constexpr int PW = W / 32;  // words per genome row
     Tile t;
-    if (!locate_tile<W>(A, t)) return;
     const int nw = A.nwords;
+    bool have = locate_tile<W>(A, t, 0);
+    for (int it = 0; have; ++it) {
+    Tile t_next;  // persistent workgroups: next tile's bucket-table loads fly under this tile's work
+    const bool have_next = locate_tile<W>(A, t_next, it + 1);
     // genome g lives at g * PITCH + (g >> 5) * skew.  PITCH is odd, so the scatter's bank is
     // (genome + word) mod 32 -- with a pitch of PW (a multiple of 32) every genome would land on
     // the banks of its position word alone.  In the transpose phase 32 lanes read word P of genome
@@ -534,7 +585,12 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
                 if (32 * P + j >= t.x_lo && 32 * P + j < t.x_hi) dst[(int64_t)j * nw] = full & ~m[j];
         }
     }
+    if (have_next) __syncthreads();  // the LDS tile is reused
+    t = t_next;
+    have = have_next;
+    }
 }
+
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
 template <typename OutT>
@@ -613,6 +669,14 @@ int g_tile_w = 0;     // 0 = choose per query
 int g_waves = 0;      // waves per tile: 0 = choose, 1 or 4
 int g_memb_algo = 0;  // membership: 0 = choose, 1 = direct scatter, 2 = doubling
 int g_force_wide = 0; // 1 = read the int64 columns even when packed rows exist
+unsigned long long *g_stamp_buffer = nullptr;  // -DMEMO_STAMPS builds: 8 words per workgroup
+int g_persist = 0;    // 0 = choose, 1 = one workgroup per tile, 2 = persistent workgroups
+
+// Persistent workgroups measured 7-20 % SLOWER on every workload (profiles/r01_persistent_ab.txt):
+// resident workgroups that start together stay in step -- every CU loads, then every CU folds --
+// whereas one workgroup per tile staggers them as earlier ones retire, which is what overlaps the
+// memory phase of one tile with the LDS phase of another.  Kept as an A/B switch only.
+bool use_persistent(int /*fmt*/) { return g_persist == 2; }
 bool g_env_read = false;
 
 void read_env_once() {
@@ -622,25 +686,39 @@ void read_env_once() {
     if (const char *v = getenv("MEMO_WAVES")) g_waves = atoi(v);
     if (const char *v = getenv("MEMO_MEMB_ALGO")) g_memb_algo = atoi(v);
     if (const char *v = getenv("MEMO_ROWS")) g_force_wide = strcmp(v, "wide") == 0;
+    if (const char *v = getenv("MEMO_PERSIST")) g_persist = atoi(v);
 }
 
 int floor_log2(uint32_t v) { return 31 - __builtin_clz(v); }
 
 using SweepKernel = void (*)(const SweepArgs);
 
-// tiles are aligned in pivot coordinates: tile 0 starts at floor(qs / w) * w
-int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st) {
+// tiles are aligned in pivot coordinates: tile 0 starts at floor(qs / w) * w.
+// persistent: launch only as many workgroups as the device keeps resident; each walks its XCD
+// group's run of tiles and looks the next tile up while it works on the current one.
+int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st,
+                 bool persistent) {
     const int sh = floor_log2((uint32_t)w);
     A.tile0 = (A.qs >> sh) << sh;  // >> on a negative int64 is arithmetic: floor
     A.ntiles = ((A.qe - A.tile0) + w - 1) >> sh;
     A.tiles_per_xcd = (A.ntiles + 7) / 8;
-    if (A.tiles_per_xcd * 8 * threads >= ((int64_t)1 << 32))
-        return fail(MEMO_EINVAL, "window too long for one launch at tile width %d", w);
+    A.blocks_per_xcd = A.tiles_per_xcd;
     if (lds > 160 * 1024) return fail(MEMO_EINVAL, "tile needs %zu bytes of LDS (> 160 KiB)", lds);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(threads), lds, st, A);
+    if (persistent) {
+        int per_cu = 0, cus = 0, dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel),
+                                                             threads, lds));
+        const int64_t resident = ((int64_t)cus * (per_cu > 0 ? per_cu : 1) + 7) / 8;  // per XCD group
+        if (resident < A.blocks_per_xcd) A.blocks_per_xcd = resident;
+    }
+    if (A.blocks_per_xcd * 8 * threads >= ((int64_t)1 << 32))
+        return fail(MEMO_EINVAL, "window too long for one launch at tile width %d", w);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(A.blocks_per_xcd * 8)), dim3(threads), lds, st, A);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }
@@ -738,6 +816,7 @@ void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32
     A.qe = qe;
     A.out = d_out;
     A.status = ix->d_status;
+    A.stamps = g_stamp_buffer;
     A.bshift = ix->bshift;
     A.km1 = k - 1;
 }
@@ -810,11 +889,23 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                              : cons_kernel<PackedRows<true, false>, OutT>(w, waves))
                                   : cons_kernel<WideRows, OutT>(w, waves);
     if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-    if ((rc = launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * (w + kLevelSkew) * 4, st))) return rc;
+    if ((rc = launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * (w + kLevelSkew) * 4, st, use_persistent(fmt)))) return rc;
     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
 }
 
 extern "C" {
+
+int memo_debug_set_stamp_buffer(uint64_t *d_buffer) {
+    g_stamp_buffer = reinterpret_cast<unsigned long long *>(d_buffer);
+    return MEMO_OK;
+}
+
+int memo_set_persistent(int32_t mode) {
+    read_env_once();
+    if (mode < 0 || mode > 2) return fail(MEMO_EINVAL, "mode must be 0 (choose), 1 (off) or 2 (on)");
+    g_persist = mode;
+    return MEMO_OK;
+}
 
 int memo_set_row_source(int32_t source) {
     read_env_once();
@@ -895,7 +986,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                                  : memb_runs_kernel<PackedRows<true, false>>(w, waves))
                                       : memb_runs_kernel<WideRows>(w, waves);
         if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-        if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st))) return rc;
+        if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st, use_persistent(fmt)))) return rc;
         return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
     }
     const bool doubling = algo == 2;
@@ -914,7 +1005,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                              : memb_kernel<PackedRows<true, false>>(w, waves, doubling))
                                   : memb_kernel<WideRows>(w, waves, doubling);
     if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-    if ((rc = launch_tiles(kern, A, w, 64 * waves, per_pos * w, st))) return rc;
+    if ((rc = launch_tiles(kern, A, w, 64 * waves, per_pos * w, st, use_persistent(fmt)))) return rc;
     return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
 }
 

@@ -135,6 +135,7 @@ def test_resident_index_windows(tile_w, waves, algo, memo, oracle):
     n_docs, length = 70, 60_000
     s, e, o = _random_index(rng, 250_000, length, n_docs, 140)
     _lib.check(_lib.lib().memo_set_tuning(tile_w, waves, algo))
+    _lib.check(_lib.lib().memo_set_persistent(1 + (tile_w // 256 + waves) % 2))     # both launch forms
     try:
         with memo.DeviceIndex.from_host(s, e, o) as ix:
             assert ix.info()["was_sorted"] == 1

@@ -3,7 +3,7 @@
 on this pool is larger than most tuning effects).  GPU box only.
 
   python tools/ab.py --workload c3 --k 31 --rounds 12 "0,0,0" "1024,1,0" "4096,4,0"
-each variant = tile_w,waves,membership_algo  (memo_set_tuning)
+each variant = tile_w,waves,membership_algo[,persistent]  (memo_set_tuning, memo_set_persistent)
 """
 import argparse
 import json
@@ -45,7 +45,8 @@ def main():
 
     for r in range(a.rounds + 1):
         for v in variants:
-            _lib.check(_lib.lib().memo_set_tuning(*v))
+            _lib.check(_lib.lib().memo_set_tuning(*v[:3]))
+            _lib.check(_lib.lib().memo_set_persistent(v[3] if len(v) > 3 else 0))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             launch()
