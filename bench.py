@@ -223,7 +223,9 @@ def main():
 
     def kernel_name(which):
         rows_t = "WideRows" if which == "wide" else f"PackedRows<{'true' if packed_fmt == 6 else 'false'}, false>"
-        return ("sweep_membership_kernel<" if membership else "sweep_conservation_kernel<") + rows_t + ", ...>"
+        if membership:      # packed rows: per-genome bit planes ("runs"); int64 rows: doubling
+            return ("sweep_membership_kernel<" if which == "wide" else "sweep_membership_runs_kernel<") + rows_t + ", ...>"
+        return "sweep_conservation_kernel<" + rows_t + ", ...>"
 
     other = None
     if not multi and k - 1 <= 255:          # the same query on the other row format, for the record
