@@ -43,6 +43,7 @@ WORKLOADS = {
     "c3": (100, 100_000_000, False),
     "c4": (100, 100_000_000, True),
     "c5": (500, 1 << 25, False),
+    "sparse": (10, 400_000_000, False),      # 0.5 rows per position (tuning experiments)
 }
 
 

@@ -875,12 +875,16 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // Short windows want many small tiles either way.
     int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
     if (!w) {
-        const size_t budget = fmt ? 32 * 1024 : 80 * 1024;
+        // int64 rows on a sparse index (< 2 rows per position: profiles/r01_sparse_index_tiles.txt) are
+        // no longer HBM-bound per tile; they want the packed rows' shape (more workgroups per CU)
+        const double span = (double)(ix->max_s - ix->min_s) + 1.0;
+        const bool sparse = (double)ix->rows < 2.0 * span;
+        const size_t budget = (fmt || sparse) ? 32 * 1024 : 80 * 1024;
         w = 4096;
         while ((size_t)A.nlev * w * 4 > budget && w > 256) w >>= 1;
-        while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
+        while (w > 256 && (qe - qs) / w < 32768) w >>= 1;
     }
-    if (!waves) waves = w >= (fmt ? 512 : 2048) ? 4 : 1;
+    if (!waves) waves = w >= 1024 ? 4 : 1;  // short windows end up with small tiles: one wave each
     while ((size_t)A.nlev * w * 4 > 160 * 1024 && w > 256) w >>= 1;
     const bool checked = ix->max_annot >= (uint64_t)A.ncols;  // some row could be outside the matrix
     SweepKernel kern = fmt == 4   ? (checked ? cons_kernel<PackedRows<false, true>, OutT>(w, waves)
