@@ -18,6 +18,9 @@
 //     atomics cannot change a bit of the result.
 //
 // Integer work only: no MFMA.  Bound: HBM bandwidth (int64 rows), HBM + LDS atomics (packed rows).
+#include <map>
+#include <utility>
+
 #include "memo_common.h"
 
 using namespace memo;
@@ -704,9 +707,17 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
     A.tiles_per_xcd = (A.ntiles + 7) / 8;
     A.blocks_per_xcd = A.tiles_per_xcd;
     if (lds > 160 * 1024) return fail(MEMO_EINVAL, "tile needs %zu bytes of LDS (> 160 KiB)", lds);
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) {  // opt in to large dynamic LDS once per (thread, device, kernel, size)
+        thread_local std::map<std::pair<const void *, int>, size_t> granted;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        size_t &have = granted[{reinterpret_cast<const void *>(kernel), dev}];
+        if (have < lds) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            have = lds;
+        }
+    }
     if (persistent) {
         int per_cu = 0, cus = 0, dev = 0;
         HIP_TRY(hipGetDevice(&dev));
