@@ -493,3 +493,78 @@ def test_dap_to_parquet_is_a_queryable_index(memo, oracle, tmp_path):
     want = oracle.conservation(*oracle.filter_rows(s[sel], e[sel], a[sel], 10, 290, 5), 10, 290, 5, 71, literal=False)
     with mq.region_index(out, names[0], 10, 290 + 5) as ix:
         assert np.array_equal(ix.conservation(10, 290, 5, 71), want)
+
+
+# ---------------------------------------------------------------------------------------
+# randomized differential test and API error paths
+# ---------------------------------------------------------------------------------------
+def test_randomized_differential(memo, oracle):
+    """many small random indexes / windows / k / N through the resident index (both row formats)"""
+    rng = np.random.default_rng(20261003)
+    for case in range(120):
+        n_docs = int(rng.choice([2, 3, 9, 32, 33, 100, 255, 256, 300]))
+        length = int(rng.choice([40, 300, 5000, 70000]))
+        m = int(rng.integers(0, 4000))
+        style = case % 4
+        if style == 0:
+            s = np.sort(rng.integers(1, length, m))
+        elif style == 1:                                  # heavy clumps: many rows on few starts
+            s = np.sort(rng.choice(rng.integers(1, length, 5), m))
+        elif style == 2:                                  # starts beyond / before the window
+            s = np.sort(rng.integers(-50, length + 500, m))
+        else:                                             # runs of consecutive starts
+            s = np.sort(np.repeat(rng.integers(1, length, m // 8 + 1), 8)[:m] + rng.integers(0, 3, m))
+        s = s.astype(np.int64)
+        e = s + rng.integers(0, int(rng.choice([3, 40, 400])), m)
+        o = rng.integers(1, n_docs, m).astype(np.int64) if n_docs > 1 else np.ones(m, np.int64)
+        k = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 101, 127, 128, 129, 255, 256, 257, 600]))
+        qs = int(rng.integers(0, length))
+        qe = int(rng.integers(qs, length + 100))
+        rows = oracle.filter_rows(s, e, o, qs, qe, k)
+        want = oracle.conservation(*rows, qs, qe, k, n_docs, literal=False)
+        wantb = oracle.membership(*rows, qs, qe, k, n_docs, literal=False)
+        with memo.DeviceIndex.from_host(s, e, o) as ix:
+            for packed in (False, True):
+                if packed:
+                    if s.size and s.min() < 0:
+                        with pytest.raises(memo.MemoError):
+                            ix.pack()
+                        break
+                    ix.pack(keep_wide=True)
+                assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (case, packed)
+                assert np.array_equal(ix.membership(qs, qe, k, n_docs), wantb), (case, packed)
+                if n_docs <= 255:
+                    assert np.array_equal(ix.conservation(qs, qe, k, n_docs, dtype=np.uint8), want.astype(np.uint8)), case
+
+
+def test_api_error_paths(memo):
+    import ctypes as C
+    from memo_amd import _lib
+    L = _lib.lib()
+    s = np.arange(1, 101, dtype=np.int64)
+    ix = memo.DeviceIndex(100, 0)
+    try:
+        _lib.check(L.memo_index_upload(ix._h, s.ctypes.data, (s + 2).ctypes.data, (s * 0 + 1).ctypes.data, 100))
+        d = C.c_void_p()
+        _lib.check(L.memo_dev_malloc(0, 4096, C.byref(d)))
+        assert L.memo_query_conservation_dev(ix._h, 0, 50, 31, 5, d, None) == _lib.MEMO_ENOTREADY
+        ix.finalize()
+        assert L.memo_query_conservation_dev(ix._h, 0, 50, 31, 0, d, None) == _lib.MEMO_EINVAL          # num_docs
+        assert L.memo_query_conservation_dev(ix._h, 0, 50, 31, 70000, d, None) == _lib.MEMO_EINVAL
+        assert L.memo_query_conservation_u8_dev(ix._h, 0, 50, 31, 300, d, None) == _lib.MEMO_EINVAL      # uint8 needs N <= 255
+        assert L.memo_query_conservation_dev(ix._h, 0, 50, 31, 5, C.c_void_p(d.value + 2), None) == _lib.MEMO_EINVAL  # alignment
+        assert L.memo_query_conservation_dev(ix._h, 0, 50, 31, 5, None, None) == _lib.MEMO_EINVAL
+        assert L.memo_query_conservation_dev(ix._h, 50, 0, 31, 5, d, None) == _lib.MEMO_EINVAL
+        assert b"ValueError" in L.memo_last_error()
+        assert L.memo_query_conservation_dev(ix._h, 0, 0, 31, 5, None, None) == 0                         # empty window
+        assert L.memo_index_upload(ix._h, s.ctypes.data, s.ctypes.data, s.ctypes.data, 99) == _lib.MEMO_EINVAL
+        assert L.memo_index_pack(ix._h, 0) == 0
+        assert L.memo_index_upload(ix._h, s.ctypes.data, s.ctypes.data, s.ctypes.data, 100) == _lib.MEMO_EINVAL  # columns dropped
+        assert L.memo_query_conservation_dev(ix._h, 0, 50, 300, 5, d, None) == _lib.MEMO_EINVAL           # k > 256 needs int64 rows
+        assert L.memo_query_conservation_dev(ix._h, 0, 50, 31, 5, d, None) == 0
+        ix.check()
+        _lib.check(L.memo_dev_free(0, d))
+        bad = C.c_void_p()
+        assert L.memo_index_create(10, 99, C.byref(bad)) == _lib.MEMO_EHIP
+    finally:
+        ix.close()
