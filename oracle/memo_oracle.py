@@ -40,7 +40,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(build())
+        L = C.CDLL(os.environ.get("MEMO_ORACLE_LIB") or build())   # override: the ASan/UBSan build (make asan)
         q = [_i64p, _i64p, _i64p, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
         for name, outp in (("oracle_literal_conservation", _u16p), ("oracle_closed_conservation", _u16p),
                            ("oracle_literal_membership", _u32p), ("oracle_closed_membership", _u32p)):
