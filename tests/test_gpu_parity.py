@@ -568,3 +568,47 @@ def test_api_error_paths(memo):
         assert L.memo_index_create(10, 99, C.byref(bad)) == _lib.MEMO_EHIP
     finally:
         ix.close()
+
+
+def test_config2_size_numpy_rng_index(memo, oracle):
+    """a NumPy-RNG index at config-2 size (random starts: ragged density, ties),
+    whole window, both row formats, against the oracle's closed form"""
+    rng = np.random.default_rng(0x4D454D4F)
+    n, L, m, k = 10, 10_000_000, 5_000_000, 31
+    s = np.sort(rng.integers(1, L, m)).astype(np.int64)
+    e = s + rng.integers(0, 60, m)
+    o = rng.integers(1, n, m).astype(np.int64)
+    want = oracle.conservation(s, e, o, 0, L, k, n, literal=False)
+    with memo.DeviceIndex.from_host(s, e, o) as ix:
+        assert np.array_equal(ix.conservation(0, L, k, n), want)
+        ix.pack(keep_wide=False)
+        assert np.array_equal(ix.conservation(0, L, k, n), want)
+        wantb = oracle.membership(*oracle.filter_rows(s, e, o, 4_000_000, 5_000_000, k), 4_000_000, 5_000_000, k, n, literal=False)
+        assert np.array_equal(ix.membership(4_000_000, 5_000_000, k, n), wantb)
+
+
+def test_config5_shard_packed_6_bytes(memo, oracle):
+    """one shard of config 5 (500 genomes, 25 rows per position, 2^25 positions, 8.4e8 rows): packed
+    6-byte rows only (the int64 columns dropped, as an HPRC-scale deployment would), k in {21, 31, 101},
+    sampled sub-windows against the oracle + the split-window property"""
+    from memo_amd import synth
+    n, L = 500, 1 << 25
+    pivot = 8 * L                                    # this is shard 3 of 8
+    qs, qe = 3 * L, 4 * L
+    num, den = synth.rows_per_position(n)
+    ix, (r0, r1) = synth.device_index(qs, qe, 101, n, pivot, pack="only")
+    with ix:
+        inf = ix.info()
+        assert inf["packed_format"] == 6 and inf["has_wide"] == 0 and inf["rows"] == r1 - r0
+        assert inf["device_bytes"] < 7 * (r1 - r0)
+        rng = np.random.default_rng(9)
+        for k in (21, 31, 101):
+            full = ix.conservation(qs, qe, k, n)
+            assert full.dtype == np.uint16 and 1 <= full.min() and full.max() <= n
+            for a in [qs, qe - 200_000] + [int(x) for x in rng.integers(qs, qe - 200_000, 3)]:
+                b = a + 200_000
+                sr0, sr1 = synth.shard_rows(a, b, k, num, den, pivot)
+                s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
+                want = oracle.conservation(s, e, o, a, b, k, n, literal=False)
+                assert np.array_equal(full[a - qs:b - qs], want), (k, a)
+                assert np.array_equal(ix.conservation(a + 3, b - 11, k, n), want[3:-11])
