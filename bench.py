@@ -128,7 +128,11 @@ def main():
     if multi:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
         else:
             dist.init_process_group("nccl", device_id=dev)

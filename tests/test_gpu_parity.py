@@ -406,7 +406,12 @@ def test_cli_sharded_path_single_rank(memo, tmp_path):
         out = tmp_path / (name + ".txt")
         argv = [sys.executable, exe, "query", "-b", os.path.join(G.GOLD, c["index"]), "-n", str(c["n"]), "-k", str(c["k"]),
                 "-r", c["region"], "-o", str(out)] + (["-m"] if c["membership"] else [])
-        r = subprocess.run(argv, capture_output=True, env=dict(os.environ, MEMO_FORCE_SHARDED="1", MASTER_PORT="29541"))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        r = subprocess.run(argv, capture_output=True,
+                           env=dict(os.environ, MEMO_FORCE_SHARDED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert G.sha(out.read_bytes()) == c["sha256"]
 
