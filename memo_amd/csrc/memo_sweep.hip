@@ -47,7 +47,9 @@ struct SweepArgs {
     int km1;    // k - 1 (>= 1 here; k <= 1 never reaches a sweep kernel)
     int ncols;  // result columns: num_docs + 1 (conservation) / num_docs (membership)
     int nlev;   // doubling levels: floor(log2(k-1)) + 1
-    int nwords; // membership: 32-bit words per position
+    int nwords; // membership: 32-bit words per position handled by this launch
+    int word_base;  // membership runs: first genome word of this launch (num_docs too large for one
+    int out_words;  //   LDS tile is swept in slices of genome words); out_words = words per position
     unsigned long long *stamps;  // diagnostic builds (-DMEMO_STAMPS): per-phase cycle sums
 };
 
@@ -555,8 +557,10 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
         for (int i = tid; i < total; i += T) lds[i] = 0;
         lds_barrier();
     };
+    const int g_lo = 32 * A.word_base, g_n = 32 * nw;  // genomes of this launch's slice
     Rows::template for_each<T, U>(A, t, clear_tile, [&](int c, int h, int col) {
-        if (h <= c) return;
+        col -= g_lo;
+        if (h <= c || (unsigned)col >= (unsigned)g_n) return;
         uint32_t *row = lds + col * PITCH + (col >> 5) * skew;
         const int w0 = c >> 5, w1 = (h - 1) >> 5;
         const uint32_t first = 0xFFFFFFFFu << (c & 31), last = 0xFFFFFFFFu >> (31 - ((h - 1) & 31));
@@ -577,15 +581,16 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 #pragma unroll
         for (int i = 0; i < 32; ++i) m[i] = lds[(32 * G + i) * PITCH + G * skew + P];
         transpose32(m);
-        const uint32_t full = full_word(A.ncols, G);
-        uint32_t *dst = out + (ob + 32 * P) * nw + G;
+        const uint32_t full = full_word(A.ncols, A.word_base + G);
+        const int64_t ow = A.out_words;
+        uint32_t *dst = out + (ob + 32 * P) * ow + A.word_base + G;
         if (32 * P >= t.x_lo && 32 * P + 32 <= t.x_hi) {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) dst[(int64_t)j * nw] = full & ~m[j];
+            for (int j = 0; j < 32; ++j) dst[(int64_t)j * ow] = full & ~m[j];
         } else {
 #pragma unroll
             for (int j = 0; j < 32; ++j)
-                if (32 * P + j >= t.x_lo && 32 * P + j < t.x_hi) dst[(int64_t)j * nw] = full & ~m[j];
+                if (32 * P + j >= t.x_lo && 32 * P + j < t.x_hi) dst[(int64_t)j * ow] = full & ~m[j];
         }
     }
     if (have_next) __syncthreads();  // the LDS tile is reused
@@ -980,19 +985,27 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // A/B on config 4 (profiles/r01_membership_algorithms.txt): packed rows 0.87 ms runs vs 1.13 ms
     // doubling; int64 rows (HBM-bound either way) 2.52 ms doubling vs 2.64 ms runs
     if (!algo) algo = (fmt || per_pos_doubling * 256 > 40 * 1024) ? 3 : 2;
+    // whatever was asked for: a tile of 256 positions has to fit in LDS, else runs (which can slice)
+    if ((algo == 2 ? per_pos_doubling : (size_t)nw * 4) * 256 > 128 * 1024 || nw > 64) algo = 3;
     const bool checked = ix->max_annot >= (uint64_t)A.ncols;
     int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
+    A.word_base = 0;
+    A.out_words = nw;
     if (algo == 3) {
         if (!waves) waves = 4;
+        // 4 * nw bytes of LDS per position: beyond 2048 genomes even a 256-position tile is too big,
+        // so the genome words are swept in slices of 64 (the rows are read once per slice; every
+        // slice writes its own words of the result)
+        const int slice = nw <= 64 ? nw : 64;
         if (!w) {  // a lane transposes one 32 x 32 block: keep nw * W / 32 >= threads
             w = 4096;
-            while ((size_t)nw * 4 * w > 32 * 1024 && w > 256) w >>= 1;
+            while ((size_t)slice * 4 * w > 32 * 1024 && w > 256) w >>= 1;
             while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
         }
         int skew = 1;
-        while (skew * 2 * nw <= 32) skew *= 2;  // largest power of two <= 32 / nw (1 when nw > 16)
+        while (skew * 2 * slice <= 32) skew *= 2;  // largest power of two <= 32 / nw (1 when nw > 16)
         A.nlev = skew;
-        auto lds_bytes = [&](int ww) { return ((size_t)32 * nw * (ww / 32 + 1) + (size_t)nw * skew) * 4; };
+        auto lds_bytes = [&](int ww) { return ((size_t)32 * slice * (ww / 32 + 1) + (size_t)slice * skew) * 4; };
         while (lds_bytes(w) > 160 * 1024 && w > 256) w >>= 1;
         const size_t lds = lds_bytes(w);
         SweepKernel kern = fmt == 4   ? (checked ? memb_runs_kernel<PackedRows<false, true>>(w, waves)
@@ -1001,7 +1014,11 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                                  : memb_runs_kernel<PackedRows<true, false>>(w, waves))
                                       : memb_runs_kernel<WideRows>(w, waves);
         if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-        if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st, use_persistent(fmt)))) return rc;
+        for (int base = 0; base < nw; base += slice) {
+            A.word_base = base;
+            A.nwords = nw - base < slice ? nw - base : slice;
+            if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st, use_persistent(fmt)))) return rc;
+        }
         return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
     }
     const bool doubling = algo == 2;

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Time-boxed differential fuzzing of the HIP path against the oracle (GPU box):
+    python tests/fuzz_gpu.py --seconds 300 [--seed S]
+Random indexes (density, clumping, annots, overlaps incl. end < start), random windows, k, N,
+tile shapes, membership algorithms, row formats, launch forms.  Exits non-zero on the first
+mismatch and prints the case."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import memo_amd  # noqa: E402
+from memo_amd import _lib  # noqa: E402
+from oracle import memo_oracle as oracle  # noqa: E402  (the checker)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=60)
+ap.add_argument("--seed", type=int, default=int(time.time()))
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+L = _lib.lib()
+t_end = time.time() + a.seconds
+cases = queries = 0
+print("seed", a.seed, flush=True)
+while time.time() < t_end:
+    cases += 1
+    n_docs = int(rng.choice([2, 5, 31, 32, 33, 64, 100, 255, 256, 257, 500, 1000]))
+    length = int(rng.choice([100, 3000, 50_000, 400_000]))
+    m = int(rng.integers(0, int(rng.choice([50, 5000, 200_000]))))
+    mode = int(rng.integers(0, 5))
+    if mode == 0:
+        s = rng.integers(1, length, m)
+    elif mode == 1:
+        s = rng.choice(rng.integers(1, length, max(int(rng.integers(1, 40)), 1)), m)
+    elif mode == 2:
+        s = rng.integers(-100, length + 1000, m)
+    elif mode == 3:
+        s = (rng.integers(1, max(length // 64, 2), m) * 64 + rng.integers(-1, 2, m))
+    else:
+        s = np.abs(rng.normal(length / 2, length / 20 + 1, m)).astype(np.int64) + 1
+    s = np.sort(s).astype(np.int64)
+    e = s + rng.integers(0, int(rng.choice([2, 30, 70, 300, 3000])), m)
+    if rng.random() < 0.25 and m:
+        neg = rng.random(m) < 0.02
+        e[neg] = s[neg] - rng.integers(1, 2000, int(neg.sum()))
+    hi_annot = n_docs if rng.random() < 0.9 else n_docs + 3          # sometimes outside the matrix
+    o = rng.integers(0 if rng.random() < 0.1 else 1, max(hi_annot, 2), m).astype(np.int64)
+    with memo_amd.DeviceIndex.from_host(s, e, o) as ix:
+        packable = not (m and s.min() < 0)
+        if packable and rng.random() < 0.7:
+            ix.pack(keep_wide=True)
+        for _ in range(6):
+            queries += 1
+            k = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 21, 31, 32, 33, 64, 65, 101, 128, 129, 255, 256, 257, 1000]))
+            qs = int(rng.integers(0, length))
+            qe = int(rng.integers(qs, length + 200))
+            tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096])), int(rng.choice([0, 1, 4])), int(rng.integers(0, 4)))
+            _lib.check(L.memo_set_tuning(*tune))
+            _lib.check(L.memo_set_persistent(int(rng.integers(0, 3))))
+            _lib.check(L.memo_set_row_source(int(rng.integers(0, 2))))
+            memb = rng.random() < 0.4
+            if memb and (qe - qs) * n_docs > 30_000_000:
+                qe = qs + 30_000_000 // n_docs
+            rows = oracle.filter_rows(s, e, o, qs, qe, k)
+            fn_o = oracle.membership if memb else oracle.conservation
+            fn_g = ix.membership if memb else ix.conservation
+            try:
+                want, werr = fn_o(*rows, qs, qe, k, n_docs, literal=False), None
+            except IndexError:
+                want, werr = None, IndexError
+            try:
+                got, gerr = fn_g(qs, qe, k, n_docs), None
+            except IndexError:
+                got, gerr = None, IndexError
+            ok = werr == gerr and (werr is not None or np.array_equal(got, want))
+            if not ok:
+                print("MISMATCH", dict(seed=a.seed, case=cases, n_docs=n_docs, length=length, m=m, mode=mode, k=k, qs=qs, qe=qe,
+                                       tune=tune, memb=memb, info=ix.info(), werr=str(werr), gerr=str(gerr)), flush=True)
+                np.savez("/tmp/fuzz_fail.npz", s=s, e=e, o=o)
+                sys.exit(1)
+_lib.check(L.memo_set_tuning(0, 0, 0))
+print(f"fuzz ok: {cases} indexes, {queries} queries in {a.seconds:.0f} s", flush=True)

@@ -235,6 +235,20 @@ def test_num_docs_word_boundaries(memo, oracle):
         assert np.array_equal(memo.conservation(s, e, o, 100, 2900, 31, n_docs), want), n_docs
 
 
+def test_membership_many_genomes_is_sliced(memo, oracle):
+    """num_docs in the thousands: the genome words do not fit one LDS tile and are swept in slices"""
+    rng = np.random.default_rng(12)
+    for n_docs in (2049, 5000, 20000):
+        s, e, o = _random_index(rng, 30000, 2000, n_docs, 60)
+        want = oracle.membership(s, e, o, 100, 1500, 31, n_docs, literal=False)
+        with memo.DeviceIndex.from_host(s, e, o) as ix:
+            assert np.array_equal(ix.membership(100, 1500, 31, n_docs), want), n_docs
+            ix.pack()
+            assert np.array_equal(ix.membership(100, 1500, 31, n_docs), want), n_docs
+            assert np.array_equal(ix.conservation(100, 1500, 31, n_docs),
+                                  oracle.conservation(s, e, o, 100, 1500, 31, n_docs, literal=False))
+
+
 def test_annot_edge_values(memo, oracle):
     """order 0, order == N (the sentinel column), negative order (NumPy wraps), order > N (IndexError)."""
     s = np.array([10, 20, 30, 40], np.int64)
