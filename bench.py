@@ -19,6 +19,7 @@ recorded on the launch stream; `cpu_baseline` is the oracle's literal port of th
 reference loop (memo_query.py:45-63,70) on one host core over a bounded sample window.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -58,6 +59,8 @@ def parse():
     ap.add_argument("--rows", default="packed", choices=["packed", "wide"],
                     help="row format the timed sweep reads: packed (memo_index_pack, 4-6 B/row) or the "
                          "int64 columns as uploaded (24 B/row); at N=1 the other one is timed too")
+    ap.add_argument("--plain-gather", action="store_true",
+                    help="N > 1: send uint8 slices as they are (default: nibble transport coding when it fits)")
     ap.add_argument("--calibrate", action="store_true",
                     help="also run the read-once calibration kernel (for the FETCH_SIZE PMC pass)")
     ap.add_argument("--force-dist", action="store_true",
@@ -165,11 +168,8 @@ def main():
     # two result buffers: the gather of step i (RCCL stream) overlaps the sweep of step i+1
     nbuf = 2 if multi else 1
     outs = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(nbuf)]
-    wires = [o.view(torch.uint8).reshape(-1) for o in outs]      # RCCL has no 16-bit integer type
-    roots = [[torch.empty_like(wires[0]) for _ in range(world)] if (multi and rank == 0) else None
-             for _ in range(nbuf)]
-    pending = [None] * nbuf
     stream = torch.cuda.current_stream()
+    lib = _lib.lib()
 
     def launch(out):
         if membership:
@@ -179,24 +179,60 @@ def main():
         else:
             ix.conservation_dev(qs, qe, k, num_docs, out, stream.cuda_stream)
 
+    # What travels to rank 0.  uint8 conservation slices go as one nibble per position plus an
+    # exception list for values >= 15 (lossless; memo_transport_*): a slice's own xGMI link is what
+    # bounds N > 1, so halving the bytes is worth a 25 us pack and a root-side unpack.  Used only if
+    # every rank's exceptions fit (same query every step, so one check before the timed region).
+    nibble = False
+    cap = max(L // 256, 1024)
+    if multi and narrow and not args.plain_gather:
+        probe = torch.empty(lib.memo_transport_bytes(L, cap), dtype=torch.uint8, device=dev)
+        launch(outs[0])
+        _lib.check(lib.memo_transport_pack_dev(outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream))
+        found, have = C.c_uint32(), C.c_uint32()
+        _lib.check(lib.memo_transport_exceptions(probe.data_ptr(), local, stream.cuda_stream, C.byref(found), C.byref(have)))
+        fits = torch.tensor([1 if found.value <= have.value else 0], device=dev)
+        dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+        nibble = bool(fits.item())
+        del probe
+    if nibble:
+        wires = [torch.empty(lib.memo_transport_bytes(L, cap), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    else:
+        wires = [o.view(torch.uint8).reshape(-1) for o in outs]  # RCCL has no 16-bit integer type
+    roots = [[torch.empty_like(wires[0]) for _ in range(world)] if (multi and rank == 0) else None
+             for _ in range(nbuf)]
+    # rank 0: the gathered slices in result form (decoded when they travelled as nibbles)
+    decoded = [[torch.empty(L, dtype=torch.uint8, device=dev) for _ in range(world)] if (nibble and rank == 0) else None
+               for _ in range(nbuf)]
+    pending = [None] * nbuf
+
+    def finish(b):                          # gather b done -> (root) slices back in result form
+        if pending[b] is None:
+            return
+        pending[b].wait()
+        pending[b] = None
+        if nibble and rank == 0:
+            for g in range(world):
+                _lib.check(lib.memo_transport_unpack_dev(roots[b][g].data_ptr(), L, decoded[b][g].data_ptr(), local,
+                                                         stream.cuda_stream))
+
     def step(i, ev=None):
         b = i % nbuf
-        if pending[b] is not None:         # buffer b is free once its previous gather is done
-            pending[b].wait()
-            pending[b] = None
+        finish(b)                           # buffer b is free once its previous gather is done
         if ev:
             ev[0].record(stream)
         launch(outs[b])
         if ev:
             ev[1].record(stream)
-        if multi:                          # result slices -> rank 0 over xGMI (RCCL send/recv)
+        if multi:                           # result slices -> rank 0 over xGMI (RCCL send/recv)
+            if nibble:
+                _lib.check(lib.memo_transport_pack_dev(outs[b].data_ptr(), L, cap, wires[b].data_ptr(), local,
+                                                       stream.cuda_stream))
             pending[b] = dist.gather(wires[b], roots[b], dst=0, async_op=True)
 
     def drain():
         for b in range(nbuf):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+            finish(b)
         torch.cuda.synchronize()
 
     if args.calibrate:
@@ -290,7 +326,7 @@ def main():
             res["without_gather"] = {"value": L * world / (kern_ms * 1e-3), "unit": "query-positions/s",
                                      "note": "aggregate of the per-rank sweeps alone (max kernel_ms over ranks); "
                                              "`value` above includes delivering every slice to rank 0, which is "
-                                             f"bound by {b_out * L / 1e6:.0f} MB per peer link per step"}
+                                             f"bound by {wires[0].numel() / 1e6:.0f} MB per peer link per step"}
         if other:
             res["other_row_format"] = other
         if world == 1 and args.cpu_sample > 0:
@@ -308,13 +344,17 @@ def main():
             a = g * L
             sr0, sr1 = synth.shard_rows(a, a + S, k, num, den, pivot)
             s_, e_, o_ = oracle.synth_rows(sr0, sr1 - sr0, num, den, num_docs)
-            got = roots[(args.steps - 1) % nbuf][g].view(dtype).reshape(shape)[:S].cpu().numpy()
+            last = (args.steps - 1) % nbuf
+            got = (decoded[last][g] if nibble else roots[last][g].view(dtype).reshape(shape))[:S].cpu().numpy()
             if membership:
                 ok = np.array_equal(got.view(np.uint32), oracle.membership(s_, e_, o_, a, a + S, k, num_docs, literal=False))
             else:
                 want = oracle.conservation(s_, e_, o_, a, a + S, k, num_docs, literal=False)
                 ok = np.array_equal(got.view(np.uint8 if narrow else np.uint16).astype(np.uint16), want)
             res["gather_parity_sample"] = {"rank": g, "positions": S, "equal_to_oracle": bool(ok)}
+            res["config"]["gather_payload"] = (f"nibble per position + {cap} exception slots "
+                                               f"({wires[0].numel()} B per slice)" if nibble else
+                                               f"plain result bytes ({wires[0].numel()} B per slice)")
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     ix.close()
     if multi:

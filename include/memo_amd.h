@@ -177,6 +177,17 @@ int64_t memo_parse_ints(const char *text, size_t len, int64_t *out, size_t cap);
 size_t memo_emit_bed(const int32_t *rec, const int64_t *start, const int64_t *end, const int32_t *annot,
                      uint64_t rows, const char *names, int32_t nrec, char *buf, size_t cap);
 
+/* ---- transport coding of uint8 conservation results (multi-GPU gather) ---------------------
+ * One nibble per position; values >= 15 travel in an exception list of `cap` slots.  Lossless.
+ * wire size = memo_transport_bytes(n, cap); pack and unpack are asynchronous on `stream`.
+ * memo_transport_exceptions() tells (synchronising `stream`) how many exceptions the sender found:
+ * more than cap means this slice has to travel as plain bytes instead. */
+size_t memo_transport_bytes(int64_t n, uint32_t cap);
+int memo_transport_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t cap, void *d_wire, int32_t device,
+                            void *stream);
+int memo_transport_unpack_dev(const void *d_wire, int64_t n, uint8_t *d_vec, int32_t device, void *stream);
+int memo_transport_exceptions(const void *d_wire, int32_t device, void *stream, uint32_t *found, uint32_t *cap);
+
 /* ---- synthetic pangenome index (BASELINE.json configs 2-5) -------------------
  * Fills rows [0, rows) of the index with global rows row_begin + i of the generator
  *   start = 1 + floor(i * den / num), end = start + mix(seed, 2i) % 60,

@@ -148,6 +148,78 @@ __global__ __launch_bounds__(256) void bin_conservation_kernel(const uint16_t *v
     }
 }
 
+// Transport coding of uint8 conservation results for the multi-GPU gather: one nibble per position
+// (values >= 15 become 15 and go to an exception list as position << 8 | value).  Lossless; halves
+// what a slice puts on its xGMI link when few values reach 15.
+__global__ __launch_bounds__(256) void nibble_pack_kernel(const uint8_t *in, int64_t n, uint32_t *nib,
+                                                          unsigned long long *exc, unsigned int *count,
+                                                          unsigned int cap) {
+    // exceptions are collected per workgroup in LDS and appended with ONE global atomic per flush:
+    // a quarter of a million same-address atomics would cost milliseconds
+    __shared__ unsigned long long held[4096];
+    __shared__ unsigned int n_held, base;
+    if (threadIdx.x == 0) n_held = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) count[1] = cap;  // header word 1
+    __syncthreads();
+    const int64_t groups = (n + 7) / 8;
+    const int64_t rounds = (groups + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
+    for (int64_t r = 0; r < rounds; ++r) {  // every thread of the workgroup makes every round (barriers inside)
+        const int64_t g = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        if (g < groups) {
+            unsigned long long eight = 0;  // 8 results in one load (the tail group byte by byte)
+            if (g * 8 + 8 <= n) {
+                eight = *reinterpret_cast<const unsigned long long *>(in + g * 8);
+            } else {
+                for (int i = 0; g * 8 + i < n; ++i) eight |= (unsigned long long)in[g * 8 + i] << (8 * i);
+            }
+            uint32_t word = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t v = (uint32_t)(eight >> (8 * i)) & 0xFFu;
+                if (v >= 15u) held[atomicAdd(&n_held, 1u)] = ((unsigned long long)(g * 8 + i) << 8) | v;
+                word |= (v < 15u ? v : 15u) << (4 * i);
+            }
+            nib[g] = word;
+        }
+        __syncthreads();
+        const unsigned int mine = n_held;
+        if (mine && (r + 1 == rounds || mine > 2048)) {  // a round adds at most 2048: flush before it could overflow
+            if (threadIdx.x == 0) base = atomicAdd(count, mine);
+            __syncthreads();
+            for (unsigned int i = threadIdx.x; i < mine; i += 256)
+                if (base + i < cap) exc[base + i] = held[i];
+            __syncthreads();
+            if (threadIdx.x == 0) n_held = 0;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void nibble_unpack_kernel(const uint32_t *nib, int64_t n, uint8_t *out) {
+    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g * 8 < n;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t word = nib[g];
+        unsigned long long eight = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) eight |= (unsigned long long)((word >> (4 * i)) & 15u) << (8 * i);
+        if (g * 8 + 8 <= n) {
+            *reinterpret_cast<unsigned long long *>(out + g * 8) = eight;
+        } else {
+            for (int i = 0; g * 8 + i < n; ++i) out[g * 8 + i] = (uint8_t)(eight >> (8 * i));
+        }
+    }
+}
+
+__global__ void nibble_exceptions_kernel(const unsigned long long *exc, const unsigned int *head, int64_t n,
+                                         uint8_t *out) {
+    const unsigned int count = head[0] < head[1] ? head[0] : head[1];  // found, capacity
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const unsigned long long e = exc[i];
+        const int64_t p = (int64_t)(e >> 8);
+        if (p < n) out[p] = (uint8_t)(e & 0xFF);
+    }
+}
+
 // PMC calibration: reads every row of the three columns exactly once with the sweep's own
 // access shape (16 B per lane, 1 KiB per wave-instruction) and nothing else, so that
 // FETCH_SIZE can be checked against a known byte count (24 B x padded rows) in the same run.
@@ -551,6 +623,64 @@ int memo_bin_conservation_dev(const uint16_t *d_vec, int64_t L, const int64_t *e
     (void)hipFree(d_edges);
     (void)hipFree(d_counts);
     return rc;
+}
+
+// wire layout: [count u32, cap u32, 8 B pad][nibbles: 4 * ceil(n / 8) B][exceptions: cap * 8 B]
+size_t memo_transport_bytes(int64_t n, uint32_t cap) {
+    return 16 + (size_t)((n + 7) / 8) * 4 + (size_t)cap * 8;
+}
+
+int memo_transport_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t cap, void *d_wire, int32_t device,
+                            void *stream) {
+    if (n < 0 || (n > 0 && (!d_vec || !d_wire))) return fail(MEMO_EINVAL, "bad transport arguments");
+    if (((uintptr_t)d_vec & 7) || ((uintptr_t)d_wire & 7)) return fail(MEMO_EINVAL, "transport buffers must be 8-byte aligned");
+    DeviceGuard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *w = static_cast<char *>(d_wire);
+    HIP_TRY(hipMemsetAsync(w, 0, 16, st));  // count = 0; the kernel fills in the capacity (no host staging)
+    const int64_t groups = (n + 7) / 8;
+    {
+        const unsigned grid = (unsigned)(groups / 256 + 1 < 8192 ? groups / 256 + 1 : 8192);
+        hipLaunchKernelGGL(nibble_pack_kernel, dim3(grid), dim3(256), 0, st, d_vec, n,
+                           reinterpret_cast<uint32_t *>(w + 16),
+                           reinterpret_cast<unsigned long long *>(w + 16 + groups * 4),
+                           reinterpret_cast<unsigned int *>(w), cap);
+        HIP_TRY(hipGetLastError());
+    }
+    return MEMO_OK;
+}
+
+int memo_transport_unpack_dev(const void *d_wire, int64_t n, uint8_t *d_vec, int32_t device, void *stream) {
+    if (n < 0 || (n > 0 && (!d_vec || !d_wire))) return fail(MEMO_EINVAL, "bad transport arguments");
+    if (((uintptr_t)d_vec & 7) || ((uintptr_t)d_wire & 7)) return fail(MEMO_EINVAL, "transport buffers must be 8-byte aligned");
+    DeviceGuard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const char *w = static_cast<const char *>(d_wire);
+    const int64_t groups = (n + 7) / 8;
+    if (groups) {
+        const unsigned grid = (unsigned)(groups / 256 + 1 < 8192 ? groups / 256 + 1 : 8192);
+        hipLaunchKernelGGL(nibble_unpack_kernel, dim3(grid), dim3(256), 0, st,
+                           reinterpret_cast<const uint32_t *>(w + 16), n, d_vec);
+        hipLaunchKernelGGL(nibble_exceptions_kernel, dim3(256), dim3(256), 0, st,
+                           reinterpret_cast<const unsigned long long *>(w + 16 + groups * 4),
+                           reinterpret_cast<const unsigned int *>(w), n, d_vec);
+        HIP_TRY(hipGetLastError());
+    }
+    return MEMO_OK;
+}
+
+// exceptions the sender found (host value; synchronises `stream`).  More than the wire's capacity
+// means the slice cannot travel in this coding.
+int memo_transport_exceptions(const void *d_wire, int32_t device, void *stream, uint32_t *found, uint32_t *cap) {
+    if (!d_wire || !found || !cap) return fail(MEMO_EINVAL, "NULL argument");
+    DeviceGuard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t head[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(head, d_wire, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *found = head[0];
+    *cap = head[1];
+    return MEMO_OK;
 }
 
 int memo_debug_stream_rows(memo_index_t *ix, void *stream) {

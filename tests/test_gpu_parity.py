@@ -631,3 +631,30 @@ def test_config5_shard_packed_6_bytes(memo, oracle):
                 want = oracle.conservation(s, e, o, a, b, k, n, literal=False)
                 assert np.array_equal(full[a - qs:b - qs], want), (k, a)
                 assert np.array_equal(ix.conservation(a + 3, b - 11, k, n), want[3:-11])
+
+
+def test_transport_nibble_coding_round_trip(memo):
+    """uint8 results -> nibbles + exception list -> uint8, for value mixes with none, few and too
+    many values >= 15"""
+    import ctypes as C
+    import torch
+    from memo_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(6)
+    for n, hi, frac in ((0, 10, 0), (1, 200, 1.0), (12345, 14, 0), (1_000_003, 200, 0.001), (1_000_000, 255, 0.01), (4096, 255, 1.0)):
+        v = rng.integers(0, 15, n).astype(np.uint8)
+        big = rng.random(n) < frac
+        v[big] = rng.integers(15, hi + 1, int(big.sum())) if hi >= 15 else v[big]
+        cap = max(n // 64, 4)
+        src = torch.from_numpy(v).cuda()
+        wire = torch.zeros(L.memo_transport_bytes(n, cap), dtype=torch.uint8, device="cuda")
+        dst = torch.full((max(n, 1),), 77, dtype=torch.uint8, device="cuda")
+        _lib.check(L.memo_transport_pack_dev(src.data_ptr(), n, cap, wire.data_ptr(), 0, None))
+        found, have = C.c_uint32(), C.c_uint32()
+        _lib.check(L.memo_transport_exceptions(wire.data_ptr(), 0, None, C.byref(found), C.byref(have)))
+        assert found.value == int((v >= 15).sum()) and have.value == cap
+        _lib.check(L.memo_transport_unpack_dev(wire.data_ptr(), n, dst.data_ptr(), 0, None))
+        torch.cuda.synchronize()
+        if found.value <= cap:
+            assert np.array_equal(dst[:n].cpu().numpy(), v), (n, hi, frac)
+        assert wire.numel() == 16 + ((n + 7) // 8) * 4 + cap * 8
