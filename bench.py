@@ -318,7 +318,7 @@ def main():
         prof = os.path.join(ROOT, "profiles", "traffic.json")    # PMC passes are separate runs
         if os.path.exists(prof):
             tj = json.load(open(prof)).get(f"{args.workload}_{args.rows}")
-            if tj:
+            if tj and tj.get("result_bytes_per_position", b_out) == b_out:   # same kernel instantiation
                 res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
         if multi:
             # what the same run delivers when the result slices stay on their GPUs (no root):

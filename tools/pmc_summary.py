@@ -55,6 +55,7 @@ def main():
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
     allw = json.load(open(path)) if os.path.exists(path) else {}
     out["round"] = tag
+    out["result_bytes_per_position"] = int(os.environ.get("RESULT_BYTES", "1"))   # bench default: uint8 results
     allw[wl] = out
     json.dump(allw, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
