@@ -397,6 +397,8 @@ int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_so
     DeviceGuard guard(ix->device);
     hipStream_t st = nullptr;
     const uint64_t rows = ix->rows;
+    drop_packed(ix);  // a device sort below would leave packed rows stale; pack again after finalize
+    ix->finalized = 0;
     {
         const uint64_t npad = ix->padded - rows;
         hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st,
