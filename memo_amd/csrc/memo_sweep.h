@@ -1,0 +1,308 @@
+// memo_sweep.h -- shared by the sweep translation units (memo_sweep.hip: launch plumbing and tuning;
+// memo_sweep_cons.hip: conservation; memo_sweep_memb.hip: membership).  Device code here is inline.
+#ifndef MEMO_SWEEP_H
+#define MEMO_SWEEP_H
+
+#include "memo_common.h"
+
+namespace memo {
+
+// ------------------------------------------------------------------------------------------
+// kernel arguments
+// ------------------------------------------------------------------------------------------
+struct SweepArgs {
+    const int64_t *s, *e, *o;
+    const uint32_t *pk;
+    const uint16_t *pa;
+    const int64_t *boff;
+    int64_t nb;
+    int64_t qs, qe;
+    int64_t tile0;          // pivot position of tile 0 (multiple of the tile width, <= qs)
+    int64_t ntiles;
+    int64_t tiles_per_xcd;  // ceil(ntiles / 8)
+    int64_t blocks_per_xcd; // workgroups per XCD group; < tiles_per_xcd when workgroups are persistent
+    void *out;
+    int *status;
+    int bshift;
+    int km1;    // k - 1 (>= 1 here; k <= 1 never reaches a sweep kernel)
+    int ncols;  // result columns: num_docs + 1 (conservation) / num_docs (membership)
+    int nlev;   // doubling levels: floor(log2(k-1)) + 1
+    int nwords; // membership: 32-bit words per position handled by this launch
+    int word_base;  // membership runs: first genome word of this launch (num_docs too large for one
+    int out_words;  //   LDS tile is swept in slices of genome words); out_words = words per position
+    unsigned long long *stamps;  // diagnostic builds (-DMEMO_STAMPS): per-phase cycle sums
+};
+
+// Diagnostic builds only (never in the product library): wave 0 of every workgroup stores the
+// shader cycles it spent in each phase of the conservation sweep to stamps[8 * block + phase]
+// (a buffer of its own, set with memo_debug_set_stamp_buffer; plain stores, no contention).
+#ifdef MEMO_STAMPS
+#define MEMO_STAMP(i)                                                                         \
+    do {                                                                                      \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();                        \
+        if (threadIdx.x == 0 && A.stamps) A.stamps[8ull * blockIdx.x + (i)] = now__ - stamp_t0; \
+        stamp_t0 = now__;                                                                     \
+    } while (0)
+#else
+#define MEMO_STAMP(i) do { } while (0)
+#endif
+
+// blockIdx -> tile.  Blocks are dealt round-robin over the 8 XCDs (b % 8 labels the XCD
+// group), so give each group one contiguous run of tiles: neighbouring tiles share their
+// k-1 halo rows and the cache lines that straddle the tile boundary, and those then hit in
+// that XCD's L2 instead of being fetched twice.  Speed only -- results do not depend on it.
+// A persistent workgroup (blocks_per_xcd < tiles_per_xcd) walks its XCD group's run with stride
+// blocks_per_xcd: `it` is its iteration.  Returns -1 past the end of the run.
+__device__ __forceinline__ int64_t tile_of_block(const SweepArgs &A, int it) {
+    const int64_t b = blockIdx.x;
+    const int64_t j = (b >> 3) + (int64_t)it * A.blocks_per_xcd;
+    return j < A.tiles_per_xcd ? (b & 7) * A.tiles_per_xcd + j : -1;
+}
+
+// Row slice [r0, r1) that can touch positions [lo_abs, hi_abs) of a tile starting at a:
+// rows with  a <= start < roundup(hi_abs + k - 1, bucket).
+__device__ __forceinline__ void row_slice(const SweepArgs &A, int64_t a, int64_t hi_abs,
+                                          uint64_t &r0, uint64_t &r1) {
+    const int64_t last = A.nb - 1;
+    int64_t b0 = a <= 0 ? 0 : (a >> A.bshift);
+    const int64_t lim = hi_abs + A.km1;  // rows with start >= lim cannot reach the tile
+    int64_t b1 = lim <= 0 ? 0 : ((lim + ((int64_t)1 << A.bshift) - 1) >> A.bshift);
+    b0 = b0 > last ? last : b0;
+    b1 = b1 > last ? last : b1;
+    r0 = a <= 0 ? 0 : (uint64_t)A.boff[b0];
+    r1 = (uint64_t)A.boff[b1];
+}
+
+__device__ __forceinline__ int clamp_to_tile(int64_t v, int lo, int hi) {
+    const int64_t l = lo, h = hi;
+    return (int)(v < l ? l : (v > h ? h : v));
+}
+
+// ------------------------------------------------------------------------------------------
+// shared pieces of the sweep kernels.  T = threads per workgroup (64 = one wave owns the tile;
+// 256 = four waves share it and meet at workgroup barriers between the phases).
+// ------------------------------------------------------------------------------------------
+#ifndef MEMO_KU
+#define MEMO_KU 4
+#endif
+
+// Level arrays of the conservation sweep are W + kLevelSkew words apart: rows that hit the same
+// position on different levels then fall into different LDS banks.
+#ifndef MEMO_SKEW
+#define MEMO_SKEW 0
+#endif
+constexpr int kLevelSkew = MEMO_SKEW;
+
+struct Tile {
+    int64_t a;     // pivot position of tile slot 0
+    int x_lo, x_hi;  // slots of the tile that lie inside the window
+    uint64_t r0, r1;  // row slice
+};
+
+template <int W>
+__device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t, int it) {
+    const int64_t tile = tile_of_block(A, it);
+    if (tile < 0 || tile >= A.ntiles) return false;
+    t.a = A.tile0 + tile * W;
+    t.x_lo = (int)(A.qs > t.a ? A.qs - t.a : 0);
+    t.x_hi = (int)(A.qe - t.a < W ? A.qe - t.a : W);
+    row_slice(A, t.a, t.a + t.x_hi, t.r0, t.r1);
+    if (t.r1 - t.r0 >= 0xFFFF0000ull) {  // the row loops count a tile's rows in 32 bits
+        if (threadIdx.x == 0) atomicOr(A.status, kStatusHugeSlice);
+        return false;
+    }
+    return true;
+}
+
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() would
+// wait for vmcnt(0) first (cdna_hip_programming.md, "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Row sources.  Each streams the tile's row slice once and hands f(c, h, col) the rows that
+// write: [c, h) = the row's interval clipped to the tile (memo_query.py:46-49: recentre,
+// shadow-cast by k-1, clip, keep casted_end < start), col = its column after the index check
+// of :62 (NumPy/Numba wrap a negative index once; anything else outside the matrix is the
+// reference's IndexError / UB and sets the sticky status flag).
+__device__ __forceinline__ bool check_col(const SweepArgs &A, int64_t o, int &col) {
+    const int64_t cc = o < 0 ? o + A.ncols : o;
+    if ((uint64_t)cc >= (uint64_t)A.ncols) {
+        atomicOr(A.status, kStatusBadAnnot);
+        return false;
+    }
+    col = (int)cc;
+    return true;
+}
+
+// the Parquet columns as they are: 3 x int64 per row.  2 rows per lane per column per load
+// (16 B / lane, 1 KiB / wave), U loads of each column in flight per lane.
+struct WideRows {
+    static constexpr int kLoads = MEMO_KU;  // loads of each column in flight per lane
+    // `between` runs once, in every thread, before any row is handed to f: the kernels clear their
+    // LDS tile there.  PackedRows issues its first batch of loads before it; here (ten batches per
+    // tile, HBM-bound) that ordering measured 5 % slower, so the tile is cleared first.
+    template <int T, int U, typename B, typename F>
+    static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, B between, F f) {
+        between();
+        const int tid = threadIdx.x;
+        auto one = [&](int64_t s, int64_t e, int64_t o) {
+            const int h = clamp_to_tile(s - t.a, t.x_lo, t.x_hi);
+            const int c = clamp_to_tile(e - t.a - A.km1, t.x_lo, t.x_hi);
+            int col;
+            // end < start: the row may reach further left than k-1 positions; long_rows_kernel owns it
+            if (h > c && e >= s && check_col(A, o, col)) f(c, h, col);
+        };
+        // 32-bit row numbers relative to the 128-byte-aligned start of the slice
+        const uint64_t base0 = t.r0 & ~(uint64_t)15;
+        const uint32_t end = (uint32_t)(t.r1 - base0);
+        const int64_t *ps = A.s + base0, *pe = A.e + base0, *po = A.o + base0;
+        for (uint32_t rel = 2 * tid; rel < end; rel += 2 * T * U) {
+            longlong2 S[U], E[U], O[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t r = rel + (uint32_t)u * 2 * T;
+                if (r < end) {
+                    S[u] = *reinterpret_cast<const longlong2 *>(ps + r);
+                    E[u] = *reinterpret_cast<const longlong2 *>(pe + r);
+                    O[u] = *reinterpret_cast<const longlong2 *>(po + r);
+                } else {
+                    S[u] = make_longlong2(kSentinel, kSentinel);
+                    E[u] = S[u];
+                    O[u] = make_longlong2(0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                // wave-uniform: nothing of this wave's load is inside the slice
+                if ((uint32_t)__builtin_amdgcn_readfirstlane(rel + (uint32_t)u * 2 * T) >= end) break;
+                one(S[u].x, E[u].x, O[u].x);
+                one(S[u].y, E[u].y, O[u].y);
+            }
+        }
+    }
+};
+
+// clamp(v, lo, hi) for lo <= hi in one instruction; hi is wave-uniform (one SGPR operand is all a
+// gfx9 VALU instruction may read), lo is a VGPR pinned by pin_vgpr() so that it is not
+// re-materialised from its SGPR before every use
+__device__ __forceinline__ int med3(int v, int lo, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "s"(hi));
+    return r;
+}
+
+__device__ __forceinline__ int pin_vgpr(int uniform) {
+    int r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(uniform));
+    return r;
+}
+
+// packed rows (memo_index_pack): one 32-bit word per row -- start mod 2^16, min(end - start,
+// 255), annot (8 bits; ANNOT16: in a second 16-bit column).  Inside a row slice every start
+// lies in [a, a + W + k + 32), far less than 2^16 from the tile start, so the low 16 bits
+// give the tile-relative start exactly; rows outside [r0, r1) are masked by index.  Exact
+// for k - 1 <= 255: a saturated length clips to "does not write" just as the true one does.
+// 4 rows per lane per load (16 B / lane).
+// CHECKED = false is chosen by the host when the largest annot of the index (known since
+// memo_index_pack) is inside the result matrix, so that no row can raise the reference's
+// IndexError; the column test then leaves the loop.
+template <bool ANNOT16, bool CHECKED>
+struct PackedRows {
+    static constexpr int kLoads = 2 * MEMO_KU;  // A/B: 8 x 16 B in flight per lane, 5 % over 4
+    template <int T, int U, typename B, typename F>
+    static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, B between, F f) {
+        const int tid = threadIdx.x;
+        const uint32_t a16 = (uint32_t)t.a & 0xFFFFu;
+        // 32-bit row numbers relative to the 128-byte-aligned start of the slice
+        const uint64_t base0 = t.r0 & ~(uint64_t)31;
+        const uint32_t first = (uint32_t)(t.r0 - base0), end = (uint32_t)(t.r1 - base0);
+        const uint32_t *pk = A.pk + base0;
+        const uint16_t *pa = ANNOT16 ? A.pa + base0 : nullptr;
+        const int x_lo = pin_vgpr(t.x_lo), x_hi = t.x_hi, km1 = A.km1;
+        const uint32_t ncols = (uint32_t)A.ncols;
+        // a row that cannot write: start == a, overlap 255 >= k - 1  ->  c >= h
+        const uint32_t dead = a16 | 0x00FF0000u;
+        uint32_t bad = 0;
+        auto one = [&](uint32_t w, uint32_t annot) {
+            const int d = (int)((w - a16) & 0xFFFFu);  // start - a
+            int h = med3(d, x_lo, x_hi);
+            const int c = med3(d + (int)__builtin_amdgcn_ubfe(w, 16, 8) - km1, x_lo, x_hi);
+            if (CHECKED && annot >= ncols) {
+                bad |= (uint32_t)(h > c);
+                h = c;
+            }
+            f(c, h, (int)annot);  // f writes iff h > c
+        };
+        bool first_batch = true;
+        for (uint32_t rel = 4 * tid; first_batch || rel < end; rel += 4 * T * U) {
+            uint4 V[U];
+            uint2 N[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t r = rel + (uint32_t)u * 4 * T;
+                if (r < end) {
+                    V[u] = *reinterpret_cast<const uint4 *>(pk + r);
+                    if (ANNOT16) N[u] = *reinterpret_cast<const uint2 *>(pa + r);
+                } else {
+                    V[u] = make_uint4(dead, dead, dead, dead);
+                    N[u] = make_uint2(0u, 0u);
+                }
+            }
+            if (first_batch) {
+                between();
+                first_batch = false;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t r = rel + (uint32_t)u * 4 * T;
+                // wave-uniform: only a load that straddles an end of the slice masks rows by number
+                const uint32_t wave_lo = __builtin_amdgcn_readfirstlane(r) & ~(uint32_t)255;
+                if (wave_lo >= end) break;  // nothing of this wave's load is inside the slice
+                if (!(wave_lo >= first && wave_lo + 256 <= end)) {
+                    V[u].x = (r + 0 >= first && r + 0 < end) ? V[u].x : dead;
+                    V[u].y = (r + 1 >= first && r + 1 < end) ? V[u].y : dead;
+                    V[u].z = (r + 2 >= first && r + 2 < end) ? V[u].z : dead;
+                    V[u].w = (r + 3 >= first && r + 3 < end) ? V[u].w : dead;
+                }
+                one(V[u].x, ANNOT16 ? (N[u].x & 0xFFFFu) : (V[u].x >> 24));
+                one(V[u].y, ANNOT16 ? (N[u].x >> 16) : (V[u].y >> 24));
+                one(V[u].z, ANNOT16 ? (N[u].y & 0xFFFFu) : (V[u].z >> 24));
+                one(V[u].w, ANNOT16 ? (N[u].y >> 16) : (V[u].w >> 24));
+            }
+        }
+        if (CHECKED && bad) atomicOr(A.status, kStatusBadAnnot);
+    }
+};
+
+__device__ __forceinline__ uint32_t full_word(int ncols, int w) {  // genomes 32w .. 32w+31 that exist
+    const int left = ncols - 32 * w;
+    return left >= 32 ? 0xFFFFFFFFu : (left <= 0 ? 0u : ((1u << left) - 1u));
+}
+
+
+// ------------------------------------------------------------------------------------------
+// launch plumbing and tuning state (defined in memo_sweep.hip)
+// ------------------------------------------------------------------------------------------
+extern int g_tile_w;      // 0 = choose per query
+extern int g_waves;       // waves per tile: 0 = choose, 1 or 4
+extern int g_memb_algo;   // membership: 0 = choose, 1 = direct scatter, 2 = doubling, 3 = runs
+extern int g_force_wide;  // 1 = read the int64 columns even when packed rows exist
+extern int g_persist;     // 0 = choose, 1 = one workgroup per tile, 2 = persistent workgroups
+extern unsigned long long *g_stamp_buffer;  // -DMEMO_STAMPS builds: 8 words per workgroup
+
+using SweepKernel = void (*)(const SweepArgs);
+
+void read_env_once();
+bool use_persistent(int fmt);
+inline int floor_log2(uint32_t v) { return 31 - __builtin_clz(v); }
+int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st,
+                 bool persistent);
+int pick_rows(const memo_index *ix, int32_t k, int &fmt);
+int check_query_args(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
+                     const void *d_out);
+void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32_t k, void *d_out);
+
+}  // namespace memo
+
+#endif  // MEMO_SWEEP_H

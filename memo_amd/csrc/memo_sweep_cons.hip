@@ -1,0 +1,256 @@
+// memo_sweep_cons.hip -- conservation sweep: doubling scatter + top-down fold, the
+// k <= 1 fill, the side pass for rows with end < start, tile-shape choice and the ABI entry points.
+// Replaces /root/reference/src/memo_query.py:42-63 + the argmax of :70.
+#include "memo_sweep.h"
+
+using namespace memo;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// conservation: doubling scatter + top-down fold
+// ------------------------------------------------------------------------------------------
+template <typename Rows, int W, int U, int T, typename OutT>
+__global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    constexpr int LS = W + kLevelSkew;  // words between level arrays
+    Tile t;
+#ifdef MEMO_STAMPS
+    unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    bool have = locate_tile<W>(A, t, 0);
+    for (int it = 0; have; ++it) {
+    // a persistent workgroup looks its next tile up now: the two bucket-table loads (2-4k cycles
+    // when HBM is busy) then return under this tile's work instead of in front of the next one's
+    Tile t_next;
+    const bool have_next = locate_tile<W>(A, t_next, it + 1);
+    MEMO_STAMP(0);  // tile location (kernarg + two bucket-table loads)
+
+    // the clipped interval [c, h) is the union of two blocks of 2^j, j = floor(log2(h - c))
+    Rows::template for_each<T, U>(
+        A, t,
+        [&]() {  // every level starts at the sentinel column N (memo_query.py:53-54)
+            const uint32_t sent = (uint32_t)(A.ncols - 1);
+            const uint4 sv = make_uint4(sent, sent, sent, sent);
+            uint4 *p = reinterpret_cast<uint4 *>(lds);
+            for (int i = tid; i < A.nlev * (LS / 4); i += T) p[i] = sv;
+            lds_barrier();
+            MEMO_STAMP(1);  // issue of the first loads + LDS clear + barrier
+        },
+        [&](int c, int h, int col) {
+            if (h > c) {
+                const int j = 31 - __builtin_clz((unsigned)(h - c));  // h - c >= 1
+                uint32_t *lv = lds + j * LS;
+                atomicMin(lv + c, (uint32_t)col);               // block [c, c + 2^j)
+                atomicMin(lv + (h - (1 << j)), (uint32_t)col);  // block [h - 2^j, h)
+            }
+        });
+    MEMO_STAMP(2);  // waiting for rows + scatter
+    __syncthreads();
+    MEMO_STAMP(3);  // barrier after the scatter
+
+    // fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1)
+    for (int j = A.nlev - 1; j >= 1; --j) {
+        const int half = 1 << (j - 1);
+        const uint32_t *hi = lds + j * LS;
+        uint32_t *lo = lds + (j - 1) * LS;
+        for (int x = 4 * tid; x < W; x += 4 * T) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(hi + x);
+            uint4 u;
+            if (half >= 4) {
+                u = x >= half ? *reinterpret_cast<const uint4 *>(hi + x - half)
+                              : make_uint4(~0u, ~0u, ~0u, ~0u);
+            } else if (half == 2) {
+                const uint2 q = x >= 2 ? *reinterpret_cast<const uint2 *>(hi + x - 2)
+                                       : make_uint2(~0u, ~0u);
+                u = make_uint4(q.x, q.y, v.x, v.y);
+            } else {
+                const uint32_t q = x >= 1 ? hi[x - 1] : ~0u;
+                u = make_uint4(q, v.x, v.y, v.z);
+            }
+            uint4 w = *reinterpret_cast<const uint4 *>(lo + x);
+            w.x = min(w.x, min(v.x, u.x));
+            w.y = min(w.y, min(v.y, u.y));
+            w.z = min(w.z, min(v.z, u.z));
+            w.w = min(w.w, min(v.w, u.w));
+            *reinterpret_cast<uint4 *>(lo + x) = w;
+        }
+        __syncthreads();
+    }
+
+    MEMO_STAMP(4);  // fold
+    // write level 0 as OutT (uint16, or uint8 when num_docs <= 255), in 16-byte pieces aligned
+    // in the OUTPUT (the tile grid is aligned in pivot coordinates, the output starts at qs)
+    constexpr int PER = 16 / (int)sizeof(OutT);  // positions per 16-byte store
+    OutT *out = static_cast<OutT *>(A.out);
+    const int64_t ob = t.a - A.qs;  // output index of tile slot 0
+    const int64_t o_lo = ob + t.x_lo, o_hi = ob + t.x_hi;
+    for (int64_t g = (o_lo & ~(int64_t)(PER - 1)) + PER * tid; g < o_hi; g += PER * T) {
+        const int x = (int)(g - ob);
+        if (g >= o_lo && g + PER <= o_hi) {
+            uint32_t pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (sizeof(OutT) == 2)
+                    pk[q] = lds[x + 2 * q] | (lds[x + 2 * q + 1] << 16);
+                else
+                    pk[q] = lds[x + 4 * q] | (lds[x + 4 * q + 1] << 8) | (lds[x + 4 * q + 2] << 16) |
+                            (lds[x + 4 * q + 3] << 24);
+            }
+            *reinterpret_cast<uint4 *>(out + g) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        } else {
+            for (int i = 0; i < PER; ++i)
+                if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)lds[x + i];
+        }
+    }
+    MEMO_STAMP(5);  // store
+#ifdef MEMO_STAMPS
+    if (threadIdx.x == 0 && A.stamps && it == 0) A.stamps[8ull * blockIdx.x + 7] = 1;
+#endif
+    if (have_next) __syncthreads();  // the LDS tile is reused
+    t = t_next;
+    have = have_next;
+    }
+}
+
+
+// k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
+template <typename OutT>
+__global__ void fill_conservation_kernel(OutT *out, int64_t n, OutT v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = v;
+}
+
+// One workgroup per row with end < start: its interval [clip(e-qs-(k-1)), clip(s-qs)) can be any
+// length, so it is applied straight to the result in HBM, after the sweep, with atomics (rows may
+// overlap each other).  filter_pq keeps such a row iff qs < start < qe + k (memo_query.py:25-27).
+template <typename OutT>
+__global__ void long_rows_conservation_kernel(const int64_t *ls, const int64_t *le, const int64_t *lo,
+                                              int64_t qs, int64_t qe, int km1, int ncols, OutT *out,
+                                              int *status) {
+    const int64_t s = ls[blockIdx.x], e = le[blockIdx.x], o = lo[blockIdx.x];
+    if (!(s > qs && s < qe + km1 + 1)) return;
+    const int64_t L = qe - qs;
+    const int64_t hi = s - qs > L ? L : s - qs;
+    int64_t c = e - qs - km1;
+    c = c < 0 ? 0 : c;
+    if (c >= hi) return;
+    const int64_t cc = o < 0 ? o + ncols : o;
+    if ((uint64_t)cc >= (uint64_t)ncols) {
+        if (threadIdx.x == 0) atomicOr(status, kStatusBadAnnot);
+        return;
+    }
+    constexpr int PER = 4 / (int)sizeof(OutT);  // results per 32-bit word
+    uint32_t *words = reinterpret_cast<uint32_t *>(out);
+    for (int64_t p = c + threadIdx.x; p < hi; p += blockDim.x) {
+        uint32_t *wp = words + p / PER;
+        const int sh = (int)(p % PER) * 8 * (int)sizeof(OutT);
+        const uint32_t field = (sizeof(OutT) == 2 ? 0xFFFFu : 0xFFu) << sh;
+        uint32_t old = *wp;
+        while (((old & field) >> sh) > (uint32_t)cc) {  // out[p] = min(out[p], col), on the field only
+            const uint32_t seen = atomicCAS(wp, old, (old & ~field) | ((uint32_t)cc << sh));
+            if (seen == old) break;
+            old = seen;
+        }
+    }
+}
+
+template <typename Rows, typename OutT>
+SweepKernel cons_kernel(int w, int waves) {
+#define MEMO_CASE(WW)                                                                         \
+    case WW:                                                                                  \
+        return waves == 4 ? (SweepKernel)sweep_conservation_kernel<Rows, WW, Rows::kLoads, 256, OutT>   \
+                          : (SweepKernel)sweep_conservation_kernel<Rows, WW, Rows::kLoads, 64, OutT>;
+    switch (w) {
+        MEMO_CASE(256)
+        MEMO_CASE(512)
+        MEMO_CASE(1024)
+        MEMO_CASE(2048)
+        MEMO_CASE(4096)
+    }
+#undef MEMO_CASE
+    return nullptr;
+}
+
+}  // namespace
+
+template <typename OutT>
+static int long_rows_conservation(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int ncols,
+                                  OutT *d_out, hipStream_t st) {
+    if (!ix->n_long) return MEMO_OK;
+    hipLaunchKernelGGL((long_rows_conservation_kernel<OutT>), dim3((unsigned)ix->n_long), dim3(256), 0, st,
+                       ix->ls, ix->le, ix->lo, qs, qe, k - 1, ncols, d_out, ix->d_status);
+    HIP_TRY(hipGetLastError());
+    return MEMO_OK;
+}
+
+template <typename OutT>
+static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
+                              OutT *d_out, void *stream) {
+    read_env_once();
+    int rc = check_query_args(ix, qs, qe, k, num_docs, d_out);
+    if (rc) return rc;
+    if (sizeof(OutT) == 1 && num_docs > 255)
+        return fail(MEMO_EINVAL, "uint8 results need num_docs <= 255, got %d", num_docs);
+    if (qe <= qs) return MEMO_OK;
+    DeviceGuard guard(ix->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (k <= 1 || ix->rows == 0) {
+        hipLaunchKernelGGL((fill_conservation_kernel<OutT>), dim3(2048), dim3(256), 0, st, d_out,
+                           qe - qs, (OutT)num_docs);
+        HIP_TRY(hipGetLastError());
+        return long_rows_conservation<OutT>(ix, qs, qe, k, num_docs + 1, d_out, st);
+    }
+    SweepArgs A;
+    fill_args(ix, A, qs, qe, k, d_out);
+    A.ncols = num_docs + 1;
+    A.nlev = floor_log2((uint32_t)(k - 1)) + 1;
+    A.nwords = 0;
+    int fmt;
+    if ((rc = pick_rows(ix, k, fmt))) return rc;
+    // Tile shape, from interleaved A/B on one device (profiles/r01_ab_*.txt).
+    //  int64 rows (HBM-bound): four waves share a 4096-position tile -- fewest k-1 row halos per
+    //    position; 1-3 % over one wave per 1024 positions at k <= 32, 10 % at k = 101.
+    //  packed rows (4-6x fewer bytes; LDS-atomic / issue-bound): waves per CU matter, but so does
+    //    the k-1 halo: 1024 positions x 4 waves wins at k = 31 (20 KiB, 8 workgroups per CU) and at
+    //    k = 101 (28 KiB) over 512 or 2048 positions.
+    // Short windows want many small tiles either way.
+    int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
+    if (!w) {
+        // int64 rows on a sparse index (< 2 rows per position: profiles/r01_sparse_index_tiles.txt) are
+        // no longer HBM-bound per tile; they want the packed rows' shape (more workgroups per CU)
+        const double span = (double)(ix->max_s - ix->min_s) + 1.0;
+        const bool sparse = (double)ix->rows < 2.0 * span;
+        const size_t budget = (fmt || sparse) ? 32 * 1024 : 80 * 1024;
+        w = 4096;
+        while ((size_t)A.nlev * w * 4 > budget && w > 256) w >>= 1;
+        while (w > 256 && (qe - qs) / w < 32768) w >>= 1;
+    }
+    if (!waves) waves = w >= 1024 ? 4 : 1;  // short windows end up with small tiles: one wave each
+    while ((size_t)A.nlev * w * 4 > 160 * 1024 && w > 256) w >>= 1;
+    const bool checked = ix->max_annot >= (uint64_t)A.ncols;  // some row could be outside the matrix
+    SweepKernel kern = fmt == 4   ? (checked ? cons_kernel<PackedRows<false, true>, OutT>(w, waves)
+                                             : cons_kernel<PackedRows<false, false>, OutT>(w, waves))
+                       : fmt == 6 ? (checked ? cons_kernel<PackedRows<true, true>, OutT>(w, waves)
+                                             : cons_kernel<PackedRows<true, false>, OutT>(w, waves))
+                                  : cons_kernel<WideRows, OutT>(w, waves);
+    if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+    if ((rc = launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * (w + kLevelSkew) * 4, st, use_persistent(fmt)))) return rc;
+    return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
+}
+
+extern "C" {
+
+int memo_query_conservation_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,
+                                int32_t num_docs, uint16_t *d_out, void *stream) {
+    return query_conservation<uint16_t>(ix, qs, qe, k, num_docs, d_out, stream);
+}
+
+int memo_query_conservation_u8_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,
+                                   int32_t num_docs, uint8_t *d_out, void *stream) {
+    return query_conservation<uint8_t>(ix, qs, qe, k, num_docs, d_out, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,364 @@
+// memo_sweep_memb.hip -- membership sweeps: per-genome bit planes + register transpose ("runs"),
+// the doubling scheme on bit cells, and the direct scatter; the k <= 1 fill, the side
+// pass for rows with end < start, algorithm / tile-shape choice and the ABI entry point.
+// Replaces /root/reference/src/memo_query.py:42-63 with rec = ones([L, N]) (:51) as bit rows.
+#include "memo_sweep.h"
+
+using namespace memo;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// membership.  Result word w of position x:  full_word(w) & ~absent[x][w].
+//   DOUBLING = false: one ds_or per covered (position, genome) bit into absent[x][w].
+//   DOUBLING = true : the same two-blocks-per-row scatter and top-down fold as conservation,
+//                     on cells of nw words (or instead of min); nlev * W * nw words of LDS.
+// ------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void store_membership(const SweepArgs &A, const Tile &t,
+                                                 const uint32_t *absent, int nw) {
+    // slots [x_lo, x_hi) are one contiguous run of words in LDS and in the output
+    uint32_t *out = static_cast<uint32_t *>(A.out);
+    const int tid = threadIdx.x;
+    const int64_t ob = (t.a - A.qs) * nw;  // output word of LDS word 0
+    const int64_t o_lo = ob + (int64_t)t.x_lo * nw, o_hi = ob + (int64_t)t.x_hi * nw;
+    for (int64_t g = (o_lo & ~(int64_t)3) + 4 * tid; g < o_hi; g += 4 * T) {
+        const int x = (int)(g - ob);
+        uint32_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = g + i >= o_lo && g + i < o_hi;
+            v[i] = in ? (full_word(A.ncols, (x + i) % nw) & ~absent[x + i]) : 0u;
+        }
+        if (g >= o_lo && g + 4 <= o_hi) {
+            *reinterpret_cast<uint4 *>(out + g) = make_uint4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int i = 0; i < 4; ++i)
+                if (g + i >= o_lo && g + i < o_hi) out[g + i] = v[i];
+        }
+    }
+}
+
+template <typename Rows, int W, int U, int T, bool DOUBLING>
+__global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    Tile t;
+    const int nw = A.nwords;
+    const int nlev = DOUBLING ? A.nlev : 1;
+    const int plane = W * nw;  // words per level
+    bool have = locate_tile<W>(A, t, 0);
+    for (int it = 0; have; ++it) {
+    Tile t_next;  // persistent workgroups: next tile's bucket-table loads fly under this tile's work
+    const bool have_next = locate_tile<W>(A, t_next, it + 1);
+
+    auto clear_tile = [&]() {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        uint4 *p = reinterpret_cast<uint4 *>(lds);
+        for (int i = tid; i < nlev * plane / 4; i += T) p[i] = z;
+        lds_barrier();
+    };
+    Rows::template for_each<T, U>(A, t, clear_tile, [&](int c, int h, int col) {
+        if (h <= c) return;
+        const uint32_t bit = 1u << (col & 31);
+        const int word = col >> 5;
+        if (DOUBLING) {
+            const int j = 31 - __builtin_clz((unsigned)(h - c));  // h - c >= 1
+            uint32_t *lv = lds + j * plane + word;
+            atomicOr(lv + c * nw, bit);
+            atomicOr(lv + (h - (1 << j)) * nw, bit);
+        } else {
+            uint32_t *cell = lds + c * nw + word;
+            for (int x = c; x < h; ++x, cell += nw) atomicOr(cell, bit);  // rec[c:h, a] = False
+        }
+    });
+    __syncthreads();
+
+    if (DOUBLING) {
+        for (int j = nlev - 1; j >= 1; --j) {
+            const int shift = (1 << (j - 1)) * nw;  // half a block, in words
+            const uint32_t *hi = lds + j * plane;
+            uint32_t *lo = lds + (j - 1) * plane;
+            if ((shift & 3) == 0) {
+                for (int i = 4 * tid; i < plane; i += 4 * T) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(hi + i);
+                    const uint4 u = i >= shift ? *reinterpret_cast<const uint4 *>(hi + i - shift)
+                                               : make_uint4(0u, 0u, 0u, 0u);
+                    uint4 w = *reinterpret_cast<const uint4 *>(lo + i);
+                    w.x |= v.x | u.x;
+                    w.y |= v.y | u.y;
+                    w.z |= v.z | u.z;
+                    w.w |= v.w | u.w;
+                    *reinterpret_cast<uint4 *>(lo + i) = w;
+                }
+            } else {
+                for (int i = tid; i < plane; i += T)
+                    lo[i] |= hi[i] | (i >= shift ? hi[i - shift] : 0u);
+            }
+            __syncthreads();
+        }
+    }
+    store_membership<T>(A, t, lds, nw);
+    if (have_next) __syncthreads();  // the LDS tile is reused
+    t = t_next;
+    have = have_next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// membership, "runs" form: bit planes per GENOME instead of per position.
+//   absent[g][P] (P = position / 32) holds 32 positions of genome g per word, so a row's interval
+//   [c, h) is one run of bits: one ds_or_b32 when it stays inside a word, two when it straddles
+//   (more only for k - 1 > 32), and rows of different genomes never share a word.  No levels, no
+//   fold; 4 * W * nw bytes of LDS.  Each lane then transposes 32 genomes x 32 positions in
+//   registers (5 butterfly stages) into the position-major result words and stores them.
+// ------------------------------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ void transpose32_stage(uint32_t (&m)[32]) {
+    constexpr uint32_t mask = J == 16 ? 0x0000FFFFu : J == 8 ? 0x00FF00FFu : J == 4 ? 0x0F0F0F0Fu
+                              : J == 2 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        if ((k & J) == 0) {  // swap the high J-bit halves of m[k] with the low halves of m[k + J]
+            const uint32_t tt = ((m[k] >> J) ^ m[k + J]) & mask;
+            m[k] ^= tt << J;
+            m[k + J] ^= tt;
+        }
+    }
+}
+
+__device__ __forceinline__ void transpose32(uint32_t (&m)[32]) {  // m[j] bit i  <-  m[i] bit j
+    transpose32_stage<16>(m);
+    transpose32_stage<8>(m);
+    transpose32_stage<4>(m);
+    transpose32_stage<2>(m);
+    transpose32_stage<1>(m);
+}
+
+template <typename Rows, int W, int U, int T>
+__global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    constexpr int PW = W / 32;  // words per genome row
+    Tile t;
+    const int nw = A.nwords;
+    bool have = locate_tile<W>(A, t, 0);
+    for (int it = 0; have; ++it) {
+    Tile t_next;  // persistent workgroups: next tile's bucket-table loads fly under this tile's work
+    const bool have_next = locate_tile<W>(A, t_next, it + 1);
+    // genome g lives at g * PITCH + (g >> 5) * skew.  PITCH is odd, so the scatter's bank is
+    // (genome + word) mod 32 -- with a pitch of PW (a multiple of 32) every genome would land on
+    // the banks of its position word alone.  In the transpose phase 32 lanes read word P of genome
+    // groups G = 0..nw-1 for 32 / nw consecutive P: skew = 32 / nw puts them on 32 different banks.
+    constexpr int PITCH = PW + 1;
+    const int skew = A.nlev;  // membership runs: the launcher passes the skew in nlev
+    const int total = 32 * nw * PITCH + nw * skew;
+    auto clear_tile = [&]() {
+        for (int i = tid; i < total; i += T) lds[i] = 0;
+        lds_barrier();
+    };
+    const int g_lo = 32 * A.word_base, g_n = 32 * nw;  // genomes of this launch's slice
+    Rows::template for_each<T, U>(A, t, clear_tile, [&](int c, int h, int col) {
+        col -= g_lo;
+        if (h <= c || (unsigned)col >= (unsigned)g_n) return;
+        uint32_t *row = lds + col * PITCH + (col >> 5) * skew;
+        const int w0 = c >> 5, w1 = (h - 1) >> 5;
+        const uint32_t first = 0xFFFFFFFFu << (c & 31), last = 0xFFFFFFFFu >> (31 - ((h - 1) & 31));
+        atomicOr(row + w0, w0 == w1 ? first & last : first);  // one instruction for both shapes
+        if (w1 > w0) {
+            for (int w = w0 + 1; w < w1; ++w) atomicOr(row + w, 0xFFFFFFFFu);
+            atomicOr(row + w1, last);
+        }
+    });
+    __syncthreads();
+
+    uint32_t *out = static_cast<uint32_t *>(A.out);
+    const int64_t ob = t.a - A.qs;  // output position of tile slot 0
+    for (int b = tid; b < nw * PW; b += T) {
+        const int G = b % nw, P = b / nw;  // genome group, position word
+        if (32 * P + 32 <= t.x_lo || 32 * P >= t.x_hi) continue;
+        uint32_t m[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) m[i] = lds[(32 * G + i) * PITCH + G * skew + P];
+        transpose32(m);
+        const uint32_t full = full_word(A.ncols, A.word_base + G);
+        const int64_t ow = A.out_words;
+        uint32_t *dst = out + (ob + 32 * P) * ow + A.word_base + G;
+        if (32 * P >= t.x_lo && 32 * P + 32 <= t.x_hi) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) dst[(int64_t)j * ow] = full & ~m[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (32 * P + j >= t.x_lo && 32 * P + j < t.x_hi) dst[(int64_t)j * ow] = full & ~m[j];
+        }
+    }
+    if (have_next) __syncthreads();  // the LDS tile is reused
+    t = t_next;
+    have = have_next;
+    }
+}
+
+
+__global__ void fill_membership_kernel(uint32_t *out, int64_t n, int nw, int ncols) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int left = ncols - 32 * (int)(i % nw);
+        out[i] = left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u);
+    }
+}
+
+__global__ void long_rows_membership_kernel(const int64_t *ls, const int64_t *le, const int64_t *lo,
+                                            int64_t qs, int64_t qe, int km1, int ncols, int nw,
+                                            uint32_t *out, int *status) {
+    const int64_t s = ls[blockIdx.x], e = le[blockIdx.x], o = lo[blockIdx.x];
+    if (!(s > qs && s < qe + km1 + 1)) return;
+    const int64_t L = qe - qs;
+    const int64_t hi = s - qs > L ? L : s - qs;
+    int64_t c = e - qs - km1;
+    c = c < 0 ? 0 : c;
+    if (c >= hi) return;
+    const int64_t cc = o < 0 ? o + ncols : o;
+    if ((uint64_t)cc >= (uint64_t)ncols) {
+        if (threadIdx.x == 0) atomicOr(status, kStatusBadAnnot);
+        return;
+    }
+    const uint32_t keep = ~(1u << (cc & 31));
+    for (int64_t p = c + threadIdx.x; p < hi; p += blockDim.x) atomicAnd(out + p * nw + (cc >> 5), keep);
+}
+
+
+template <typename Rows>
+SweepKernel memb_kernel(int w, int waves, bool doubling) {
+#define MEMO_CASE(WW)                                                                              \
+    case WW:                                                                                       \
+        if (doubling)                                                                              \
+            return waves == 4 ? (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 256, true>      \
+                              : (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 64, true>;      \
+        return waves == 4 ? (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 256, false>         \
+                          : (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 64, false>;
+    switch (w) {
+        MEMO_CASE(256)
+        MEMO_CASE(512)
+        MEMO_CASE(1024)
+        MEMO_CASE(2048)
+        MEMO_CASE(4096)
+    }
+#undef MEMO_CASE
+    return nullptr;
+}
+
+template <typename Rows>
+SweepKernel memb_runs_kernel(int w, int waves) {
+#define MEMO_CASE(WW)                                                                                \
+    case WW:                                                                                         \
+        return waves == 4 ? (SweepKernel)sweep_membership_runs_kernel<Rows, WW, Rows::kLoads, 256>   \
+                          : (SweepKernel)sweep_membership_runs_kernel<Rows, WW, Rows::kLoads, 64>;
+    switch (w) {
+        MEMO_CASE(256)
+        MEMO_CASE(512)
+        MEMO_CASE(1024)
+        MEMO_CASE(2048)
+        MEMO_CASE(4096)
+    }
+#undef MEMO_CASE
+    return nullptr;
+}
+}  // namespace
+
+static int long_rows_membership(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int ncols, int nw,
+                                uint32_t *d_out, hipStream_t st) {
+    if (!ix->n_long) return MEMO_OK;
+    hipLaunchKernelGGL(long_rows_membership_kernel, dim3((unsigned)ix->n_long), dim3(256), 0, st, ix->ls,
+                       ix->le, ix->lo, qs, qe, k - 1, ncols, nw, d_out, ix->d_status);
+    HIP_TRY(hipGetLastError());
+    return MEMO_OK;
+}
+
+extern "C" {
+
+int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,
+                              int32_t num_docs, uint32_t *d_out, void *stream) {
+    read_env_once();
+    int rc = check_query_args(ix, qs, qe, k, num_docs, d_out);
+    if (rc) return rc;
+    if (qe <= qs) return MEMO_OK;
+    DeviceGuard guard(ix->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nw = (num_docs + 31) / 32;
+    if (k <= 1 || ix->rows == 0) {
+        hipLaunchKernelGGL(fill_membership_kernel, dim3(2048), dim3(256), 0, st, d_out,
+                           (qe - qs) * nw, nw, num_docs);
+        HIP_TRY(hipGetLastError());
+        return long_rows_membership(ix, qs, qe, k, num_docs, nw, d_out, st);
+    }
+    SweepArgs A;
+    fill_args(ix, A, qs, qe, k, d_out);
+    A.ncols = num_docs;
+    A.nlev = floor_log2((uint32_t)(k - 1)) + 1;
+    A.nwords = nw;
+    int fmt;
+    if ((rc = pick_rows(ix, k, fmt))) return rc;
+    // algorithm: 3 = runs (bit planes per genome + register transpose), 2 = doubling, 1 = direct
+    const size_t per_pos_doubling = (size_t)A.nlev * nw * 4;
+    int algo = g_memb_algo;
+    // A/B on config 4 (profiles/r01_membership_algorithms.txt): packed rows 0.87 ms runs vs 1.13 ms
+    // doubling; int64 rows (HBM-bound either way) 2.52 ms doubling vs 2.64 ms runs
+    if (!algo) algo = (fmt || per_pos_doubling * 256 > 40 * 1024) ? 3 : 2;
+    // whatever was asked for: a tile of 256 positions has to fit in LDS, else runs (which can slice)
+    if ((algo == 2 ? per_pos_doubling : (size_t)nw * 4) * 256 > 128 * 1024 || nw > 64) algo = 3;
+    const bool checked = ix->max_annot >= (uint64_t)A.ncols;
+    int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
+    A.word_base = 0;
+    A.out_words = nw;
+    if (algo == 3) {
+        if (!waves) waves = 4;
+        // 4 * nw bytes of LDS per position: beyond 2048 genomes even a 256-position tile is too big,
+        // so the genome words are swept in slices of 64 (the rows are read once per slice; every
+        // slice writes its own words of the result)
+        const int slice = nw <= 64 ? nw : 64;
+        if (!w) {  // a lane transposes one 32 x 32 block: keep nw * W / 32 >= threads
+            w = 4096;
+            while ((size_t)slice * 4 * w > 32 * 1024 && w > 256) w >>= 1;
+            while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
+        }
+        int skew = 1;
+        while (skew * 2 * slice <= 32) skew *= 2;  // largest power of two <= 32 / nw (1 when nw > 16)
+        A.nlev = skew;
+        auto lds_bytes = [&](int ww) { return ((size_t)32 * slice * (ww / 32 + 1) + (size_t)slice * skew) * 4; };
+        while (lds_bytes(w) > 160 * 1024 && w > 256) w >>= 1;
+        const size_t lds = lds_bytes(w);
+        SweepKernel kern = fmt == 4   ? (checked ? memb_runs_kernel<PackedRows<false, true>>(w, waves)
+                                                 : memb_runs_kernel<PackedRows<false, false>>(w, waves))
+                           : fmt == 6 ? (checked ? memb_runs_kernel<PackedRows<true, true>>(w, waves)
+                                                 : memb_runs_kernel<PackedRows<true, false>>(w, waves))
+                                      : memb_runs_kernel<WideRows>(w, waves);
+        if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+        for (int base = 0; base < nw; base += slice) {
+            A.word_base = base;
+            A.nwords = nw - base < slice ? nw - base : slice;
+            if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st, use_persistent(fmt)))) return rc;
+        }
+        return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
+    }
+    const bool doubling = algo == 2;
+    const size_t per_pos = doubling ? per_pos_doubling : (size_t)nw * 4;
+    if (!waves) waves = doubling ? 4 : 1;
+    if (!w) {  // config 4 A/B: int64 rows 512 positions x 4 waves (40 KiB); packed rows 256 x 4 (20 KiB)
+        const size_t budget = (waves == 4 ? (fmt ? 20u : 40u) : 20u) * 1024;
+        w = 4096;
+        while (per_pos * w > budget && w > 256) w >>= 1;
+        while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
+    }
+    while (per_pos * w > 160 * 1024 && w > 256) w >>= 1;
+    SweepKernel kern = fmt == 4   ? (checked ? memb_kernel<PackedRows<false, true>>(w, waves, doubling)
+                                             : memb_kernel<PackedRows<false, false>>(w, waves, doubling))
+                       : fmt == 6 ? (checked ? memb_kernel<PackedRows<true, true>>(w, waves, doubling)
+                                             : memb_kernel<PackedRows<true, false>>(w, waves, doubling))
+                                  : memb_kernel<WideRows>(w, waves, doubling);
+    if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+    if ((rc = launch_tiles(kern, A, w, 64 * waves, per_pos * w, st, use_persistent(fmt)))) return rc;
+    return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
+}
+
+}  // extern "C"
