@@ -226,7 +226,8 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         const size_t budget = (fmt || sparse) ? 32 * 1024 : 80 * 1024;
         w = 4096;
         while ((size_t)A.nlev * w * 4 > budget && w > 256) w >>= 1;
-        while (w > 256 && (qe - qs) / w < 32768) w >>= 1;
+        while (w > 1024 && (qe - qs) / w < 8192) w >>= 1;                 // big 4-wave tiles: a few thousand suffice
+        while (w > 256 && w <= 1024 && (qe - qs) / w < 32768) w >>= 1;   // short windows: many small tiles
     }
     if (!waves) waves = w >= 1024 ? 4 : 1;  // short windows end up with small tiles: one wave each
     while ((size_t)A.nlev * w * 4 > 160 * 1024 && w > 256) w >>= 1;
