@@ -160,3 +160,27 @@ def test_synth_host_rows_equal_oracle(oracle):
         got = synth.host_rows(rb, n, num, den, nd)
         want = oracle.synth_rows(rb, n, num, den, nd)
         assert all(np.array_equal(g, w) for g, w in zip(got, want))
+
+
+def test_region_chunks_without_statistics_or_with_dictionary_f0(memo, tmp_path):
+    """index files written by other tools: no row-group statistics (nothing can be pruned), f0
+    dictionary-encoded -- the slice is the same"""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from memo_amd import memo_query as mq
+    rng = np.random.default_rng(5)
+    n = 9000
+    s = np.sort(rng.integers(1, 30_000, n))
+    names = np.where(np.arange(n) < 6000, "chr1", "chr2")
+    order = np.lexsort((s, names))
+    tab = pa.table({"f0": pa.array(names[order]).dictionary_encode(), "f1": s[order], "f2": s[order] + 3,
+                    "f3": rng.integers(1, 5, n)})
+    for kw in (dict(write_statistics=False), dict(use_dictionary=True), dict(compression="NONE")):
+        path = str(tmp_path / "x.parquet")
+        pq.write_table(tab, path, row_group_size=700, **kw)
+        for rec, qs, qe in (("chr1", 100, 9000), ("chr2", 0, 40_000), ("chr3", 0, 10)):
+            want = mq.filter_pq(path, rec, qs, qe)
+            bound, chunks = mq.region_chunks(path, rec, qs, qe)
+            got = list(chunks)
+            cat = np.concatenate([c[0] for c in got]) if got else np.zeros(0, np.int64)
+            assert np.array_equal(cat, want.start) and len(want) <= bound
