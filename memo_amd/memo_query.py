@@ -20,7 +20,6 @@ import argparse
 import os
 
 import numpy as np
-import pyarrow.dataset as ds
 
 from .index import DeviceIndex, emit_conservation_buffer, emit_membership_buffer, words
 
@@ -52,6 +51,7 @@ def filter_pq(in_file, query_record, query_start, query_end, spanning_rows=False
     every one of them (their start clips to 0, so casted_end < start cannot hold, :46-49);
     they are read only when spanning_rows=True, which reproduces the reference's return
     value row for row (spanning rows first)."""
+    import pyarrow.dataset as ds          # pulls in pandas: kept off the CLI's path (region_index)
     pq_ds = ds.dataset(in_file, format="parquet")
     rec = ds.field("f0") == query_record
     inside = pq_ds.to_table(filter=rec & (ds.field("f1") > query_start) & (ds.field("f1") < query_end),
