@@ -266,7 +266,9 @@ def main():
         rows_t = "WideRows" if which == "wide" else f"PackedRows<{'true' if packed_fmt == 6 else 'false'}, false>"
         if membership:      # packed rows: per-genome bit planes ("runs"); int64 rows: doubling
             return ("sweep_membership_kernel<" if which == "wide" else "sweep_membership_runs_kernel<") + rows_t + ", ...>"
-        return "sweep_conservation_kernel<" + rows_t + ", ...>"
+        # packed rows on an index with >= 1 row per position: the unclipped scatter (memo_sweep_cons.hip)
+        halo = which != "wide" and rows >= L and os.environ.get("MEMO_SCATTER", "0") in ("0", "2")
+        return ("sweep_conservation_halo_kernel<" if halo else "sweep_conservation_kernel<") + rows_t + ", ...>"
 
     other = None
     if not multi and k - 1 <= 255:          # the same query on the other row format, for the record

@@ -209,6 +209,12 @@ int memo_set_row_source(int32_t source);
  * resident; each walks a run of tiles and looks the next one up under the current one's work).
  * Also MEMO_PERSIST.  Results are identical. */
 int memo_set_persistent(int32_t mode);
+/* conservation scatter with packed rows: 0 = library's choice, 1 = clip every interval to the tile,
+ * 2 = unclipped into level arrays with a halo (fewer instructions and registers per row; only when
+ * every annot of the index is inside the result matrix and workgroups are not persistent, else 1 is
+ * used anyway).  tile_w of memo_set_tuning is then the size of a level array, halo included.
+ * Also MEMO_SCATTER.  Results are identical. */
+int memo_set_scatter(int32_t mode);
 
 /* profiling aid: one pass that reads the three columns exactly once (24 B/row) with the
  * sweep's access shape, to calibrate the FETCH_SIZE counter on a known byte count */

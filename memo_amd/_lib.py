@@ -79,6 +79,7 @@ SYMBOLS = {
     "memo_debug_set_stamp_buffer": (C.c_int, [_P]),
     "memo_debug_stream_rows": (C.c_int, [_P, _P]),
     "memo_set_persistent": (C.c_int, [_I32]),
+    "memo_set_scatter": (C.c_int, [_I32]),
     "memo_set_row_source": (C.c_int, [_I32]),
     "memo_set_tuning": (C.c_int, [_I32, _I32, _I32]),
 }

@@ -28,6 +28,8 @@ struct SweepArgs {
     int ncols;  // result columns: num_docs + 1 (conservation) / num_docs (membership)
     int nlev;   // doubling levels: floor(log2(k-1)) + 1
     int nwords; // membership: 32-bit words per position handled by this launch
+    int ls, hl;  // conservation, unclipped scatter: words per level array, words of left halo
+    int w;       //   ... and its tile width (a multiple of 32, not a template parameter there)
     int word_base;  // membership runs: first genome word of this launch (num_docs too large for one
     int out_words;  //   LDS tile is swept in slices of genome words); out_words = words per position
     unsigned long long *stamps;  // diagnostic builds (-DMEMO_STAMPS): per-phase cycle sums
@@ -99,8 +101,7 @@ struct Tile {
     uint64_t r0, r1;  // row slice
 };
 
-template <int W>
-__device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t, int it) {
+__device__ __forceinline__ bool locate_tile_w(const SweepArgs &A, Tile &t, int it, int W) {
     const int64_t tile = tile_of_block(A, it);
     if (tile < 0 || tile >= A.ntiles) return false;
     t.a = A.tile0 + tile * W;
@@ -112,6 +113,11 @@ __device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t, int it)
         return false;
     }
     return true;
+}
+
+template <int W>
+__device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t, int it) {
+    return locate_tile_w(A, t, it, W);
 }
 
 // Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() would
@@ -210,21 +216,15 @@ __device__ __forceinline__ int pin_vgpr(int uniform) {
 template <bool ANNOT16, bool CHECKED>
 struct PackedRows {
     static constexpr int kLoads = 2 * MEMO_KU;  // A/B: 8 x 16 B in flight per lane, 5 % over 4
+    static constexpr bool kAnnot16 = ANNOT16;
+    // f(c, h, col): the clipped interval, as WideRows hands it out
     template <int T, int U, typename B, typename F>
     static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, B between, F f) {
-        const int tid = threadIdx.x;
         const uint32_t a16 = (uint32_t)t.a & 0xFFFFu;
-        // 32-bit row numbers relative to the 128-byte-aligned start of the slice
-        const uint64_t base0 = t.r0 & ~(uint64_t)31;
-        const uint32_t first = (uint32_t)(t.r0 - base0), end = (uint32_t)(t.r1 - base0);
-        const uint32_t *pk = A.pk + base0;
-        const uint16_t *pa = ANNOT16 ? A.pa + base0 : nullptr;
         const int x_lo = pin_vgpr(t.x_lo), x_hi = t.x_hi, km1 = A.km1;
         const uint32_t ncols = (uint32_t)A.ncols;
-        // a row that cannot write: start == a, overlap 255 >= k - 1  ->  c >= h
-        const uint32_t dead = a16 | 0x00FF0000u;
         uint32_t bad = 0;
-        auto one = [&](uint32_t w, uint32_t annot) {
+        for_each_raw<T, U>(A, t, between, [&](uint32_t w, uint32_t annot) {
             const int d = (int)((w - a16) & 0xFFFFu);  // start - a
             int h = med3(d, x_lo, x_hi);
             const int c = med3(d + (int)__builtin_amdgcn_ubfe(w, 16, 8) - km1, x_lo, x_hi);
@@ -233,45 +233,77 @@ struct PackedRows {
                 h = c;
             }
             f(c, h, (int)annot);  // f writes iff h > c
-        };
-        bool first_batch = true;
-        for (uint32_t rel = 4 * tid; first_batch || rel < end; rel += 4 * T * U) {
+        });
+        if (CHECKED && bad) atomicOr(A.status, kStatusBadAnnot);
+    }
+
+    // g(word, annot): every row of the slice as it is stored; the rows a 16-byte load holds outside
+    // the slice arrive as a word that cannot write (start == a, overlap 255 >= k - 1)
+    template <int T, int U, typename B, typename G>
+    static __device__ __forceinline__ void for_each_raw(const SweepArgs &A, const Tile &t, B between, G g) {
+        const uint32_t nb = batches<T, U>(t);
+        for (uint32_t b = 0; b == 0 || b < nb; ++b) {
             uint4 V[U];
             uint2 N[U];
+            issue<T, U>(A, t, b, V, N);
+            if (b == 0) between();
+            consume<T, U>(A, t, b, V, N, g);
+        }
+    }
+
+    // The two halves of a batch (U loads of 16 B per lane), for kernels that put other work between
+    // issuing a tile's loads and using them.  Row numbers are 32-bit, relative to the 128-byte-aligned
+    // start of the slice.
+    template <int T, int U>
+    static __device__ __forceinline__ uint32_t batches(const Tile &t) {
+        const uint32_t end = (uint32_t)(t.r1 - (t.r0 & ~(uint64_t)31));
+        return (end + 4 * T * U - 1) / (4 * T * U);
+    }
+
+    template <int T, int U>
+    static __device__ __forceinline__ void issue(const SweepArgs &A, const Tile &t, uint32_t batch, uint4 (&V)[U],
+                                                 uint2 (&N)[U]) {
+        const uint64_t base0 = t.r0 & ~(uint64_t)31;
+        const uint32_t end = (uint32_t)(t.r1 - base0);
+        const uint32_t *pk = A.pk + base0;
+        const uint16_t *pa = ANNOT16 ? A.pa + base0 : nullptr;
+        const uint32_t rel = batch * (4 * T * U) + 4 * threadIdx.x;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t r = rel + (uint32_t)u * 4 * T;
-                if (r < end) {
-                    V[u] = *reinterpret_cast<const uint4 *>(pk + r);
-                    if (ANNOT16) N[u] = *reinterpret_cast<const uint2 *>(pa + r);
-                } else {
-                    V[u] = make_uint4(dead, dead, dead, dead);
-                    N[u] = make_uint2(0u, 0u);
-                }
-            }
-            if (first_batch) {
-                between();
-                first_batch = false;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t r = rel + (uint32_t)u * 4 * T;
-                // wave-uniform: only a load that straddles an end of the slice masks rows by number
-                const uint32_t wave_lo = __builtin_amdgcn_readfirstlane(r) & ~(uint32_t)255;
-                if (wave_lo >= end) break;  // nothing of this wave's load is inside the slice
-                if (!(wave_lo >= first && wave_lo + 256 <= end)) {
-                    V[u].x = (r + 0 >= first && r + 0 < end) ? V[u].x : dead;
-                    V[u].y = (r + 1 >= first && r + 1 < end) ? V[u].y : dead;
-                    V[u].z = (r + 2 >= first && r + 2 < end) ? V[u].z : dead;
-                    V[u].w = (r + 3 >= first && r + 3 < end) ? V[u].w : dead;
-                }
-                one(V[u].x, ANNOT16 ? (N[u].x & 0xFFFFu) : (V[u].x >> 24));
-                one(V[u].y, ANNOT16 ? (N[u].x >> 16) : (V[u].y >> 24));
-                one(V[u].z, ANNOT16 ? (N[u].y & 0xFFFFu) : (V[u].z >> 24));
-                one(V[u].w, ANNOT16 ? (N[u].y >> 16) : (V[u].w >> 24));
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = rel + (uint32_t)u * 4 * T;
+            // wave-uniform (consume() tests the same): a wave loads its 256 rows or nothing.  The rows
+            // it reads past the slice lie inside the index or its kPadRows sentinel rows.
+            if ((__builtin_amdgcn_readfirstlane(r) & ~(uint32_t)255) < end) {
+                V[u] = *reinterpret_cast<const uint4 *>(pk + r);
+                if (ANNOT16) N[u] = *reinterpret_cast<const uint2 *>(pa + r);
             }
         }
-        if (CHECKED && bad) atomicOr(A.status, kStatusBadAnnot);
+    }
+
+    template <int T, int U, typename G>
+    static __device__ __forceinline__ void consume(const SweepArgs &A, const Tile &t, uint32_t batch, uint4 (&V)[U],
+                                                   uint2 (&N)[U], G g) {
+        const uint64_t base0 = t.r0 & ~(uint64_t)31;
+        const uint32_t first = (uint32_t)(t.r0 - base0), end = (uint32_t)(t.r1 - base0);
+        const uint32_t dead = ((uint32_t)t.a & 0xFFFFu) | 0x00FF0000u;
+        const uint32_t rel = batch * (4 * T * U) + 4 * threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = rel + (uint32_t)u * 4 * T;
+            // wave-uniform: only a load that straddles an end of the slice masks rows by number
+            const uint32_t wave_lo = __builtin_amdgcn_readfirstlane(r) & ~(uint32_t)255;
+            if (wave_lo >= end) break;  // nothing of this wave's load is inside the slice
+            if (!(wave_lo >= first && wave_lo + 256 <= end)) {
+                V[u].x = (r + 0 >= first && r + 0 < end) ? V[u].x : dead;
+                V[u].y = (r + 1 >= first && r + 1 < end) ? V[u].y : dead;
+                V[u].z = (r + 2 >= first && r + 2 < end) ? V[u].z : dead;
+                V[u].w = (r + 3 >= first && r + 3 < end) ? V[u].w : dead;
+            }
+            g(V[u].x, ANNOT16 ? (N[u].x & 0xFFFFu) : (V[u].x >> 24));
+            g(V[u].y, ANNOT16 ? (N[u].x >> 16) : (V[u].y >> 24));
+            g(V[u].z, ANNOT16 ? (N[u].y & 0xFFFFu) : (V[u].z >> 24));
+            g(V[u].w, ANNOT16 ? (N[u].y >> 16) : (V[u].w >> 24));
+        }
     }
 };
 
@@ -289,6 +321,7 @@ extern int g_waves;       // waves per tile: 0 = choose, 1 or 4
 extern int g_memb_algo;   // membership: 0 = choose, 1 = direct scatter, 2 = doubling, 3 = runs
 extern int g_force_wide;  // 1 = read the int64 columns even when packed rows exist
 extern int g_persist;     // 0 = choose, 1 = one workgroup per tile, 2 = persistent workgroups
+extern int g_scatter;     // conservation, packed rows: 0 = choose, 1 = clipped, 2 = unclipped + halo
 extern unsigned long long *g_stamp_buffer;  // -DMEMO_STAMPS builds: 8 words per workgroup
 
 using SweepKernel = void (*)(const SweepArgs);
@@ -297,7 +330,7 @@ void read_env_once();
 bool use_persistent(int fmt);
 inline int floor_log2(uint32_t v) { return 31 - __builtin_clz(v); }
 int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st,
-                 bool persistent);
+                 int run);  // run: tiles per workgroup; 0 = persistent workgroups
 int pick_rows(const memo_index *ix, int32_t k, int &fmt);
 int check_query_args(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
                      const void *d_out);

@@ -33,6 +33,7 @@ int g_memb_algo = 0;  // membership: 0 = choose, 1 = direct scatter, 2 = doublin
 int g_force_wide = 0; // 1 = read the int64 columns even when packed rows exist
 unsigned long long *g_stamp_buffer = nullptr;  // -DMEMO_STAMPS builds: 8 words per workgroup
 int g_persist = 0;    // 0 = choose, 1 = one workgroup per tile, 2 = persistent workgroups
+int g_scatter = 0;    // conservation, packed rows: 0 = choose, 1 = clipped, 2 = unclipped + halo
 
 // Persistent workgroups measured 7-20 % SLOWER on every workload (profiles/r01_persistent_ab.txt):
 // resident workgroups that start together stay in step -- every CU loads, then every CU folds --
@@ -49,16 +50,17 @@ void read_env_once() {
     if (const char *v = getenv("MEMO_MEMB_ALGO")) g_memb_algo = atoi(v);
     if (const char *v = getenv("MEMO_ROWS")) g_force_wide = strcmp(v, "wide") == 0;
     if (const char *v = getenv("MEMO_PERSIST")) g_persist = atoi(v);
+    if (const char *v = getenv("MEMO_SCATTER")) g_scatter = atoi(v);
 }
 
-// tiles are aligned in pivot coordinates: tile 0 starts at floor(qs / w) * w.
-// persistent: launch only as many workgroups as the device keeps resident; each walks its XCD
-// group's run of tiles and looks the next tile up while it works on the current one.
-int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st,
-                 bool persistent) {
-    const int sh = floor_log2((uint32_t)w);
-    A.tile0 = (A.qs >> sh) << sh;  // >> on a negative int64 is arithmetic: floor
-    A.ntiles = ((A.qe - A.tile0) + w - 1) >> sh;
+// tiles are aligned in pivot coordinates: tile 0 starts at floor(qs / w) * w  (w: any multiple of
+// the bucket width).  run = tiles per workgroup: 1, or 0 = persistent: only as many workgroups as
+// the device keeps resident, each walking its XCD group's run of tiles with that stride.
+int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st, int run) {
+    int64_t q = A.qs / w;
+    if (A.qs % w < 0) --q;  // floor
+    A.tile0 = q * w;
+    A.ntiles = ((A.qe - A.tile0) + w - 1) / w;
     A.tiles_per_xcd = (A.ntiles + 7) / 8;
     A.blocks_per_xcd = A.tiles_per_xcd;
     if (lds > 160 * 1024) return fail(MEMO_EINVAL, "tile needs %zu bytes of LDS (> 160 KiB)", lds);
@@ -73,7 +75,7 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
             have = lds;
         }
     }
-    if (persistent) {
+    if (run == 0) {
         int per_cu = 0, cus = 0, dev = 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -149,6 +151,13 @@ int memo_set_persistent(int32_t mode) {
     read_env_once();
     if (mode < 0 || mode > 2) return fail(MEMO_EINVAL, "mode must be 0 (choose), 1 (off) or 2 (on)");
     g_persist = mode;
+    return MEMO_OK;
+}
+
+int memo_set_scatter(int32_t mode) {
+    read_env_once();
+    if (mode < 0 || mode > 2) return fail(MEMO_EINVAL, "mode must be 0 (choose), 1 (clipped) or 2 (unclipped)");
+    g_scatter = mode;
     return MEMO_OK;
 }
 

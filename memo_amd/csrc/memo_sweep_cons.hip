@@ -115,6 +115,153 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
 }
 
 
+// ------------------------------------------------------------------------------------------
+// conservation, packed rows whose annot is known to be inside the matrix: the same doubling scatter
+// WITHOUT clipping.
+//
+// Every level array carries a halo -- HL cells left of the tile, HR right of it -- wide enough for
+// any interval a row of the slice can have (start - a in [0, W + k + 30], length n = k - 1 -
+// overlap in [1, k - 1]); what falls into the right halo is never read back, the left halo is
+// folded like the rest (a block that starts left of the tile can cover tile positions).  With
+// nothing to clip, the level and both cells follow from n and start - a alone: 10 VALU
+// instructions per row instead of 17, and 60 VGPRs instead of 70 (8 waves per SIMD).  Levels are
+// stored by leading-zero count (slot = clz(n) - clz(k - 1)): slot 0 = longest blocks.  The tile
+// width W = A.w is what leaves the level array (HL + W + HR) at a round size; it is a multiple of
+// the bucket width, not a power of two.
+// (Measured and dropped, profiles/r01_unclipped_scatter.txt: a workgroup walking 2..32 tiles with
+// the next tile's rows in flight under the fold -- 6-17 % slower than one tile per workgroup.)
+// ------------------------------------------------------------------------------------------
+#ifndef MEMO_HALO_WAVES
+#define MEMO_HALO_WAVES 8
+#endif
+template <typename Rows, int U, int T, typename OutT>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
+void sweep_conservation_halo_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const int LS = A.ls, HL = A.hl, W = A.w;
+    Tile t;
+    if (!locate_tile_w(A, t, 0, W)) return;
+    uint4 V[U];
+    uint2 N[U];
+    Rows::template issue<T, U>(A, t, 0, V, N);
+    {  // under the loads: every level starts at the sentinel column N (memo_query.py:53-54)
+        const uint32_t sent = (uint32_t)(A.ncols - 1);
+        const uint4 sv = make_uint4(sent, sent, sent, sent);
+        uint4 *p = reinterpret_cast<uint4 *>(lds);
+        for (int i = tid; i < A.nlev * (LS / 4); i += T) p[i] = sv;
+        lds_barrier();
+    }
+
+    const int km1 = A.km1;
+    // LDS byte address of tile slot x on the level with clz(n) = f:  base + 4 * ((f - fmin) * LS + HL + x)
+    const uint32_t ls4 = 4u * (uint32_t)LS;
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
+    const uint32_t bias4 = pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)(32 - A.nlev) * ls4));
+    const uint32_t top_bit = pin_vgpr((int)0x80000000u);
+    const uint32_t a16 = pin_vgpr((int)((uint32_t)t.a & 0xFFFFu));
+    auto scatter = [&](uint32_t w, uint32_t col) {
+        const int n = km1 - (int)__builtin_amdgcn_ubfe(w, 16, 8);  // length of [end - (k-1), start)
+        if (n > 0) {
+            // f = clz(n); 2^j = 2^31 >> f; x4 = address of cell `start` on level f;
+            // ds_min into the cells of blocks [start - n, .. + 2^j) and [start - 2^j, start).
+            // (v_sub_u16: gfx9 16-bit VALU results have a zero high half.)  The compiler's own
+            // rendering of this needs 13 VALU instructions, one of them a quarter-rate multiply.
+            uint32_t r0, r1, r2;
+            if (Rows::kAnnot16)
+                asm volatile(
+                    "v_ffbh_u32 %0, %3\n\t"
+                    "v_sub_u16 %1, %4, %5\n\t"
+                    "v_mad_u32_u24 %2, %0, %6, %7\n\t"
+                    "v_lshl_add_u32 %2, %1, 2, %2\n\t"
+                    "v_mad_i32_i24 %1, %3, -4, %2\n\t"
+                    "v_ashrrev_i32 %0, %0, %8\n\t"
+                    "v_lshl_add_u32 %2, %0, 2, %2\n\t"
+                    "ds_min_u32 %1, %9\n\t"
+                    "ds_min_u32 %2, %9"
+                    : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+                    : "v"(n), "v"(w), "v"(a16), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(col)
+                    : "memory");
+            else
+                asm volatile(
+                    "v_ffbh_u32 %0, %3\n\t"
+                    "v_sub_u16 %1, %4, %5\n\t"
+                    "v_mad_u32_u24 %2, %0, %6, %7\n\t"
+                    "v_lshl_add_u32 %2, %1, 2, %2\n\t"
+                    "v_mad_i32_i24 %1, %3, -4, %2\n\t"
+                    "v_ashrrev_i32 %0, %0, %8\n\t"
+                    "v_lshl_add_u32 %2, %0, 2, %2\n\t"
+                    "v_lshrrev_b32 %0, 24, %4\n\t"
+                    "ds_min_u32 %1, %0\n\t"
+                    "ds_min_u32 %2, %0"
+                    : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+                    : "v"(n), "v"(w), "v"(a16), "s"(ls4), "v"(bias4), "v"(top_bit)
+                    : "memory");
+        }
+    };
+    Rows::template consume<T, U>(A, t, 0, V, N, scatter);
+    for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
+        Rows::template issue<T, U>(A, t, b, V, N);
+        Rows::template consume<T, U>(A, t, b, V, N, scatter);
+    }
+    lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
+
+    // fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1); the left halo too
+    const int cells = HL + W;
+    for (int slot = 0; slot + 1 < A.nlev; ++slot) {
+        const int half = 1 << (A.nlev - 2 - slot);
+        const uint32_t *hi = lds + slot * LS;
+        uint32_t *lo = lds + (slot + 1) * LS;
+        for (int x = 4 * tid; x < cells; x += 4 * T) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(hi + x);
+            uint4 u;
+            if (half >= 4) {
+                u = x >= half ? *reinterpret_cast<const uint4 *>(hi + x - half)
+                              : make_uint4(~0u, ~0u, ~0u, ~0u);
+            } else if (half == 2) {
+                const uint2 q = x >= 2 ? *reinterpret_cast<const uint2 *>(hi + x - 2)
+                                       : make_uint2(~0u, ~0u);
+                u = make_uint4(q.x, q.y, v.x, v.y);
+            } else {
+                const uint32_t q = x >= 1 ? hi[x - 1] : ~0u;
+                u = make_uint4(q, v.x, v.y, v.z);
+            }
+            uint4 r = *reinterpret_cast<const uint4 *>(lo + x);
+            r.x = min(r.x, min(v.x, u.x));
+            r.y = min(r.y, min(v.y, u.y));
+            r.z = min(r.z, min(v.z, u.z));
+            r.w = min(r.w, min(v.w, u.w));
+            *reinterpret_cast<uint4 *>(lo + x) = r;
+        }
+        lds_barrier();
+    }
+
+    // write the last level (single positions) as OutT, in 16-byte pieces aligned in the OUTPUT
+    const uint32_t *res = lds + (A.nlev - 1) * LS + HL;
+    constexpr int PER = 16 / (int)sizeof(OutT);
+    OutT *out = static_cast<OutT *>(A.out);
+    const int64_t ob = t.a - A.qs;  // output index of tile slot 0
+    const int64_t o_lo = ob + t.x_lo, o_hi = ob + t.x_hi;
+    for (int64_t g = (o_lo & ~(int64_t)(PER - 1)) + PER * tid; g < o_hi; g += PER * T) {
+        const int x = (int)(g - ob);
+        if (g >= o_lo && g + PER <= o_hi) {
+            uint32_t pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (sizeof(OutT) == 2)
+                    pk[q] = res[x + 2 * q] | (res[x + 2 * q + 1] << 16);
+                else
+                    pk[q] = res[x + 4 * q] | (res[x + 4 * q + 1] << 8) | (res[x + 4 * q + 2] << 16) |
+                            (res[x + 4 * q + 3] << 24);
+            }
+            *reinterpret_cast<uint4 *>(out + g) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        } else {
+            for (int i = 0; i < PER; ++i)
+                if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)res[x + i];
+        }
+    }
+}
+
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
 template <typename OutT>
 __global__ void fill_conservation_kernel(OutT *out, int64_t n, OutT v) {
@@ -176,6 +323,17 @@ SweepKernel cons_kernel(int w, int waves) {
 
 }  // namespace
 
+#ifndef MEMO_HALO_LOADS
+#define MEMO_HALO_LOADS 6
+#endif
+constexpr int kHaloLoads = MEMO_HALO_LOADS;  // 16-byte loads in flight per lane
+
+template <typename Rows, typename OutT>
+static SweepKernel halo_kernel(int waves) {
+    return waves == 4 ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 256, OutT>
+                      : (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 64, OutT>;
+}
+
 template <typename OutT>
 static int long_rows_conservation(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int ncols,
                                   OutT *d_out, hipStream_t st) {
@@ -218,11 +376,11 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     //    k = 101 (28 KiB) over 512 or 2048 positions.
     // Short windows want many small tiles either way.
     int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
+    // int64 rows on a sparse index (< 2 rows per position: profiles/r01_sparse_index_tiles.txt) are
+    // no longer HBM-bound per tile; they want the packed rows' shape (more workgroups per CU)
+    const double span = (double)(ix->max_s - ix->min_s) + 1.0;
+    const bool sparse = (double)ix->rows < 2.0 * span;
     if (!w) {
-        // int64 rows on a sparse index (< 2 rows per position: profiles/r01_sparse_index_tiles.txt) are
-        // no longer HBM-bound per tile; they want the packed rows' shape (more workgroups per CU)
-        const double span = (double)(ix->max_s - ix->min_s) + 1.0;
-        const bool sparse = (double)ix->rows < 2.0 * span;
         const size_t budget = (fmt || sparse) ? 32 * 1024 : 80 * 1024;
         w = 4096;
         while ((size_t)A.nlev * w * 4 > budget && w > 256) w >>= 1;
@@ -230,15 +388,49 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         while (w > 256 && w <= 1024 && (qe - qs) / w < 32768) w >>= 1;   // short windows: many small tiles
     }
     if (!waves) waves = w >= 1024 ? 4 : 1;  // short windows end up with small tiles: one wave each
-    while ((size_t)A.nlev * w * 4 > 160 * 1024 && w > 256) w >>= 1;
     const bool checked = ix->max_annot >= (uint64_t)A.ncols;  // some row could be outside the matrix
-    SweepKernel kern = fmt == 4   ? (checked ? cons_kernel<PackedRows<false, true>, OutT>(w, waves)
-                                             : cons_kernel<PackedRows<false, false>, OutT>(w, waves))
-                       : fmt == 6 ? (checked ? cons_kernel<PackedRows<true, true>, OutT>(w, waves)
-                                             : cons_kernel<PackedRows<true, false>, OutT>(w, waves))
-                                  : cons_kernel<WideRows, OutT>(w, waves);
-    if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-    if ((rc = launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * (w + kLevelSkew) * 4, st, use_persistent(fmt)))) return rc;
+    // unclipped scatter (PackedRows, every annot inside the matrix): w is the size of a level array,
+    // HL + tile + HR cells (start - a <= tile + k + 30 inside a slice); the tile is what is left
+    // after the halo, rounded down to whole buckets
+    // (below one row per position the halo's extra clear and fold cost more than the scatter saves)
+    bool halo = fmt && !checked && !use_persistent(fmt) &&
+                (g_scatter == 2 || (g_scatter == 0 && (double)ix->rows >= span));
+    if (halo) {
+        // A/B (profiles/r01_unclipped_scatter.txt): arrays of 1024 cells x 4 waves win at every window
+        // length from 10^6 positions up and at k = 21 .. 101
+        const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + 31 + 3) & ~3, bw = 1 << ix->bshift;
+        if (!g_tile_w) w = 1024;
+        int tw = 0;
+        for (;; w <<= 1) {
+            tw = (w - hl - hr) / bw * bw;
+            if ((tw >= bw && 2 * tw >= hl + hr) || w >= 4096) break;  // keep the halo under two thirds of the array
+        }
+        while ((size_t)A.nlev * (hl + tw + hr) * 4 > 160 * 1024 && tw > bw) tw = (tw / 2 + bw - 1) / bw * bw;
+        if (tw < bw) halo = false;
+        else {
+            A.hl = hl;
+            A.w = tw;
+            A.ls = hl + tw + hr;
+            if (g_waves == 0) waves = w >= 1024 ? 4 : 1;
+            SweepKernel kern = fmt == 4 ? halo_kernel<PackedRows<false, false>, OutT>(waves)
+                                        : halo_kernel<PackedRows<true, false>, OutT>(waves);
+            if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)A.nlev * A.ls * 4, st, 1))) return rc;
+        }
+    }
+    if (!halo) {
+        while ((size_t)A.nlev * (w + kLevelSkew) * 4 > 160 * 1024 && w > 256) w >>= 1;
+        A.hl = 0;
+        A.w = w;
+        A.ls = w + kLevelSkew;
+        SweepKernel kern = fmt == 4   ? (checked ? cons_kernel<PackedRows<false, true>, OutT>(w, waves)
+                                                 : cons_kernel<PackedRows<false, false>, OutT>(w, waves))
+                           : fmt == 6 ? (checked ? cons_kernel<PackedRows<true, true>, OutT>(w, waves)
+                                                 : cons_kernel<PackedRows<true, false>, OutT>(w, waves))
+                                      : cons_kernel<WideRows, OutT>(w, waves);
+        if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+        if ((rc = launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * A.ls * 4, st, use_persistent(fmt) ? 0 : 1)))
+            return rc;
+    }
     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
 }
 

@@ -337,7 +337,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         for (int base = 0; base < nw; base += slice) {
             A.word_base = base;
             A.nwords = nw - base < slice ? nw - base : slice;
-            if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st, use_persistent(fmt)))) return rc;
+            if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st, use_persistent(fmt) ? 0 : 1))) return rc;
         }
         return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
     }
@@ -357,7 +357,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                              : memb_kernel<PackedRows<true, false>>(w, waves, doubling))
                                   : memb_kernel<WideRows>(w, waves, doubling);
     if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-    if ((rc = launch_tiles(kern, A, w, 64 * waves, per_pos * w, st, use_persistent(fmt)))) return rc;
+    if ((rc = launch_tiles(kern, A, w, 64 * waves, per_pos * w, st, use_persistent(fmt) ? 0 : 1))) return rc;
     return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
 }
 

@@ -62,6 +62,7 @@ while time.time() < t_end:
             _lib.check(L.memo_set_tuning(*tune))
             _lib.check(L.memo_set_persistent(int(rng.integers(0, 3))))
             _lib.check(L.memo_set_row_source(int(rng.integers(0, 2))))
+            _lib.check(L.memo_set_scatter(int(rng.integers(0, 3))))
             memb = rng.random() < 0.4
             if memb and (qe - qs) * n_docs > 30_000_000:
                 qe = qs + 30_000_000 // n_docs
@@ -83,4 +84,5 @@ while time.time() < t_end:
                 np.savez("/tmp/fuzz_fail.npz", s=s, e=e, o=o)
                 sys.exit(1)
 _lib.check(L.memo_set_tuning(0, 0, 0))
+_lib.check(L.memo_set_scatter(0))
 print(f"fuzz ok: {cases} indexes, {queries} queries in {a.seconds:.0f} s", flush=True)

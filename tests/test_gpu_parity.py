@@ -174,13 +174,19 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle):
                     qs = int(rng.integers(0, length // 2))
                     qe = int(rng.integers(qs + 1, length + 100))
                     want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
-                    assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (k, qs, qe, tile_w)
+                    for scatter in (1, 2):              # clipped to the tile / unclipped with a halo
+                        _lib.check(_lib.lib().memo_set_scatter(scatter))
+                        assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (k, qs, qe, tile_w, scatter)
+                        if n_docs <= 255:
+                            assert np.array_equal(ix.conservation(qs, qe, k, n_docs, dtype=np.uint8),
+                                                  want.astype(np.uint8)), (k, qs, qe, tile_w, scatter)
                     if k in (3, 31, 256):
                         qe = min(qe, qs + 6000)
                         want = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
                         assert np.array_equal(ix.membership(qs, qe, k, n_docs), want), (k, qs, qe, tile_w)
         finally:
             _lib.check(_lib.lib().memo_set_tuning(0, 0, 0))
+            _lib.check(_lib.lib().memo_set_scatter(0))
         if keep_wide:
             want = oracle.conservation(*oracle.filter_rows(s, e, o, 100, 9000, 300), 100, 9000, 300, n_docs, literal=False)
             assert np.array_equal(ix.conservation(100, 9000, 300, n_docs), want)

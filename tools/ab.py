@@ -3,7 +3,8 @@
 on this pool is larger than most tuning effects).  GPU box only.
 
   python tools/ab.py --workload c3 --k 31 --rounds 12 "0,0,0" "1024,1,0" "4096,4,0"
-each variant = tile_w,waves,membership_algo[,persistent]  (memo_set_tuning, memo_set_persistent)
+each variant = tile_w,waves,membership_algo[,persistent[,scatter]]  (memo_set_tuning, memo_set_persistent,
+memo_set_scatter)
 """
 import argparse
 import json
@@ -24,11 +25,15 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--u8", action="store_true")
+    ap.add_argument("--length", type=int, default=0, help="query [0, length) instead of the whole pivot")
+    ap.add_argument("--density", default="5/100", help="rows per genome and position")
     ap.add_argument("--pack", default=None, choices=[None, "keep", "only"])
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     num_docs, L, membership = WORKLOADS[a.workload]
-    ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L, pack=a.pack)
+    L = a.length or L
+    from fractions import Fraction
+    ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L, density=Fraction(a.density), pack=a.pack)
     W = (num_docs + 31) // 32
     out = torch.empty((L, W) if membership else (L,), dtype=torch.int32 if membership else torch.int16, device="cuda")
     st = torch.cuda.current_stream()
@@ -47,6 +52,7 @@ def main():
         for v in variants:
             _lib.check(_lib.lib().memo_set_tuning(*v[:3]))
             _lib.check(_lib.lib().memo_set_persistent(v[3] if len(v) > 3 else 0))
+            _lib.check(_lib.lib().memo_set_scatter(v[4] if len(v) > 4 else 0))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             launch()
