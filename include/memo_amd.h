@@ -199,8 +199,9 @@ int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t
 /* ---- tuning knobs (process-wide; also read once from the environment: MEMO_TILE_W,
  * MEMO_WAVES, MEMO_MEMB_ALGO).  0 = let the library choose.  tile_w: positions per tile
  * (256..4096); waves: 1 or 4 waves share a tile; membership_algo: 1 = direct scatter,
- * 2 = doubling, 3 = runs (bit planes per genome + register transpose).  Results never depend
- * on these. */
+ * 2 = doubling, 3 = runs (bit planes per genome + register transpose), 4 = the same planes without
+ * clipping and with the result staged through LDS (packed rows, k <= 32, <= 512 genomes; else 3).
+ * Results never depend on these. */
 int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo);
 /* 0 = queries read the packed rows when the index has them (default); 1 = always the int64
  * columns (also MEMO_ROWS=wide).  For A/B measurements; results are identical. */

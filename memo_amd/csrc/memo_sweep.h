@@ -30,6 +30,7 @@ struct SweepArgs {
     int nwords; // membership: 32-bit words per position handled by this launch
     int ls, hl;  // conservation, unclipped scatter: words per level array, words of left halo
     int w;       //   ... and its tile width (a multiple of 32, not a template parameter there)
+    uint32_t magic;  // membership planes: ceil(2^32 / (32 * nwords)), for q / (32 * nwords) by v_mul_hi
     int word_base;  // membership runs: first genome word of this launch (num_docs too large for one
     int out_words;  //   LDS tile is swept in slices of genome words); out_words = words per position
     unsigned long long *stamps;  // diagnostic builds (-DMEMO_STAMPS): per-phase cycle sums

@@ -200,6 +200,109 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 }
 
 
+// ------------------------------------------------------------------------------------------
+// membership, bit planes per genome, unclipped, with the result staged through LDS
+// (packed rows whose annot is known to be inside the matrix, k - 1 <= 31, at most 16 result words).
+//
+//   * a genome's plane row covers one word left of the tile and three right of it, so that the run
+//     of any row of the slice (start - a in [0, W + k + 30], n = k - 1 - overlap <= 31 bits ending at
+//     start) fits without clipping: the run is (2^n - 1) << first bit as a 64-bit value, ds_or of
+//     its two halves into neighbouring words -- 14 VALU instructions per row instead of ~30 and no
+//     divergent branches;
+//   * lane (G, p) then reads the 32 plane rows of genome group G at position word p, transposes
+//     the 32 x 32 bits in registers and writes the 32 result words position-major into LDS, over
+//     the planes (all reads are behind a barrier by then);
+//   * the workgroup copies the staged tile to the result in whole 16-byte pieces, 1 KiB per
+//     wave-instruction (the transposing lanes themselves could only store 4-byte words 16*nw apart).
+//   Plane rows are PITCH words apart (odd) with SKEW words per 32-genome group, the staged words
+//   nw words of padding per position word: both chosen so that the lanes of a wave (nw groups x
+//   64/nw position words) fall on 64 different banks.
+// ------------------------------------------------------------------------------------------
+template <typename Rows, int U, int T>
+__global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const int W = A.w, nw = A.nwords, PITCH = A.ls, SKEW = A.hl;
+    Tile t;
+    if (!locate_tile_w(A, t, 0, W)) return;
+    uint4 V[U];
+    uint2 N[U];
+    Rows::template issue<T, U>(A, t, 0, V, N);
+    {
+        const int plane_pieces = (32 * nw * PITCH + nw * SKEW + 1 + 3) / 4;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        uint4 *pz = reinterpret_cast<uint4 *>(lds);
+        for (int i = tid; i < plane_pieces; i += T) pz[i] = z;
+        lds_barrier();
+    }
+
+    const int km1 = A.km1;
+    const uint32_t a16m = pin_vgpr((int)((uint32_t)(t.a - 32) & 0xFFFFu));  // bit 32 of a plane row = tile slot 0
+    auto scatter = [&](uint32_t w, uint32_t col) {
+        const int n = km1 - (int)__builtin_amdgcn_ubfe(w, 16, 8);  // bits of the run [end - (k-1), start)
+        if (n > 0) {
+            uint32_t d;  // start - a + 32 (gfx9 16-bit VALU results have a zero high half)
+            asm("v_sub_u16 %0, %1, %2" : "=v"(d) : "v"(w), "v"(a16m));
+            const uint32_t first = d - (uint32_t)n;
+            const uint64_t run = (uint64_t)((1u << n) - 1u) << (first & 31u);
+            uint32_t *cell = lds + (__umul24(col, (uint32_t)PITCH) + __umul24(col >> 5, (uint32_t)SKEW) + (first >> 5));
+            atomicOr(cell, (uint32_t)run);
+            atomicOr(cell + 1, (uint32_t)(run >> 32));
+        }
+    };
+    Rows::template consume<T, U>(A, t, 0, V, N, scatter);
+    for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
+        Rows::template issue<T, U>(A, t, b, V, N);
+        Rows::template consume<T, U>(A, t, b, V, N, scatter);
+    }
+    __syncthreads();
+
+    // transpose: lane (G, p), G fastest
+    const int PW = W / 32, blocks = nw * PW;
+    const int G = tid % nw, p = tid / nw;
+    uint32_t m[32];
+    if (tid < blocks) {
+        const uint32_t *src = lds + (32 * G) * PITCH + G * SKEW + p + 1;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) m[i] = src[i * PITCH];
+    }
+    __syncthreads();  // the planes are dead: the staged result goes over them
+    const int stride = 32 * nw + nw;  // staged words per position word (nw of padding)
+    if (tid < blocks) {
+        transpose32(m);
+        const uint32_t full = full_word(A.ncols, G);
+        uint32_t *dst = lds + p * stride + G;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) dst[j * nw] = full & ~m[j];
+    }
+    __syncthreads();
+
+    // copy: slots [x_lo, x_hi) are one contiguous run of words in the output
+    uint32_t *out = static_cast<uint32_t *>(A.out);
+    const int64_t ob = (t.a - A.qs) * nw;  // output word of tile slot 0, word 0
+    const int64_t o_lo = ob + (int64_t)t.x_lo * nw, o_hi = ob + (int64_t)t.x_hi * nw;
+    // staged word of output word q of the tile: q + (q / (32 nw)) * nw; the quotient by v_mul_hi (q < 2^15)
+    auto staged = [&](int q) { return lds[q + (int)__umulhi((uint32_t)q, A.magic) * nw]; };
+    for (int64_t g = (o_lo & ~(int64_t)3) + 4 * tid; g < o_hi; g += 4 * T) {
+        const int q = (int)(g - ob);  // may be negative by up to 3 at the window's first piece
+        if (g >= o_lo && g + 4 <= o_hi) {
+            uint4 v;
+            if ((nw & 3) == 0) {  // 4 | nw: a piece never straddles a position word, and is 16-byte aligned in LDS
+                v = *reinterpret_cast<const uint4 *>(lds + q + (int)__umulhi((uint32_t)q, A.magic) * nw);
+            } else {
+                v.x = staged(q);
+                v.y = staged(q + 1);
+                v.z = staged(q + 2);
+                v.w = staged(q + 3);
+            }
+            *reinterpret_cast<uint4 *>(out + g) = v;
+        } else {
+            for (int i = 0; i < 4; ++i)
+                if (g + i >= o_lo && g + i < o_hi) out[g + i] = staged(q + i);
+        }
+    }
+}
+
 __global__ void fill_membership_kernel(uint32_t *out, int64_t n, int nw, int ncols) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -311,6 +414,34 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
     A.word_base = 0;
     A.out_words = nw;
+    // 4 = unclipped bit planes + staged result: packed rows with every annot inside the matrix,
+    // k - 1 <= 31, at most 16 result words; otherwise whatever else was chosen
+    if ((algo == 4 || (g_memb_algo == 0 && algo == 3)) && fmt && !checked && k - 1 <= 31 && nw <= 16 &&
+        !use_persistent(fmt)) {
+        const int bw = 1 << ix->bshift, T = waves == 1 ? 64 : 256;
+        int tw = w ? w : 1024;
+        if (tw > 32 * (T / nw)) tw = 32 * (T / nw);  // one 32 x 32 block per lane
+        tw = tw / bw * bw;
+        if (tw >= bw && tw >= 32) {
+            const int pw = tw / 32;
+            int skew = 0;
+            for (int pow2 = 4; pow2 <= 64; pow2 <<= 1)
+                if (nw == pow2) skew = (64 / nw + 32) & 63;  // G * (32 * PITCH + skew) = G * 64 / nw (mod 64), PITCH odd
+            A.w = tw;
+            A.ls = (pw + 3) | 1;
+            A.hl = skew;
+            A.magic = (uint32_t)((((uint64_t)1 << 32) + 32 * nw - 1) / (32 * nw));
+            const size_t planes = ((size_t)32 * nw * A.ls + (size_t)nw * skew + 8) * 4;
+            const size_t staged = ((size_t)pw * (32 * nw + nw) + 4) * 4;
+            SweepKernel kern = fmt == 4 ? (T == 64 ? (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false>, 6, 64>
+                                                   : (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false>, 6, 256>)
+                                        : (T == 64 ? (SweepKernel)sweep_membership_planes_kernel<PackedRows<true, false>, 6, 64>
+                                                   : (SweepKernel)sweep_membership_planes_kernel<PackedRows<true, false>, 6, 256>);
+            if ((rc = launch_tiles(kern, A, tw, T, planes > staged ? planes : staged, st, 1))) return rc;
+            return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
+        }
+    }
+    if (algo == 4) algo = 3;
     if (algo == 3) {
         if (!waves) waves = 4;
         // 4 * nw bytes of LDS per position: beyond 2048 genomes even a 256-position tile is too big,

@@ -124,7 +124,7 @@ def _random_index(rng, n_rows, length, n_docs, maxlen):
 
 
 TUNINGS = [(0, 0, 0)] + [(w, wv, al) for w in (256, 512, 1024, 2048, 4096) for wv, al in ((1, 1), (4, 2))] + \
-    [(512, 1, 2), (1024, 4, 1)] + [(w, wv, 3) for w in (256, 512, 1024, 2048, 4096) for wv in (1, 4)]
+    [(512, 1, 2), (1024, 4, 1)] + [(w, wv, al) for al in (3, 4) for w in (256, 512, 1024, 2048, 4096) for wv in (1, 4)]
 
 
 @pytest.mark.parametrize("tile_w,waves,algo", TUNINGS)
@@ -168,7 +168,8 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle):
         assert inf["packed_format"] == (4 if n_docs <= 256 else 6) and inf["has_wide"] == int(keep_wide)
         try:
             for tile_w, waves, algo in [(0, 0, 0), (256, 1, 1), (512, 4, 2), (1024, 1, 2), (2048, 4, 1), (4096, 4, 0),
-                                        (256, 4, 3), (2048, 4, 3), (1024, 1, 3)]:
+                                        (256, 4, 3), (2048, 4, 3), (1024, 1, 3), (0, 0, 4), (256, 1, 4), (512, 4, 4),
+                                        (1024, 4, 4), (2048, 4, 4), (4096, 1, 4)]:
                 _lib.check(_lib.lib().memo_set_tuning(tile_w, waves, algo))
                 for k in (2, 3, 17, 31, 32, 101, 255, 256):
                     qs = int(rng.integers(0, length // 2))
