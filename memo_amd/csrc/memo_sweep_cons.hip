@@ -120,7 +120,7 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
 // WITHOUT clipping.
 //
 // Every level array carries a halo -- HL cells left of the tile, HR right of it -- wide enough for
-// any interval a row of the slice can have (start - a in [0, W + k + 30], length n = k - 1 -
+// any interval a row of the slice can have (start - a in [0, W + k - 1 + bucket - 2], length n = k - 1 -
 // overlap in [1, k - 1]); what falls into the right halo is never read back, the left halo is
 // folded like the rest (a block that starts left of the tile can cover tile positions).  With
 // nothing to clip, the level and both cells follow from n and start - a alone: 10 VALU
@@ -398,7 +398,8 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     if (halo) {
         // A/B (profiles/r01_unclipped_scatter.txt): arrays of 1024 cells x 4 waves win at every window
         // length from 10^6 positions up and at k = 21 .. 101
-        const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + 31 + 3) & ~3, bw = 1 << ix->bshift;
+        const int bw = 1 << ix->bshift;  // a slice ends at a bucket boundary: start - a <= tile + k - 1 + bw - 2
+        const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + bw - 1 + 3) & ~3;
         if (!g_tile_w) w = 1024;
         int tw = 0;
         for (;; w <<= 1) {

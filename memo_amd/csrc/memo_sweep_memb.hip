@@ -204,9 +204,9 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 // membership, bit planes per genome, unclipped, with the result staged through LDS
 // (packed rows whose annot is known to be inside the matrix, k - 1 <= 31, at most 16 result words).
 //
-//   * a genome's plane row covers one word left of the tile and three right of it, so that the run
-//     of any row of the slice (start - a in [0, W + k + 30], n = k - 1 - overlap <= 31 bits ending at
-//     start) fits without clipping: the run is (2^n - 1) << first bit as a 64-bit value, ds_or of
+//   * a genome's plane row covers one word left of the tile and three right of it (32-position
+//     buckets), so that the run of any row of the slice (start - a <= W + k - 1 + bucket - 2,
+//     n = k - 1 - overlap <= 31 bits ending at start) fits without clipping: the run is (2^n - 1) << first bit as a 64-bit value, ds_or of
 //     its two halves into neighbouring words -- 14 VALU instructions per row instead of ~30 and no
 //     divergent branches;
 //   * lane (G, p) then reads the 32 plane rows of genome group G at position word p, transposes
@@ -428,7 +428,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             for (int pow2 = 4; pow2 <= 64; pow2 <<= 1)
                 if (nw == pow2) skew = (64 / nw + 32) & 63;  // G * (32 * PITCH + skew) = G * 64 / nw (mod 64), PITCH odd
             A.w = tw;
-            A.ls = (pw + 3) | 1;
+            A.ls = (pw + ((k - 1 + bw + 29) >> 5) + 1) | 1;  // last bit of a run: 32 + tile + k - 1 + bw - 3, and one word for the second ds_or
             A.hl = skew;
             A.magic = (uint32_t)((((uint64_t)1 << 32) + 32 * nw - 1) / (32 * nw));
             const size_t planes = ((size_t)32 * nw * A.ls + (size_t)nw * skew + 8) * 4;

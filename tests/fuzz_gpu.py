@@ -49,7 +49,7 @@ while time.time() < t_end:
         e[neg] = s[neg] - rng.integers(1, 2000, int(neg.sum()))
     hi_annot = n_docs if rng.random() < 0.9 else n_docs + 3          # sometimes outside the matrix
     o = rng.integers(0 if rng.random() < 0.1 else 1, max(hi_annot, 2), m).astype(np.int64)
-    with memo_amd.DeviceIndex.from_host(s, e, o) as ix:
+    with memo_amd.DeviceIndex.from_host(s, e, o, bucket_shift=int(rng.choice([0, 0, 0, 1, 3, 6, 8]))) as ix:
         packable = not (m and s.min() < 0)
         if packable and rng.random() < 0.7:
             ix.pack(keep_wide=True)

@@ -199,6 +199,40 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle):
             ix.conservation(0, length, 31, 3)
 
 
+@pytest.mark.parametrize("bucket_shift", [1, 3, 6, 8])
+def test_bucket_widths(bucket_shift, memo, oracle):
+    """bucket tables of 2 .. 256 positions: a tile's row slice ends at a bucket boundary, which is what
+    sizes the halo of the unclipped kernels; tile widths are whole buckets"""
+    from memo_amd import _lib
+    rng = np.random.default_rng(40 + bucket_shift)
+    n_docs, length = 90, 80_000
+    s, e, o = _random_index(rng, 400_000, length, n_docs, 70)
+    with memo.DeviceIndex.from_host(s, e, o, bucket_shift=bucket_shift) as ix:
+        assert ix.info()["bucket_shift"] == bucket_shift
+        for packed in (False, True):
+            if packed:
+                ix.pack(keep_wide=True)
+            try:
+                for tile_w, waves, algo in ((0, 0, 0), (256, 1, 3), (512, 4, 4), (2048, 4, 4), (1024, 4, 2)):
+                    _lib.check(_lib.lib().memo_set_tuning(tile_w, waves, algo))
+                    for k in (2, 17, 31, 32, 33, 101, 256):
+                        qs = int(rng.integers(0, length // 2))
+                        qe = int(rng.integers(qs + 1, length + 100))
+                        rows = oracle.filter_rows(s, e, o, qs, qe, k)
+                        want = oracle.conservation(*rows, qs, qe, k, n_docs, literal=False)
+                        for scatter in (1, 2):
+                            _lib.check(_lib.lib().memo_set_scatter(scatter))
+                            assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (packed, k, qs, qe, tile_w, scatter)
+                        if k in (17, 31, 32, 101):
+                            qe = min(qe, qs + 7000)
+                            rows = oracle.filter_rows(s, e, o, qs, qe, k)
+                            wantb = oracle.membership(*rows, qs, qe, k, n_docs, literal=False)
+                            assert np.array_equal(ix.membership(qs, qe, k, n_docs), wantb), (packed, k, qs, qe, tile_w)
+            finally:
+                _lib.check(_lib.lib().memo_set_tuning(0, 0, 0))
+                _lib.check(_lib.lib().memo_set_scatter(0))
+
+
 def test_ragged_density_and_edges(memo, oracle):
     """clumped starts, empty stretches, window beyond the last row, window before the first."""
     rng = np.random.default_rng(99)
