@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 import memo_amd  # noqa: E402
 from memo_amd import synth  # noqa: E402
 
+XGMI_LINK_BYTES_PER_S = 75e9   # one direction of one xGMI link (MI355X_MICROARCH.md: ~153 GB/s per link, both ways)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 WORKLOADS = {
@@ -60,7 +61,11 @@ def parse():
                     help="row format the timed sweep reads: packed (memo_index_pack, 4-6 B/row) or the "
                          "int64 columns as uploaded (24 B/row); at N=1 the other one is timed too")
     ap.add_argument("--plain-gather", action="store_true",
-                    help="N > 1: send uint8 slices as they are (default: nibble transport coding when it fits)")
+                    help="N > 1: send uint8 slices as they are (default: the densest transport coding that fits)")
+    ap.add_argument("--code-own-slice", action="store_true",
+                    help="N > 1: rank 0 packs and unpacks its own slice too (exercises the coded path on one GPU)")
+    ap.add_argument("--nibble-gather", action="store_true",
+                    help="N > 1: skip the dense transport coding (nibble coding when it fits, else plain)")
     ap.add_argument("--calibrate", action="store_true",
                     help="also run the read-once calibration kernel (for the FETCH_SIZE PMC pass)")
     ap.add_argument("--force-dist", action="store_true",
@@ -179,23 +184,88 @@ def main():
         else:
             ix.conservation_dev(qs, qe, k, num_docs, out, stream.cuda_stream)
 
-    # What travels to rank 0.  uint8 conservation slices go as one nibble per position plus an
-    # exception list for values >= 15 (lossless; memo_transport_*): a slice's own xGMI link is what
-    # bounds N > 1, so halving the bytes is worth a 25 us pack and a root-side unpack.  Used only if
-    # every rank's exceptions fit (same query every step, so one check before the timed region).
-    nibble = False
+    # What travels to rank 0.  A slice's own xGMI link is what bounds N > 1, so uint8
+    # conservation slices go in a lossless transport coding: "dense" (2 bits per position + a nibble per
+    # value outside 1..3, memo_transport_dense_*), "nibble" (one nibble per position, memo_transport_*), or
+    # plain bytes.  Every rank sizes the codings on its own first result (the same query runs every
+    # step); a coding is usable when every rank's slice fits it.  Fewer bytes is not all: rank 0 decodes
+    # world - 1 slices per step, so among the usable codings it takes the one whose modelled step
+    #     max(sweep + (world - 1) * decode of one slice, wire bytes / XGMI_LINK_BYTES_PER_S)
+    # is shortest, with sweep and decode timed here on rank 0.
+    coding, b_cap = "plain", 0
     cap = max(L // 256, 1024)
+    choice = None
     if multi and narrow and not args.plain_gather:
+        found, have, taken, room = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+
+        def timed(fn, reps=3):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                fn()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e-3
+
+        t_sweep = timed(lambda: launch(outs[0]))
+        scratch = torch.empty(L, dtype=torch.uint8, device=dev)
+        usable = {"plain": (L, 0.0)}                                       # coding -> (wire bytes, decode seconds)
+        # dense
+        trial_b = ((L // 2 + 4 * (L // 32768 + 1)) + 3) & ~3              # every position an escape
+        probe = torch.empty(lib.memo_transport_dense_bytes(L, trial_b, cap), dtype=torch.uint8, device=dev)
+        _lib.check(lib.memo_transport_dense_pack_dev(outs[0].data_ptr(), L, trial_b, cap, probe.data_ptr(), local,
+                                                     stream.cuda_stream))
+        _lib.check(lib.memo_transport_dense_stats(probe.data_ptr(), local, stream.cuda_stream, C.byref(found),
+                                                  C.byref(have), C.byref(taken), C.byref(room)))
+        need = torch.tensor([taken.value, found.value], dtype=torch.int64, device=dev)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        b_cap = (int(need[0].item()) + 4096 + 3) & ~3                      # exact + slack
+        dense_cap = int(need[1].item()) + 1024
+        if not args.nibble_gather:
+            t = timed(lambda: _lib.check(lib.memo_transport_dense_unpack_dev(
+                probe.data_ptr(), L, trial_b, cap, scratch.data_ptr(), local, stream.cuda_stream)))
+            usable["dense"] = (lib.memo_transport_dense_bytes(L, b_cap, dense_cap), t)
+        # nibble
         probe = torch.empty(lib.memo_transport_bytes(L, cap), dtype=torch.uint8, device=dev)
-        launch(outs[0])
         _lib.check(lib.memo_transport_pack_dev(outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream))
-        found, have = C.c_uint32(), C.c_uint32()
         _lib.check(lib.memo_transport_exceptions(probe.data_ptr(), local, stream.cuda_stream, C.byref(found), C.byref(have)))
         fits = torch.tensor([1 if found.value <= have.value else 0], device=dev)
         dist.all_reduce(fits, op=dist.ReduceOp.MIN)
-        nibble = bool(fits.item())
-        del probe
-    if nibble:
+        if fits.item():
+            t = timed(lambda: _lib.check(lib.memo_transport_unpack_dev(
+                probe.data_ptr(), L, scratch.data_ptr(), local, stream.cuda_stream)))
+            usable["nibble"] = (lib.memo_transport_bytes(L, cap), t)
+        del probe, scratch
+        model = {c: max(t_sweep + (world - 1) * t, nbytes / XGMI_LINK_BYTES_PER_S) for c, (nbytes, t) in usable.items()}
+        names = sorted(usable)
+        pick = torch.tensor([names.index(min(model, key=model.get))], device=dev)
+        dist.broadcast(pick, src=0)                                        # rank 0's timings decide for everybody
+        coding = names[int(pick.item())]
+        if coding == "dense":
+            cap = dense_cap
+        choice = {"picked": coding, "sweep_ms": t_sweep * 1e3, "link_bytes_per_s_assumed": XGMI_LINK_BYTES_PER_S,
+                  "candidates": {c: {"wire_bytes": int(usable[c][0]), "decode_ms_per_slice": usable[c][1] * 1e3,
+                                     "modelled_step_ms": model[c] * 1e3} for c in names}}
+    nibble = coding != "plain"              # (name kept: "the slices travel coded")
+
+    def pack(src, wire):
+        if coding == "dense":
+            _lib.check(lib.memo_transport_dense_pack_dev(src.data_ptr(), L, b_cap, cap, wire.data_ptr(), local,
+                                                         stream.cuda_stream))
+        else:
+            _lib.check(lib.memo_transport_pack_dev(src.data_ptr(), L, cap, wire.data_ptr(), local, stream.cuda_stream))
+
+    def unpack(wire, dst):
+        if coding == "dense":
+            _lib.check(lib.memo_transport_dense_unpack_dev(wire.data_ptr(), L, b_cap, cap, dst.data_ptr(), local,
+                                                           stream.cuda_stream))
+        else:
+            _lib.check(lib.memo_transport_unpack_dev(wire.data_ptr(), L, dst.data_ptr(), local, stream.cuda_stream))
+
+    if coding == "dense":
+        wires = [torch.empty(lib.memo_transport_dense_bytes(L, b_cap, cap), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    elif coding == "nibble":
         wires = [torch.empty(lib.memo_transport_bytes(L, cap), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     else:
         wires = [o.view(torch.uint8).reshape(-1) for o in outs]  # RCCL has no 16-bit integer type
@@ -205,6 +275,12 @@ def main():
     decoded = [[torch.empty(L, dtype=torch.uint8, device=dev) for _ in range(world)] if (nibble and rank == 0) else None
                for _ in range(nbuf)]
     pending = [None] * nbuf
+    # rank 0's own slice never travels: its sweep writes straight into the gathered result (no pack, no
+    # unpack; the wire it contributes to the gather is ignored).  --code-own-slice codes it like a
+    # peer's, so that one GPU can exercise the whole path.
+    skip_own = nibble and rank == 0 and not args.code_own_slice
+    if skip_own:
+        outs = [decoded[b][0] for b in range(nbuf)]
 
     def finish(b):                          # gather b done -> (root) slices back in result form
         if pending[b] is None:
@@ -212,9 +288,8 @@ def main():
         pending[b].wait()
         pending[b] = None
         if nibble and rank == 0:
-            for g in range(world):
-                _lib.check(lib.memo_transport_unpack_dev(roots[b][g].data_ptr(), L, decoded[b][g].data_ptr(), local,
-                                                         stream.cuda_stream))
+            for g in range(1 if skip_own else 0, world):
+                unpack(roots[b][g], decoded[b][g])
 
     def step(i, ev=None):
         b = i % nbuf
@@ -225,9 +300,8 @@ def main():
         if ev:
             ev[1].record(stream)
         if multi:                           # result slices -> rank 0 over xGMI (RCCL send/recv)
-            if nibble:
-                _lib.check(lib.memo_transport_pack_dev(outs[b].data_ptr(), L, cap, wires[b].data_ptr(), local,
-                                                       stream.cuda_stream))
+            if nibble and not skip_own:
+                pack(outs[b], wires[b])
             pending[b] = dist.gather(wires[b], roots[b], dst=0, async_op=True)
 
     def drain():
@@ -357,9 +431,22 @@ def main():
                 want = oracle.conservation(s_, e_, o_, a, a + S, k, num_docs, literal=False)
                 ok = np.array_equal(got.view(np.uint8 if narrow else np.uint16).astype(np.uint16), want)
             res["gather_parity_sample"] = {"rank": g, "positions": S, "equal_to_oracle": bool(ok)}
-            res["config"]["gather_payload"] = (f"nibble per position + {cap} exception slots "
-                                               f"({wires[0].numel()} B per slice)" if nibble else
-                                               f"plain result bytes ({wires[0].numel()} B per slice)")
+            if coding != "plain":       # every gathered slice of the last step decodes to the sender's own result?
+                whole = True            # (rank 0's own slice against its buffer; the peers' wires report their fill)
+                own = decoded[last][0]
+                whole &= bool(torch.equal(own, outs[last].reshape(-1)))
+                for g2 in range(1 if skip_own else 0, world):
+                    head = roots[last][g2][:16].cpu().numpy().view(np.uint32)
+                    whole &= bool(head[0] <= head[1]) and (coding != "dense" or bool(head[2] <= head[3]))
+                res["gather_parity_sample"]["every_slice_complete"] = whole
+            res["config"]["gather_payload"] = (
+                f"dense coding: 2 bits per position + {b_cap} B of escape nibbles + {cap} exception slots "
+                f"({wires[0].numel()} B per slice, {8 * wires[0].numel() / L:.2f} bits per position)"
+                if coding == "dense" else
+                f"nibble per position + {cap} exception slots ({wires[0].numel()} B per slice)" if coding == "nibble" else
+                f"plain result bytes ({wires[0].numel()} B per slice)")
+            if choice:
+                res["config"]["gather_coding_choice"] = choice
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     ix.close()
     if multi:

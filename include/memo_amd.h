@@ -188,6 +188,20 @@ int memo_transport_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t cap, void 
 int memo_transport_unpack_dev(const void *d_wire, int64_t n, uint8_t *d_vec, int32_t device, void *stream);
 int memo_transport_exceptions(const void *d_wire, int32_t device, void *stream, uint32_t *found, uint32_t *cap);
 
+/* Second, denser coding for the same purpose (memo_transport.hip): 2 bits per position (values 1..3;
+ * 0 = escape) + one nibble per escape, allocated exactly per 32768 positions from a B region of
+ * `b_capacity` bytes (a multiple of 4), + the same exception list (nibble 15: values > 17).  Buffers
+ * 16-byte aligned.  _stats (synchronising `stream`) returns the exceptions found and their capacity,
+ * the B bytes taken and the B capacity: the slice is complete iff neither exceeds.  Pack once with
+ * generous capacities to learn what a workload needs (at most n / 2 + 4 * ceil(n / 32768) bytes of B). */
+size_t memo_transport_dense_bytes(int64_t n, uint32_t b_capacity, uint32_t cap);
+int memo_transport_dense_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t b_capacity, uint32_t cap,
+                                  void *d_wire, int32_t device, void *stream);
+int memo_transport_dense_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint32_t cap,
+                                    uint8_t *d_vec, int32_t device, void *stream);
+int memo_transport_dense_stats(const void *d_wire, int32_t device, void *stream, uint32_t *found, uint32_t *cap,
+                               uint32_t *b_taken, uint32_t *b_capacity);
+
 /* ---- synthetic pangenome index (BASELINE.json configs 2-5) -------------------
  * Fills rows [0, rows) of the index with global rows row_begin + i of the generator
  *   start = 1 + floor(i * den / num), end = start + mix(seed, 2i) % 60,

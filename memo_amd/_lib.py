@@ -75,6 +75,11 @@ SYMBOLS = {
     "memo_transport_pack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
     "memo_transport_unpack_dev": (C.c_int, [_P, _I64, _P, _I32, _P]),
     "memo_transport_exceptions": (C.c_int, [_P, _I32, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "memo_transport_dense_bytes": (_SZ, [_I64, C.c_uint32, C.c_uint32]),
+    "memo_transport_dense_pack_dev": (C.c_int, [_P, _I64, C.c_uint32, C.c_uint32, _P, _I32, _P]),
+    "memo_transport_dense_unpack_dev": (C.c_int, [_P, _I64, C.c_uint32, C.c_uint32, _P, _I32, _P]),
+    "memo_transport_dense_stats": (C.c_int, [_P, _I32, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                             C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "memo_synth_fill": (C.c_int, [_P, _U64, _U64, _U64, _I32, _U64]),
     "memo_debug_set_stamp_buffer": (C.c_int, [_P]),
     "memo_debug_stream_rows": (C.c_int, [_P, _P]),

@@ -1,0 +1,279 @@
+// memo_transport.hip -- second transport coding of uint8 conservation results for the multi-GPU
+// gather.  The sweep produces a slice faster than a peer's xGMI link to the
+// root carries it as bytes, so what a slice costs on the wire decides N > 1.
+//
+// Conservation values are minima over the rows that cover a position: small values dominate
+// (config 3: 32 %, 22 %, 15 % for 1, 2, 3; entropy 2.8 bits).  "Dense" coding:
+//   stream A   2 bits per position: 1, 2, 3 = the value; 0 = escape              1024 B per 4096 positions
+//   stream B   one nibble per escape, in position order: 0 = value 0, 1..14 = value 4..17,
+//              15 = see the exception list.  A workgroup codes a block of 32768 positions, collects
+//              its nibbles in LDS and takes exactly the bytes it needs from the B region with one
+//              atomic add; a table holds every block's offset and nibble count (8 B per block), so
+//              the order of the blocks inside B does not matter.
+//   exceptions position << 8 | value for nibble 15 (8 B each), collected per workgroup in LDS
+// One pass in both directions, no global scan.  Neighbouring positions share their covering rows,
+// so the escapes of a chunk vary far more than a binomial would (config 3: mean 1254, up to 1664
+// per 4096 positions): fixed-size slots sized for the worst chunk would give the saving away,
+// which is why B is allocated exactly.  The caller sizes the B region and the exception list for
+// its data from one trial pack (memo_transport_dense_stats) and checks that both were enough.
+//
+// Not on the reference's path (the reference has one process and no wire): it carries the input
+// of print_res (memo_query.py:65-71) from the ranks that computed it to the one that prints it.
+#include "memo_common.h"
+
+using namespace memo;
+
+namespace {
+
+constexpr int kChunk = 4096;     // positions per round of a workgroup
+constexpr int kPerThread = 16;   // positions per thread and round (one 16-byte load / store)
+constexpr int kBlock = 8 * kChunk;  // positions per workgroup: one allocation in the B region
+constexpr int kHeld = kChunk + 1024;  // exceptions a workgroup holds between flushes
+
+// exclusive prefix of v over the 256 threads of the workgroup; total = sum over all of them
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wave_tot, int &total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wave_tot[w] = inc;
+    __syncthreads();
+    int off = 0;
+    for (int i = 0; i < w; ++i) off += wave_tot[i];
+    total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    return off + inc - v;
+}
+
+// head: [0] exceptions found, [1] their capacity, [2] B bytes taken, [3] B capacity
+__global__ __launch_bounds__(256) void dense_pack_kernel(const uint8_t *in, int64_t n, uint32_t *A, uint8_t *B,
+                                                         uint2 *table, unsigned long long *exc,
+                                                         unsigned int *head, unsigned int cap, unsigned int b_cap) {
+    __shared__ uint32_t nib[kBlock / 8];          // every position an escape: 32768 nibbles = 16 KiB
+    __shared__ unsigned long long held[kHeld];    // exceptions, appended with one global atomic per flush
+    __shared__ int wave_tot[4];
+    __shared__ unsigned int n_held, base, b_off;
+    const int tid = threadIdx.x;
+    const int64_t block = blockIdx.x;
+    if (tid == 0) n_held = 0;
+    if (block == 0 && tid == 0) {
+        head[1] = cap;
+        head[3] = b_cap;
+    }
+    for (int i = tid; i < kBlock / 8; i += 256) nib[i] = 0;
+    __syncthreads();
+    auto flush = [&]() {  // every thread of the workgroup calls it
+        const unsigned int mine = n_held;
+        if (tid == 0 && mine) base = atomicAdd(head, mine);
+        __syncthreads();
+        for (unsigned int i = tid; i < mine; i += 256)
+            if (base + i < cap) exc[base + i] = held[i];
+        __syncthreads();
+        if (tid == 0) n_held = 0;
+        __syncthreads();
+    };
+    int taken = 0;  // nibbles of this block so far
+    for (int c = 0; c < kBlock / kChunk; ++c) {
+        const int64_t chunk = block * (kBlock / kChunk) + c;
+        const int64_t p0 = chunk * kChunk + (int64_t)tid * kPerThread;
+        if (chunk * kChunk >= n) break;  // (uniform)
+        if (n_held > kHeld - kChunk) flush();  // (uniform: n_held is read behind a barrier)
+        uint32_t w[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};  // past the end: value 1, no escape
+        if (p0 + kPerThread <= n) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(in + p0);
+            w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+        } else {
+            for (int i = 0; i < kPerThread && p0 + i < n; ++i)
+                w[i >> 2] = (w[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((uint32_t)in[p0 + i] << (8 * (i & 3)));
+        }
+        uint32_t a = 0, esc = 0;
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            const uint32_t v = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            const bool direct = v - 1u < 3u;
+            a |= (direct ? v : 0u) << (2 * i);
+            esc |= (direct ? 0u : 1u) << i;
+        }
+        A[chunk * 256 + tid] = a;
+        int total;
+        int r = taken + block_exclusive_scan(__popc(esc), wave_tot, total);
+        while (esc) {
+            const int i = __ffs(esc) - 1;
+            esc &= esc - 1;
+            const uint32_t v = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            const uint32_t e = v == 0 ? 0u : (v <= 17u ? v - 3u : 15u);
+            atomicOr(&nib[r >> 3], e << (4 * (r & 7)));
+            if (e == 15u) held[atomicAdd(&n_held, 1u)] = ((unsigned long long)(p0 + i) << 8) | v;
+            ++r;
+        }
+        taken += total;
+        __syncthreads();  // wave_tot is reused; n_held is read by the next round
+    }
+    // take (taken + 1) / 2 bytes, rounded to 4, from the B region
+    const unsigned int bytes = (unsigned int)(((taken + 1) / 2 + 3) & ~3);
+    if (tid == 0) {
+        b_off = bytes ? atomicAdd(head + 2, bytes) : 0u;
+        table[block] = make_uint2(b_off, (unsigned int)taken);
+    }
+    __syncthreads();
+    if (bytes && (uint64_t)b_off + bytes <= b_cap) {  // else: head[2] > head[3] tells the caller
+        uint32_t *dst = reinterpret_cast<uint32_t *>(B + b_off);
+        for (unsigned int i = tid; i < bytes / 4; i += 256) dst[i] = nib[i];
+    }
+    flush();
+}
+
+__global__ __launch_bounds__(256) void dense_unpack_kernel(const uint32_t *A, const uint8_t *B, const uint2 *table,
+                                                           unsigned int b_cap, int64_t n, uint8_t *out) {
+    __shared__ uint32_t nib[kBlock / 8];
+    __shared__ int wave_tot[4];
+    const int tid = threadIdx.x;
+    const int64_t block = blockIdx.x;
+    const uint2 where = table[block];
+    const unsigned int bytes = (unsigned int)((((int)where.y + 1) / 2 + 3) & ~3);
+    const bool have = (uint64_t)where.x + bytes <= b_cap && where.y <= (unsigned int)kBlock;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(B + where.x);
+    for (unsigned int i = tid; i < bytes / 4 && have; i += 256) nib[i] = src[i];
+    __syncthreads();
+    int taken = 0;
+    for (int c = 0; c < kBlock / kChunk; ++c) {
+        const int64_t chunk = block * (kBlock / kChunk) + c;
+        if (chunk * kChunk >= n) break;
+        const uint32_t a = A[chunk * 256 + tid];
+        uint32_t esc = 0;
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) esc |= (((a >> (2 * i)) & 3u) == 0u ? 1u : 0u) << i;
+        int total;
+        int r = taken + block_exclusive_scan(__popc(esc), wave_tot, total);
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            uint32_t v = (a >> (2 * i)) & 3u;
+            if (v == 0u) {  // nibble 15 is a placeholder: the exception pass writes the value
+                const uint32_t e = have && r < kBlock ? (nib[r >> 3] >> (4 * (r & 7))) & 15u : 0u;
+                v = e == 0u ? 0u : e + 3u;
+                ++r;
+            }
+            w[i >> 2] |= v << (8 * (i & 3));
+        }
+        taken += total;
+        const int64_t p0 = chunk * kChunk + (int64_t)tid * kPerThread;
+        if (p0 + kPerThread <= n) {
+            *reinterpret_cast<uint4 *>(out + p0) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int i = 0; i < kPerThread && p0 + i < n; ++i) out[p0 + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+        }
+        __syncthreads();  // wave_tot is reused
+    }
+}
+
+__global__ void dense_exceptions_kernel(const unsigned long long *exc, const unsigned int *head, int64_t n,
+                                        uint8_t *out) {
+    const unsigned int count = head[0] < head[1] ? head[0] : head[1];  // found, capacity
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const unsigned long long e = exc[i];
+        const int64_t p = (int64_t)(e >> 8);
+        if (p < n) out[p] = (uint8_t)(e & 0xFF);
+    }
+}
+
+struct Layout {
+    int64_t chunks, blocks;
+    size_t t_off, a_off, b_off, x_off, bytes;
+};
+
+Layout layout(int64_t n, uint32_t b_cap, uint32_t cap) {
+    Layout l;
+    l.chunks = (n + kChunk - 1) / kChunk;
+    l.blocks = (n + kBlock - 1) / kBlock;
+    l.t_off = 16;
+    l.a_off = l.t_off + (size_t)l.blocks * 8;
+    l.b_off = l.a_off + (size_t)l.chunks * 1024;
+    l.x_off = (l.b_off + (size_t)b_cap + 7) & ~(size_t)7;
+    l.bytes = (l.x_off + (size_t)cap * 8 + 15) & ~(size_t)15;
+    return l;
+}
+
+int check_args(const void *d_vec, const void *d_wire, int64_t n, uint32_t b_cap) {
+    if (n < 0 || (n > 0 && (!d_vec || !d_wire))) return fail(MEMO_EINVAL, "bad transport arguments");
+    if (n >= ((int64_t)1 << 40)) return fail(MEMO_EINVAL, "slice longer than 2^40");
+    if (b_cap % 4) return fail(MEMO_EINVAL, "the B region's capacity must be a multiple of 4");
+    if (((uintptr_t)d_vec & 15) || ((uintptr_t)d_wire & 15))
+        return fail(MEMO_EINVAL, "transport buffers must be 16-byte aligned");
+    return MEMO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// wire layout: [exceptions found u32, their capacity u32, B bytes taken u32, B capacity u32]
+//              [table: (offset in B, nibbles) per 32768 positions][A: 1024 B per 4096 positions]
+//              [B: b_capacity bytes][exceptions: cap * 8 B]
+size_t memo_transport_dense_bytes(int64_t n, uint32_t b_capacity, uint32_t cap) {
+    return n < 0 ? 0 : layout(n, b_capacity, cap).bytes;
+}
+
+int memo_transport_dense_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t b_capacity, uint32_t cap,
+                                  void *d_wire, int32_t device, void *stream) {
+    int rc = check_args(d_vec, d_wire, n, b_capacity);
+    if (rc) return rc;
+    DeviceGuard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *w = static_cast<char *>(d_wire);
+    if (!w) return MEMO_OK;
+    const Layout l = layout(n, b_capacity, cap);
+    HIP_TRY(hipMemsetAsync(w, 0, 16, st));
+    if (l.blocks) {
+        if (l.blocks >= ((int64_t)1 << 31)) return fail(MEMO_EINVAL, "slice too long for one launch");
+        hipLaunchKernelGGL(dense_pack_kernel, dim3((unsigned)l.blocks), dim3(256), 0, st, d_vec, n,
+                           reinterpret_cast<uint32_t *>(w + l.a_off), reinterpret_cast<uint8_t *>(w + l.b_off),
+                           reinterpret_cast<uint2 *>(w + l.t_off),
+                           reinterpret_cast<unsigned long long *>(w + l.x_off),
+                           reinterpret_cast<unsigned int *>(w), cap, b_capacity);
+        HIP_TRY(hipGetLastError());
+    }
+    return MEMO_OK;
+}
+
+int memo_transport_dense_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint32_t cap,
+                                    uint8_t *d_vec, int32_t device, void *stream) {
+    int rc = check_args(d_vec, d_wire, n, b_capacity);
+    if (rc) return rc;
+    DeviceGuard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const char *w = static_cast<const char *>(d_wire);
+    const Layout l = layout(n, b_capacity, cap);
+    if (l.blocks) {
+        hipLaunchKernelGGL(dense_unpack_kernel, dim3((unsigned)l.blocks), dim3(256), 0, st,
+                           reinterpret_cast<const uint32_t *>(w + l.a_off),
+                           reinterpret_cast<const uint8_t *>(w + l.b_off),
+                           reinterpret_cast<const uint2 *>(w + l.t_off), b_capacity, n, d_vec);
+        hipLaunchKernelGGL(dense_exceptions_kernel, dim3(256), dim3(256), 0, st,
+                           reinterpret_cast<const unsigned long long *>(w + l.x_off),
+                           reinterpret_cast<const unsigned int *>(w), n, d_vec);
+        HIP_TRY(hipGetLastError());
+    }
+    return MEMO_OK;
+}
+
+// what the sender found (host values; synchronises `stream`): exceptions against their capacity,
+// B bytes taken against the B region's capacity.  The slice is complete iff neither exceeds.
+int memo_transport_dense_stats(const void *d_wire, int32_t device, void *stream, uint32_t *found, uint32_t *cap,
+                               uint32_t *b_taken, uint32_t *b_capacity) {
+    if (!d_wire || !found || !cap || !b_taken || !b_capacity) return fail(MEMO_EINVAL, "NULL argument");
+    DeviceGuard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t head[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(head, d_wire, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *found = head[0];
+    *cap = head[1];
+    *b_taken = head[2];
+    *b_capacity = head[3];
+    return MEMO_OK;
+}
+
+}  // extern "C"

@@ -699,3 +699,61 @@ def test_transport_nibble_coding_round_trip(memo):
         if found.value <= cap:
             assert np.array_equal(dst[:n].cpu().numpy(), v), (n, hi, frac)
         assert wire.numel() == 16 + ((n + 7) // 8) * 4 + cap * 8
+
+
+@pytest.mark.gpu
+def test_transport_dense_coding_round_trip(memo):
+    """uint8 results -> 2 bits + escape nibbles (allocated exactly per 32768 positions) + exception list
+    -> uint8: geometric value mixes (what conservation looks like), all-escape and no-escape data,
+    ragged lengths around the 4096-position rounds and 32768-position blocks, capacities that do not
+    suffice (reported, never silent)"""
+    import ctypes as C
+    import torch
+    from memo_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(16)
+
+    def round_trip(v, b_cap, cap):
+        n = len(v)
+        src = torch.from_numpy(v).cuda() if n else torch.zeros(16, dtype=torch.uint8, device="cuda")
+        wire = torch.zeros(L.memo_transport_dense_bytes(n, b_cap, cap), dtype=torch.uint8, device="cuda")
+        dst = torch.full((max(n, 16),), 77, dtype=torch.uint8, device="cuda")
+        _lib.check(L.memo_transport_dense_pack_dev(src.data_ptr(), n, b_cap, cap, wire.data_ptr(), 0, None))
+        found, have, taken, room = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.check(L.memo_transport_dense_stats(wire.data_ptr(), 0, None, C.byref(found), C.byref(have),
+                                                C.byref(taken), C.byref(room)))
+        _lib.check(L.memo_transport_dense_unpack_dev(wire.data_ptr(), n, b_cap, cap, dst.data_ptr(), 0, None))
+        torch.cuda.synchronize()
+        return dst[:n].cpu().numpy(), found.value, have.value, taken.value, room.value, wire.numel()
+
+    for n in (0, 1, 15, 16, 17, 4095, 4096, 4097, 12345, 32767, 32768, 32769, 1_000_003, 3_000_000):
+        for mix in ("geometric", "uniform", "ones", "zeros", "big"):
+            if mix == "geometric":
+                v = np.minimum(rng.geometric(0.33, n), 200).astype(np.uint8)
+            elif mix == "uniform":
+                v = rng.integers(0, 256, n).astype(np.uint8)
+            elif mix == "ones":
+                v = rng.integers(1, 4, n).astype(np.uint8)
+            elif mix == "zeros":
+                v = np.zeros(n, np.uint8)
+            else:
+                v = rng.integers(18, 256, n).astype(np.uint8)
+            escapes = ~((v >= 1) & (v <= 3))
+            per_block = [int(escapes[i:i + 32768].sum()) for i in range(0, n, 32768)]
+            b_want = sum((((c + 1) // 2) + 3) & ~3 for c in per_block)
+            exc_want = int((v > 17).sum())
+            got, found, have, taken, room, size = round_trip(v, b_want, max(exc_want, 4))
+            assert (found, have, taken, room) == ((exc_want, max(exc_want, 4), b_want, b_want) if n else (0, 0, 0, 0)), (n, mix)
+            assert np.array_equal(got, v), (n, mix)
+            blocks, chunks = len(per_block), (n + 4095) // 4096
+            assert size == ((((16 + 8 * blocks + 1024 * chunks + b_want + 7) & ~7) + 8 * max(exc_want, 4) + 15) & ~15)
+            if mix == "geometric" and n >= 1_000_000:
+                assert size < 0.46 * n                             # 3.7 bits per position at this mix
+    # capacities that do not suffice are reported, not silently accepted
+    v = rng.integers(18, 256, 100_000).astype(np.uint8)
+    got, found, have, taken, room, size = round_trip(v, 50_016, 10)
+    assert found == 100_000 and have == 10 and taken <= room
+    got, found, have, taken, room, size = round_trip(v, 20_000, 100_000)
+    assert taken > room and found == 100_000
+    with pytest.raises(memo.MemoError):
+        round_trip(v, 6, 10)                                       # not a multiple of 4
