@@ -190,8 +190,9 @@ def main():
     # plain bytes.  Every rank sizes the codings on its own first result (the same query runs every
     # step); a coding is usable when every rank's slice fits it.  Fewer bytes is not all: rank 0 decodes
     # world - 1 slices per step, so among the usable codings it takes the one whose modelled step
-    #     max(sweep + (world - 1) * decode of one slice, wire bytes / XGMI_LINK_BYTES_PER_S)
-    # is shortest, with sweep and decode timed here on rank 0.
+    #     max(sweep + encode [a peer], sweep + (world - 1) * decode of one slice [rank 0],
+    #         wire bytes / XGMI_LINK_BYTES_PER_S [a peer's link])
+    # is shortest, with sweep, encode and decode timed here on rank 0.
     coding, b_cap = "plain", 0
     cap = max(L // 256, 1024)
     choice = None
@@ -210,7 +211,7 @@ def main():
 
         t_sweep = timed(lambda: launch(outs[0]))
         scratch = torch.empty(L, dtype=torch.uint8, device=dev)
-        usable = {"plain": (L, 0.0)}                                       # coding -> (wire bytes, decode seconds)
+        usable = {"plain": (L, 0.0, 0.0)}                                  # coding -> (wire bytes, decode s, encode s)
         # dense
         trial_b = ((L // 2 + 4 * (L // 32768 + 1)) + 3) & ~3              # every position an escape
         probe = torch.empty(lib.memo_transport_dense_bytes(L, trial_b, cap), dtype=torch.uint8, device=dev)
@@ -225,7 +226,9 @@ def main():
         if not args.nibble_gather:
             t = timed(lambda: _lib.check(lib.memo_transport_dense_unpack_dev(
                 probe.data_ptr(), L, trial_b, cap, scratch.data_ptr(), local, stream.cuda_stream)))
-            usable["dense"] = (lib.memo_transport_dense_bytes(L, b_cap, dense_cap), t)
+            tp = timed(lambda: _lib.check(lib.memo_transport_dense_pack_dev(
+                outs[0].data_ptr(), L, trial_b, cap, probe.data_ptr(), local, stream.cuda_stream)))
+            usable["dense"] = (lib.memo_transport_dense_bytes(L, b_cap, dense_cap), t, tp)
         # nibble
         probe = torch.empty(lib.memo_transport_bytes(L, cap), dtype=torch.uint8, device=dev)
         _lib.check(lib.memo_transport_pack_dev(outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream))
@@ -235,9 +238,12 @@ def main():
         if fits.item():
             t = timed(lambda: _lib.check(lib.memo_transport_unpack_dev(
                 probe.data_ptr(), L, scratch.data_ptr(), local, stream.cuda_stream)))
-            usable["nibble"] = (lib.memo_transport_bytes(L, cap), t)
+            tp = timed(lambda: _lib.check(lib.memo_transport_pack_dev(
+                outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream)))
+            usable["nibble"] = (lib.memo_transport_bytes(L, cap), t, tp)
         del probe, scratch
-        model = {c: max(t_sweep + (world - 1) * t, nbytes / XGMI_LINK_BYTES_PER_S) for c, (nbytes, t) in usable.items()}
+        model = {c: max(t_sweep + tp, t_sweep + (world - 1) * t, nbytes / XGMI_LINK_BYTES_PER_S)
+                 for c, (nbytes, t, tp) in usable.items()}
         names = sorted(usable)
         pick = torch.tensor([names.index(min(model, key=model.get))], device=dev)
         dist.broadcast(pick, src=0)                                        # rank 0's timings decide for everybody
@@ -245,7 +251,7 @@ def main():
         if coding == "dense":
             cap = dense_cap
         choice = {"picked": coding, "sweep_ms": t_sweep * 1e3, "link_bytes_per_s_assumed": XGMI_LINK_BYTES_PER_S,
-                  "candidates": {c: {"wire_bytes": int(usable[c][0]), "decode_ms_per_slice": usable[c][1] * 1e3,
+                  "candidates": {c: {"wire_bytes": int(usable[c][0]), "decode_ms_per_slice": usable[c][1] * 1e3, "encode_ms": usable[c][2] * 1e3,
                                      "modelled_step_ms": model[c] * 1e3} for c in names}}
     nibble = coding != "plain"              # (name kept: "the slices travel coded")
 

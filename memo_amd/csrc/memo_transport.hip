@@ -28,34 +28,37 @@ namespace {
 constexpr int kChunk = 4096;     // positions per round of a workgroup
 constexpr int kPerThread = 16;   // positions per thread and round (one 16-byte load / store)
 constexpr int kBlock = 8 * kChunk;  // positions per workgroup: one allocation in the B region
-constexpr int kHeld = kChunk + 1024;  // exceptions a workgroup holds between flushes
+constexpr int kHeld = 1024;  // exceptions a workgroup collects in LDS (more than that: one global atomic each)
 
-// exclusive prefix of v over the 256 threads of the workgroup; total = sum over all of them
-__device__ __forceinline__ int block_exclusive_scan(int v, int *wave_tot, int &total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int inc = v;
+constexpr int kRounds = kBlock / kChunk;
+
+// inclusive prefix of v over the 64 lanes of the wave
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
     }
-    if (lane == 63) wave_tot[w] = inc;
-    __syncthreads();
-    int off = 0;
-    for (int i = 0; i < w; ++i) off += wave_tot[i];
-    total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    return off + inc - v;
+    return v;
 }
 
+// Both kernels have the same shape: a workgroup of 256 threads owns a block of 32768 positions as
+// 8 rounds of 4096 (thread t: 16 consecutive positions per round, so loads and stores are whole
+// 16-byte pieces, 1 KiB per wave-instruction).  Phase 1 touches all 8 rounds at once -- 8 loads in
+// flight per lane -- and leaves every (round, wave)'s escape count in LDS; one barrier; phase 2
+// ranks each thread's escapes inside the block (position order = round, wave, lane) from those
+// 32 counts and its own wave prefix.
+//
 // head: [0] exceptions found, [1] their capacity, [2] B bytes taken, [3] B capacity
 __global__ __launch_bounds__(256) void dense_pack_kernel(const uint8_t *in, int64_t n, uint32_t *A, uint8_t *B,
                                                          uint2 *table, unsigned long long *exc,
                                                          unsigned int *head, unsigned int cap, unsigned int b_cap) {
-    __shared__ uint32_t nib[kBlock / 8];          // every position an escape: 32768 nibbles = 16 KiB
-    __shared__ unsigned long long held[kHeld];    // exceptions, appended with one global atomic per flush
-    __shared__ int wave_tot[4];
+    __shared__ uint32_t nib[kBlock / 8 + 2];      // every position an escape: 32768 nibbles = 16 KiB (+ spill words)
+    __shared__ unsigned long long held[kHeld];    // exceptions, appended with one global atomic at the end
+    __shared__ int wave_sum[kRounds][4];
     __shared__ unsigned int n_held, base, b_off;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wv = tid >> 6;
     const int64_t block = blockIdx.x;
     if (tid == 0) n_held = 0;
     if (block == 0 && tid == 0) {
@@ -63,94 +66,143 @@ __global__ __launch_bounds__(256) void dense_pack_kernel(const uint8_t *in, int6
         head[3] = b_cap;
     }
     for (int i = tid; i < kBlock / 8; i += 256) nib[i] = 0;
-    __syncthreads();
-    auto flush = [&]() {  // every thread of the workgroup calls it
-        const unsigned int mine = n_held;
-        if (tid == 0 && mine) base = atomicAdd(head, mine);
-        __syncthreads();
-        for (unsigned int i = tid; i < mine; i += 256)
-            if (base + i < cap) exc[base + i] = held[i];
-        __syncthreads();
-        if (tid == 0) n_held = 0;
-        __syncthreads();
-    };
-    int taken = 0;  // nibbles of this block so far
-    for (int c = 0; c < kBlock / kChunk; ++c) {
-        const int64_t chunk = block * (kBlock / kChunk) + c;
-        const int64_t p0 = chunk * kChunk + (int64_t)tid * kPerThread;
-        if (chunk * kChunk >= n) break;  // (uniform)
-        if (n_held > kHeld - kChunk) flush();  // (uniform: n_held is read behind a barrier)
-        uint32_t w[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};  // past the end: value 1, no escape
+
+    uint32_t w[kRounds][4];
+    int prefix[kRounds];
+    uint32_t esc[kRounds];
+#pragma unroll
+    for (int c = 0; c < kRounds; ++c) {
+        const int64_t p0 = (block * kRounds + c) * kChunk + (int64_t)tid * kPerThread;
+        w[c][0] = w[c][1] = w[c][2] = w[c][3] = 0x01010101u;  // past the end: value 1, no escape
         if (p0 + kPerThread <= n) {
             const uint4 q = *reinterpret_cast<const uint4 *>(in + p0);
-            w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+            w[c][0] = q.x, w[c][1] = q.y, w[c][2] = q.z, w[c][3] = q.w;
         } else {
             for (int i = 0; i < kPerThread && p0 + i < n; ++i)
-                w[i >> 2] = (w[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((uint32_t)in[p0 + i] << (8 * (i & 3)));
+                w[c][i >> 2] = (w[c][i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((uint32_t)in[p0 + i] << (8 * (i & 3)));
         }
-        uint32_t a = 0, esc = 0;
+    }
+#pragma unroll
+    for (int c = 0; c < kRounds; ++c) {
+        uint32_t a = 0, e = 0;
 #pragma unroll
         for (int i = 0; i < kPerThread; ++i) {
-            const uint32_t v = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            const uint32_t v = (w[c][i >> 2] >> (8 * (i & 3))) & 0xFFu;
             const bool direct = v - 1u < 3u;
             a |= (direct ? v : 0u) << (2 * i);
-            esc |= (direct ? 0u : 1u) << i;
+            e |= (direct ? 0u : 1u) << i;
         }
-        A[chunk * 256 + tid] = a;
-        int total;
-        int r = taken + block_exclusive_scan(__popc(esc), wave_tot, total);
-        while (esc) {
-            const int i = __ffs(esc) - 1;
-            esc &= esc - 1;
-            const uint32_t v = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            const uint32_t e = v == 0 ? 0u : (v <= 17u ? v - 3u : 15u);
-            atomicOr(&nib[r >> 3], e << (4 * (r & 7)));
-            if (e == 15u) held[atomicAdd(&n_held, 1u)] = ((unsigned long long)(p0 + i) << 8) | v;
-            ++r;
-        }
-        taken += total;
-        __syncthreads();  // wave_tot is reused; n_held is read by the next round
+        esc[c] = e;
+        const int64_t chunk = block * kRounds + c;
+        if (chunk * kChunk < n) A[chunk * 256 + tid] = a;
+        const int pc = __popc(e), inc = wave_inclusive_scan(pc);
+        prefix[c] = inc - pc;
+        if ((tid & 63) == 63) wave_sum[c][wv] = inc;
     }
-    // take (taken + 1) / 2 bytes, rounded to 4, from the B region
-    const unsigned int bytes = (unsigned int)(((taken + 1) / 2 + 3) & ~3);
+    __syncthreads();
+
+    int run = 0;  // nibbles of the rounds before this one
+#pragma unroll
+    for (int c = 0; c < kRounds; ++c) {
+        const int s0 = wave_sum[c][0], s1 = wave_sum[c][1], s2 = wave_sum[c][2], s3 = wave_sum[c][3];
+        int r = run + (wv > 0 ? s0 : 0) + (wv > 1 ? s1 : 0) + (wv > 2 ? s2 : 0) + prefix[c];
+        run += s0 + s1 + s2 + s3;
+        const int64_t p0 = (block * kRounds + c) * kChunk + (int64_t)tid * kPerThread;
+        // this thread's nibbles of the round as one string (at most 16 nibbles), built without
+        // branches, then or-ed into the block's nibble array at nibble r: three LDS atomics
+        // whatever the count (a loop over the escapes costs one atomic each and diverges)
+        uint64_t str = 0;
+        uint32_t big = 0;
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            const uint32_t v = (w[c][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            const uint32_t is_esc = (esc[c] >> i) & 1u;
+            const uint32_t e = v == 0 ? 0u : (v <= 17u ? v - 3u : 15u);
+            str |= (uint64_t)(is_esc ? e : 0u) << (4 * cnt);
+            big |= (v > 17u ? 1u : 0u) << i;
+            cnt += (int)is_esc;
+        }
+        if (cnt) {
+            const int sh = 4 * (r & 7);
+            const uint64_t low = str << sh;
+            const uint32_t top = sh ? (uint32_t)(str >> (64 - sh)) : 0u;
+            uint32_t *cell = &nib[r >> 3];
+            atomicOr(cell, (uint32_t)low);
+            if ((uint32_t)(low >> 32)) atomicOr(cell + 1, (uint32_t)(low >> 32));
+            if (top) atomicOr(cell + 2, top);
+        }
+        while (big) {  // values > 17: nibble 15 + an exception (one position in a thousand on config 3)
+            const int i = __ffs(big) - 1;
+            big &= big - 1;
+            const uint32_t v = (w[c][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            const unsigned long long entry = ((unsigned long long)(p0 + i) << 8) | v;
+            const unsigned int slot = atomicAdd(&n_held, 1u);
+            if (slot < (unsigned int)kHeld) {
+                held[slot] = entry;
+            } else {  // more than kHeld exceptions in one block: straight to the list, one atomic each
+                const unsigned int at = atomicAdd(head, 1u);
+                if (at < cap) exc[at] = entry;
+            }
+        }
+    }
+    // take (nibbles + 1) / 2 bytes, rounded to 4, from the B region
+    const unsigned int bytes = (unsigned int)(((run + 1) / 2 + 3) & ~3);
+    __syncthreads();
+    const unsigned int mine = n_held < (unsigned int)kHeld ? n_held : (unsigned int)kHeld;
     if (tid == 0) {
         b_off = bytes ? atomicAdd(head + 2, bytes) : 0u;
-        table[block] = make_uint2(b_off, (unsigned int)taken);
+        table[block] = make_uint2(b_off, (unsigned int)run);
+        if (mine) base = atomicAdd(head, mine);
     }
     __syncthreads();
     if (bytes && (uint64_t)b_off + bytes <= b_cap) {  // else: head[2] > head[3] tells the caller
         uint32_t *dst = reinterpret_cast<uint32_t *>(B + b_off);
         for (unsigned int i = tid; i < bytes / 4; i += 256) dst[i] = nib[i];
     }
-    flush();
+    for (unsigned int i = tid; i < mine; i += 256)
+        if (base + i < cap) exc[base + i] = held[i];
 }
 
 __global__ __launch_bounds__(256) void dense_unpack_kernel(const uint32_t *A, const uint8_t *B, const uint2 *table,
                                                            unsigned int b_cap, int64_t n, uint8_t *out) {
     __shared__ uint32_t nib[kBlock / 8];
-    __shared__ int wave_tot[4];
-    const int tid = threadIdx.x;
+    __shared__ int wave_sum[kRounds][4];
+    const int tid = threadIdx.x, wv = tid >> 6;
     const int64_t block = blockIdx.x;
     const uint2 where = table[block];
     const unsigned int bytes = (unsigned int)((((int)where.y + 1) / 2 + 3) & ~3);
     const bool have = (uint64_t)where.x + bytes <= b_cap && where.y <= (unsigned int)kBlock;
+    uint32_t a[kRounds];
+#pragma unroll
+    for (int c = 0; c < kRounds; ++c) {
+        const int64_t chunk = block * kRounds + c;
+        a[c] = chunk * kChunk < n ? A[chunk * 256 + tid] : 0x55555555u;  // past the end: no escapes
+    }
     const uint32_t *src = reinterpret_cast<const uint32_t *>(B + where.x);
     for (unsigned int i = tid; i < bytes / 4 && have; i += 256) nib[i] = src[i];
-    __syncthreads();
-    int taken = 0;
-    for (int c = 0; c < kBlock / kChunk; ++c) {
-        const int64_t chunk = block * (kBlock / kChunk) + c;
-        if (chunk * kChunk >= n) break;
-        const uint32_t a = A[chunk * 256 + tid];
-        uint32_t esc = 0;
+    int prefix[kRounds];
 #pragma unroll
-        for (int i = 0; i < kPerThread; ++i) esc |= (((a >> (2 * i)) & 3u) == 0u ? 1u : 0u) << i;
-        int total;
-        int r = taken + block_exclusive_scan(__popc(esc), wave_tot, total);
+    for (int c = 0; c < kRounds; ++c) {
+        // a position is an escape iff both bits of its code are 0
+        const uint32_t any = a[c] | (a[c] >> 1);
+        const int pc = kPerThread - __popc(any & 0x55555555u), inc = wave_inclusive_scan(pc);
+        prefix[c] = inc - pc;
+        if ((tid & 63) == 63) wave_sum[c][wv] = inc;
+    }
+    __syncthreads();
+    int run = 0;
+#pragma unroll
+    for (int c = 0; c < kRounds; ++c) {
+        const int s0 = wave_sum[c][0], s1 = wave_sum[c][1], s2 = wave_sum[c][2], s3 = wave_sum[c][3];
+        int r = run + (wv > 0 ? s0 : 0) + (wv > 1 ? s1 : 0) + (wv > 2 ? s2 : 0) + prefix[c];
+        run += s0 + s1 + s2 + s3;
+        const int64_t p0 = (block * kRounds + c) * kChunk + (int64_t)tid * kPerThread;
+        if (p0 >= n) continue;
         uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < kPerThread; ++i) {
-            uint32_t v = (a >> (2 * i)) & 3u;
+            uint32_t v = (a[c] >> (2 * i)) & 3u;
             if (v == 0u) {  // nibble 15 is a placeholder: the exception pass writes the value
                 const uint32_t e = have && r < kBlock ? (nib[r >> 3] >> (4 * (r & 7))) & 15u : 0u;
                 v = e == 0u ? 0u : e + 3u;
@@ -158,14 +210,11 @@ __global__ __launch_bounds__(256) void dense_unpack_kernel(const uint32_t *A, co
             }
             w[i >> 2] |= v << (8 * (i & 3));
         }
-        taken += total;
-        const int64_t p0 = chunk * kChunk + (int64_t)tid * kPerThread;
         if (p0 + kPerThread <= n) {
             *reinterpret_cast<uint4 *>(out + p0) = make_uint4(w[0], w[1], w[2], w[3]);
         } else {
             for (int i = 0; i < kPerThread && p0 + i < n; ++i) out[p0 + i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
         }
-        __syncthreads();  // wave_tot is reused
     }
 }
 
