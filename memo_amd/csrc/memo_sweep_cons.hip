@@ -80,30 +80,7 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
     }
 
     MEMO_STAMP(4);  // fold
-    // write level 0 as OutT (uint16, or uint8 when num_docs <= 255), in 16-byte pieces aligned
-    // in the OUTPUT (the tile grid is aligned in pivot coordinates, the output starts at qs)
-    constexpr int PER = 16 / (int)sizeof(OutT);  // positions per 16-byte store
-    OutT *out = static_cast<OutT *>(A.out);
-    const int64_t ob = t.a - A.qs;  // output index of tile slot 0
-    const int64_t o_lo = ob + t.x_lo, o_hi = ob + t.x_hi;
-    for (int64_t g = (o_lo & ~(int64_t)(PER - 1)) + PER * tid; g < o_hi; g += PER * T) {
-        const int x = (int)(g - ob);
-        if (g >= o_lo && g + PER <= o_hi) {
-            uint32_t pk[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (sizeof(OutT) == 2)
-                    pk[q] = lds[x + 2 * q] | (lds[x + 2 * q + 1] << 16);
-                else
-                    pk[q] = lds[x + 4 * q] | (lds[x + 4 * q + 1] << 8) | (lds[x + 4 * q + 2] << 16) |
-                            (lds[x + 4 * q + 3] << 24);
-            }
-            *reinterpret_cast<uint4 *>(out + g) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        } else {
-            for (int i = 0; i < PER; ++i)
-                if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)lds[x + i];
-        }
-    }
+    store_conservation<OutT, T>(A, t, lds);  // level 0, as uint16 or (num_docs <= 255) uint8
     MEMO_STAMP(5);  // store
 #ifdef MEMO_STAMPS
     if (threadIdx.x == 0 && A.stamps && it == 0) A.stamps[8ull * blockIdx.x + 7] = 1;
@@ -236,30 +213,7 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
         lds_barrier();
     }
 
-    // write the last level (single positions) as OutT, in 16-byte pieces aligned in the OUTPUT
-    const uint32_t *res = lds + (A.nlev - 1) * LS + HL;
-    constexpr int PER = 16 / (int)sizeof(OutT);
-    OutT *out = static_cast<OutT *>(A.out);
-    const int64_t ob = t.a - A.qs;  // output index of tile slot 0
-    const int64_t o_lo = ob + t.x_lo, o_hi = ob + t.x_hi;
-    for (int64_t g = (o_lo & ~(int64_t)(PER - 1)) + PER * tid; g < o_hi; g += PER * T) {
-        const int x = (int)(g - ob);
-        if (g >= o_lo && g + PER <= o_hi) {
-            uint32_t pk[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (sizeof(OutT) == 2)
-                    pk[q] = res[x + 2 * q] | (res[x + 2 * q + 1] << 16);
-                else
-                    pk[q] = res[x + 4 * q] | (res[x + 4 * q + 1] << 8) | (res[x + 4 * q + 2] << 16) |
-                            (res[x + 4 * q + 3] << 24);
-            }
-            *reinterpret_cast<uint4 *>(out + g) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        } else {
-            for (int i = 0; i < PER; ++i)
-                if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)res[x + i];
-        }
-    }
+    store_conservation<OutT, T>(A, t, lds + (A.nlev - 1) * LS + HL);  // the last level: single positions
 }
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
