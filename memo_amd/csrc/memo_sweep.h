@@ -308,33 +308,54 @@ struct PackedRows {
     }
 };
 
-// Conservation results of one tile, LDS -> HBM.  res[x] = result of tile slot x (32-bit cells).  A lane
-// takes 4 neighbouring cells (one ds_read_b128; the 64 lanes of a wave read 1 KiB in a row, no bank
-// conflicts -- 16 cells per lane put the lanes 16 words apart, 4 banks for the whole wave) and
-// stores them as 4 or 8 bytes: 256-512 contiguous bytes per wave-instruction.  Pieces are aligned
-// in the OUTPUT (the tile grid is aligned in pivot coordinates, the output starts at qs); when that
-// leaves the LDS side unaligned the cells are read one by one.
+// Conservation results of one tile, LDS -> HBM, with the last fold on the way.  lv0[x] = level 0 of
+// tile slot x (blocks of one position), lv1 = level 1 (blocks of two: lv1[x] covers x and x + 1) or
+// NULL when k - 1 = 1; the result is min(lv0[x], lv1[x], lv1[x - 1]), lv1 being readable from index
+// x_min on.  A lane takes 4 neighbouring slots (ds_read_b128 x 2 + one word; the 64 lanes of a wave
+// read 1 KiB in a row, no bank conflicts -- 16 slots per lane would put the lanes 16 words apart, 4
+// banks for the whole wave) and stores them as 4 or 8 bytes: 256-512 contiguous bytes per
+// wave-instruction.  Pieces are aligned in the OUTPUT (the tile grid is aligned in pivot
+// coordinates, the output starts at qs); when that leaves the LDS side unaligned the cells are read
+// one by one.
 template <typename OutT, int T>
-__device__ __forceinline__ void store_conservation(const SweepArgs &A, const Tile &t, const uint32_t *res) {
+__device__ __forceinline__ void store_conservation(const SweepArgs &A, const Tile &t, const uint32_t *lv0,
+                                                   const uint32_t *lv1, int x_min) {
     OutT *out = static_cast<OutT *>(A.out);
     const int64_t ob = t.a - A.qs;  // output index of tile slot 0
     const int64_t o_lo = ob + t.x_lo, o_hi = ob + t.x_hi;
     const bool aligned = (ob & 3) == 0;
+    auto one = [&](int x) {
+        uint32_t r = lv0[x];
+        if (lv1) {
+            r = min(r, lv1[x]);
+            if (x > x_min) r = min(r, lv1[x - 1]);
+        }
+        return r;
+    };
     for (int64_t g = (o_lo & ~(int64_t)3) + 4 * threadIdx.x; g < o_hi; g += 4 * T) {
         const int x = (int)(g - ob);
         if (g >= o_lo && g + 4 <= o_hi) {
             uint4 v;
-            if (aligned)
-                v = *reinterpret_cast<const uint4 *>(res + x);
-            else
-                v = make_uint4(res[x], res[x + 1], res[x + 2], res[x + 3]);
+            if (aligned) {
+                v = *reinterpret_cast<const uint4 *>(lv0 + x);
+                if (lv1) {
+                    const uint4 u = *reinterpret_cast<const uint4 *>(lv1 + x);
+                    const uint32_t left = x > x_min ? lv1[x - 1] : ~0u;
+                    v.x = min(v.x, min(u.x, left));
+                    v.y = min(v.y, min(u.y, u.x));
+                    v.z = min(v.z, min(u.z, u.y));
+                    v.w = min(v.w, min(u.w, u.z));
+                }
+            } else {
+                v = make_uint4(one(x), one(x + 1), one(x + 2), one(x + 3));
+            }
             if (sizeof(OutT) == 1)
                 *reinterpret_cast<uint32_t *>(out + g) = v.x | (v.y << 8) | (v.z << 16) | (v.w << 24);
             else
                 *reinterpret_cast<uint2 *>(out + g) = make_uint2(v.x | (v.y << 16), v.z | (v.w << 16));
         } else {
             for (int i = 0; i < 4; ++i)
-                if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)res[x + i];
+                if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)one(x + i);
         }
     }
 }

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
     MEMO_STAMP(3);  // barrier after the scatter
 
     // fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1)
-    for (int j = A.nlev - 1; j >= 1; --j) {
+    for (int j = A.nlev - 1; j >= 2; --j) {  // (level 1 -> 0 happens in store_conservation)
         const int half = 1 << (j - 1);
         const uint32_t *hi = lds + j * LS;
         uint32_t *lo = lds + (j - 1) * LS;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
     }
 
     MEMO_STAMP(4);  // fold
-    store_conservation<OutT, T>(A, t, lds);  // level 0, as uint16 or (num_docs <= 255) uint8
+    store_conservation<OutT, T>(A, t, lds, A.nlev > 1 ? lds + LS : nullptr, 0);  // as uint16 or (num_docs <= 255) uint8
     MEMO_STAMP(5);  // store
 #ifdef MEMO_STAMPS
     if (threadIdx.x == 0 && A.stamps && it == 0) A.stamps[8ull * blockIdx.x + 7] = 1;
@@ -185,7 +185,7 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
 
     // fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1); the left halo too
     const int cells = HL + W;
-    for (int slot = 0; slot + 1 < A.nlev; ++slot) {
+    for (int slot = 0; slot + 2 < A.nlev; ++slot) {  // (the last fold happens in store_conservation)
         const int half = 1 << (A.nlev - 2 - slot);
         const uint32_t *hi = lds + slot * LS;
         uint32_t *lo = lds + (slot + 1) * LS;
@@ -213,7 +213,8 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
         lds_barrier();
     }
 
-    store_conservation<OutT, T>(A, t, lds + (A.nlev - 1) * LS + HL);  // the last level: single positions
+    store_conservation<OutT, T>(A, t, lds + (A.nlev - 1) * LS + HL,
+                                A.nlev > 1 ? lds + (A.nlev - 2) * LS + HL : nullptr, -HL);
 }
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
