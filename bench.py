@@ -344,10 +344,10 @@ def main():
 
     def kernel_name(which):
         rows_t = "WideRows" if which == "wide" else f"PackedRows<{'true' if packed_fmt == 6 else 'false'}, false>"
-        if membership:      # packed rows: per-genome bit planes (unclipped + staged when k <= 32 and <= 512 genomes,
+        if membership:      # packed rows: per-genome bit planes (unclipped + staged up to 512 genomes,
             if which == "wide":                                      # else the clipped "runs"); int64 rows: doubling
                 return "sweep_membership_kernel<" + rows_t + ", ...>"
-            planes = k - 1 <= 31 and num_docs <= 512 and os.environ.get("MEMO_MEMB_ALGO", "0") in ("0", "4")
+            planes = num_docs <= 512 and os.environ.get("MEMO_MEMB_ALGO", "0") in ("0", "4")
             return ("sweep_membership_planes_kernel<" if planes else "sweep_membership_runs_kernel<") + rows_t + ", ...>"
         # packed rows on an index with >= 1 row per position: the unclipped scatter (memo_sweep_cons.hip)
         halo = which != "wide" and rows >= L and os.environ.get("MEMO_SCATTER", "0") in ("0", "2")

@@ -214,7 +214,7 @@ int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t
  * MEMO_WAVES, MEMO_MEMB_ALGO).  0 = let the library choose.  tile_w: positions per tile
  * (256..4096); waves: 1 or 4 waves share a tile; membership_algo: 1 = direct scatter,
  * 2 = doubling, 3 = runs (bit planes per genome + register transpose), 4 = the same planes without
- * clipping and with the result staged through LDS (packed rows, k <= 32, <= 512 genomes; else 3).
+ * clipping and with the result staged through LDS (packed rows, <= 512 genomes; else 3).
  * Results never depend on these. */
 int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo);
 /* 0 = queries read the packed rows when the index has them (default); 1 = always the int64

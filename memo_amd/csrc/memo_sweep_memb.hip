@@ -202,13 +202,13 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 
 // ------------------------------------------------------------------------------------------
 // membership, bit planes per genome, unclipped, with the result staged through LDS
-// (packed rows whose annot is known to be inside the matrix, k - 1 <= 31, at most 16 result words).
+// (packed rows whose annot is known to be inside the matrix, at most 16 result words).
 //
-//   * a genome's plane row covers one word left of the tile and three right of it (32-position
-//     buckets), so that the run of any row of the slice (start - a <= W + k - 1 + bucket - 2,
-//     n = k - 1 - overlap <= 31 bits ending at start) fits without clipping: the run is (2^n - 1) << first bit as a 64-bit value, ds_or of
-//     its two halves into neighbouring words -- 14 VALU instructions per row instead of ~30 and no
-//     divergent branches;
+//   * a genome's plane row covers ceil((k-1)/32) words left of the tile and a few right of it, so that
+//     the run of any row of the slice (start - a <= W + k - 1 + bucket - 2, n = k - 1 - overlap bits
+//     ending at start) fits without clipping.  k <= 32: the run is (2^n - 1) << first bit as a 64-bit
+//     value, ds_or of its two halves into neighbouring words -- 18 VALU instructions per row instead
+//     of ~30 and no divergent branches; larger k: first word, whole words, last word;
 //   * lane (G, p) then reads the 32 plane rows of genome group G at position word p, transposes
 //     the 32 x 32 bits in registers and writes the 32 result words position-major into LDS, over
 //     the planes (all reads are behind a barrier by then);
@@ -237,17 +237,27 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
     }
 
     const int km1 = A.km1;
-    const uint32_t a16m = pin_vgpr((int)((uint32_t)(t.a - 32) & 0xFFFFu));  // bit 32 of a plane row = tile slot 0
+    const int HLW = A.nlev;  // words of halo left of the tile: ceil((k - 1) / 32)
+    const uint32_t a16m = pin_vgpr((int)((uint32_t)(t.a - 32 * HLW) & 0xFFFFu));  // bit 32 * HLW of a plane row = tile slot 0
     auto scatter = [&](uint32_t w, uint32_t col) {
         const int n = km1 - (int)__builtin_amdgcn_ubfe(w, 16, 8);  // bits of the run [end - (k-1), start)
         if (n > 0) {
-            uint32_t d;  // start - a + 32 (gfx9 16-bit VALU results have a zero high half)
+            uint32_t d;  // start - a + 32 * HLW (gfx9 16-bit VALU results have a zero high half)
             asm("v_sub_u16 %0, %1, %2" : "=v"(d) : "v"(w), "v"(a16m));
             const uint32_t first = d - (uint32_t)n;
-            const uint64_t run = (uint64_t)((1u << n) - 1u) << (first & 31u);
             uint32_t *cell = lds + (__umul24(col, (uint32_t)PITCH) + __umul24(col >> 5, (uint32_t)SKEW) + (first >> 5));
-            atomicOr(cell, (uint32_t)run);
-            atomicOr(cell + 1, (uint32_t)(run >> 32));
+            if (km1 <= 31) {  // (uniform) the run fits two words: no branches
+                const uint64_t run = (uint64_t)((1u << n) - 1u) << (first & 31u);
+                atomicOr(cell, (uint32_t)run);
+                atomicOr(cell + 1, (uint32_t)(run >> 32));
+            } else {  // up to 255 bits: first word, whole words, last word
+                const uint32_t last = d - 1u;
+                const int more = (int)(last >> 5) - (int)(first >> 5);
+                const uint32_t head = 0xFFFFFFFFu << (first & 31u), tail = 0xFFFFFFFFu >> (31u - (last & 31u));
+                atomicOr(cell, more ? head : head & tail);
+                for (int i = 1; i < more; ++i) atomicOr(cell + i, 0xFFFFFFFFu);
+                if (more) atomicOr(cell + more, tail);
+            }
         }
     };
     Rows::template consume<T, U>(A, t, 0, V, N, scatter);
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
     const int G = tid % nw, p = tid / nw;
     uint32_t m[32];
     if (tid < blocks) {
-        const uint32_t *src = lds + (32 * G) * PITCH + G * SKEW + p + 1;
+        const uint32_t *src = lds + (32 * G) * PITCH + G * SKEW + p + HLW;
 #pragma unroll
         for (int i = 0; i < 32; ++i) m[i] = src[i * PITCH];
     }
@@ -414,10 +424,9 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
     A.word_base = 0;
     A.out_words = nw;
-    // 4 = unclipped bit planes + staged result: packed rows with every annot inside the matrix,
-    // k - 1 <= 31, at most 16 result words; otherwise whatever else was chosen
-    if ((algo == 4 || (g_memb_algo == 0 && algo == 3)) && fmt && !checked && k - 1 <= 31 && nw <= 16 &&
-        !use_persistent(fmt)) {
+    // 4 = unclipped bit planes + staged result: packed rows with every annot inside the matrix, at most
+    // 16 result words; otherwise whatever else was chosen
+    if ((algo == 4 || (g_memb_algo == 0 && algo == 3)) && fmt && !checked && nw <= 16 && !use_persistent(fmt)) {
         const int bw = 1 << ix->bshift, T = waves == 1 ? 64 : 256;
         int tw = w ? w : 1024;
         if (tw > 32 * (T / nw)) tw = 32 * (T / nw);  // one 32 x 32 block per lane
@@ -428,7 +437,10 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             for (int pow2 = 4; pow2 <= 64; pow2 <<= 1)
                 if (nw == pow2) skew = (64 / nw + 32) & 63;  // G * (32 * PITCH + skew) = G * 64 / nw (mod 64), PITCH odd
             A.w = tw;
-            A.ls = (pw + ((k - 1 + bw + 29) >> 5) + 1) | 1;  // last bit of a run: 32 + tile + k - 1 + bw - 3, and one word for the second ds_or
+            const int hlw = (k - 1 + 31) / 32;
+            A.nlev = hlw;  // words of halo left of the tile
+            // last bit of a run: 32 hlw + tile + k - 1 + bw - 3; one more word for the short path's second ds_or
+            A.ls = (hlw + pw + ((k - 1 + bw - 3) >> 5) + 1) | 1;
             A.hl = skew;
             A.magic = (uint32_t)((((uint64_t)1 << 32) + 32 * nw - 1) / (32 * nw));
             const size_t planes = ((size_t)32 * nw * A.ls + (size_t)nw * skew + 8) * 4;
