@@ -212,7 +212,8 @@ int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t
 
 /* ---- tuning knobs (process-wide; also read once from the environment: MEMO_TILE_W,
  * MEMO_WAVES, MEMO_MEMB_ALGO).  0 = let the library choose.  tile_w: positions per tile
- * (256..4096); waves: 1 or 4 waves share a tile; membership_algo: 1 = direct scatter,
+ * (256..4096); waves: 1 or 4 waves share a tile (8: the unclipped conservation kernel only, else
+ * the library's choice); membership_algo: 1 = direct scatter,
  * 2 = doubling, 3 = runs (bit planes per genome + register transpose), 4 = the same planes without
  * clipping and with the result staged through LDS (packed rows, <= 512 genomes; else 3).
  * Results never depend on these. */

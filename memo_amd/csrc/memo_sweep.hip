@@ -173,7 +173,7 @@ int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo) {
     if (tile_w != 0 && tile_w != 256 && tile_w != 512 && tile_w != 1024 && tile_w != 2048 &&
         tile_w != 4096)
         return fail(MEMO_EINVAL, "tile_w must be 0, 256, 512, 1024, 2048 or 4096");
-    if (waves != 0 && waves != 1 && waves != 4) return fail(MEMO_EINVAL, "waves must be 0, 1 or 4");
+    if (waves != 0 && waves != 1 && waves != 4 && waves != 8) return fail(MEMO_EINVAL, "waves must be 0, 1, 4 or 8");
     if (membership_algo < 0 || membership_algo > 4) return fail(MEMO_EINVAL, "membership_algo must be 0..4");
     g_tile_w = tile_w;
     g_waves = waves;

@@ -285,8 +285,9 @@ constexpr int kHaloLoads = MEMO_HALO_LOADS;  // 16-byte loads in flight per lane
 
 template <typename Rows, typename OutT>
 static SweepKernel halo_kernel(int waves) {
-    return waves == 4 ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 256, OutT>
-                      : (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 64, OutT>;
+    return waves == 8   ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 512, OutT>
+           : waves == 4 ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 256, OutT>
+                        : (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 64, OutT>;
 }
 
 template <typename OutT>
@@ -368,6 +369,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.w = tw;
             A.ls = hl + tw + hr;
             if (g_waves == 0) waves = w >= 1024 ? 4 : 1;
+            if (g_waves == 8) waves = 8;  // (experiment: eight waves share a tile; only this kernel has that shape)
             SweepKernel kern = fmt == 4 ? halo_kernel<PackedRows<false, false>, OutT>(waves)
                                         : halo_kernel<PackedRows<true, false>, OutT>(waves);
             if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)A.nlev * A.ls * 4, st, 1))) return rc;
