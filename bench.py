@@ -52,8 +52,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--wide", action="store_true", help="uint16 conservation results even when num_docs <= 255")
@@ -322,19 +322,28 @@ def main():
     drain()
     ix.check(stream.cuda_stream)           # raises if the kernel flagged a bad row
 
+    # HIP events on the launch stream.  N > 1: a pair around every step's sweep (pack and gather follow
+    # it on the same stream).  N = 1: the K sweeps run back to back, so ONE pair around all of them --
+    # two event packets between every two launches cost the timed region 5-7 us per step.
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+          for _ in range(args.steps if multi else 1)]
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, ev[i])
+    if multi:
+        for i in range(args.steps):
+            step(i, ev[i])
+    else:
+        ev[0][0].record(stream)
+        for i in range(args.steps):
+            step(i)
+        ev[0][1].record(stream)
     drain()
     if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / (1 if multi else args.steps)
     if multi:
         t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
