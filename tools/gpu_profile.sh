@@ -5,15 +5,15 @@ TAG=${1:-r05}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json
 for rows in packed wide; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$rows -o c3 -- python bench.py --rows $rows --steps 10 --warmup 2 --cpu-sample 0 > $OUT/prof_$rows.json 2>> $OUT/prof.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$rows -o c3 -- python bench.py --rows $rows --steps 100 --warmup 20 --cpu-sample 0 > $OUT/prof_$rows.json 2>> $OUT/prof.err
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$rows/pmc_$c -o c3 -- python bench.py --rows $rows --steps 3 --warmup 1 --cpu-sample 0 --calibrate > /dev/null 2>> $OUT/prof.err
   done
 done
 head -6 $OUT/prof_packed/c3_kernel_stats.csv | cut -c1-200
-for wl in c2 c4 c5; do timeout 300 python bench.py --workload $wl --steps 10 --warmup 2 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.txt; done
-timeout 300 python bench.py --k 101 --steps 10 --warmup 2 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.txt
-timeout 300 python bench.py --k 21 --steps 10 --warmup 2 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.txt
+for wl in c2 c4 c5; do timeout 300 python bench.py --workload $wl --steps 100 --warmup 20 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.txt; done
+timeout 300 python bench.py --k 101 --steps 100 --warmup 20 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.txt
+timeout 300 python bench.py --k 21 --steps 100 --warmup 20 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.txt
 timeout 300 python bench.py --force-dist --steps 10 --warmup 2 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.txt
 python - <<PY
 import json
