@@ -233,14 +233,15 @@ def main():
         probe = torch.empty(lib.memo_transport_bytes(L, cap), dtype=torch.uint8, device=dev)
         _lib.check(lib.memo_transport_pack_dev(outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream))
         _lib.check(lib.memo_transport_exceptions(probe.data_ptr(), local, stream.cuda_stream, C.byref(found), C.byref(have)))
-        fits = torch.tensor([1 if found.value <= have.value else 0], device=dev)
-        dist.all_reduce(fits, op=dist.ReduceOp.MIN)
-        if fits.item():
+        need = torch.tensor([found.value], dtype=torch.int64, device=dev)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        nibble_cap = int(need.item()) + int(need.item()) // 16 + 1024          # what the ranks found + slack
+        if nibble_cap * 8 <= L // 8:                                       # else the list outweighs the saving
             t = timed(lambda: _lib.check(lib.memo_transport_unpack_dev(
                 probe.data_ptr(), L, scratch.data_ptr(), local, stream.cuda_stream)))
             tp = timed(lambda: _lib.check(lib.memo_transport_pack_dev(
                 outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream)))
-            usable["nibble"] = (lib.memo_transport_bytes(L, cap), t, tp)
+            usable["nibble"] = (lib.memo_transport_bytes(L, nibble_cap), t, tp)
         del probe, scratch
         model = {c: max(t_sweep + tp, t_sweep + (world - 1) * t, nbytes / XGMI_LINK_BYTES_PER_S)
                  for c, (nbytes, t, tp) in usable.items()}
@@ -250,6 +251,8 @@ def main():
         coding = names[int(pick.item())]
         if coding == "dense":
             cap = dense_cap
+        elif coding == "nibble":
+            cap = nibble_cap
         choice = {"picked": coding, "sweep_ms": t_sweep * 1e3, "link_bytes_per_s_assumed": XGMI_LINK_BYTES_PER_S,
                   "candidates": {c: {"wire_bytes": int(usable[c][0]), "decode_ms_per_slice": usable[c][1] * 1e3, "encode_ms": usable[c][2] * 1e3,
                                      "modelled_step_ms": model[c] * 1e3} for c in names}}
