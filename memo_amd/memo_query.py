@@ -102,7 +102,7 @@ def region_chunks(in_file, query_record, query_start, query_end):
     def chunks():
         # row groups decode in parallel (Arrow releases the GIL), a bounded window ahead of the
         # consumer, and are handed over in file order so that the rows stay start-sorted
-        depth = max(1, min(int(os.environ.get("MEMO_DECODE_THREADS", "8")), os.cpu_count() or 1))
+        depth = max(1, min(int(os.environ.get("MEMO_DECODE_THREADS", "16")), os.cpu_count() or 1))
         with cf.ThreadPoolExecutor(max_workers=depth) as pool:
             window = [pool.submit(load, g) for g in groups[:depth]]
             for n in range(len(groups)):
