@@ -58,7 +58,7 @@ while time.time() < t_end:
             k = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 21, 31, 32, 33, 64, 65, 101, 128, 129, 255, 256, 257, 1000]))
             qs = int(rng.integers(0, length))
             qe = int(rng.integers(qs, length + 200))
-            tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096])), int(rng.choice([0, 1, 4])), int(rng.integers(0, 5)))
+            tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096])), int(rng.choice([0, 1, 4, 8])), int(rng.integers(0, 5)))
             _lib.check(L.memo_set_tuning(*tune))
             _lib.check(L.memo_set_persistent(int(rng.integers(0, 3))))
             _lib.check(L.memo_set_row_source(int(rng.integers(0, 2))))

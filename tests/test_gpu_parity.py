@@ -169,6 +169,7 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle):
         try:
             for tile_w, waves, algo in [(0, 0, 0), (256, 1, 1), (512, 4, 2), (1024, 1, 2), (2048, 4, 1), (4096, 4, 0),
                                         (256, 4, 3), (2048, 4, 3), (1024, 1, 3), (0, 0, 4), (256, 1, 4), (512, 4, 4),
+                                        (2048, 8, 0), (512, 8, 4),
                                         (1024, 4, 4), (2048, 4, 4), (4096, 1, 4)]:
                 _lib.check(_lib.lib().memo_set_tuning(tile_w, waves, algo))
                 for k in (2, 3, 17, 31, 32, 101, 255, 256):
