@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 import memo_amd  # noqa: E402
 from memo_amd import synth  # noqa: E402
 
-XGMI_LINK_BYTES_PER_S = 75e9   # one direction of one xGMI link (MI355X_MICROARCH.md: ~153 GB/s per link, both ways)
+XGMI_LINK_BYTES_PER_S = 75e9   # one direction of one xGMI link (7 links x ~153 GB/s per GPU, both directions summed)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 WORKLOADS = {
