@@ -118,7 +118,11 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
     const int tid = threadIdx.x;
     const int LS = A.ls, HL = A.hl, W = A.w;
     Tile t;
+#ifdef MEMO_STAMPS
+    unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
     if (!locate_tile_w(A, t, 0, W)) return;
+    MEMO_STAMP(0);  // tile location (kernarg + two bucket-table loads)
     uint4 V[U];
     uint2 N[U];
     Rows::template issue<T, U>(A, t, 0, V, N);
@@ -129,6 +133,7 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
         for (int i = tid; i < A.nlev * (LS / 4); i += T) p[i] = sv;
         lds_barrier();
     }
+    MEMO_STAMP(1);  // issue of the loads + LDS clear + barrier
 
     const int km1 = A.km1;
     // LDS byte address of tile slot x on the level with clz(n) = f:  base + 4 * ((f - fmin) * LS + HL + x)
@@ -181,7 +186,9 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
         Rows::template issue<T, U>(A, t, b, V, N);
         Rows::template consume<T, U>(A, t, b, V, N, scatter);
     }
+    MEMO_STAMP(2);  // waiting for rows + scatter
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
+    MEMO_STAMP(3);  // barrier after the scatter
 
     // fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1); the left halo too
     const int cells = HL + W;
@@ -213,8 +220,13 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
         lds_barrier();
     }
 
+    MEMO_STAMP(4);  // fold (all levels but the last)
     store_conservation<OutT, T>(A, t, lds + (A.nlev - 1) * LS + HL,
                                 A.nlev > 1 ? lds + (A.nlev - 2) * LS + HL : nullptr, -HL);
+    MEMO_STAMP(5);  // last fold + store
+#ifdef MEMO_STAMPS
+    if (threadIdx.x == 0 && A.stamps) A.stamps[8ull * blockIdx.x + 7] = 1;
+#endif
 }
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value

@@ -25,7 +25,7 @@ out = torch.empty(L, dtype=torch.int16, device="cuda")
 _lib.check(_lib.lib().memo_set_tuning(*[int(x) for x in a.tuning.split(",")]))
 names = ["locate tile", "issue loads + clear LDS + barrier", "wait for rows + scatter", "barrier after scatter", "fold",
          "store", "-", "tiles"]
-nblocks = 8 * ((L // 256 + 8) // 8 + 1) + 8
+nblocks = 8 * ((L // 128 + 8) // 8 + 1) + 8
 buf = torch.zeros(8 * nblocks, dtype=torch.int64, device="cuda")
 _lib.check(_lib.lib().memo_debug_set_stamp_buffer(C.c_void_p(buf.data_ptr())))
 for rep in range(2):
