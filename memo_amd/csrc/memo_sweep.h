@@ -26,10 +26,12 @@ struct SweepArgs {
     int bshift;
     int km1;    // k - 1 (>= 1 here; k <= 1 never reaches a sweep kernel)
     int ncols;  // result columns: num_docs + 1 (conservation) / num_docs (membership)
-    int nlev;   // doubling levels: floor(log2(k-1)) + 1
+    int nlev;   // doubling levels: floor(log2(k-1)) + 1.  Membership bit planes reuse it: runs kernel = words
+                //   of skew per 32-genome group; planes kernel = words of halo left of the tile
     int nwords; // membership: 32-bit words per position handled by this launch
     int ls, hl;  // conservation, unclipped scatter: words per level array, words of left halo
-    int w;       //   ... and its tile width (a multiple of 32, not a template parameter there)
+                 //   (membership planes kernel: words per genome's plane row, words of skew per 32-genome group)
+    int w;       //   ... and the tile width of both (a multiple of the bucket width, not a template parameter there)
     uint32_t magic;  // membership planes: ceil(2^32 / (32 * nwords)), for q / (32 * nwords) by v_mul_hi
     int word_base;  // membership runs: first genome word of this launch (num_docs too large for one
     int out_words;  //   LDS tile is swept in slices of genome words); out_words = words per position
