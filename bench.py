@@ -34,9 +34,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import memo_amd  # noqa: E402
-from memo_amd import synth  # noqa: E402
+from memo_amd import shard, synth  # noqa: E402
 
-XGMI_LINK_BYTES_PER_S = 75e9   # one direction of one xGMI link (7 links x ~153 GB/s per GPU, both directions summed)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 WORKLOADS = {
@@ -199,7 +198,7 @@ def main():
     # step); a coding is usable when every rank's slice fits it.  Fewer bytes is not all: rank 0 decodes
     # world - 1 slices per step, so among the usable codings it takes the one whose modelled step
     #     max(sweep + encode [a peer], sweep + (world - 1) * decode of one slice [rank 0],
-    #         wire bytes / XGMI_LINK_BYTES_PER_S [a peer's link])
+    #         wire bytes / 75 GB/s [a peer's link])           (memo_amd.shard.pick_coding)
     # is shortest, with sweep, encode and decode timed here on rank 0.
     coding, b_cap = "plain", 0
     cap = max(L // 256, 1024)
@@ -251,17 +250,16 @@ def main():
                 outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream)))
             usable["nibble"] = (lib.memo_transport_bytes(L, nibble_cap), t, tp)
         del probe, scratch
-        model = {c: max(t_sweep + tp, t_sweep + (world - 1) * t, nbytes / XGMI_LINK_BYTES_PER_S)
-                 for c, (nbytes, t, tp) in usable.items()}
+        best, model = shard.pick_coding(world, t_sweep, usable)
         names = sorted(usable)
-        pick = torch.tensor([names.index(min(model, key=model.get))], device=dev)
+        pick = torch.tensor([names.index(best)], device=dev)
         dist.broadcast(pick, src=0)                                        # rank 0's timings decide for everybody
         coding = names[int(pick.item())]
         if coding == "dense":
             cap = dense_cap
         elif coding == "nibble":
             cap = nibble_cap
-        choice = {"picked": coding, "sweep_ms": t_sweep * 1e3, "link_bytes_per_s_assumed": XGMI_LINK_BYTES_PER_S,
+        choice = {"picked": coding, "sweep_ms": t_sweep * 1e3, "link_bytes_per_s_assumed": shard.XGMI_LINK_BYTES_PER_S,
                   "candidates": {c: {"wire_bytes": int(usable[c][0]), "decode_ms_per_slice": usable[c][1] * 1e3, "encode_ms": usable[c][2] * 1e3,
                                      "modelled_step_ms": model[c] * 1e3} for c in names}}
     nibble = coding != "plain"              # (name kept: "the slices travel coded")

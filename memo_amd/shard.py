@@ -56,3 +56,21 @@ def sharded_query(sweep, qs, qe, k, rank, world, dist, alloc, dst=0):
         sweep(a, b, out)
     res = gather_slices(out, per, [w[1] - w[0] for w in wins], rank, world, dist, dst)
     return res, (a, b)
+
+
+# ---- what a result slice should travel as (bench.py, N > 1) ---------------------------------------
+XGMI_LINK_BYTES_PER_S = 75e9   # one direction of one xGMI link (7 links x ~153 GB/s per GPU, both directions summed)
+
+
+def modelled_step(world, t_sweep, wire_bytes, t_decode, t_encode, link=XGMI_LINK_BYTES_PER_S):
+    """seconds per step when every peer's slice goes to rank 0 coded: the slowest of a peer (sweep +
+    encode), rank 0 (its own sweep + decoding the world - 1 slices it received; its own slice never
+    travels) and a peer's link to rank 0 (each peer has its own; gather i overlaps sweep i + 1)."""
+    return max(t_sweep + t_encode, t_sweep + (world - 1) * t_decode, wire_bytes / link)
+
+
+def pick_coding(world, t_sweep, usable, link=XGMI_LINK_BYTES_PER_S):
+    """usable: coding name -> (wire bytes, decode seconds per slice, encode seconds).  Returns the name
+    with the shortest modelled step (ties: alphabetical, so that every rank would agree) and the model."""
+    model = {c: modelled_step(world, t_sweep, *usable[c], link=link) for c in usable}
+    return min(sorted(model), key=model.get), model

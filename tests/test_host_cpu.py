@@ -184,3 +184,24 @@ def test_region_chunks_without_statistics_or_with_dictionary_f0(memo, tmp_path):
             got = list(chunks)
             cat = np.concatenate([c[0] for c in got]) if got else np.zeros(0, np.int64)
             assert np.array_equal(cat, want.start) and len(want) <= bound
+
+
+def test_transport_coding_choice_model():
+    """memo_amd.shard.pick_coding: the step model bench.py uses to choose what a slice travels as.
+    Inputs = the figures measured on config 3: fewer bytes win while rank 0's
+    decoding of world - 1 slices stays under the link time."""
+    from memo_amd import shard
+    sweep = 0.37e-3
+    usable = {"plain": (100_000_000, 0.0, 0.0),
+              "nibble": (53_101_352, 0.031e-3, 0.108e-3),
+              "dense": (41_250_080, 0.058e-3, 0.153e-3)}
+    picks = {w: shard.pick_coding(w, sweep, usable)[0] for w in (2, 4, 8)}
+    assert picks == {2: "dense", 4: "dense", 8: "nibble"}
+    best, model = shard.pick_coding(8, sweep, usable)
+    assert abs(model["plain"] - 100e6 / 75e9) < 1e-9                      # link-bound
+    assert abs(model["dense"] - (sweep + 7 * 0.058e-3)) < 1e-9           # rank 0's decoding
+    assert abs(model["nibble"] - 53_101_352 / 75e9) < 1e-9               # link-bound
+    # a slow link makes bytes matter more; a fast one makes the coding pointless
+    assert shard.pick_coding(8, sweep, usable, link=20e9)[0] == "dense"
+    assert shard.pick_coding(2, sweep, usable, link=1e12)[0] == "plain"
+    assert shard.modelled_step(1, sweep, 10, 1.0, 0.0) == sweep          # nobody to decode for
