@@ -63,6 +63,9 @@ typedef struct memo_index_info {
     uint64_t device_bytes;  /* HBM held by this index (columns + padding + bucket table) */
     int32_t packed_format;  /* 0 = none, 4 = 4 B/row, 6 = 6 B/row (memo_index_pack) */
     int32_t has_wide;       /* 1 while the three int64 columns are resident */
+    float pack_ms;          /* device time of the last memo_index_pack: annot census + packing kernel,
+                               HIP events on its stream (the narrowing pass, timed apart) */
+    int32_t reserved;
 } memo_index_info_t;
 
 const char *memo_last_error(void);
@@ -152,56 +155,6 @@ size_t memo_emit_membership(const uint32_t *bits, int64_t L, int32_t num_docs, c
 int memo_bin_conservation_dev(const uint16_t *d_vec, int64_t L, const int64_t *edges, int32_t nbins,
                               int32_t num_docs, uint64_t *counts, int32_t device, void *stream);
 
-/* ---- index-row construction: dap_to_bed.py:55-134 (--mem [--order] [--overlap]) -------------
- * A DAP (src/index.sh:83) has one row per pivot position: the matching statistic of every
- * non-pivot genome at that position.  Rows go in as a HOST int32 matrix [positions][columns],
- * consecutive positions starting at 0, in as many pushes as the caller likes (state carries over);
- * each push produces, on `device`, the (record, start, end, annot) rows the reference would print
- * for those positions, in its order.  rec_begin: nrec + 1 cumulative record offsets of the pivot
- * (from its .fai).  memo_dap_fetch copies the rows of the last push; memo_dap_finish returns the
- * chr-end rows of a DAP that stops inside a record (at most `columns` rows). */
-typedef struct memo_dap memo_dap_t;
-int memo_dap_create(int32_t columns, const int64_t *rec_begin, int32_t nrec, int32_t sort_order,
-                    int32_t overlaps, int32_t device, memo_dap_t **out);
-int memo_dap_push(memo_dap_t *h, const int32_t *lcp, int64_t positions, uint64_t *out_rows);
-int memo_dap_fetch(memo_dap_t *h, int32_t *rec, int64_t *start, int64_t *end, int32_t *annot);
-int memo_dap_finish(memo_dap_t *h, int32_t *rec, int64_t *start, int64_t *end, int32_t *annot,
-                    uint64_t *out_rows);
-void memo_dap_destroy(memo_dap_t *h);
-/* host-side parser for the DAP text (whitespace-separated decimal integers), multi-threaded.
- * Returns how many integers the text holds (they are written only when cap is enough), -1 on a
- * malformed character. */
-int64_t memo_parse_ints(const char *text, size_t len, int64_t *out, size_t cap);
-/* BED text of such rows: "name\tstart\tend\tannot\n" (dap_to_bed.py:105,109).  names: nrec
- * NUL-terminated strings back to back.  Returns the bytes needed; writes only if they fit. */
-size_t memo_emit_bed(const int32_t *rec, const int64_t *start, const int64_t *end, const int32_t *annot,
-                     uint64_t rows, const char *names, int32_t nrec, char *buf, size_t cap);
-
-/* ---- transport coding of uint8 conservation results (multi-GPU gather) ---------------------
- * One nibble per position; values >= 15 travel in an exception list of `cap` slots.  Lossless.
- * wire size = memo_transport_bytes(n, cap); pack and unpack are asynchronous on `stream`.
- * memo_transport_exceptions() tells (synchronising `stream`) how many exceptions the sender found:
- * more than cap means this slice has to travel as plain bytes instead. */
-size_t memo_transport_bytes(int64_t n, uint32_t cap);
-int memo_transport_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t cap, void *d_wire, int32_t device,
-                            void *stream);
-int memo_transport_unpack_dev(const void *d_wire, int64_t n, uint8_t *d_vec, int32_t device, void *stream);
-int memo_transport_exceptions(const void *d_wire, int32_t device, void *stream, uint32_t *found, uint32_t *cap);
-
-/* Second, denser coding for the same purpose (memo_transport.hip): 2 bits per position (values 1..3;
- * 0 = escape) + one nibble per escape, allocated exactly per 32768 positions from a B region of
- * `b_capacity` bytes (a multiple of 4), + the same exception list (nibble 15: values > 17).  Buffers
- * 16-byte aligned.  _stats (synchronising `stream`) returns the exceptions found and their capacity,
- * the B bytes taken and the B capacity: the slice is complete iff neither exceeds.  Pack once with
- * generous capacities to learn what a workload needs (at most n / 2 + 4 * ceil(n / 32768) bytes of B). */
-size_t memo_transport_dense_bytes(int64_t n, uint32_t b_capacity, uint32_t cap);
-int memo_transport_dense_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t b_capacity, uint32_t cap,
-                                  void *d_wire, int32_t device, void *stream);
-int memo_transport_dense_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint32_t cap,
-                                    uint8_t *d_vec, int32_t device, void *stream);
-int memo_transport_dense_stats(const void *d_wire, int32_t device, void *stream, uint32_t *found, uint32_t *cap,
-                               uint32_t *b_taken, uint32_t *b_capacity);
-
 /* ---- synthetic pangenome index (BASELINE.json configs 2-5) -------------------
  * Fills rows [0, rows) of the index with global rows row_begin + i of the generator
  *   start = 1 + floor(i * den / num), end = start + mix(seed, 2i) % 60,
@@ -209,36 +162,6 @@ int memo_transport_dense_stats(const void *d_wire, int32_t device, void *stream,
  * on the device (no host copy).  Same generator as oracle_synth_rows. */
 int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t den,
                     int32_t num_docs, uint64_t seed);
-
-/* ---- tuning knobs (process-wide; also read once from the environment: MEMO_TILE_W,
- * MEMO_WAVES, MEMO_MEMB_ALGO).  0 = let the library choose.  tile_w: positions per tile
- * (256..4096); waves: 1 or 4 waves share a tile (8: the unclipped conservation kernel only, else
- * the library's choice); membership_algo: 1 = direct scatter,
- * 2 = doubling, 3 = runs (bit planes per genome + register transpose), 4 = the same planes without
- * clipping and with the result staged through LDS (packed rows, <= 512 genomes; else 3).
- * Results never depend on these. */
-int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo);
-/* 0 = queries read the packed rows when the index has them (default); 1 = always the int64
- * columns (also MEMO_ROWS=wide).  For A/B measurements; results are identical. */
-int memo_set_row_source(int32_t source);
-/* 0 = library's choice, 1 = one workgroup per tile, 2 = persistent workgroups (as many as stay
- * resident; each walks a run of tiles and looks the next one up under the current one's work).
- * Also MEMO_PERSIST.  Results are identical. */
-int memo_set_persistent(int32_t mode);
-/* conservation scatter with packed rows: 0 = library's choice, 1 = clip every interval to the tile,
- * 2 = unclipped into level arrays with a halo (fewer instructions and registers per row; only when
- * every annot of the index is inside the result matrix and workgroups are not persistent, else 1 is
- * used anyway).  tile_w of memo_set_tuning is then the size of a level array, halo included.
- * Also MEMO_SCATTER.  Results are identical. */
-int memo_set_scatter(int32_t mode);
-
-/* profiling aid: one pass that reads the three columns exactly once (24 B/row) with the
- * sweep's access shape, to calibrate the FETCH_SIZE counter on a known byte count */
-int memo_debug_stream_rows(memo_index_t *ix, void *stream);
-/* profiling aid for -DMEMO_STAMPS builds of the conservation sweep: a device buffer of 8 uint64
- * per workgroup that receives the cycles wave 0 spent in each phase (NULL = off; ignored by the
- * product library, which contains no stamp) */
-int memo_debug_set_stamp_buffer(uint64_t *d_buffer);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,36 @@
+/*
+ * memo_amd_debug.h -- A/B switches and profiling aids.  NOT part of the product ABI: these are
+ * exported only by libmemo_amd_ab.so (the product objects + memo_amd/csrc/memo_debug.hip), which
+ * tests/, tests/fuzz_gpu.py, tools/ab.py and the PMC calibration pass load instead of
+ * libmemo_amd.so.  Results never depend on any of them; they replace nothing in the reference.
+ */
+#ifndef MEMO_AMD_DEBUG_H
+#define MEMO_AMD_DEBUG_H
+
+#include "memo_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Kernel-shape choices of ONE index (0 = let the library choose, which is all the product does).
+ * tile_w: positions per tile (256..4096; unclipped conservation: cells per level array, halo included);
+ * waves: 1 or 4 waves share a tile (8: the unclipped conservation kernel only);
+ * membership_algo: 2 = doubling, 3 = runs (clipped bit planes per genome + register transpose),
+ *   4 = planes (unclipped, result staged through LDS; packed rows, <= 512 genomes; else 3);
+ * row_source: 1 = read the int64 columns even when packed rows exist;
+ * scatter (conservation, packed rows): 1 = clip every interval to the tile, 2 = unclipped into level
+ *   arrays with a halo (only when every annot of the index is inside the result matrix, else 1). */
+int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32_t membership_algo,
+                          int32_t row_source, int32_t scatter);
+/* one pass that reads the three int64 columns exactly once (24 B/row) with the sweep's access
+ * shape, to calibrate the FETCH_SIZE counter on a known byte count */
+int memo_debug_stream_rows(memo_index_t *ix, void *stream);
+/* -DMEMO_STAMPS builds of the conservation sweep: a device buffer of 8 uint64 per workgroup that
+ * receives the cycles wave 0 spent in each phase (NULL = off) */
+int memo_debug_set_stamp_buffer(uint64_t *d_buffer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEMO_AMD_DEBUG_H */

@@ -1,0 +1,45 @@
+/*
+ * memo_amd_transport.h -- lossless transport codings of uint8 conservation slices for the multi-GPU gather
+ * (new: the reference is single-process).
+ * Part of the C ABI of libmemo_amd.so (see memo_amd.h for conventions: plain C types, 0 or a negative
+ * code, memo_last_error()).
+ */
+#ifndef MEMO_AMD_TRANSPORT_H
+#define MEMO_AMD_TRANSPORT_H
+
+#include "memo_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- transport coding of uint8 conservation results (multi-GPU gather) ---------------------
+ * One nibble per position; values >= 15 travel in an exception list of `cap` slots.  Lossless.
+ * wire size = memo_transport_bytes(n, cap); pack and unpack are asynchronous on `stream`.
+ * memo_transport_exceptions() tells (synchronising `stream`) how many exceptions the sender found:
+ * more than cap means this slice has to travel as plain bytes instead. */
+size_t memo_transport_bytes(int64_t n, uint32_t cap);
+int memo_transport_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t cap, void *d_wire, int32_t device,
+                            void *stream);
+int memo_transport_unpack_dev(const void *d_wire, int64_t n, uint8_t *d_vec, int32_t device, void *stream);
+int memo_transport_exceptions(const void *d_wire, int32_t device, void *stream, uint32_t *found, uint32_t *cap);
+
+/* Second, denser coding for the same purpose (memo_transport.hip): 2 bits per position (values 1..3;
+ * 0 = escape) + one nibble per escape, allocated exactly per 32768 positions from a B region of
+ * `b_capacity` bytes (a multiple of 4), + the same exception list (nibble 15: values > 17).  Buffers
+ * 16-byte aligned.  _stats (synchronising `stream`) returns the exceptions found and their capacity,
+ * the B bytes taken and the B capacity: the slice is complete iff neither exceeds.  Pack once with
+ * generous capacities to learn what a workload needs (at most n / 2 + 4 * ceil(n / 32768) bytes of B). */
+size_t memo_transport_dense_bytes(int64_t n, uint32_t b_capacity, uint32_t cap);
+int memo_transport_dense_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t b_capacity, uint32_t cap,
+                                  void *d_wire, int32_t device, void *stream);
+int memo_transport_dense_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint32_t cap,
+                                    uint8_t *d_vec, int32_t device, void *stream);
+int memo_transport_dense_stats(const void *d_wire, int32_t device, void *stream, uint32_t *found, uint32_t *cap,
+                               uint32_t *b_taken, uint32_t *b_capacity);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEMO_AMD_TRANSPORT_H */

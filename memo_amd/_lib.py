@@ -1,4 +1,4 @@
-"""ctypes binding of the C ABI declared in include/memo_amd.h.
+"""ctypes binding of the C ABI declared in include/memo_amd.h, memo_amd_dap.h and memo_amd_transport.h.
 
 There is NO fallback: if libmemo_amd.so is missing or a HIP call fails, this raises.
 The CPU restatement under oracle/ is test infrastructure and is never imported here.
@@ -9,6 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MEMO_AMD_LIB") or os.path.join(_HERE, "libmemo_amd.so")   # override: A/B of builds
+# the product objects + the A/B switches of include/memo_amd_debug.h (tests, fuzzers, tools/ab.py)
+AB_SO_PATH = os.environ.get("MEMO_AMD_AB_LIB") or os.path.join(_HERE, "libmemo_amd_ab.so")
 
 MEMO_OK, MEMO_EINVAL, MEMO_EHIP, MEMO_ENOTREADY, MEMO_EUNSORTED, MEMO_ELONGROW = 0, -1, -2, -3, -4, -5
 
@@ -33,10 +35,11 @@ class IndexInfo(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("min_start", C.c_int64), ("max_start", C.c_int64),
                 ("device", C.c_int32), ("bucket_shift", C.c_int32), ("buckets", C.c_uint64),
                 ("was_sorted", C.c_int32), ("finalized", C.c_int32), ("device_bytes", C.c_uint64),
-                ("packed_format", C.c_int32), ("has_wide", C.c_int32)]
+                ("packed_format", C.c_int32), ("has_wide", C.c_int32), ("pack_ms", C.c_float),
+                ("reserved", C.c_int32)]
 
 
-# every symbol include/memo_amd.h declares: name -> (restype, argtypes)
+# every symbol the product headers declare: name -> (restype, argtypes)
 _P, _I32, _I64, _U64, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
 SYMBOLS = {
     "memo_last_error": (C.c_char_p, []),
@@ -81,12 +84,13 @@ SYMBOLS = {
     "memo_transport_dense_stats": (C.c_int, [_P, _I32, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "memo_synth_fill": (C.c_int, [_P, _U64, _U64, _U64, _I32, _U64]),
-    "memo_debug_set_stamp_buffer": (C.c_int, [_P]),
+}
+
+# include/memo_amd_debug.h: exported by libmemo_amd_ab.so only
+DEBUG_SYMBOLS = {
+    "memo_debug_set_tuning": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32]),
     "memo_debug_stream_rows": (C.c_int, [_P, _P]),
-    "memo_set_persistent": (C.c_int, [_I32]),
-    "memo_set_scatter": (C.c_int, [_I32]),
-    "memo_set_row_source": (C.c_int, [_I32]),
-    "memo_set_tuning": (C.c_int, [_I32, _I32, _I32]),
+    "memo_debug_set_stamp_buffer": (C.c_int, [_P]),
 }
 
 
@@ -100,10 +104,37 @@ def build(force=False):
 
 
 _lib = None
+_product = None
+_ab = None
+
+
+def _bind(path, symbols):
+    L = C.CDLL(path)
+    for name, (res, args) in symbols.items():
+        f = getattr(L, name)        # AttributeError if the library does not export it
+        f.restype = res
+        f.argtypes = args
+    return L
+
+
+def use_ab(on=True):
+    """Make lib() hand out libmemo_amd_ab.so (product objects + the A/B switches) instead of the
+    product library -- for tests and tools that set kernel shapes.  Returns the library now in use."""
+    global _lib, _ab
+    lib()
+    if on:
+        if _ab is None:
+            if not os.path.exists(AB_SO_PATH):
+                build()
+            _ab = _bind(AB_SO_PATH, {**SYMBOLS, **DEBUG_SYMBOLS})
+        _lib = _ab
+    else:
+        _lib = _product
+    return _lib
 
 
 def lib():
-    global _lib
+    global _lib, _product
     if _lib is None:
         if not os.path.exists(SO_PATH) and not os.environ.get("MEMO_AMD_LIB"):
             try:                                  # compile the real thing; never substitute for it
@@ -113,12 +144,7 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise ImportError(f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                               "g.build()'` or `make -C memo_amd/csrc` -- there is no CPU fallback")
-        L = C.CDLL(SO_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            f = getattr(L, name)        # AttributeError if the library does not export it
-            f.restype = res
-            f.argtypes = args
-        _lib = L
+        _product = _lib = _bind(SO_PATH, SYMBOLS)
     return _lib
 
 

@@ -11,6 +11,8 @@
 #include <cstring>
 
 #include "memo_amd.h"
+#include "memo_amd_dap.h"
+#include "memo_amd_transport.h"
 
 namespace memo {
 
@@ -48,9 +50,22 @@ constexpr int kStatusHugeSlice = 2;           // sticky device flag: >= 2^32 row
                               __FILE__, __LINE__);                                             \
     } while (0)
 
+// Kernel-shape choices of one index.  All zero in the product (= the library chooses per query);
+// only libmemo_amd_ab.so (memo_debug.hip, include/memo_amd_debug.h) can set them, for A/B timing and
+// for the tests that walk every tile shape.  Per index, so two threads on two indexes never share
+// mutable state.  Results never depend on these.
+struct memo_tuning {
+    int tile_w = 0;      // positions per tile (256..4096); unclipped kernels: cells per level array
+    int waves = 0;       // waves per tile: 1, 4 (8: unclipped conservation only)
+    int memb_algo = 0;   // membership: 2 = doubling, 3 = runs, 4 = planes
+    int force_wide = 0;  // 1 = read the int64 columns even when packed rows exist
+    int scatter = 0;     // conservation, packed rows: 1 = clipped, 2 = unclipped + halo
+};
+
 // one chromosome's rows, resident in HBM (the opaque memo_index_t of the ABI)
 struct memo_index {
     int device = 0;
+    memo_tuning tune;
     uint64_t rows = 0;
     uint64_t padded = 0;
     int64_t *s = nullptr, *e = nullptr, *o = nullptr;
@@ -64,6 +79,8 @@ struct memo_index {
     uint32_t *pk = nullptr;
     uint16_t *pa = nullptr;    // format 6 only: 16-bit annot per row (the word's top byte is 0)
     int packed_fmt = 0;        // 0 = none, 4 = word only (annot <= 255), 6 = word + 16-bit annot
+    uint64_t packed_rows = 0;  // rows the pk (pa) allocation holds (reused by the next memo_index_pack)
+    float pack_ms = 0.f;       // device time of the last memo_index_pack (census + packing kernel)
     uint64_t max_annot = 0;    // largest annot of the packed rows
     int has_wide = 1;          // the three int64 columns are still resident
     // rows with end < start (never written by the reference's index builder, but legal input to

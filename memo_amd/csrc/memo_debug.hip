@@ -1,0 +1,71 @@
+// memo_debug.hip -- A/B switches and profiling aids (include/memo_amd_debug.h).  Linked only into
+// libmemo_amd_ab.so, which is the product library plus this file: the tests that walk every tile
+// shape, tests/fuzz_gpu.py, tools/ab.py and the PMC calibration pass load that one.  The product
+// library exports none of this and its kernel-shape choices cannot be changed from outside.
+#include "memo_amd_debug.h"
+#include "memo_sweep.h"
+
+using namespace memo;
+
+namespace {
+
+// PMC calibration: reads every row of the three columns exactly once with the sweep's own
+// access shape (16 B per lane, 1 KiB per wave-instruction) and nothing else, so that
+// FETCH_SIZE can be checked against a known byte count (24 B x padded rows) in the same run.
+__global__ void stream_rows_kernel(const int64_t *s, const int64_t *e, const int64_t *o,
+                                   uint64_t rows, unsigned long long *sink) {
+    long long acc = 0;
+    for (uint64_t i = 2 * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x); i < rows;
+         i += 2 * (uint64_t)gridDim.x * blockDim.x) {
+        const longlong2 a = *reinterpret_cast<const longlong2 *>(s + i);
+        const longlong2 b = *reinterpret_cast<const longlong2 *>(e + i);
+        const longlong2 c = *reinterpret_cast<const longlong2 *>(o + i);
+        acc += a.x ^ a.y ^ b.x ^ b.y ^ c.x ^ c.y;
+    }
+    if (acc == 0x7fffffffffffffffll) atomicAdd(sink, 1ull);  // keeps the loads alive
+}
+
+}  // namespace
+
+extern "C" {
+
+int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32_t membership_algo,
+                          int32_t row_source, int32_t scatter) {
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (tile_w != 0 && tile_w != 256 && tile_w != 512 && tile_w != 1024 && tile_w != 2048 && tile_w != 4096)
+        return fail(MEMO_EINVAL, "tile_w must be 0, 256, 512, 1024, 2048 or 4096");
+    if (waves != 0 && waves != 1 && waves != 4 && waves != 8) return fail(MEMO_EINVAL, "waves must be 0, 1, 4 or 8");
+    if (membership_algo != 0 && (membership_algo < 2 || membership_algo > 4))
+        return fail(MEMO_EINVAL, "membership_algo must be 0 (choose), 2 (doubling), 3 (runs) or 4 (planes)");
+    if (row_source != 0 && row_source != 1) return fail(MEMO_EINVAL, "row_source must be 0 (packed when present) or 1 (int64 columns)");
+    if (scatter < 0 || scatter > 2) return fail(MEMO_EINVAL, "scatter must be 0 (choose), 1 (clipped) or 2 (unclipped)");
+    ix->tune.tile_w = tile_w;
+    ix->tune.waves = waves;
+    ix->tune.memb_algo = membership_algo;
+    ix->tune.force_wide = row_source;
+    ix->tune.scatter = scatter;
+    return MEMO_OK;
+}
+
+int memo_debug_stream_rows(memo_index_t *ix, void *stream) {
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns were dropped");
+    DeviceGuard guard(ix->device);
+    hipLaunchKernelGGL(stream_rows_kernel, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       ix->s, ix->e, ix->o, ix->rows & ~(uint64_t)1,
+                       reinterpret_cast<unsigned long long *>(ix->d_scratch));
+    HIP_TRY(hipGetLastError());
+    return MEMO_OK;
+}
+
+int memo_debug_set_stamp_buffer(uint64_t *d_buffer) {
+#ifdef MEMO_STAMPS
+    g_stamp_buffer = reinterpret_cast<unsigned long long *>(d_buffer);
+    return MEMO_OK;
+#else
+    (void)d_buffer;
+    return fail(MEMO_EINVAL, "this build carries no phase stamps (compile with EXTRA=-DMEMO_STAMPS)");
+#endif
+}
+
+}  // extern "C"

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "memo_amd.h"
+#include "memo_amd_dap.h"
 
 // ---- print_res (memo_query.py:65-71) -----------------------------------------------------
 // Host-side formatters, split over threads: the text of config 3 is ~290 MB (conservation) and

@@ -10,7 +10,7 @@
 
 using namespace memo;
 
-extern "C" int memo_sort_rows_by_start(int64_t *s, int64_t *e, int64_t *o, uint64_t rows,
+extern "C" __attribute__((visibility("hidden"))) int memo_sort_rows_by_start(int64_t *s, int64_t *e, int64_t *o, uint64_t rows,
                                        uint64_t padded_rows, hipStream_t stream, char *err,
                                        size_t errcap);
 
@@ -220,22 +220,6 @@ __global__ void nibble_exceptions_kernel(const unsigned long long *exc, const un
     }
 }
 
-// PMC calibration: reads every row of the three columns exactly once with the sweep's own
-// access shape (16 B per lane, 1 KiB per wave-instruction) and nothing else, so that
-// FETCH_SIZE can be checked against a known byte count (24 B x padded rows) in the same run.
-__global__ void stream_rows_kernel(const int64_t *s, const int64_t *e, const int64_t *o,
-                                   uint64_t rows, unsigned long long *sink) {
-    long long acc = 0;
-    for (uint64_t i = 2 * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x); i < rows;
-         i += 2 * (uint64_t)gridDim.x * blockDim.x) {
-        const longlong2 a = *reinterpret_cast<const longlong2 *>(s + i);
-        const longlong2 b = *reinterpret_cast<const longlong2 *>(e + i);
-        const longlong2 c = *reinterpret_cast<const longlong2 *>(o + i);
-        acc += a.x ^ a.y ^ b.x ^ b.y ^ c.x ^ c.y;
-    }
-    if (acc == 0x7fffffffffffffffll) atomicAdd(sink, 1ull);  // keeps the loads alive
-}
-
 __device__ __forceinline__ uint64_t mix64(uint64_t seed, uint64_t x) {
     uint64_t z = seed + (x + 1) * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -276,7 +260,12 @@ static void drop_packed(memo_index *ix) {  // the rows are about to change
     ix->pk = nullptr;
     ix->pa = nullptr;
     ix->packed_fmt = 0;
+    ix->packed_rows = 0;
 }
+
+// the rows are about to change but the index keeps its size: the packed copy is stale, its buffers
+// can serve the next memo_index_pack
+static void stale_packed(memo_index *ix) { ix->packed_fmt = 0; }
 
 int memo_index_create(uint64_t rows, int32_t device, memo_index_t **out) {
     if (!out) return fail(MEMO_EINVAL, "out is NULL");
@@ -397,7 +386,7 @@ int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_so
     DeviceGuard guard(ix->device);
     hipStream_t st = nullptr;
     const uint64_t rows = ix->rows;
-    drop_packed(ix);  // a device sort below would leave packed rows stale; pack again after finalize
+    stale_packed(ix);  // a device sort below would leave packed rows stale; pack again after finalize
     ix->finalized = 0;
     {
         const uint64_t npad = ix->padded - rows;
@@ -474,8 +463,27 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
     if (ix->rows && ix->min_s < 0) return fail(MEMO_EINVAL, "rows with a negative start cannot be packed");
     DeviceGuard guard(ix->device);
     hipStream_t st = nullptr;
-    drop_packed(ix);
+    // the pass is timed on the device (info.pack_ms): SURVEY.md 8(d) wants the narrowing pass reported
+    // apart from the query.  Event pair around the census and the packing kernel; allocation is outside.
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    HIP_TRY(hipEventCreate(&ev0));
+    if (hipEventCreate(&ev1) != hipSuccess) {
+        (void)hipEventDestroy(ev0);
+        return fail(MEMO_EHIP, "hipEventCreate failed");
+    }
+    struct Events {
+        hipEvent_t a, b;
+        ~Events() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    } events{ev0, ev1};
+    // a packed copy of the same size is reused (packing again after a re-finalize, or to time the pass)
+    const bool had = ix->pk && ix->packed_rows == ix->padded;
+    const bool had_pa = had && ix->pa;
+    if (!had) drop_packed(ix);
+    ix->packed_fmt = 0;
+    if (!ix->pk) HIP_TRY(hipMalloc(&ix->pk, ix->padded * sizeof(uint32_t)));
+    ix->packed_rows = ix->padded;
     uint64_t h[8] = {0};
+    HIP_TRY(hipEventRecord(ev0, st));
     if (ix->rows) {
         HIP_TRY(hipMemsetAsync(ix->d_scratch, 0, 64, st));
         const unsigned grid = (unsigned)(ix->rows / 256 + 1 < 4096 ? ix->rows / 256 + 1 : 4096);
@@ -488,12 +496,19 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
     }
     const int fmt = h[4] ? 6 : 4;
     ix->max_annot = h[5];
-    HIP_TRY(hipMalloc(&ix->pk, ix->padded * sizeof(uint32_t)));
-    if (fmt == 6) HIP_TRY(hipMalloc(&ix->pa, ix->padded * sizeof(uint16_t)));
+    if (fmt == 6 && !ix->pa) HIP_TRY(hipMalloc(&ix->pa, ix->padded * sizeof(uint16_t)));
+    if (fmt == 4 && had_pa) {
+        (void)hipFree(ix->pa);
+        ix->pa = nullptr;
+    }
     hipLaunchKernelGGL(pack_rows_kernel, dim3(4096), dim3(256), 0, st, ix->s, ix->e, ix->o, ix->rows,
-                       ix->padded, ix->pk, ix->pa);
+                       ix->padded, ix->pk, fmt == 6 ? ix->pa : nullptr);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    ix->pack_ms = ms;
     ix->packed_fmt = fmt;
     if (!keep_wide) {
         (void)hipFree(ix->s);
@@ -517,6 +532,7 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     info->finalized = ix->finalized;
     info->packed_format = ix->packed_fmt;
     info->has_wide = ix->has_wide;
+    info->pack_ms = ix->pack_ms;
     info->device_bytes = (ix->has_wide ? ix->padded * 3 * sizeof(int64_t) : 0) + ix->nb * sizeof(int64_t) + 128 +
                          (ix->pk ? ix->padded * 4 : 0) + (ix->pa ? ix->padded * 2 : 0);
     return MEMO_OK;
@@ -599,12 +615,29 @@ int memo_bin_conservation_dev(const uint16_t *d_vec, int64_t L, const int64_t *e
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ncols = num_docs + 1;
     const size_t cbytes = (size_t)nbins * ncols * sizeof(uint64_t);
-    int64_t *d_edges = nullptr;
-    unsigned long long *d_counts = nullptr;
-    int rc = MEMO_OK;
-    hipError_t err = hipMalloc(&d_edges, (size_t)(nbins + 1) * sizeof(int64_t));
-    if (err == hipSuccess) err = hipMalloc(&d_counts, cbytes);
-    if (err == hipSuccess) err = hipMemcpyAsync(d_edges, edges, (size_t)(nbins + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);
+    const size_t ebytes = ((size_t)(nbins + 1) * sizeof(int64_t) + 15) & ~(size_t)15;
+    // edges + counts live in one scratch buffer per (thread, device) that only ever grows: `memo view`
+    // bins the same vector at several resolutions, and a hipMalloc / hipFree pair per call costs more
+    // than the histogram
+    struct Scratch {
+        char *p = nullptr;
+        size_t cap = 0;
+        int dev = -1;  // (never freed at thread exit: the HIP runtime may be gone by then)
+    };
+    thread_local Scratch scratch;
+    if (scratch.dev != device || scratch.cap < ebytes + cbytes) {
+        if (scratch.p) (void)hipFree(scratch.p);
+        scratch.p = nullptr;
+        scratch.cap = 0;
+        const size_t want = ebytes + cbytes < (1u << 20) ? (1u << 20) : ebytes + cbytes;
+        hipError_t err = hipMalloc(&scratch.p, want);
+        if (err != hipSuccess) return fail(MEMO_EHIP, "hipMalloc(%zu): %s", want, hipGetErrorString(err));
+        scratch.cap = want;
+        scratch.dev = device;
+    }
+    int64_t *d_edges = reinterpret_cast<int64_t *>(scratch.p);
+    unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(scratch.p + ebytes);
+    hipError_t err = hipMemcpyAsync(d_edges, edges, (size_t)(nbins + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st);
     if (err == hipSuccess) err = hipMemsetAsync(d_counts, 0, cbytes, st);
     if (err == hipSuccess) {
         // enough workgroups to fill the chip, at least one per bin
@@ -621,10 +654,8 @@ int memo_bin_conservation_dev(const uint16_t *d_vec, int64_t L, const int64_t *e
     }
     if (err == hipSuccess) err = hipMemcpyAsync(counts, d_counts, cbytes, hipMemcpyDeviceToHost, st);
     if (err == hipSuccess) err = hipStreamSynchronize(st);
-    if (err != hipSuccess) rc = fail(MEMO_EHIP, "binning failed: %s", hipGetErrorString(err));
-    (void)hipFree(d_edges);
-    (void)hipFree(d_counts);
-    return rc;
+    if (err != hipSuccess) return fail(MEMO_EHIP, "binning failed: %s", hipGetErrorString(err));
+    return MEMO_OK;
 }
 
 // wire layout: [count u32, cap u32, 8 B pad][nibbles: 4 * ceil(n / 8) B][exceptions: cap * 8 B]
@@ -682,17 +713,6 @@ int memo_transport_exceptions(const void *d_wire, int32_t device, void *stream, 
     HIP_TRY(hipStreamSynchronize(st));
     *found = head[0];
     *cap = head[1];
-    return MEMO_OK;
-}
-
-int memo_debug_stream_rows(memo_index_t *ix, void *stream) {
-    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
-    if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns were dropped");
-    DeviceGuard guard(ix->device);
-    hipLaunchKernelGGL(stream_rows_kernel, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       ix->s, ix->e, ix->o, ix->rows & ~(uint64_t)1,
-                       reinterpret_cast<unsigned long long *>(ix->d_scratch));
-    HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }
 

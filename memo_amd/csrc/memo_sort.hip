@@ -42,7 +42,7 @@ __global__ void gather_kernel(const int64_t *src, const uint64_t *perm, int64_t 
 
 }  // namespace
 
-extern "C" int memo_sort_rows_by_start(int64_t *s, int64_t *e, int64_t *o, uint64_t rows,
+extern "C" __attribute__((visibility("hidden"))) int memo_sort_rows_by_start(int64_t *s, int64_t *e, int64_t *o, uint64_t rows,
                                        uint64_t padded_rows, hipStream_t stream, char *err,
                                        size_t errcap) {
     (void)padded_rows;

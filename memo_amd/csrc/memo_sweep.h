@@ -20,7 +20,6 @@ struct SweepArgs {
     int64_t tile0;          // pivot position of tile 0 (multiple of the tile width, <= qs)
     int64_t ntiles;
     int64_t tiles_per_xcd;  // ceil(ntiles / 8)
-    int64_t blocks_per_xcd; // workgroups per XCD group; < tiles_per_xcd when workgroups are persistent
     void *out;
     int *status;
     int bshift;
@@ -56,12 +55,11 @@ struct SweepArgs {
 // group), so give each group one contiguous run of tiles: neighbouring tiles share their
 // k-1 halo rows and the cache lines that straddle the tile boundary, and those then hit in
 // that XCD's L2 instead of being fetched twice.  Speed only -- results do not depend on it.
-// A persistent workgroup (blocks_per_xcd < tiles_per_xcd) walks its XCD group's run with stride
-// blocks_per_xcd: `it` is its iteration.  Returns -1 past the end of the run.
-__device__ __forceinline__ int64_t tile_of_block(const SweepArgs &A, int it) {
+// (One workgroup per tile.  Persistent workgroups walking a run of tiles measured 7-20 % slower on
+// every workload, profiles/r01_persistent_ab.txt, and are gone.)
+__device__ __forceinline__ int64_t tile_of_block(const SweepArgs &A) {
     const int64_t b = blockIdx.x;
-    const int64_t j = (b >> 3) + (int64_t)it * A.blocks_per_xcd;
-    return j < A.tiles_per_xcd ? (b & 7) * A.tiles_per_xcd + j : -1;
+    return (b & 7) * A.tiles_per_xcd + (b >> 3);
 }
 
 // Row slice [r0, r1) that can touch positions [lo_abs, hi_abs) of a tile starting at a:
@@ -104,9 +102,9 @@ struct Tile {
     uint64_t r0, r1;  // row slice
 };
 
-__device__ __forceinline__ bool locate_tile_w(const SweepArgs &A, Tile &t, int it, int W) {
-    const int64_t tile = tile_of_block(A, it);
-    if (tile < 0 || tile >= A.ntiles) return false;
+__device__ __forceinline__ bool locate_tile_w(const SweepArgs &A, Tile &t, int W) {
+    const int64_t tile = tile_of_block(A);
+    if (tile >= A.ntiles) return false;
     t.a = A.tile0 + tile * W;
     t.x_lo = (int)(A.qs > t.a ? A.qs - t.a : 0);
     t.x_hi = (int)(A.qe - t.a < W ? A.qe - t.a : W);
@@ -119,8 +117,8 @@ __device__ __forceinline__ bool locate_tile_w(const SweepArgs &A, Tile &t, int i
 }
 
 template <int W>
-__device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t, int it) {
-    return locate_tile_w(A, t, it, W);
+__device__ __forceinline__ bool locate_tile(const SweepArgs &A, Tile &t) {
+    return locate_tile_w(A, t, W);
 }
 
 // Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() would
@@ -369,23 +367,17 @@ __device__ __forceinline__ uint32_t full_word(int ncols, int w) {  // genomes 32
 
 
 // ------------------------------------------------------------------------------------------
-// launch plumbing and tuning state (defined in memo_sweep.hip)
+// launch plumbing (defined in memo_sweep.hip).  Kernel-shape choices come from ix->tune (all zero in
+// the product: the library chooses per query).
 // ------------------------------------------------------------------------------------------
-extern int g_tile_w;      // 0 = choose per query
-extern int g_waves;       // waves per tile: 0 = choose, 1 or 4
-extern int g_memb_algo;   // membership: 0 = choose, 1 = direct scatter, 2 = doubling, 3 = runs
-extern int g_force_wide;  // 1 = read the int64 columns even when packed rows exist
-extern int g_persist;     // 0 = choose, 1 = one workgroup per tile, 2 = persistent workgroups
-extern int g_scatter;     // conservation, packed rows: 0 = choose, 1 = clipped, 2 = unclipped + halo
-extern unsigned long long *g_stamp_buffer;  // -DMEMO_STAMPS builds: 8 words per workgroup
+#ifdef MEMO_STAMPS
+extern unsigned long long *g_stamp_buffer;  // diagnostic builds: 8 words per workgroup
+#endif
 
 using SweepKernel = void (*)(const SweepArgs);
 
-void read_env_once();
-bool use_persistent(int fmt);
 inline int floor_log2(uint32_t v) { return 31 - __builtin_clz(v); }
-int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st,
-                 int run);  // run: tiles per workgroup; 0 = persistent workgroups
+int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st);
 int pick_rows(const memo_index *ix, int32_t k, int &fmt);
 int check_query_args(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
                      const void *d_out);

@@ -32,42 +32,18 @@
 
 namespace memo {
 
-int g_tile_w = 0;     // 0 = choose per query
-int g_waves = 0;      // waves per tile: 0 = choose, 1 or 4
-int g_memb_algo = 0;  // membership: 0 = choose, 1 = direct scatter, 2 = doubling
-int g_force_wide = 0; // 1 = read the int64 columns even when packed rows exist
-unsigned long long *g_stamp_buffer = nullptr;  // -DMEMO_STAMPS builds: 8 words per workgroup
-int g_persist = 0;    // 0 = choose, 1 = one workgroup per tile, 2 = persistent workgroups
-int g_scatter = 0;    // conservation, packed rows: 0 = choose, 1 = clipped, 2 = unclipped + halo
-
-// Persistent workgroups measured 7-20 % SLOWER on every workload (profiles/r01_persistent_ab.txt):
-// resident workgroups that start together stay in step -- every CU loads, then every CU folds --
-// whereas one workgroup per tile staggers them as earlier ones retire, which is what overlaps the
-// memory phase of one tile with the LDS phase of another.  Kept as an A/B switch only.
-bool use_persistent(int /*fmt*/) { return g_persist == 2; }
-static bool g_env_read = false;
-
-void read_env_once() {
-    if (g_env_read) return;
-    g_env_read = true;
-    if (const char *v = getenv("MEMO_TILE_W")) g_tile_w = atoi(v);
-    if (const char *v = getenv("MEMO_WAVES")) g_waves = atoi(v);
-    if (const char *v = getenv("MEMO_MEMB_ALGO")) g_memb_algo = atoi(v);
-    if (const char *v = getenv("MEMO_ROWS")) g_force_wide = strcmp(v, "wide") == 0;
-    if (const char *v = getenv("MEMO_PERSIST")) g_persist = atoi(v);
-    if (const char *v = getenv("MEMO_SCATTER")) g_scatter = atoi(v);
-}
+#ifdef MEMO_STAMPS
+unsigned long long *g_stamp_buffer = nullptr;  // diagnostic builds: 8 words per workgroup
+#endif
 
 // tiles are aligned in pivot coordinates: tile 0 starts at floor(qs / w) * w  (w: any multiple of
-// the bucket width).  run = tiles per workgroup: 1, or 0 = persistent: only as many workgroups as
-// the device keeps resident, each walking its XCD group's run of tiles with that stride.
-int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st, int run) {
+// the bucket width).  One workgroup per tile.
+int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st) {
     int64_t q = A.qs / w;
     if (A.qs % w < 0) --q;  // floor
     A.tile0 = q * w;
     A.ntiles = ((A.qe - A.tile0) + w - 1) / w;
     A.tiles_per_xcd = (A.ntiles + 7) / 8;
-    A.blocks_per_xcd = A.tiles_per_xcd;
     if (lds > 160 * 1024) return fail(MEMO_EINVAL, "tile needs %zu bytes of LDS (> 160 KiB)", lds);
     if (lds > 64 * 1024) {  // opt in to large dynamic LDS once per (thread, device, kernel, size)
         thread_local std::map<std::pair<const void *, int>, size_t> granted;
@@ -80,27 +56,17 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
             have = lds;
         }
     }
-    if (run == 0) {
-        int per_cu = 0, cus = 0, dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel),
-                                                             threads, lds));
-        const int64_t resident = ((int64_t)cus * (per_cu > 0 ? per_cu : 1) + 7) / 8;  // per XCD group
-        if (resident < A.blocks_per_xcd) A.blocks_per_xcd = resident;
-    }
-    if (A.blocks_per_xcd * 8 * threads >= ((int64_t)1 << 32))
+    if (A.tiles_per_xcd * 8 * threads >= ((int64_t)1 << 32))
         return fail(MEMO_EINVAL, "window too long for one launch at tile width %d", w);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)(A.blocks_per_xcd * 8)), dim3(threads), lds, st, A);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(threads), lds, st, A);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }
 
-// which row source a query reads: packed when the index has it and k - 1 <= 255 (MEMO_ROWS=wide
-// forces the int64 columns), else the int64 columns
+// which row source a query reads: packed when the index has it and k - 1 <= 255, else the int64 columns
 int pick_rows(const memo_index *ix, int32_t k, int &fmt) {
     fmt = 0;
-    if (ix->packed_fmt && k - 1 <= 255 && !(g_force_wide && ix->has_wide)) fmt = ix->packed_fmt;
+    if (ix->packed_fmt && k - 1 <= 255 && !(ix->tune.force_wide && ix->has_wide)) fmt = ix->packed_fmt;
     if (!fmt && !ix->has_wide)
         return fail(MEMO_EINVAL, "k = %d needs the int64 columns, which this index dropped when it was packed", k);
     return MEMO_OK;
@@ -135,7 +101,11 @@ void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32
     A.qe = qe;
     A.out = d_out;
     A.status = ix->d_status;
+#ifdef MEMO_STAMPS
     A.stamps = g_stamp_buffer;
+#else
+    A.stamps = nullptr;
+#endif
     A.bshift = ix->bshift;
     A.km1 = k - 1;
 }
@@ -146,45 +116,6 @@ void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32
 using namespace memo;
 
 extern "C" {
-
-int memo_debug_set_stamp_buffer(uint64_t *d_buffer) {
-    g_stamp_buffer = reinterpret_cast<unsigned long long *>(d_buffer);
-    return MEMO_OK;
-}
-
-int memo_set_persistent(int32_t mode) {
-    read_env_once();
-    if (mode < 0 || mode > 2) return fail(MEMO_EINVAL, "mode must be 0 (choose), 1 (off) or 2 (on)");
-    g_persist = mode;
-    return MEMO_OK;
-}
-
-int memo_set_scatter(int32_t mode) {
-    read_env_once();
-    if (mode < 0 || mode > 2) return fail(MEMO_EINVAL, "mode must be 0 (choose), 1 (clipped) or 2 (unclipped)");
-    g_scatter = mode;
-    return MEMO_OK;
-}
-
-int memo_set_row_source(int32_t source) {
-    read_env_once();
-    if (source != 0 && source != 1) return fail(MEMO_EINVAL, "source must be 0 (packed when present) or 1 (int64 columns)");
-    g_force_wide = source;
-    return MEMO_OK;
-}
-
-int memo_set_tuning(int32_t tile_w, int32_t waves, int32_t membership_algo) {
-    read_env_once();
-    if (tile_w != 0 && tile_w != 256 && tile_w != 512 && tile_w != 1024 && tile_w != 2048 &&
-        tile_w != 4096)
-        return fail(MEMO_EINVAL, "tile_w must be 0, 256, 512, 1024, 2048 or 4096");
-    if (waves != 0 && waves != 1 && waves != 4 && waves != 8) return fail(MEMO_EINVAL, "waves must be 0, 1, 4 or 8");
-    if (membership_algo < 0 || membership_algo > 4) return fail(MEMO_EINVAL, "membership_algo must be 0..4");
-    g_tile_w = tile_w;
-    g_waves = waves;
-    g_memb_algo = membership_algo;
-    return MEMO_OK;
-}
 
 int memo_query_check(memo_index_t *ix, void *stream) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");

@@ -19,12 +19,7 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
 #ifdef MEMO_STAMPS
     unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    bool have = locate_tile<W>(A, t, 0);
-    for (int it = 0; have; ++it) {
-    // a persistent workgroup looks its next tile up now: the two bucket-table loads (2-4k cycles
-    // when HBM is busy) then return under this tile's work instead of in front of the next one's
-    Tile t_next;
-    const bool have_next = locate_tile<W>(A, t_next, it + 1);
+    if (!locate_tile<W>(A, t)) return;
     MEMO_STAMP(0);  // tile location (kernarg + two bucket-table loads)
 
     // the clipped interval [c, h) is the union of two blocks of 2^j, j = floor(log2(h - c))
@@ -83,12 +78,8 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
     store_conservation<OutT, T>(A, t, lds, A.nlev > 1 ? lds + LS : nullptr, 0);  // as uint16 or (num_docs <= 255) uint8
     MEMO_STAMP(5);  // store
 #ifdef MEMO_STAMPS
-    if (threadIdx.x == 0 && A.stamps && it == 0) A.stamps[8ull * blockIdx.x + 7] = 1;
+    if (threadIdx.x == 0 && A.stamps) A.stamps[8ull * blockIdx.x + 7] = 1;
 #endif
-    if (have_next) __syncthreads();  // the LDS tile is reused
-    t = t_next;
-    have = have_next;
-    }
 }
 
 
@@ -121,7 +112,7 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
 #ifdef MEMO_STAMPS
     unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (!locate_tile_w(A, t, 0, W)) return;
+    if (!locate_tile_w(A, t, W)) return;
     MEMO_STAMP(0);  // tile location (kernarg + two bucket-table loads)
     uint4 V[U];
     uint2 N[U];
@@ -240,23 +231,36 @@ __global__ void fill_conservation_kernel(OutT *out, int64_t n, OutT v) {
 // One workgroup per row with end < start: its interval [clip(e-qs-(k-1)), clip(s-qs)) can be any
 // length, so it is applied straight to the result in HBM, after the sweep, with atomics (rows may
 // overlap each other).  filter_pq keeps such a row iff qs < start < qe + k (memo_query.py:25-27).
+// The result has no 8- or 16-bit atomics, so a value is min-ed by a CAS on its 32-bit word; the word
+// that holds the last L % (4 / sizeof(OutT)) values would reach past the caller's buffer, so those
+// (at most 3) positions are left to long_rows_tail_kernel.
+template <typename OutT>
+__device__ __forceinline__ bool long_row_interval(int64_t s, int64_t e, int64_t o, int64_t qs, int64_t qe, int km1,
+                                                  int ncols, int *status, int64_t &c, int64_t &hi, int64_t &cc) {
+    if (!(s > qs && s < qe + km1 + 1)) return false;
+    const int64_t L = qe - qs;
+    hi = s - qs > L ? L : s - qs;
+    c = e - qs - km1;
+    c = c < 0 ? 0 : c;
+    if (c >= hi) return false;
+    cc = o < 0 ? o + ncols : o;
+    if ((uint64_t)cc >= (uint64_t)ncols) {
+        if (threadIdx.x == 0) atomicOr(status, kStatusBadAnnot);
+        return false;
+    }
+    return true;
+}
+
 template <typename OutT>
 __global__ void long_rows_conservation_kernel(const int64_t *ls, const int64_t *le, const int64_t *lo,
                                               int64_t qs, int64_t qe, int km1, int ncols, OutT *out,
                                               int *status) {
-    const int64_t s = ls[blockIdx.x], e = le[blockIdx.x], o = lo[blockIdx.x];
-    if (!(s > qs && s < qe + km1 + 1)) return;
-    const int64_t L = qe - qs;
-    const int64_t hi = s - qs > L ? L : s - qs;
-    int64_t c = e - qs - km1;
-    c = c < 0 ? 0 : c;
-    if (c >= hi) return;
-    const int64_t cc = o < 0 ? o + ncols : o;
-    if ((uint64_t)cc >= (uint64_t)ncols) {
-        if (threadIdx.x == 0) atomicOr(status, kStatusBadAnnot);
+    int64_t c, hi, cc;
+    if (!long_row_interval<OutT>(ls[blockIdx.x], le[blockIdx.x], lo[blockIdx.x], qs, qe, km1, ncols, status, c, hi, cc))
         return;
-    }
     constexpr int PER = 4 / (int)sizeof(OutT);  // results per 32-bit word
+    const int64_t whole = (qe - qs) / PER * PER;  // positions whose word lies inside the buffer
+    if (hi > whole) hi = whole;
     uint32_t *words = reinterpret_cast<uint32_t *>(out);
     for (int64_t p = c + threadIdx.x; p < hi; p += blockDim.x) {
         uint32_t *wp = words + p / PER;
@@ -269,6 +273,34 @@ __global__ void long_rows_conservation_kernel(const int64_t *ls, const int64_t *
             old = seen;
         }
     }
+}
+
+// the last L % PER positions: one workgroup reduces, per position, the smallest column over ALL rows
+// with end < start and stores it with a plain element store (nothing else writes there any more)
+template <typename OutT>
+__global__ __launch_bounds__(256) void long_rows_tail_kernel(const int64_t *ls, const int64_t *le, const int64_t *lo,
+                                                             uint64_t n_long, int64_t qs, int64_t qe, int km1,
+                                                             int ncols, OutT *out, int *status) {
+    constexpr int PER = 4 / (int)sizeof(OutT);
+    const int64_t L = qe - qs, whole = L / PER * PER;
+    __shared__ uint32_t best[4];
+    if (threadIdx.x < 4) best[threadIdx.x] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint64_t r = threadIdx.x; r < n_long; r += 256) {
+        int64_t c, hi, cc;
+        // (the bad-annot flag is raised by thread 0 of the main kernel's workgroup for this row)
+        const int64_t s = ls[r], e = le[r], o = lo[r];
+        if (!(s > qs && s < qe + km1 + 1)) continue;
+        hi = s - qs > L ? L : s - qs;
+        c = e - qs - km1;
+        c = c < 0 ? 0 : c;
+        cc = o < 0 ? o + ncols : o;
+        if (c >= hi || (uint64_t)cc >= (uint64_t)ncols) continue;
+        for (int64_t p = whole > c ? whole : c; p < hi; ++p) atomicMin(&best[p - whole], (uint32_t)cc);
+    }
+    __syncthreads();
+    if (threadIdx.x < L - whole && best[threadIdx.x] < (uint32_t)out[whole + threadIdx.x])
+        out[whole + threadIdx.x] = (OutT)best[threadIdx.x];
 }
 
 template <typename Rows, typename OutT>
@@ -308,6 +340,9 @@ static int long_rows_conservation(const memo_index *ix, int64_t qs, int64_t qe, 
     if (!ix->n_long) return MEMO_OK;
     hipLaunchKernelGGL((long_rows_conservation_kernel<OutT>), dim3((unsigned)ix->n_long), dim3(256), 0, st,
                        ix->ls, ix->le, ix->lo, qs, qe, k - 1, ncols, d_out, ix->d_status);
+    if ((qe - qs) % (4 / (int)sizeof(OutT)))
+        hipLaunchKernelGGL((long_rows_tail_kernel<OutT>), dim3(1), dim3(256), 0, st, ix->ls, ix->le, ix->lo,
+                           (uint64_t)ix->n_long, qs, qe, k - 1, ncols, d_out, ix->d_status);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }
@@ -315,7 +350,6 @@ static int long_rows_conservation(const memo_index *ix, int64_t qs, int64_t qe, 
 template <typename OutT>
 static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
                               OutT *d_out, void *stream) {
-    read_env_once();
     int rc = check_query_args(ix, qs, qe, k, num_docs, d_out);
     if (rc) return rc;
     if (sizeof(OutT) == 1 && num_docs > 255)
@@ -343,7 +377,8 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     //    the k-1 halo: 1024 positions x 4 waves wins at k = 31 (20 KiB, 8 workgroups per CU) and at
     //    k = 101 (28 KiB) over 512 or 2048 positions.
     // Short windows want many small tiles either way.
-    int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
+    const memo_tuning &tune = ix->tune;
+    int w = tune.tile_w, waves = tune.waves == 1 || tune.waves == 4 ? tune.waves : 0;
     // int64 rows on a sparse index (< 2 rows per position: profiles/r01_sparse_index_tiles.txt) are
     // no longer HBM-bound per tile; they want the packed rows' shape (more workgroups per CU)
     const double span = (double)(ix->max_s - ix->min_s) + 1.0;
@@ -361,14 +396,13 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // HL + tile + HR cells (start - a <= tile + k + 30 inside a slice); the tile is what is left
     // after the halo, rounded down to whole buckets
     // (below one row per position the halo's extra clear and fold cost more than the scatter saves)
-    bool halo = fmt && !checked && !use_persistent(fmt) &&
-                (g_scatter == 2 || (g_scatter == 0 && (double)ix->rows >= span));
+    bool halo = fmt && !checked && (tune.scatter == 2 || (tune.scatter == 0 && (double)ix->rows >= span));
     if (halo) {
         // A/B (profiles/r01_unclipped_scatter.txt): arrays of 1024 cells x 4 waves win at every window
         // length from 10^6 positions up and at k = 21 .. 101
         const int bw = 1 << ix->bshift;  // a slice ends at a bucket boundary: start - a <= tile + k - 1 + bw - 2
         const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + bw - 1 + 3) & ~3;
-        if (!g_tile_w) w = 1024;
+        if (!tune.tile_w) w = 1024;
         int tw = 0;
         for (;; w <<= 1) {
             tw = (w - hl - hr) / bw * bw;
@@ -380,11 +414,11 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.hl = hl;
             A.w = tw;
             A.ls = hl + tw + hr;
-            if (g_waves == 0) waves = w >= 1024 ? 4 : 1;
-            if (g_waves == 8) waves = 8;  // (experiment: eight waves share a tile; only this kernel has that shape)
+            if (tune.waves == 0) waves = w >= 1024 ? 4 : 1;
+            if (tune.waves == 8) waves = 8;  // (experiment: eight waves share a tile; only this kernel has that shape)
             SweepKernel kern = fmt == 4 ? halo_kernel<PackedRows<false, false>, OutT>(waves)
                                         : halo_kernel<PackedRows<true, false>, OutT>(waves);
-            if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)A.nlev * A.ls * 4, st, 1))) return rc;
+            if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)A.nlev * A.ls * 4, st))) return rc;
         }
     }
     if (!halo) {
@@ -398,8 +432,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                                  : cons_kernel<PackedRows<true, false>, OutT>(w, waves))
                                       : cons_kernel<WideRows, OutT>(w, waves);
         if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-        if ((rc = launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * A.ls * 4, st, use_persistent(fmt) ? 0 : 1)))
-            return rc;
+        if ((rc = launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * A.ls * 4, st))) return rc;
     }
     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
 }

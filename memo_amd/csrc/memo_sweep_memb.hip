@@ -1,5 +1,5 @@
-// memo_sweep_memb.hip -- membership sweeps: per-genome bit planes + register transpose ("runs"),
-// the doubling scheme on bit cells, and the direct scatter; the k <= 1 fill, the side
+// memo_sweep_memb.hip -- membership sweeps: per-genome bit planes + register transpose ("runs",
+// "planes") and the doubling scheme on bit cells; the k <= 1 fill, the side
 // pass for rows with end < start, algorithm / tile-shape choice and the ABI entry point.
 // Replaces /root/reference/src/memo_query.py:42-63 with rec = ones([L, N]) (:51) as bit rows.
 #include "memo_sweep.h"
@@ -9,10 +9,10 @@ using namespace memo;
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// membership.  Result word w of position x:  full_word(w) & ~absent[x][w].
-//   DOUBLING = false: one ds_or per covered (position, genome) bit into absent[x][w].
-//   DOUBLING = true : the same two-blocks-per-row scatter and top-down fold as conservation,
-//                     on cells of nw words (or instead of min); nlev * W * nw words of LDS.
+// membership, doubling form.  Result word w of position x:  full_word(w) & ~absent[x][w].
+//   The same two-blocks-per-row scatter and top-down fold as conservation, on cells of nw words
+//   (or instead of min); nlev * W * nw words of LDS.  (The first version, one ds_or per covered
+//   (position, genome) bit, took 4.35 ms on config 4 against 2.5 and is gone.)
 // ------------------------------------------------------------------------------------------
 template <int T>
 __device__ __forceinline__ void store_membership(const SweepArgs &A, const Tile &t,
@@ -39,18 +39,15 @@ __device__ __forceinline__ void store_membership(const SweepArgs &A, const Tile 
     }
 }
 
-template <typename Rows, int W, int U, int T, bool DOUBLING>
+template <typename Rows, int W, int U, int T>
 __global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
     Tile t;
     const int nw = A.nwords;
-    const int nlev = DOUBLING ? A.nlev : 1;
+    const int nlev = A.nlev;
     const int plane = W * nw;  // words per level
-    bool have = locate_tile<W>(A, t, 0);
-    for (int it = 0; have; ++it) {
-    Tile t_next;  // persistent workgroups: next tile's bucket-table loads fly under this tile's work
-    const bool have_next = locate_tile<W>(A, t_next, it + 1);
+    if (!locate_tile<W>(A, t)) return;
 
     auto clear_tile = [&]() {
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -62,19 +59,14 @@ __global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) 
         if (h <= c) return;
         const uint32_t bit = 1u << (col & 31);
         const int word = col >> 5;
-        if (DOUBLING) {
-            const int j = 31 - __builtin_clz((unsigned)(h - c));  // h - c >= 1
-            uint32_t *lv = lds + j * plane + word;
-            atomicOr(lv + c * nw, bit);
-            atomicOr(lv + (h - (1 << j)) * nw, bit);
-        } else {
-            uint32_t *cell = lds + c * nw + word;
-            for (int x = c; x < h; ++x, cell += nw) atomicOr(cell, bit);  // rec[c:h, a] = False
-        }
+        const int j = 31 - __builtin_clz((unsigned)(h - c));  // h - c >= 1
+        uint32_t *lv = lds + j * plane + word;
+        atomicOr(lv + c * nw, bit);  // rec[c:h, a] = False as two blocks of 2^j
+        atomicOr(lv + (h - (1 << j)) * nw, bit);
     });
     __syncthreads();
 
-    if (DOUBLING) {
+    {
         for (int j = nlev - 1; j >= 1; --j) {
             const int shift = (1 << (j - 1)) * nw;  // half a block, in words
             const uint32_t *hi = lds + j * plane;
@@ -99,10 +91,6 @@ __global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) 
         }
     }
     store_membership<T>(A, t, lds, nw);
-    if (have_next) __syncthreads();  // the LDS tile is reused
-    t = t_next;
-    have = have_next;
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -142,10 +130,7 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
     constexpr int PW = W / 32;  // words per genome row
     Tile t;
     const int nw = A.nwords;
-    bool have = locate_tile<W>(A, t, 0);
-    for (int it = 0; have; ++it) {
-    Tile t_next;  // persistent workgroups: next tile's bucket-table loads fly under this tile's work
-    const bool have_next = locate_tile<W>(A, t_next, it + 1);
+    if (!locate_tile<W>(A, t)) return;
     // genome g lives at g * PITCH + (g >> 5) * skew.  PITCH is odd, so the scatter's bank is
     // (genome + word) mod 32 -- with a pitch of PW (a multiple of 32) every genome would land on
     // the banks of its position word alone.  In the transpose phase 32 lanes read word P of genome
@@ -193,10 +178,6 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
                 if (32 * P + j >= t.x_lo && 32 * P + j < t.x_hi) dst[(int64_t)j * ow] = full & ~m[j];
         }
     }
-    if (have_next) __syncthreads();  // the LDS tile is reused
-    t = t_next;
-    have = have_next;
-    }
 }
 
 
@@ -224,7 +205,7 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
     const int tid = threadIdx.x;
     const int W = A.w, nw = A.nwords, PITCH = A.ls, SKEW = A.hl;
     Tile t;
-    if (!locate_tile_w(A, t, 0, W)) return;
+    if (!locate_tile_w(A, t, W)) return;
     uint4 V[U];
     uint2 N[U];
     Rows::template issue<T, U>(A, t, 0, V, N);
@@ -342,14 +323,11 @@ __global__ void long_rows_membership_kernel(const int64_t *ls, const int64_t *le
 
 
 template <typename Rows>
-SweepKernel memb_kernel(int w, int waves, bool doubling) {
+SweepKernel memb_kernel(int w, int waves) {
 #define MEMO_CASE(WW)                                                                              \
     case WW:                                                                                       \
-        if (doubling)                                                                              \
-            return waves == 4 ? (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 256, true>      \
-                              : (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 64, true>;      \
-        return waves == 4 ? (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 256, false>         \
-                          : (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 64, false>;
+        return waves == 4 ? (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 256>      \
+                          : (SweepKernel)sweep_membership_kernel<Rows, WW, Rows::kLoads, 64>;
     switch (w) {
         MEMO_CASE(256)
         MEMO_CASE(512)
@@ -392,7 +370,6 @@ extern "C" {
 
 int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k,
                               int32_t num_docs, uint32_t *d_out, void *stream) {
-    read_env_once();
     int rc = check_query_args(ix, qs, qe, k, num_docs, d_out);
     if (rc) return rc;
     if (qe <= qs) return MEMO_OK;
@@ -412,21 +389,23 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     A.nwords = nw;
     int fmt;
     if ((rc = pick_rows(ix, k, fmt))) return rc;
-    // algorithm: 3 = runs (bit planes per genome + register transpose), 2 = doubling, 1 = direct
+    // algorithm: 4 = planes (unclipped bit planes per genome, result staged), 3 = runs (clipped bit planes
+    // + register transpose), 2 = doubling
+    const memo_tuning &tune = ix->tune;
     const size_t per_pos_doubling = (size_t)A.nlev * nw * 4;
-    int algo = g_memb_algo;
+    int algo = tune.memb_algo;
     // A/B on config 4 (profiles/r01_membership_algorithms.txt): packed rows 0.87 ms runs vs 1.13 ms
     // doubling; int64 rows (HBM-bound either way) 2.52 ms doubling vs 2.64 ms runs
     if (!algo) algo = (fmt || per_pos_doubling * 256 > 40 * 1024) ? 3 : 2;
     // whatever was asked for: a tile of 256 positions has to fit in LDS, else runs (which can slice)
-    if ((algo == 2 ? per_pos_doubling : (size_t)nw * 4) * 256 > 128 * 1024 || nw > 64) algo = 3;
+    if (algo == 2 && (per_pos_doubling * 256 > 128 * 1024 || nw > 64)) algo = 3;
     const bool checked = ix->max_annot >= (uint64_t)A.ncols;
-    int w = g_tile_w, waves = g_waves == 1 || g_waves == 4 ? g_waves : 0;
+    int w = tune.tile_w, waves = tune.waves == 1 || tune.waves == 4 ? tune.waves : 0;
     A.word_base = 0;
     A.out_words = nw;
     // 4 = unclipped bit planes + staged result: packed rows with every annot inside the matrix, at most
     // 16 result words; otherwise whatever else was chosen
-    if ((algo == 4 || (g_memb_algo == 0 && algo == 3)) && fmt && !checked && nw <= 16 && !use_persistent(fmt)) {
+    if ((algo == 4 || (tune.memb_algo == 0 && algo == 3)) && fmt && !checked && nw <= 16) {
         const int bw = 1 << ix->bshift, T = waves == 1 ? 64 : 256;
         int tw = w ? w : 1024;
         if (tw > 32 * (T / nw)) tw = 32 * (T / nw);  // one 32 x 32 block per lane
@@ -449,7 +428,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                                    : (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false>, 6, 256>)
                                         : (T == 64 ? (SweepKernel)sweep_membership_planes_kernel<PackedRows<true, false>, 6, 64>
                                                    : (SweepKernel)sweep_membership_planes_kernel<PackedRows<true, false>, 6, 256>);
-            if ((rc = launch_tiles(kern, A, tw, T, planes > staged ? planes : staged, st, 1))) return rc;
+            if ((rc = launch_tiles(kern, A, tw, T, planes > staged ? planes : staged, st))) return rc;
             return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
         }
     }
@@ -480,13 +459,12 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         for (int base = 0; base < nw; base += slice) {
             A.word_base = base;
             A.nwords = nw - base < slice ? nw - base : slice;
-            if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st, use_persistent(fmt) ? 0 : 1))) return rc;
+            if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st))) return rc;
         }
         return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
     }
-    const bool doubling = algo == 2;
-    const size_t per_pos = doubling ? per_pos_doubling : (size_t)nw * 4;
-    if (!waves) waves = doubling ? 4 : 1;
+    const size_t per_pos = per_pos_doubling;
+    if (!waves) waves = 4;
     if (!w) {  // config 4 A/B: int64 rows 512 positions x 4 waves (40 KiB); packed rows 256 x 4 (20 KiB)
         const size_t budget = (waves == 4 ? (fmt ? 20u : 40u) : 20u) * 1024;
         w = 4096;
@@ -494,13 +472,13 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
     }
     while (per_pos * w > 160 * 1024 && w > 256) w >>= 1;
-    SweepKernel kern = fmt == 4   ? (checked ? memb_kernel<PackedRows<false, true>>(w, waves, doubling)
-                                             : memb_kernel<PackedRows<false, false>>(w, waves, doubling))
-                       : fmt == 6 ? (checked ? memb_kernel<PackedRows<true, true>>(w, waves, doubling)
-                                             : memb_kernel<PackedRows<true, false>>(w, waves, doubling))
-                                  : memb_kernel<WideRows>(w, waves, doubling);
+    SweepKernel kern = fmt == 4   ? (checked ? memb_kernel<PackedRows<false, true>>(w, waves)
+                                             : memb_kernel<PackedRows<false, false>>(w, waves))
+                       : fmt == 6 ? (checked ? memb_kernel<PackedRows<true, true>>(w, waves)
+                                             : memb_kernel<PackedRows<true, false>>(w, waves))
+                                  : memb_kernel<WideRows>(w, waves);
     if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
-    if ((rc = launch_tiles(kern, A, w, 64 * waves, per_pos * w, st, use_persistent(fmt) ? 0 : 1))) return rc;
+    if ((rc = launch_tiles(kern, A, w, 64 * waves, per_pos * w, st))) return rc;
     return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
 }
 

@@ -247,7 +247,10 @@ Layout layout(int64_t n, uint32_t b_cap, uint32_t cap) {
 
 int check_args(const void *d_vec, const void *d_wire, int64_t n, uint32_t b_cap) {
     if (n < 0 || (n > 0 && (!d_vec || !d_wire))) return fail(MEMO_EINVAL, "bad transport arguments");
-    if (n >= ((int64_t)1 << 40)) return fail(MEMO_EINVAL, "slice longer than 2^40");
+    // the B region is addressed with 32-bit offsets (table entries, the head[2] counter): the worst case --
+    // every position an escape, n / 2 bytes + 4 per block of rounding -- has to fit
+    if (n / 2 + 4 * ((n + kBlock - 1) / kBlock) >= ((int64_t)1 << 32) - 64)
+        return fail(MEMO_EINVAL, "slice too long for the dense coding (at most ~2^33 positions per slice)");
     if (b_cap % 4) return fail(MEMO_EINVAL, "the B region's capacity must be a multiple of 4");
     if (((uintptr_t)d_vec & 15) || ((uintptr_t)d_wire & 15))
         return fail(MEMO_EINVAL, "transport buffers must be 16-byte aligned");

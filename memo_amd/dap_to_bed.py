@@ -9,6 +9,10 @@ undefined name and cannot run.)  The DAP text is read in blocks, parsed to an in
 pushed through memo_dap_* (memo_amd/csrc/memo_dap.hip); rows come back in the reference's print
 order and are formatted by memo_emit_bed.  `dap_to_parquet` writes the Parquet index directly
 (schema of parquet_compress_bed.py:19-38) without the BED detour.
+
+Limits the reference does not have (each raises, none wraps silently): a record shorter than 2^30
+positions, at most 4096 DAP columns, DAP rows numbered 0, 1, 2, ... in the first column, values in
+[0, 2^31).
 """
 import argparse
 import ctypes as C
@@ -83,6 +87,13 @@ class DapConverter:
         return (np.empty(n, np.int32), np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.int32))
 
     def push(self, lcp):
+        lcp = np.asarray(lcp)
+        if lcp.size and lcp.dtype != np.int32:
+            # matching statistics are lengths inside a record (< 2^30 here): anything else would wrap
+            # silently in the int32 matrix the device works on
+            lo, hi = int(lcp.min()), int(lcp.max())
+            if lo < 0 or hi >= 2 ** 31:
+                raise ValueError(f"DAP values must lie in [0, 2^31): found {lo if lo < 0 else hi}")
         lcp = np.ascontiguousarray(lcp, np.int32)
         n = C.c_uint64()
         check(lib().memo_dap_push(self._h, lcp.ctypes.data, lcp.shape[0], C.byref(n)))

@@ -93,8 +93,13 @@ class DeviceIndex:
     def membership_dev(self, qs, qe, k, num_docs, out, stream=None):
         check(lib().memo_query_membership_dev(self._h, qs, qe, k, num_docs, _ptr(out), _ptr(stream)))
 
+    # ---- include/memo_amd_debug.h: only with _lib.use_ab() (libmemo_amd_ab.so) ----
     def debug_stream_rows(self, stream=None):
         check(lib().memo_debug_stream_rows(self._h, _ptr(stream)))
+
+    def debug_set_tuning(self, tile_w=0, waves=0, membership_algo=0, row_source=0, scatter=0):
+        check(lib().memo_debug_set_tuning(self._h, tile_w, waves, membership_algo, row_source, scatter))
+        return self
 
     def check(self, stream=None):
         check(lib().memo_query_check(self._h, _ptr(stream)))

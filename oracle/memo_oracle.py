@@ -125,6 +125,41 @@ def synth_rows(row_begin, count, num, den, n_docs, seed=0x4D454D4F):
     return s, e, o
 
 
+def synth_window_compare(got, qs, qe, k, n_docs, pivot, membership=False, threads=None, chunk=2_000_000,
+                         density=(5, 100)):
+    """Whole-window check of a result on the synthetic index (memo_amd/synth.py): the window is cut into
+    chunks, every chunk regenerates the rows it sees (qs' < start < qe' + k) and runs the closed-form
+    restatement, one chunk per thread (the C calls release the GIL).  `got` is the device result for
+    [qs, qe) (uint8 / uint16 vector, or uint32 [L, W] bit rows).  Returns (number of chunks that
+    differ, FNV-1a of the concatenated per-chunk FNV-1a values of the ORACLE's result) -- the second
+    is a checksum of checksums that two runs of any implementation can be compared by."""
+    import concurrent.futures as cf
+    from fractions import Fraction
+    f = Fraction(*density) * n_docs
+    num, den = f.numerator, f.denominator
+
+    def first_row_at_or_after(x):
+        return 0 if x <= 1 else -((-(x - 1) * num) // den)
+    total = first_row_at_or_after(pivot)
+    threads = threads or max(1, min(os.cpu_count() or 1, 64))
+    cuts = list(range(qs, qe, chunk)) + [qe]
+    is_memb = bool(membership)
+
+    def part(i):
+        a, b = cuts[i], cuts[i + 1]
+        r0 = min(first_row_at_or_after(a + 1), total)
+        r1 = max(min(first_row_at_or_after(b + k), total), r0)
+        s, e, o = synth_rows(r0, r1 - r0, num, den, n_docs)
+        want = (globals()["membership"] if is_memb else conservation)(s, e, o, a, b, k, n_docs, literal=False)
+        mine = got[a - qs:b - qs]
+        same = np.array_equal(mine.astype(want.dtype) if not is_memb else mine, want)
+        return (0 if same else 1), fnv1a(want)
+    with cf.ThreadPoolExecutor(threads) as pool:
+        res = list(pool.map(part, range(len(cuts) - 1)))
+    bad = sum(r[0] for r in res)
+    return bad, fnv1a(np.array([r[1] for r in res], np.uint64))
+
+
 def fnv1a(arr):
     b = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
     return int(lib().oracle_fnv1a(b, b.size))

@@ -2,7 +2,7 @@
 """Time-boxed differential fuzzing of the HIP path against the oracle (GPU box):
     python tests/fuzz_gpu.py --seconds 300 [--seed S]
 Random indexes (density, clumping, annots, overlaps incl. end < start), random windows, k, N,
-tile shapes, membership algorithms, row formats, launch forms.  Exits non-zero on the first
+tile shapes, membership algorithms, row formats, scatters.  Exits non-zero on the first
 mismatch and prints the case."""
 import argparse
 import os
@@ -22,7 +22,7 @@ ap.add_argument("--seconds", type=float, default=60)
 ap.add_argument("--seed", type=int, default=int(time.time()))
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
-L = _lib.lib()
+L = _lib.use_ab(True)          # libmemo_amd_ab.so: the product objects + per-index kernel-shape switches
 t_end = time.time() + a.seconds
 cases = queries = 0
 print("seed", a.seed, flush=True)
@@ -58,11 +58,9 @@ while time.time() < t_end:
             k = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 21, 31, 32, 33, 64, 65, 101, 128, 129, 255, 256, 257, 1000]))
             qs = int(rng.integers(0, length))
             qe = int(rng.integers(qs, length + 200))
-            tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096])), int(rng.choice([0, 1, 4, 8])), int(rng.integers(0, 5)))
-            _lib.check(L.memo_set_tuning(*tune))
-            _lib.check(L.memo_set_persistent(int(rng.integers(0, 3))))
-            _lib.check(L.memo_set_row_source(int(rng.integers(0, 2))))
-            _lib.check(L.memo_set_scatter(int(rng.integers(0, 3))))
+            tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096])), int(rng.choice([0, 1, 4, 8])),
+                    int(rng.choice([0, 2, 3, 4])), int(rng.integers(0, 2)), int(rng.integers(0, 3)))
+            ix.debug_set_tuning(*tune)
             memb = rng.random() < 0.4
             if memb and (qe - qs) * n_docs > 30_000_000:
                 qe = qs + 30_000_000 // n_docs
@@ -83,6 +81,4 @@ while time.time() < t_end:
                                        tune=tune, memb=memb, info=ix.info(), werr=str(werr), gerr=str(gerr)), flush=True)
                 np.savez("/tmp/fuzz_fail.npz", s=s, e=e, o=o)
                 sys.exit(1)
-_lib.check(L.memo_set_tuning(0, 0, 0))
-_lib.check(L.memo_set_scatter(0))
 print(f"fuzz ok: {cases} indexes, {queries} queries in {a.seconds:.0f} s", flush=True)

@@ -19,6 +19,15 @@ def memo():
     return memo_amd
 
 
+@pytest.fixture
+def ab(memo):
+    """tests that set kernel shapes run against libmemo_amd_ab.so (product objects + memo_debug.o)"""
+    from memo_amd import _lib
+    _lib.use_ab(True)
+    yield _lib
+    _lib.use_ab(False)
+
+
 def _cons(memo, rows, qs, qe, k, n):
     return memo.conservation(*rows, qs, qe, k, n)
 
@@ -123,21 +132,19 @@ def _random_index(rng, n_rows, length, n_docs, maxlen):
     return s, e, o
 
 
-TUNINGS = [(0, 0, 0)] + [(w, wv, al) for w in (256, 512, 1024, 2048, 4096) for wv, al in ((1, 1), (4, 2))] + \
-    [(512, 1, 2), (1024, 4, 1)] + [(w, wv, al) for al in (3, 4) for w in (256, 512, 1024, 2048, 4096) for wv in (1, 4)]
+TUNINGS = [(0, 0, 0)] + [(w, wv, 2) for w in (256, 512, 1024, 2048, 4096) for wv in (1, 4)] + \
+    [(w, wv, al) for al in (3, 4) for w in (256, 512, 1024, 2048, 4096) for wv in (1, 4)]
 
 
 @pytest.mark.parametrize("tile_w,waves,algo", TUNINGS)
-def test_resident_index_windows(tile_w, waves, algo, memo, oracle):
-    """every tile width x {1, 4} waves per tile x membership {direct, doubling}"""
-    from memo_amd import _lib
+def test_resident_index_windows(tile_w, waves, algo, memo, oracle, ab):
+    """every tile width x {1, 4} waves per tile x membership {doubling, runs, planes}"""
     rng = np.random.default_rng(tile_w + 7 + waves)
     n_docs, length = 70, 60_000
     s, e, o = _random_index(rng, 250_000, length, n_docs, 140)
-    _lib.check(_lib.lib().memo_set_tuning(tile_w, waves, algo))
-    _lib.check(_lib.lib().memo_set_persistent(1 + (tile_w // 256 + waves) % 2))     # both launch forms
-    try:
+    if True:
         with memo.DeviceIndex.from_host(s, e, o) as ix:
+            ix.debug_set_tuning(tile_w, waves, algo)
             assert ix.info()["was_sorted"] == 1
             for k in (2, 3, 4, 5, 8, 9, 16, 17, 21, 31, 32, 33, 64, 65, 101, 129, 300):
                 qs = int(rng.integers(0, length // 2))
@@ -149,12 +156,10 @@ def test_resident_index_windows(tile_w, waves, algo, memo, oracle):
                     qe = min(qe, qs + 9000)
                     want = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
                     assert np.array_equal(ix.membership(qs, qe, k, n_docs), want), (k, qs, qe)
-    finally:
-        _lib.check(_lib.lib().memo_set_tuning(0, 0, 0))
 
 
 @pytest.mark.parametrize("n_docs,keep_wide", [(70, True), (70, False), (256, True), (257, True), (500, False)])
-def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle):
+def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle, ab):
     """memo_index_pack: 4 B/row (annot <= 255) and 6 B/row formats, every tile shape, k up to 256;
     k > 256 falls back to the int64 columns, or is refused when they were dropped."""
     from memo_amd import _lib
@@ -167,17 +172,16 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle):
         inf = ix.info()
         assert inf["packed_format"] == (4 if n_docs <= 256 else 6) and inf["has_wide"] == int(keep_wide)
         try:
-            for tile_w, waves, algo in [(0, 0, 0), (256, 1, 1), (512, 4, 2), (1024, 1, 2), (2048, 4, 1), (4096, 4, 0),
+            for tile_w, waves, algo in [(0, 0, 0), (256, 1, 2), (512, 4, 2), (1024, 1, 2), (2048, 4, 2), (4096, 4, 0),
                                         (256, 4, 3), (2048, 4, 3), (1024, 1, 3), (0, 0, 4), (256, 1, 4), (512, 4, 4),
                                         (2048, 8, 0), (512, 8, 4),
                                         (1024, 4, 4), (2048, 4, 4), (4096, 1, 4)]:
-                _lib.check(_lib.lib().memo_set_tuning(tile_w, waves, algo))
                 for k in (2, 3, 17, 31, 32, 101, 255, 256):
                     qs = int(rng.integers(0, length // 2))
                     qe = int(rng.integers(qs + 1, length + 100))
                     want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
                     for scatter in (1, 2):              # clipped to the tile / unclipped with a halo
-                        _lib.check(_lib.lib().memo_set_scatter(scatter))
+                        ix.debug_set_tuning(tile_w, waves, algo, 0, scatter)
                         assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (k, qs, qe, tile_w, scatter)
                         if n_docs <= 255:
                             assert np.array_equal(ix.conservation(qs, qe, k, n_docs, dtype=np.uint8),
@@ -187,8 +191,7 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle):
                         want = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
                         assert np.array_equal(ix.membership(qs, qe, k, n_docs), want), (k, qs, qe, tile_w)
         finally:
-            _lib.check(_lib.lib().memo_set_tuning(0, 0, 0))
-            _lib.check(_lib.lib().memo_set_scatter(0))
+            ix.debug_set_tuning()
         if keep_wide:
             want = oracle.conservation(*oracle.filter_rows(s, e, o, 100, 9000, 300), 100, 9000, 300, n_docs, literal=False)
             assert np.array_equal(ix.conservation(100, 9000, 300, n_docs), want)
@@ -201,7 +204,7 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle):
 
 
 @pytest.mark.parametrize("bucket_shift", [1, 3, 6, 8])
-def test_bucket_widths(bucket_shift, memo, oracle):
+def test_bucket_widths(bucket_shift, memo, oracle, ab):
     """bucket tables of 2 .. 256 positions: a tile's row slice ends at a bucket boundary, which is what
     sizes the halo of the unclipped kernels; tile widths are whole buckets"""
     from memo_amd import _lib
@@ -215,14 +218,13 @@ def test_bucket_widths(bucket_shift, memo, oracle):
                 ix.pack(keep_wide=True)
             try:
                 for tile_w, waves, algo in ((0, 0, 0), (256, 1, 3), (512, 4, 4), (2048, 4, 4), (1024, 4, 2)):
-                    _lib.check(_lib.lib().memo_set_tuning(tile_w, waves, algo))
                     for k in (2, 17, 31, 32, 33, 101, 256):
                         qs = int(rng.integers(0, length // 2))
                         qe = int(rng.integers(qs + 1, length + 100))
                         rows = oracle.filter_rows(s, e, o, qs, qe, k)
                         want = oracle.conservation(*rows, qs, qe, k, n_docs, literal=False)
                         for scatter in (1, 2):
-                            _lib.check(_lib.lib().memo_set_scatter(scatter))
+                            ix.debug_set_tuning(tile_w, waves, algo, 0, scatter)
                             assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (packed, k, qs, qe, tile_w, scatter)
                         if k in (17, 31, 32, 101):
                             qe = min(qe, qs + 7000)
@@ -230,8 +232,7 @@ def test_bucket_widths(bucket_shift, memo, oracle):
                             wantb = oracle.membership(*rows, qs, qe, k, n_docs, literal=False)
                             assert np.array_equal(ix.membership(qs, qe, k, n_docs), wantb), (packed, k, qs, qe, tile_w)
             finally:
-                _lib.check(_lib.lib().memo_set_tuning(0, 0, 0))
-                _lib.check(_lib.lib().memo_set_scatter(0))
+                ix.debug_set_tuning()
 
 
 def test_ragged_density_and_edges(memo, oracle):
@@ -373,44 +374,52 @@ def test_config2_full_window(memo, oracle):
         assert np.array_equal(m, oracle.membership(s, e, o, 0, 3_000_000, k, n, literal=False))
 
 
-@pytest.mark.parametrize("membership", [False, True])
-def test_config3_full_size_properties(membership, memo, oracle):
-    """configs 3/4: 100 genomes x 100 Mbp, 500 M rows (12 GB in HBM).  The full result is
-    checked on sampled sub-windows against the oracle (rows regenerated per sub-window) and
-    through the split-window property (any sub-window query == slice of the full query)."""
+# config 3 conservation whole-window FNV of the closed-form oracle (checksum of per-chunk checksums,
+# oracle.synth_window_compare): every instantiation below must reproduce it
+_C3_FNV = {}
+
+
+@pytest.mark.parametrize("membership,pack,dtype", [
+    (False, None, np.uint16), (False, "keep", np.uint16), (False, "keep", np.uint8), (False, "only", np.uint8),
+    (True, None, None), (True, "keep", None)],
+    ids=["cons-int64-u16", "cons-packed-u16", "cons-packed-u8", "cons-packedonly-u8", "memb-int64", "memb-packed"])
+def test_config3_full_size_properties(membership, pack, dtype, memo, oracle):
+    """configs 3/4 at full size: 100 genomes x 100 Mbp, 500 M rows, on the int64 columns AND on the
+    packed rows (the benchmarked kernels: sweep_conservation_halo_kernel<PackedRows<false,false>,..,uint8>,
+    sweep_membership_planes_kernel), uint16 and uint8 results.  The WHOLE result is compared with the
+    closed-form oracle (chunks regenerate their rows; all host cores), its checksum of checksums must be
+    the same for every instantiation, and the split-window property (any sub-window query == slice of the
+    full query) is checked on sampled sub-windows."""
     import ctypes as C
     from memo_amd import synth, _lib
     n, L, k = 100, 100_000_000, 31
-    num, den = synth.rows_per_position(n)
-    ix, (r0, r1) = synth.device_index(0, L, k, n, L)
+    ix, (r0, r1) = synth.device_index(0, L, k, n, L, pack=pack)
     W = (n + 31) // 32
     with ix:
-        assert ix.info()["rows"] == r1 - r0 and abs((r1 - r0) - 500_000_000) < 1000
-        full = np.empty((L, W), np.uint32) if membership else np.empty(L, np.uint16)
+        inf = ix.info()
+        assert inf["rows"] == r1 - r0 and abs((r1 - r0) - 500_000_000) < 1000
+        assert inf["packed_format"] == (4 if pack else 0) and inf["has_wide"] == (0 if pack == "only" else 1)
+        full = np.empty((L, W), np.uint32) if membership else np.empty(L, dtype)
         d = C.c_void_p()
         _lib.check(_lib.lib().memo_dev_malloc(0, full.nbytes, C.byref(d)))
         try:
             if membership:
                 ix.membership_dev(0, L, k, n, d.value)
+            elif dtype == np.uint8:
+                ix.conservation_u8_dev(0, L, k, n, d.value)
             else:
                 ix.conservation_dev(0, L, k, n, d.value)
             ix.check()
             _lib.check(_lib.lib().memo_dev_download(0, full.ctypes.data, d, full.nbytes, None))
         finally:
             _lib.lib().memo_dev_free(0, d)
+        bad, fnv = oracle.synth_window_compare(full, 0, L, k, n, L, membership=membership)
+        assert bad == 0, f"{bad} chunks of the whole-window result differ from the oracle"
+        assert _C3_FNV.setdefault(membership, fnv) == fnv
         rng = np.random.default_rng(3)
-        starts = [0, L - 300_000] + [int(x) for x in rng.integers(0, L - 300_000, 6)]
-        for a in starts:
+        for a in [0, L - 300_000] + [int(x) for x in rng.integers(0, L - 300_000, 4)]:
             b = a + 300_000
-            sr0, sr1 = synth.shard_rows(a, b, k, num, den, L)
-            s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
-            if membership:
-                want = oracle.membership(s, e, o, a, b, k, n, literal=False)
-                sub = ix.membership(a + 17, b - 5, k, n)
-            else:
-                want = oracle.conservation(s, e, o, a, b, k, n, literal=False)
-                sub = ix.conservation(a + 17, b - 5, k, n)
-            assert np.array_equal(full[a:b], want), a
+            sub = ix.membership(a + 17, b - 5, k, n) if membership else ix.conservation(a + 17, b - 5, k, n, dtype=dtype)
             assert np.array_equal(sub, full[a + 17:b - 5]), a
         if not membership:
             assert full.min() >= 1 and full.max() == n
@@ -472,7 +481,7 @@ def test_cli_sharded_path_single_rank(memo, tmp_path):
         assert G.sha(out.read_bytes()) == c["sha256"]
 
 
-def test_more_than_2_pow_32_rows(memo, oracle):
+def test_more_than_2_pow_32_rows(memo, oracle, ab):
     """4.4e9 rows (106 GB of int64 columns + 18 GB packed in HBM): row numbers, byte offsets and
     pivot coordinates beyond 32 bits; windows at both ends against the oracle."""
     from memo_amd import synth
@@ -482,10 +491,9 @@ def test_more_than_2_pow_32_rows(memo, oracle):
     ix, (r0, r1) = synth.device_index(0, pivot, k, n, pivot, pack="keep")
     with ix:
         assert r1 - r0 > 2 ** 32 and ix.info()["rows"] == r1 - r0 and ix.info()["packed_format"] == 4
-        from memo_amd import _lib
         for source in (0, 1):                       # packed rows, then the int64 columns
-            _lib.check(_lib.lib().memo_set_row_source(source))
-            try:
+            ix.debug_set_tuning(row_source=source)
+            if True:
                 for a in (0, 2 ** 32 - 70_000, pivot - 150_000):
                     b = min(a + 140_001, pivot + 100)
                     sr0, sr1 = synth.shard_rows(a, b, k, num, den, pivot)
@@ -494,8 +502,6 @@ def test_more_than_2_pow_32_rows(memo, oracle):
                     assert np.array_equal(ix.conservation(a, b, k, n), want), (source, a)
                     wantb = oracle.membership(s, e, o, a, a + 3000, k, n, literal=False)
                     assert np.array_equal(ix.membership(a, a + 3000, k, n), wantb), (source, a)
-            finally:
-                _lib.check(_lib.lib().memo_set_row_source(0))
 
 
 # ---------------------------------------------------------------------------------------

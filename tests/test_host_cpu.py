@@ -20,17 +20,37 @@ def memo():
     return memo_amd
 
 
+def _declared(*headers):
+    out = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)            # declarations only, not comments
+        out |= set(re.findall(r"\b(memo_[a-z_0-9]+)\s*\(", src))
+    return out
+
+
+def _exported(path):
+    import subprocess
+    txt = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in txt.splitlines() if ln.split()[-1].startswith("memo_")}
+
+
 def test_library_exports_every_declared_symbol(memo):
+    """the product library exports exactly what the product headers declare -- and none of the A/B
+    switches, which live in include/memo_amd_debug.h and libmemo_amd_ab.so"""
     from memo_amd import _lib
-    header = open(os.path.join(ROOT, "include", "memo_amd.h")).read()
-    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)          # declarations only, not comments
-    declared = set(re.findall(r"\b(memo_[a-z_0-9]+)\s*\(", header))
+    declared = _declared("memo_amd.h", "memo_amd_dap.h", "memo_amd_transport.h")
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert len(_declared("memo_amd.h")) <= 40
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name)
     assert b"gfx950" in L.memo_version()
+    assert _exported(_lib.SO_PATH) == declared
+    debug = _declared("memo_amd_debug.h")
+    assert debug == set(_lib.DEBUG_SYMBOLS) and all(n.startswith("memo_debug_") for n in debug)
+    assert _exported(_lib.AB_SO_PATH) == declared | debug
 
 
 def test_no_gpu_fails_loudly(memo):

@@ -3,8 +3,8 @@
 on this pool is larger than most tuning effects).  GPU box only.
 
   python tools/ab.py --workload c3 --k 31 --rounds 12 "0,0,0" "1024,1,0" "4096,4,0"
-each variant = tile_w,waves,membership_algo[,persistent[,scatter]]  (memo_set_tuning, memo_set_persistent,
-memo_set_scatter)
+each variant = tile_w,waves,membership_algo[,row_source[,scatter]]  (memo_debug_set_tuning, per index;
+libmemo_amd_ab.so)
 """
 import argparse
 import json
@@ -33,6 +33,7 @@ def main():
     num_docs, L, membership = WORKLOADS[a.workload]
     L = a.length or L
     from fractions import Fraction
+    _lib.use_ab(True)
     ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L, density=Fraction(a.density), pack=a.pack)
     W = (num_docs + 31) // 32
     out = torch.empty((L, W) if membership else (L,), dtype=torch.int32 if membership else torch.int16, device="cuda")
@@ -50,9 +51,7 @@ def main():
 
     for r in range(a.rounds + 1):
         for v in variants:
-            _lib.check(_lib.lib().memo_set_tuning(*v[:3]))
-            _lib.check(_lib.lib().memo_set_persistent(v[3] if len(v) > 3 else 0))
-            _lib.check(_lib.lib().memo_set_scatter(v[4] if len(v) > 4 else 0))
+            ix.debug_set_tuning(*(list(v) + [0] * 5)[:5])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             launch()

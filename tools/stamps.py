@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase cycle shares of the conservation sweep (diagnostic -DMEMO_STAMPS build only):
-  MEMO_AMD_LIB=$PWD/memo_amd/libmemo_amd_stamps.so python tools/stamps.py --workload c3 --pack only"""
+  MEMO_AMD_AB_LIB=$PWD/memo_amd/libmemo_amd_stamps.so python tools/stamps.py --workload c3 --pack only"""
 import argparse
 import ctypes as C
 import os
@@ -20,9 +20,10 @@ ap.add_argument("--pack", default=None)
 ap.add_argument("--tuning", default="0,0,0")
 a = ap.parse_args()
 num_docs, L, _ = WORKLOADS[a.workload]
+_lib.use_ab(True)              # the stamps build is an AB build (make EXTRA=-DMEMO_STAMPS OUT_AB=...)
 ix, _ = synth.device_index(0, L, a.k, num_docs, L, pack=a.pack)
 out = torch.empty(L, dtype=torch.int16, device="cuda")
-_lib.check(_lib.lib().memo_set_tuning(*[int(x) for x in a.tuning.split(",")]))
+ix.debug_set_tuning(*[int(x) for x in a.tuning.split(",")])
 names = ["locate tile", "issue loads + clear LDS + barrier", "wait for rows + scatter", "barrier after scatter", "fold",
          "store", "-", "tiles"]
 nblocks = 8 * ((L // 128 + 8) // 8 + 1) + 8
