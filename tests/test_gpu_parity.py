@@ -235,6 +235,49 @@ def test_bucket_widths(bucket_shift, memo, oracle, ab):
                 ix.debug_set_tuning()
 
 
+def test_two_threads_two_indexes(memo, oracle):
+    """one index per thread.  No mutable state is shared between indexes (the
+    kernel-shape choices are per index, the error message is thread-local), so two threads querying two
+    different indexes at once -- one of them raising the reference's IndexError every other query --
+    get their own results and their own errors."""
+    import threading
+    rng = np.random.default_rng(77)
+    data = [_random_index(rng, 120_000, 50_000, nd, 90) for nd in (40, 300)]
+    n_docs = (40, 300)
+    errors = []
+
+    def worker(t):
+        try:
+            s, e, o = data[t]
+            r = np.random.default_rng(t)
+            with memo.DeviceIndex.from_host(s, e, o) as ix:
+                if t == 1:
+                    ix.pack(keep_wide=True)
+                for i in range(40):
+                    k = int(r.choice([3, 21, 31, 101]))
+                    qs = int(r.integers(0, 30_000))
+                    qe = qs + int(r.integers(1, 20_000))
+                    if t == 0 and i % 2:
+                        with pytest.raises(IndexError):
+                            ix.conservation(0, 50_000, 31, 5)        # annots up to 39 do not fit 6 columns
+                    rows = oracle.filter_rows(s, e, o, qs, qe, k)
+                    want = oracle.conservation(*rows, qs, qe, k, n_docs[t], literal=False)
+                    assert np.array_equal(ix.conservation(qs, qe, k, n_docs[t]), want), (t, i, k, qs, qe)
+                    qe = min(qe, qs + 4000)
+                    rows = oracle.filter_rows(s, e, o, qs, qe, k)
+                    wantb = oracle.membership(*rows, qs, qe, k, n_docs[t], literal=False)
+                    assert np.array_equal(ix.membership(qs, qe, k, n_docs[t]), wantb), (t, i, k, qs, qe)
+        except BaseException as exc:       # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(exc)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in (0, 1)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+
+
 def test_ragged_density_and_edges(memo, oracle):
     """clumped starts, empty stretches, window beyond the last row, window before the first."""
     rng = np.random.default_rng(99)
