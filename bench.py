@@ -62,9 +62,10 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--wide", action="store_true", help="uint16 conservation results even when num_docs <= 255")
-    ap.add_argument("--rows", default="packed", choices=["packed", "wide"],
-                    help="row format the timed sweep reads: packed (memo_index_pack, 4-6 B/row) or the "
-                         "int64 columns as uploaded (24 B/row); at N=1 the other one is timed too")
+    ap.add_argument("--rows", default="auto", choices=["auto", "dense", "packed", "wide"],
+                    help="row format the timed sweep reads: dense (memo_index_pack_dense, 3 B/row: conservation, "
+                         "k <= 64, num_docs <= 255), packed (memo_index_pack, 4-6 B/row), or the int64 columns as "
+                         "uploaded (24 B/row); auto = the densest that can answer; at N=1 the others are timed too")
     ap.add_argument("--plain-gather", action="store_true",
                     help="N > 1: send uint8 slices as they are (default: the densest transport coding that fits)")
     ap.add_argument("--code-own-slice", action="store_true",
@@ -157,36 +158,56 @@ def main():
     from memo_amd import _lib
     if args.calibrate:
         _lib.use_ab(True)                   # the PMC calibration kernel lives in libmemo_amd_ab.so only
+    can_dense = (not membership) and k - 1 <= 63 and num_docs <= 255 and not args.wide
+    if args.rows == "auto":
+        args.rows = "wide" if k - 1 > 255 else ("dense" if can_dense else "packed")
+    if args.rows == "dense" and not can_dense:
+        raise SystemExit("--rows dense answers conservation with k <= 64 and num_docs <= 255 only")
     if k - 1 > 255:
         args.rows = "wide"                  # packed rows answer k <= 256 only
-    # Two resident indexes of the same rows: the int64 columns as uploaded (24 B/row) and the packed query
-    # format (memo_index_pack, int64 columns dropped).  SURVEY.md 8(d): the pass that narrows the rows is
-    # timed apart from the query -- on the device, by the library (HIP event pair around the annot census
-    # and the packing kernel, buffers allocated by the first call and reused by the second).
-    indexes, pack_pass, packed_fmt = {}, None, 0
-    want_both = (world == 1 and not args.force_dist and k - 1 <= 255)
-    if args.rows == "wide" or want_both:
-        indexes["wide"], (r0, r1) = synth.device_index(qs, qe, k, num_docs, pivot, device=local)
-    if args.rows == "packed" or want_both:
-        ixp, (r0, r1) = synth.device_index(qs, qe, k, num_docs, pivot, device=local)
-        ixp.pack(keep_wide=True)            # allocates the packed rows
-        ixp.pack(keep_wide=True)            # the timed pass: same buffers
-        info = ixp.info()
-        packed_fmt = info["packed_format"]
+    # Resident indexes of the same rows, one per row format: the int64 columns as uploaded (24 B/row), the
+    # packed query format (memo_index_pack: 4 / 6 B/row, int64 columns dropped) and the 3-byte rows
+    # (memo_index_pack_dense, everything else dropped).  SURVEY.md 8(d): the passes that narrow the rows are
+    # timed apart from the query -- on the device (HIP event pair around the annot census and the packing
+    # kernel inside memo_index_pack, buffers allocated by the first call and reused by the second; an event
+    # pair on the same stream around memo_index_pack_dense).
+    indexes, pack_pass, dense_pass, packed_fmt = {}, None, None, 0
+    others = (world == 1 and not args.force_dist)
+    formats = [args.rows] + ([f for f in ("wide", "packed", "dense") if f != args.rows and
+                              (f != "dense" or can_dense) and (f == "wide" or k - 1 <= 255)] if others else [])
+    for f in formats:
+        ixf, (r0, r1) = synth.device_index(qs, qe, k, num_docs, pivot, device=local)
         nrows = r1 - r0
-        pack_bytes = (24 + packed_fmt) * nrows + 8 * nrows      # census reads the annot column once more
-        pack_pass = {"what": "memo_index_pack: int64 columns -> packed rows, once per index, not part of a query "
-                             "(annot_census_kernel reads 8 B/row; pack_rows_kernel reads 24 B and writes "
-                             "%d B per row)" % packed_fmt,
-                     "ms": info["pack_ms"], "rows": nrows, "bytes": pack_bytes,
-                     "GBs": pack_bytes / (info["pack_ms"] * 1e-3) / 1e9 if info["pack_ms"] > 0 else None,
-                     "timed_with": "HIP event pair inside memo_index_pack (memo_index_info.pack_ms), second call "
-                                   "on reused buffers"}
-        ixp.pack(keep_wide=False)           # drop the int64 columns: this index answers from packed rows only
-        indexes["packed"] = ixp
+        if f != "wide":
+            ixf.pack(keep_wide=True)            # allocates the packed rows
+            ixf.pack(keep_wide=True)            # the timed pass: same buffers
+            info = ixf.info()
+            packed_fmt = info["packed_format"]
+            pack_bytes = (24 + packed_fmt) * nrows + 8 * nrows      # census reads the annot column once more
+            pack_pass = {"what": "memo_index_pack: int64 columns -> packed rows, once per index, not part of a query "
+                                 "(annot_census_kernel reads 8 B/row; pack_rows_kernel reads 24 B and writes "
+                                 "%d B per row)" % packed_fmt,
+                         "ms": info["pack_ms"], "rows": nrows, "bytes": pack_bytes,
+                         "GBs": pack_bytes / (info["pack_ms"] * 1e-3) / 1e9 if info["pack_ms"] > 0 else None,
+                         "timed_with": "HIP event pair inside memo_index_pack (memo_index_info.pack_ms), second call "
+                                       "on reused buffers"}
+            ixf.pack(keep_wide=False)           # drop the int64 columns
+        if f == "dense":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            null_stream = torch.cuda.default_stream()           # memo_index_pack_dense works on the NULL stream
+            e0.record(null_stream)
+            ixf.pack_dense(keep_packed=False)
+            e1.record(null_stream)
+            torch.cuda.synchronize()
+            dms = e0.elapsed_time(e1)
+            dense_pass = {"what": "memo_index_pack_dense: 4-byte rows -> 3-byte rows (reads 4 B, writes 3 B per row; "
+                                  "includes the hipMalloc of the 3-byte rows), once per index",
+                          "ms": dms, "rows": nrows, "bytes": 7 * nrows, "GBs": 7 * nrows / (dms * 1e-3) / 1e9}
+        indexes[f] = ixf
     rows = r1 - r0
     ix = indexes[args.rows]
-    row_bytes = 24 if args.rows == "wide" else packed_fmt
+    fmt_bytes = {"wide": 24, "packed": packed_fmt, "dense": 3}
+    row_bytes = fmt_bytes[args.rows]
     W = (num_docs + 31) // 32
     # result element: membership = W uint32 words; conservation = uint8 when num_docs <= 255 (the
     # same at every N; it also halves what the slices put on xGMI), else uint16
@@ -345,6 +366,8 @@ def main():
         torch.cuda.synchronize()
 
     def kernel_name(which):
+        if which == "dense":
+            return "sweep_conservation_halo3_kernel<...> (PackedRows3)"
         rows_t = "WideRows" if which == "wide" else f"PackedRows<{'true' if packed_fmt == 6 else 'false'}, false>"
         if membership:      # packed rows: per-genome bit planes (unclipped + staged up to 512 genomes,
             if which == "wide":                                      # else the clipped "runs"); int64 rows: doubling
@@ -369,20 +392,19 @@ def main():
 
     # (1) the same query on the OTHER row format, for the record -- and first, so that the headline's
     # timed region does not sit in the clock ramp of a cold device (the driver runs --steps 20 --warmup 5)
-    other = None
-    if not multi and len(indexes) == 2:
-        which = "wide" if args.rows == "packed" else "packed"
-        ob = 24 if which == "wide" else packed_fmt
+    other = []
+    for which in formats[1:]:
+        ob = fmt_bytes[which]
         for i in range(max(args.warmup, 5)):
             launch(outs[0], indexes[which])
         ms2 = per_step(lambda: launch(outs[0], indexes[which]), max(args.steps, 20))
         indexes[which].check(stream.cuda_stream)
         alg2 = ob * rows + b_out * L
         med2 = float(np.median(ms2))
-        other = {"rows": which, "row_bytes": ob, "kernel": kernel_name(which), "kernel_ms": float(np.mean(ms2)),
-                 "kernel_ms_median": med2, "kernel_ms_min": float(np.min(ms2)),
-                 "query_positions_per_s": L / (med2 * 1e-3), "algorithmic_bytes": alg2,
-                 "achieved_GBs": alg2 / (med2 * 1e-3) / 1e9, "frac": alg2 / (med2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        other.append({"rows": which, "row_bytes": ob, "kernel": kernel_name(which), "kernel_ms": float(np.mean(ms2)),
+                      "kernel_ms_median": med2, "kernel_ms_min": float(np.min(ms2)),
+                      "query_positions_per_s": L / (med2 * 1e-3), "algorithmic_bytes": alg2,
+                      "achieved_GBs": alg2 / (med2 * 1e-3) / 1e9, "frac": alg2 / (med2 * 1e-3) / 1e9 / HBM_PEAK_GBS})
 
     # (2) clock ramp: headline launches, untimed, until a batch of 20 is no faster than the one before
     # (within 1 %) -- at least 3 batches, at most 1.5 s of them
@@ -455,9 +477,11 @@ def main():
                        "num_docs": num_docs, "window_per_gpu": L, "rows_per_gpu": rows, "k": k,
                        "query": "membership" if membership else "conservation",
                        "row_format": "3 x int64 per row as uploaded (24 B)" if args.rows == "wide" else
-                                     f"packed {packed_fmt} B/row built once per index by memo_index_pack",
+                                     f"packed {packed_fmt} B/row built once per index by memo_index_pack" if args.rows == "packed"
+                                     else "3 B/row (start mod 2^10, length saturated at 63, 8-bit order) built once per "
+                                          "index by memo_index_pack + memo_index_pack_dense",
                        "row_bytes": row_bytes, "result_bytes_per_position": b_out,
-                       "row_format_pass": pack_pass,
+                       "row_format_pass": pack_pass, "dense_format_pass": dense_pass,
                        "clock_ramp": {"what": "untimed headline launches before the warm-up steps, until a batch "
                                               "of 20 is no faster than the one before", **ramp},
                        "sharding": f"window split into {world} contiguous sub-windows, slices gathered to rank 0 "
@@ -487,7 +511,7 @@ def main():
                                              "`value` above includes delivering every slice to rank 0, which is "
                                              f"bound by {wires[0].numel() / 1e6:.0f} MB per peer link per step"}
         if other:
-            res["other_row_format"] = other
+            res["other_row_formats"] = other
         if world == 1 and args.cpu_sample > 0:
             def gpu_slice(S):
                 h = out[:S].cpu().numpy()

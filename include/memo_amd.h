@@ -48,6 +48,8 @@ extern "C" {
 #define MEMO_EUNSORTED (-4) /* rows not sorted by start and sorting was disabled */
 #define MEMO_ELONGROW (-5)  /* more than 2^22 rows have end < start.  dap_to_bed.py:93-98 never emits
                                such a row; a few are accepted and applied by a side pass */
+#define MEMO_EUNPACKABLE (-6) /* memo_builder_*: these rows cannot take the packed way in (unsorted, negative
+                               start, annot outside [0, 65535]); use memo_index_upload + _finalize */
 
 typedef struct memo_index memo_index_t; /* one chromosome's rows, resident in HBM */
 
@@ -65,7 +67,7 @@ typedef struct memo_index_info {
     int32_t has_wide;       /* 1 while the three int64 columns are resident */
     float pack_ms;          /* device time of the last memo_index_pack: annot census + packing kernel,
                                HIP events on its stream (the narrowing pass, timed apart) */
-    int32_t reserved;
+    int32_t dense_rows;     /* 1 while the 3-byte rows of memo_index_pack_dense are resident */
 } memo_index_info_t;
 
 const char *memo_last_error(void);
@@ -103,8 +105,33 @@ int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_so
  * columns (an HPRC-scale shard is 37 GB packed against 225 GB as int64); such an index answers
  * k <= 256 only and cannot be re-uploaded.  Needs 0 <= annot <= 65535 on every row. */
 int memo_index_pack(memo_index_t *ix, int32_t keep_wide);
+/* A denser copy of the packed rows for the queries most windows are: 3 bytes per row,
+ *     (start mod 2^10) << 6 | min(end - start, 63)   +   annot (8 bits)          12 B per 4 rows
+ * Exact for k <= 64 on the unclipped conservation sweep (level arrays of <= 1024 cells, num_docs <= 255);
+ * every other query keeps reading the 4-byte rows / the int64 columns.  Needs memo_index_pack first and
+ * every annot <= 255.  keep_packed == 0 frees the 4-byte rows (such an index answers only what the 3-byte
+ * rows or, if still resident, the int64 columns can). */
+int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed);
 int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);
 void memo_index_destroy(memo_index_t *ix);
+
+/* ---- packed upload: the fast way in for host rows ------------------------------------------
+ * Stands in for the same arrays (memo_query.py:28-36, :45) when they arrive start-sorted, as every
+ * region slice of an index does.  Rows are pushed in as many start-ordered pieces as the caller
+ * likes (a Parquet row group at a time); worker threads narrow the three int64 columns to the packed
+ * query format into a ring of PINNED buffers, and each piece crosses PCIe with hipMemcpyAsync while
+ * the next one is being packed: 4-6 B per row on the link instead of 24, from pinned memory.  The same
+ * pass validates the rows and builds the start-bucket table, so memo_builder_finish() returns an index
+ * that is finalized and packed (int64 columns never reach the GPU; it answers k <= 256).
+ * Rows that cannot be packed make _push return MEMO_EUNPACKABLE: start over with memo_index_upload.
+ * Nothing of the caller's memory is referenced after _push returns.  One builder per thread. */
+typedef struct memo_builder memo_builder_t;
+int memo_builder_create(uint64_t max_rows, int32_t device, int32_t bucket_shift, memo_builder_t **out);
+int memo_builder_push(memo_builder_t *b, const int64_t *start, const int64_t *end, const int64_t *annot,
+                      uint64_t rows);
+/* hands the index over (destroy the builder afterwards; it cannot be used again) */
+int memo_builder_finish(memo_builder_t *b, memo_index_t **out);
+void memo_builder_destroy(memo_builder_t *b);
 
 /* ---- the hot path: memo_init + memo_query + reduction (memo_query.py:42-63, :70) ----
  * d_out is a DEVICE pointer (16-byte aligned) in the index's device; the launch is
@@ -124,8 +151,10 @@ int memo_query_conservation_u8_dev(memo_index_t *ix, int64_t qs, int64_t qe, int
 int memo_query_check(memo_index_t *ix, void *stream);
 
 /* ---- one-shot host form: the drop-in for memo_query.py:103-104 + :70 ------------------
- * Host pointers in and out; uploads, finalizes, queries, downloads, frees.  `device`
- * is a HIP device ordinal. */
+ * Host pointers in and out; uploads, queries, downloads, frees.  `device` is a HIP device ordinal.
+ * For k <= 256 and packable rows (see memo_builder_*) the rows take the packed, pinned way in and the
+ * sweep reads 4-6 B per row; the result comes back through the same pinned ring.  Anything else is
+ * uploaded as int64 columns, validated (and sorted if need be) on the device. */
 int memo_conservation(const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows,
                       int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint16_t *out,
                       int32_t device);

@@ -9,7 +9,7 @@ Layout (only what the path needs):
   synth.py         the synthetic pangenome workloads of BASELINE.json
   shard.py         window sharding across ranks + gather (torch.distributed)
 """
-from ._lib import MemoError, build, lib  # noqa: F401
-from .index import DeviceIndex, conservation, membership, emit_conservation, emit_membership  # noqa: F401
+from ._lib import MemoError, MemoUnpackable, build, lib  # noqa: F401
+from .index import DeviceIndex, IndexBuilder, conservation, membership, emit_conservation, emit_membership  # noqa: F401
 
 __version__ = "0.1.0"

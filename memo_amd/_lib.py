@@ -12,7 +12,7 @@ SO_PATH = os.environ.get("MEMO_AMD_LIB") or os.path.join(_HERE, "libmemo_amd.so"
 # the product objects + the A/B switches of include/memo_amd_debug.h (tests, fuzzers, tools/ab.py)
 AB_SO_PATH = os.environ.get("MEMO_AMD_AB_LIB") or os.path.join(_HERE, "libmemo_amd_ab.so")
 
-MEMO_OK, MEMO_EINVAL, MEMO_EHIP, MEMO_ENOTREADY, MEMO_EUNSORTED, MEMO_ELONGROW = 0, -1, -2, -3, -4, -5
+MEMO_OK, MEMO_EINVAL, MEMO_EHIP, MEMO_ENOTREADY, MEMO_EUNSORTED, MEMO_ELONGROW, MEMO_EUNPACKABLE = 0, -1, -2, -3, -4, -5, -6
 
 
 class MemoError(RuntimeError):
@@ -31,12 +31,16 @@ class MemoValueError(MemoError, ValueError):
     """The reference raises ValueError here (window end before window start)."""
 
 
+class MemoUnpackable(MemoError):
+    """memo_builder_*: the rows cannot take the packed way in; upload them as int64 columns."""
+
+
 class IndexInfo(C.Structure):
     _fields_ = [("rows", C.c_uint64), ("min_start", C.c_int64), ("max_start", C.c_int64),
                 ("device", C.c_int32), ("bucket_shift", C.c_int32), ("buckets", C.c_uint64),
                 ("was_sorted", C.c_int32), ("finalized", C.c_int32), ("device_bytes", C.c_uint64),
                 ("packed_format", C.c_int32), ("has_wide", C.c_int32), ("pack_ms", C.c_float),
-                ("reserved", C.c_int32)]
+                ("dense_rows", C.c_int32)]
 
 
 # every symbol the product headers declare: name -> (restype, argtypes)
@@ -52,8 +56,13 @@ SYMBOLS = {
     "memo_index_columns": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "memo_index_finalize": (C.c_int, [_P, _I32, _I32]),
     "memo_index_pack": (C.c_int, [_P, _I32]),
+    "memo_index_pack_dense": (C.c_int, [_P, _I32]),
     "memo_index_get_info": (C.c_int, [_P, C.POINTER(IndexInfo)]),
     "memo_index_destroy": (None, [_P]),
+    "memo_builder_create": (C.c_int, [_U64, _I32, _I32, C.POINTER(_P)]),
+    "memo_builder_push": (C.c_int, [_P, _P, _P, _P, _U64]),
+    "memo_builder_finish": (C.c_int, [_P, C.POINTER(_P)]),
+    "memo_builder_destroy": (None, [_P]),
     "memo_query_conservation_dev": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P]),
     "memo_query_membership_dev": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P]),
     "memo_query_conservation_u8_dev": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P]),
@@ -155,5 +164,7 @@ def check(rc):
             raise MemoIndexError(rc, msg)
         if rc == MEMO_EINVAL and "ValueError" in msg:
             raise MemoValueError(rc, msg)
+        if rc == MEMO_EUNPACKABLE:
+            raise MemoUnpackable(rc, msg)
         raise MemoError(rc, msg)
     return rc

@@ -66,7 +66,7 @@ private:
     HostPool() {
         unsigned hw = std::thread::hardware_concurrency();
         if (hw == 0) hw = 1;
-        unsigned want = hw < 48 ? hw : 48;
+        unsigned want = hw < 32 ? hw : 32;  // profiles/r02_oneshot_host_threads.txt: 32 threads pack fastest; 64 and up lose a third
         if (const char *v = getenv("MEMO_HOST_THREADS")) {
             const int n = atoi(v);
             if (n > 0) want = (unsigned)n;

@@ -3,6 +3,7 @@
 //
 // Counterpart of the arrays /root/reference/src/memo_query.py hands from filter_pq to memo_init
 // (:28-36, :45): three int64 columns, kept in HBM so that many windows reuse one upload.
+#include <chrono>
 #include <cstdarg>
 #include <new>
 
@@ -98,6 +99,22 @@ __global__ void pack_rows_kernel(const int64_t *s, const int64_t *e, const int64
         }
         if (pa) pa[i] = (uint16_t)a; else w |= a << 24;
         pk[i] = w;
+    }
+}
+
+// memo_index_pack_dense: 4-byte words -> 3-byte rows, 12 bytes per group of 4 (layout: PackedRows3, memo_sweep.h)
+__global__ void pack3_rows_kernel(const uint32_t *pk, uint64_t groups, uint32_t *p3) {
+    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < groups;
+         g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(pk + 4 * g);
+        auto B = [](uint32_t x) {  // (start & 1023) << 6 | min(length, 63)
+            const uint32_t len = (x >> 16) & 0xFFu;
+            return ((x & 1023u) << 6) | (len > 63u ? 63u : len);
+        };
+        uint32_t *dst = p3 + 3 * g;
+        dst[0] = B(w.x) | ((w.x >> 24) << 16) | ((w.y >> 24) << 24);
+        dst[1] = B(w.y) | (B(w.z) << 16);
+        dst[2] = B(w.w) | ((w.z >> 24) << 16) | ((w.w >> 24) << 24);
     }
 }
 
@@ -257,15 +274,21 @@ int memo_device_count(void) {
 static void drop_packed(memo_index *ix) {  // the rows are about to change
     (void)hipFree(ix->pk);
     (void)hipFree(ix->pa);
+    (void)hipFree(ix->p3);
     ix->pk = nullptr;
     ix->pa = nullptr;
+    ix->p3 = nullptr;
     ix->packed_fmt = 0;
     ix->packed_rows = 0;
 }
 
 // the rows are about to change but the index keeps its size: the packed copy is stale, its buffers
 // can serve the next memo_index_pack
-static void stale_packed(memo_index *ix) { ix->packed_fmt = 0; }
+static void stale_packed(memo_index *ix) {
+    ix->packed_fmt = 0;
+    (void)hipFree(ix->p3);
+    ix->p3 = nullptr;
+}
 
 int memo_index_create(uint64_t rows, int32_t device, memo_index_t **out) {
     if (!out) return fail(MEMO_EINVAL, "out is NULL");
@@ -305,6 +328,7 @@ void memo_index_destroy(memo_index_t *ix) {
     (void)hipFree(ix->boff);
     (void)hipFree(ix->pk);
     (void)hipFree(ix->pa);
+    (void)hipFree(ix->p3);
     (void)hipFree(ix->ls);
     (void)hipFree(ix->le);
     (void)hipFree(ix->lo);
@@ -476,6 +500,8 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
         ~Events() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
     } events{ev0, ev1};
     // a packed copy of the same size is reused (packing again after a re-finalize, or to time the pass)
+    (void)hipFree(ix->p3);  // derived from the words that are about to be rewritten
+    ix->p3 = nullptr;
     const bool had = ix->pk && ix->packed_rows == ix->padded;
     const bool had_pa = had && ix->pa;
     if (!had) drop_packed(ix);
@@ -520,6 +546,35 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
     return MEMO_OK;
 }
 
+int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed) {
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (!ix->finalized) return fail(MEMO_ENOTREADY, "index not finalized");
+    if (ix->p3) {
+        if (!keep_packed && ix->pk) {
+            DeviceGuard guard(ix->device);
+            (void)hipFree(ix->pk);
+            ix->pk = nullptr;
+            ix->packed_rows = 0;
+        }
+        return MEMO_OK;
+    }
+    if (ix->packed_fmt != 4 || !ix->pk)
+        return fail(MEMO_EINVAL, "3-byte rows are built from the 4-byte rows: memo_index_pack first, and every annot <= 255");
+    DeviceGuard guard(ix->device);
+    hipStream_t st = nullptr;
+    const uint64_t groups = ix->padded / 4;  // padded is a multiple of 16
+    HIP_TRY(hipMalloc(&ix->p3, groups * 12));
+    hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, ix->pk, groups, ix->p3);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!keep_packed) {
+        (void)hipFree(ix->pk);
+        ix->pk = nullptr;
+        ix->packed_rows = 0;
+    }
+    return MEMO_OK;
+}
+
 int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     if (!ix || !info) return fail(MEMO_EINVAL, "NULL argument");
     info->rows = ix->rows;
@@ -533,25 +588,60 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     info->packed_format = ix->packed_fmt;
     info->has_wide = ix->has_wide;
     info->pack_ms = ix->pack_ms;
+    info->dense_rows = ix->p3 ? 1 : 0;
     info->device_bytes = (ix->has_wide ? ix->padded * 3 * sizeof(int64_t) : 0) + ix->nb * sizeof(int64_t) + 128 +
-                         (ix->pk ? ix->padded * 4 : 0) + (ix->pa ? ix->padded * 2 : 0);
+                         (ix->pk ? ix->padded * 4 : 0) + (ix->pa ? ix->padded * 2 : 0) + (ix->p3 ? ix->padded * 3 : 0);
     return MEMO_OK;
 }
 
+// The drop-in for memo_query.py:103-104 + :70: host columns in, host result out.  Rows that can be packed
+// (start-sorted, start >= 0, annot in [0, 65535]: every index dap_to_bed.py writes) and k <= 256 take the
+// fast way in -- narrowed on the host into pinned memory, 4-6 B/row over PCIe, PackedRows kernels
+// (memo_hostpack.hip); anything else is uploaded as int64 columns and finalized on the device.
 static int one_shot(const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows,
                     int64_t qs, int64_t qe, int32_t k, int32_t num_docs, void *out, int32_t device,
                     bool membership) {
+    if (rows && (!start || !end || !annot)) return fail(MEMO_EINVAL, "column pointer is NULL");
     memo_index_t *ix = nullptr;
-    int rc = memo_index_create(rows, device, &ix);
-    if (rc) return rc;
+    int rc = MEMO_OK;
+    // MEMO_TIMING=1: phase times of the call on stderr (host clock; every phase ends synchronised)
+    const bool timing = getenv("MEMO_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
+    if (rows && k > 1 && k - 1 <= 255 && !getenv("MEMO_ONESHOT_WIDE")) {
+        memo_builder_t *b = nullptr;
+        if ((rc = memo_builder_create(rows, device, 0, &b))) return rc;
+        rc = memo_builder_push(b, start, end, annot, rows);
+        if (!rc) rc = memo_builder_finish(b, &ix);
+        memo_builder_destroy(b);
+        if (rc == MEMO_EUNPACKABLE) {
+            rc = MEMO_OK;
+            ix = nullptr;
+        } else if (rc) {
+            return rc;
+        }
+    }
+    if (!ix) {
+        if ((rc = memo_index_create(rows, device, &ix))) return rc;
+        rc = memo_index_upload(ix, start, end, annot, rows);
+        if (!rc) rc = memo_index_finalize(ix, 0, 1);
+        if (rc) {
+            memo_index_destroy(ix);
+            return rc;
+        }
+    }
+    const auto t1 = now();
+    auto t2 = t1;
     void *d_out = nullptr;
+    size_t bytes = 0;
     do {
-        if ((rc = memo_index_upload(ix, start, end, annot, rows))) break;
-        if ((rc = memo_index_finalize(ix, 0, 1))) break;
         if (qe < qs) { rc = fail(MEMO_EINVAL, "ValueError: negative dimensions are not allowed (window end < start)"); break; }
         const int64_t L = qe - qs;
         if (L > 0 && !out) { rc = fail(MEMO_EINVAL, "output pointer is NULL"); break; }
-        const size_t bytes = membership ? (size_t)L * ((num_docs + 31) / 32) * 4 : (size_t)L * 2;
+        bytes = membership ? (size_t)L * ((num_docs + 31) / 32) * 4 : (size_t)L * 2;
         DeviceGuard guard(device);
         if (bytes) {
             hipError_t err = hipMalloc(&d_out, bytes);
@@ -561,11 +651,18 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
                         : memo_query_conservation_dev(ix, qs, qe, k, num_docs, (uint16_t *)d_out, nullptr);
         if (rc) break;
         if ((rc = memo_query_check(ix, nullptr))) break;
-        if (bytes) {
-            hipError_t err = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
-            if (err != hipSuccess) { rc = fail(MEMO_EHIP, "hipMemcpy D2H: %s", hipGetErrorString(err)); break; }
-        }
+        t2 = now();
+        if (bytes) rc = download_pipelined(device, out, d_out, bytes, nullptr);
     } while (0);
+    if (timing && !rc) {
+        const auto t3 = now();
+        fprintf(stderr,
+                "memo one-shot: %llu rows %s: rows in %.1f ms (%.1f GB/s of int64 columns), result alloc + sweep + check "
+                "%.1f ms, result out %.1f ms (%.1f GB/s), total %.1f ms\n",
+                (unsigned long long)rows, ix->has_wide ? "as int64 columns" : (ix->packed_fmt == 6 ? "packed to 6 B" : "packed to 4 B"),
+                ms(t0, t1), rows * 24.0 / 1e6 / (ms(t0, t1) + 1e-9), ms(t1, t2), ms(t2, t3),
+                bytes / 1e6 / (ms(t2, t3) + 1e-9), ms(t0, t3));
+    }
     if (d_out) {
         DeviceGuard guard(device);
         (void)hipFree(d_out);

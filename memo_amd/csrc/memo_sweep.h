@@ -14,6 +14,7 @@ struct SweepArgs {
     const int64_t *s, *e, *o;
     const uint32_t *pk;
     const uint16_t *pa;
+    const uint32_t *p3;     // 3-byte rows (PackedRows3), 3 words per 4 rows
     const int64_t *boff;
     int64_t nb;
     int64_t qs, qe;
@@ -308,6 +309,72 @@ struct PackedRows {
     }
 };
 
+// 3-byte rows (memo_index_pack_dense): start mod 2^10, min(end - start, 63), annot (8 bits) -- 24 bits per
+// row, 12 bytes per group of 4 rows, one global_load_dwordx3 per lane.  Exact for k - 1 <= 63 (a
+// saturated length clips to "does not write" just as the true one does) in kernels whose row slice
+// spans fewer than 2^10 positions (the unclipped conservation sweep with level arrays of <= 1024 cells).
+// Inside a group the fields are laid out so that no field straddles a dword and every 16-bit
+// (start, length) field sits in a 16-bit half, where the 16-bit VALU forms and SDWA reach it for free:
+//     dword 0 = B0 | A0 << 16 | A1 << 24      B = (start & 1023) << 6 | min(end - start, 63)
+//     dword 1 = B1 | B2 << 16                 A = annot
+//     dword 2 = B3 | A2 << 16 | A3 << 24
+// The start lives in the TOP ten bits of B: (B - (a & 1023) << 6) mod 2^16 leaves the length alone and
+// gives (start - a) mod 2^10 with no borrow to repair.
+struct PackedRows3 {
+    static constexpr int kLoads = 8;
+    static constexpr bool kAnnot16 = false;
+    static constexpr uint64_t kAlign = 127;  // slices start at a multiple of 128 rows = 3 cache lines
+
+    template <int T, int U>
+    static __device__ __forceinline__ uint32_t batches(const Tile &t) {
+        const uint32_t end = (uint32_t)(t.r1 - (t.r0 & ~kAlign));
+        return (end + 4 * T * U - 1) / (4 * T * U);
+    }
+
+    template <int T, int U>
+    static __device__ __forceinline__ void issue(const SweepArgs &A, const Tile &t, uint32_t batch, uint3 (&V)[U]) {
+        const uint64_t base0 = t.r0 & ~kAlign;
+        const uint32_t end = (uint32_t)(t.r1 - base0);
+        const uint32_t *p3 = A.p3 + (base0 >> 2) * 3;
+        const uint32_t rel = batch * (4 * T * U) + 4 * threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = rel + (uint32_t)u * 4 * T;
+            // wave-uniform (consume() tests the same): a wave loads its 256 rows or nothing
+            if ((__builtin_amdgcn_readfirstlane(r) & ~(uint32_t)255) < end)
+                V[u] = *reinterpret_cast<const uint3 *>(p3 + (r >> 2) * 3);
+        }
+    }
+
+    // g(slot-specific registers): g0(d0) .. handled by the caller through four callbacks, one per slot of
+    // the group, because every slot finds its fields in different places.  Rows outside [r0, r1) get
+    // the dead field (start = a, length 63: never writes when k - 1 <= 63).
+    template <int T, int U, typename G0, typename G1, typename G2, typename G3>
+    static __device__ __forceinline__ void consume(const SweepArgs &A, const Tile &t, uint32_t batch, uint3 (&V)[U],
+                                                   G0 g0, G1 g1, G2 g2, G3 g3) {
+        const uint64_t base0 = t.r0 & ~kAlign;
+        const uint32_t first = (uint32_t)(t.r0 - base0), end = (uint32_t)(t.r1 - base0);
+        const uint32_t dead = ((((uint32_t)t.a & 1023u) << 6) | 63u);
+        const uint32_t rel = batch * (4 * T * U) + 4 * threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = rel + (uint32_t)u * 4 * T;
+            const uint32_t wave_lo = __builtin_amdgcn_readfirstlane(r) & ~(uint32_t)255;
+            if (wave_lo >= end) break;  // nothing of this wave's load is inside the slice
+            if (!(wave_lo >= first && wave_lo + 256 <= end)) {  // a load that straddles an end of the slice
+                if (!(r + 0 >= first && r + 0 < end)) V[u].x = (V[u].x & 0xFFFF0000u) | dead;
+                if (!(r + 1 >= first && r + 1 < end)) V[u].y = (V[u].y & 0xFFFF0000u) | dead;
+                if (!(r + 2 >= first && r + 2 < end)) V[u].y = (V[u].y & 0x0000FFFFu) | (dead << 16);
+                if (!(r + 3 >= first && r + 3 < end)) V[u].z = (V[u].z & 0xFFFF0000u) | dead;
+            }
+            g0(V[u].x);          // B in the low half, annot in byte 2
+            g1(V[u].y, V[u].x);  // B in the low half of dword 1, annot in byte 3 of dword 0
+            g2(V[u].y, V[u].z);  // B in the HIGH half of dword 1, annot in byte 2 of dword 2
+            g3(V[u].z);          // B in the low half, annot in byte 3
+        }
+    }
+};
+
 // Conservation results of one tile, LDS -> HBM, with the last fold on the way.  lv0[x] = level 0 of
 // tile slot x (blocks of one position), lv1 = level 1 (blocks of two: lv1[x] covers x and x + 1) or
 // NULL when k - 1 = 1; the result is min(lv0[x], lv1[x], lv1[x - 1]), lv1 being readable from index
@@ -317,7 +384,9 @@ struct PackedRows {
 // wave-instruction.  Pieces are aligned in the OUTPUT (the tile grid is aligned in pivot
 // coordinates, the output starts at qs); when that leaves the LDS side unaligned the cells are read
 // one by one.
-template <typename OutT, int T>
+// TOP8: the cells hold whole row words whose top byte is the order (the unclipped kernels min the words
+// as they are -- the junk below the order only breaks ties); the result is that byte.
+template <typename OutT, int T, bool TOP8 = false>
 __device__ __forceinline__ void store_conservation(const SweepArgs &A, const Tile &t, const uint32_t *lv0,
                                                    const uint32_t *lv1, int x_min) {
     OutT *out = static_cast<OutT *>(A.out);
@@ -330,7 +399,7 @@ __device__ __forceinline__ void store_conservation(const SweepArgs &A, const Til
             r = min(r, lv1[x]);
             if (x > x_min) r = min(r, lv1[x - 1]);
         }
-        return r;
+        return TOP8 ? r >> 24 : r;
     };
     for (int64_t g = (o_lo & ~(int64_t)3) + 4 * threadIdx.x; g < o_hi; g += 4 * T) {
         const int x = (int)(g - ob);
@@ -345,6 +414,17 @@ __device__ __forceinline__ void store_conservation(const SweepArgs &A, const Til
                     v.y = min(v.y, min(u.y, u.x));
                     v.z = min(v.z, min(u.z, u.y));
                     v.w = min(v.w, min(u.w, u.z));
+                }
+                if (TOP8) {  // byte 3 of each word -> the packed result, one v_perm_b32 per two words
+                    if (sizeof(OutT) == 1) {
+                        const uint32_t lo = __builtin_amdgcn_perm(v.y, v.x, 0x0C0C0703u);  // [x3, y3, 0, 0]
+                        const uint32_t hi = __builtin_amdgcn_perm(v.w, v.z, 0x07030C0Cu);  // [0, 0, z3, w3]
+                        *reinterpret_cast<uint32_t *>(out + g) = lo | hi;
+                    } else {
+                        *reinterpret_cast<uint2 *>(out + g) = make_uint2(__builtin_amdgcn_perm(v.y, v.x, 0x0C070C03u),
+                                                                         __builtin_amdgcn_perm(v.w, v.z, 0x0C070C03u));
+                    }
+                    continue;
                 }
             } else {
                 v = make_uint4(one(x), one(x + 1), one(x + 2), one(x + 3));

@@ -63,10 +63,13 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
     return MEMO_OK;
 }
 
-// which row source a query reads: packed when the index has it and k - 1 <= 255, else the int64 columns
+// which row source a query reads: packed when the index has it and k - 1 <= 255, else the int64 columns.
+// fmt: 0 = int64 columns, 4 / 6 = packed words (+ 16-bit order column), 3 = only the 3-byte rows are left
+// (memo_index_pack_dense dropped the words): k - 1 <= 63, and only kernels that read PackedRows3
 int pick_rows(const memo_index *ix, int32_t k, int &fmt) {
     fmt = 0;
-    if (ix->packed_fmt && k - 1 <= 255 && !(ix->tune.force_wide && ix->has_wide)) fmt = ix->packed_fmt;
+    if (ix->packed_fmt && k - 1 <= 255 && !(ix->tune.force_wide && ix->has_wide)) fmt = ix->pk ? ix->packed_fmt : 0;
+    if (!fmt && ix->p3 && k - 1 <= 63 && !(ix->tune.force_wide && ix->has_wide)) fmt = 3;
     if (!fmt && !ix->has_wide)
         return fail(MEMO_EINVAL, "k = %d needs the int64 columns, which this index dropped when it was packed", k);
     return MEMO_OK;
@@ -94,6 +97,7 @@ void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32
     A.e = ix->e;
     A.o = ix->o;
     A.pk = ix->pk;
+    A.p3 = ix->p3;
     A.pa = ix->pa;
     A.boff = ix->boff;
     A.nb = (int64_t)ix->nb;

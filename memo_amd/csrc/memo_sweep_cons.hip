@@ -102,92 +102,27 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
 #ifndef MEMO_HALO_WAVES
 #define MEMO_HALO_WAVES 8
 #endif
-template <typename Rows, int U, int T, typename OutT>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
-void sweep_conservation_halo_kernel(const SweepArgs A) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int tid = threadIdx.x;
+
+// every level starts at the sentinel column N (memo_query.py:53-54); under the first loads
+template <int T>
+__device__ __forceinline__ void halo_clear(const SweepArgs &A, uint32_t *lds, uint32_t sent) {
+    const uint4 sv = make_uint4(sent, sent, sent, sent);
+    uint4 *p = reinterpret_cast<uint4 *>(lds);
+    for (int i = threadIdx.x; i < A.nlev * (A.ls / 4); i += T) p[i] = sv;
+    lds_barrier();
+}
+
+// fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1); the left halo too.
+// Then the last fold + store (store_conservation).
+template <typename OutT, int T, bool TOP8>
+__device__ __forceinline__ void halo_fold_store(const SweepArgs &A, const Tile &t, uint32_t *lds) {
     const int LS = A.ls, HL = A.hl, W = A.w;
-    Tile t;
-#ifdef MEMO_STAMPS
-    unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
-#endif
-    if (!locate_tile_w(A, t, W)) return;
-    MEMO_STAMP(0);  // tile location (kernarg + two bucket-table loads)
-    uint4 V[U];
-    uint2 N[U];
-    Rows::template issue<T, U>(A, t, 0, V, N);
-    {  // under the loads: every level starts at the sentinel column N (memo_query.py:53-54)
-        const uint32_t sent = (uint32_t)(A.ncols - 1);
-        const uint4 sv = make_uint4(sent, sent, sent, sent);
-        uint4 *p = reinterpret_cast<uint4 *>(lds);
-        for (int i = tid; i < A.nlev * (LS / 4); i += T) p[i] = sv;
-        lds_barrier();
-    }
-    MEMO_STAMP(1);  // issue of the loads + LDS clear + barrier
-
-    const int km1 = A.km1;
-    // LDS byte address of tile slot x on the level with clz(n) = f:  base + 4 * ((f - fmin) * LS + HL + x)
-    const uint32_t ls4 = 4u * (uint32_t)LS;
-    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
-    const uint32_t bias4 = pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)(32 - A.nlev) * ls4));
-    const uint32_t top_bit = pin_vgpr((int)0x80000000u);
-    const uint32_t a16 = pin_vgpr((int)((uint32_t)t.a & 0xFFFFu));
-    auto scatter = [&](uint32_t w, uint32_t col) {
-        const int n = km1 - (int)__builtin_amdgcn_ubfe(w, 16, 8);  // length of [end - (k-1), start)
-        if (n > 0) {
-            // f = clz(n); 2^j = 2^31 >> f; x4 = address of cell `start` on level f;
-            // ds_min into the cells of blocks [start - n, .. + 2^j) and [start - 2^j, start).
-            // (v_sub_u16: gfx9 16-bit VALU results have a zero high half.)  The compiler's own
-            // rendering of this needs 13 VALU instructions, one of them a quarter-rate multiply.
-            uint32_t r0, r1, r2;
-            if (Rows::kAnnot16)
-                asm volatile(
-                    "v_ffbh_u32 %0, %3\n\t"
-                    "v_sub_u16 %1, %4, %5\n\t"
-                    "v_mad_u32_u24 %2, %0, %6, %7\n\t"
-                    "v_lshl_add_u32 %2, %1, 2, %2\n\t"
-                    "v_mad_i32_i24 %1, %3, -4, %2\n\t"
-                    "v_ashrrev_i32 %0, %0, %8\n\t"
-                    "v_lshl_add_u32 %2, %0, 2, %2\n\t"
-                    "ds_min_u32 %1, %9\n\t"
-                    "ds_min_u32 %2, %9"
-                    : "=&v"(r0), "=&v"(r1), "=&v"(r2)
-                    : "v"(n), "v"(w), "v"(a16), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(col)
-                    : "memory");
-            else
-                asm volatile(
-                    "v_ffbh_u32 %0, %3\n\t"
-                    "v_sub_u16 %1, %4, %5\n\t"
-                    "v_mad_u32_u24 %2, %0, %6, %7\n\t"
-                    "v_lshl_add_u32 %2, %1, 2, %2\n\t"
-                    "v_mad_i32_i24 %1, %3, -4, %2\n\t"
-                    "v_ashrrev_i32 %0, %0, %8\n\t"
-                    "v_lshl_add_u32 %2, %0, 2, %2\n\t"
-                    "v_lshrrev_b32 %0, 24, %4\n\t"
-                    "ds_min_u32 %1, %0\n\t"
-                    "ds_min_u32 %2, %0"
-                    : "=&v"(r0), "=&v"(r1), "=&v"(r2)
-                    : "v"(n), "v"(w), "v"(a16), "s"(ls4), "v"(bias4), "v"(top_bit)
-                    : "memory");
-        }
-    };
-    Rows::template consume<T, U>(A, t, 0, V, N, scatter);
-    for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
-        Rows::template issue<T, U>(A, t, b, V, N);
-        Rows::template consume<T, U>(A, t, b, V, N, scatter);
-    }
-    MEMO_STAMP(2);  // waiting for rows + scatter
-    lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
-    MEMO_STAMP(3);  // barrier after the scatter
-
-    // fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1); the left halo too
     const int cells = HL + W;
     for (int slot = 0; slot + 2 < A.nlev; ++slot) {  // (the last fold happens in store_conservation)
         const int half = 1 << (A.nlev - 2 - slot);
         const uint32_t *hi = lds + slot * LS;
         uint32_t *lo = lds + (slot + 1) * LS;
-        for (int x = 4 * tid; x < cells; x += 4 * T) {
+        for (int x = 4 * threadIdx.x; x < cells; x += 4 * T) {
             const uint4 v = *reinterpret_cast<const uint4 *>(hi + x);
             uint4 u;
             if (half >= 4) {
@@ -210,14 +145,142 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
         }
         lds_barrier();
     }
+    store_conservation<OutT, T, TOP8>(A, t, lds + (A.nlev - 1) * LS + HL,
+                                      A.nlev > 1 ? lds + (A.nlev - 2) * LS + HL : nullptr, -HL);
+}
 
-    MEMO_STAMP(4);  // fold (all levels but the last)
-    store_conservation<OutT, T>(A, t, lds + (A.nlev - 1) * LS + HL,
-                                A.nlev > 1 ? lds + (A.nlev - 2) * LS + HL : nullptr, -HL);
-    MEMO_STAMP(5);  // last fold + store
+// 4- and 6-byte rows.  The 4-byte rows carry their order in the top byte of the word, and the cells
+// take the WORD (ds_min_u32 of the row as it was loaded: the min of the words has the min order on
+// top, the junk below it only breaks ties) -- one VALU instruction per row less than extracting it;
+// the store keeps the top byte (TOP8; needs num_docs <= 255 for the sentinel).  Otherwise the cells
+// hold the order itself: the word's top byte shifted down, or the 16-bit order column.
+template <typename Rows, int U, int T, typename OutT, bool TOP8>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
+void sweep_conservation_halo_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    static_assert(!(TOP8 && Rows::kAnnot16), "the order byte rides in the word only in the 4-byte format");
+    const int LS = A.ls, HL = A.hl, W = A.w;
+    Tile t;
+#ifdef MEMO_STAMPS
+    unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    if (!locate_tile_w(A, t, W)) return;
+    MEMO_STAMP(0);  // tile location (kernarg + two bucket-table loads)
+    uint4 V[U];
+    uint2 N[U];
+    Rows::template issue<T, U>(A, t, 0, V, N);
+    const uint32_t sent = (uint32_t)(A.ncols - 1);
+    halo_clear<T>(A, lds, TOP8 ? (sent << 24) | 0x00FFFFFFu : sent);
+    MEMO_STAMP(1);  // issue of the loads + LDS clear + barrier
+
+    const int km1 = A.km1;
+    // LDS byte address of tile slot x on the level with clz(n) = f:  base + 4 * ((f - fmin) * LS + HL + x)
+    const uint32_t ls4 = 4u * (uint32_t)LS;
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
+    const uint32_t bias4 = pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)(32 - A.nlev) * ls4));
+    const uint32_t top_bit = pin_vgpr((int)0x80000000u);
+    const uint32_t a16 = pin_vgpr((int)((uint32_t)t.a & 0xFFFFu));
+    auto scatter = [&](uint32_t w, uint32_t col) {
+        const int n = km1 - (int)__builtin_amdgcn_ubfe(w, 16, 8);  // length of [end - (k-1), start)
+        if (n > 0) {
+            // f = clz(n); 2^j = 2^31 >> f; x4 = address of cell `start` on level f;
+            // ds_min into the cells of blocks [start - n, .. + 2^j) and [start - 2^j, start).
+            // (v_sub_u16: gfx9 16-bit VALU results have a zero high half.)  The compiler's own
+            // rendering of this needs 13 VALU instructions, one of them a quarter-rate multiply.
+            uint32_t r0, r1, r2;
+            asm volatile(
+                "v_ffbh_u32 %0, %3\n\t"
+                "v_sub_u16 %1, %4, %5\n\t"
+                "v_mad_u32_u24 %2, %0, %6, %7\n\t"
+                "v_lshl_add_u32 %2, %1, 2, %2\n\t"
+                "v_mad_i32_i24 %1, %3, -4, %2\n\t"
+                "v_ashrrev_i32 %0, %0, %8\n\t"
+                "v_lshl_add_u32 %2, %0, 2, %2\n\t"
+                "ds_min_u32 %1, %9\n\t"
+                "ds_min_u32 %2, %9"
+                : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+                : "v"(n), "v"(w), "v"(a16), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(TOP8 ? w : col)
+                : "memory");
+        }
+    };
+    Rows::template consume<T, U>(A, t, 0, V, N, scatter);
+    for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
+        Rows::template issue<T, U>(A, t, b, V, N);
+        Rows::template consume<T, U>(A, t, b, V, N, scatter);
+    }
+    MEMO_STAMP(2);  // waiting for rows + scatter
+    lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
+    MEMO_STAMP(3);  // barrier after the scatter
+    halo_fold_store<OutT, T, TOP8>(A, t, lds);
+    MEMO_STAMP(5);  // folds + store
 #ifdef MEMO_STAMPS
     if (threadIdx.x == 0 && A.stamps) A.stamps[8ull * blockIdx.x + 7] = 1;
 #endif
+}
+
+// The same sweep on the 3-byte rows (PackedRows3, k - 1 <= 63, level arrays of at most 1024 cells).
+// Per row: 16-bit subtract (start - a, length untouched below it), and, subtract, compare | ffbh, bfe,
+// mad, lshl_add, mad, ashr, lshl_add, (shift of the order byte for two of the four slots), ds_min x 2.
+template <int U, int T, typename OutT>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
+void sweep_conservation_halo3_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    using Rows = PackedRows3;
+    const int LS = A.ls, HL = A.hl, W = A.w;
+    Tile t;
+    if (!locate_tile_w(A, t, W)) return;
+    uint3 V[U];
+    Rows::template issue<T, U>(A, t, 0, V);
+    halo_clear<T>(A, lds, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
+
+    const int km1 = A.km1;
+    const uint32_t ls4 = 4u * (uint32_t)LS;
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
+    const uint32_t bias4 = pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)(32 - A.nlev) * ls4));
+    const uint32_t top_bit = pin_vgpr((int)0x80000000u);
+    const uint32_t a10s = pin_vgpr((int)(((uint32_t)t.a & 1023u) << 6));
+    // r = (start - a) mod 2^10 << 6 | length;  data = a word with the row's order in its top byte
+    auto scatter = [&](uint32_t r, uint32_t data) {
+        const int n = km1 - (int)(r & 63u);
+        if (n > 0) {
+            uint32_t r0, r1, r2;
+            asm volatile(
+                "v_ffbh_u32 %0, %3\n\t"
+                "v_bfe_u32 %1, %4, 6, 10\n\t"
+                "v_mad_u32_u24 %2, %0, %5, %6\n\t"
+                "v_lshl_add_u32 %2, %1, 2, %2\n\t"
+                "v_mad_i32_i24 %1, %3, -4, %2\n\t"
+                "v_ashrrev_i32 %0, %0, %7\n\t"
+                "v_lshl_add_u32 %2, %0, 2, %2\n\t"
+                "ds_min_u32 %1, %8\n\t"
+                "ds_min_u32 %2, %8"
+                : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+                : "v"(n), "v"(r), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(data)
+                : "memory");
+        }
+    };
+    auto sub_lo = [&](uint32_t d) {  // 16-bit subtract on the low halves; the result's high half is zero
+        uint32_t r;
+        asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(d), "v"(a10s));
+        return r;
+    };
+    auto sub_hi = [&](uint32_t d) {  // ... with the HIGH half of d as the minuend (SDWA: no shift instruction)
+        uint32_t r;
+        asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0"
+            : "=v"(r) : "v"(d), "v"(a10s));
+        return r;
+    };
+    auto g0 = [&](uint32_t d0) { scatter(sub_lo(d0), d0 << 8); };
+    auto g1 = [&](uint32_t d1, uint32_t d0) { scatter(sub_lo(d1), d0); };
+    auto g2 = [&](uint32_t d1, uint32_t d2) { scatter(sub_hi(d1), d2 << 8); };
+    auto g3 = [&](uint32_t d2) { scatter(sub_lo(d2), d2); };
+    Rows::template consume<T, U>(A, t, 0, V, g0, g1, g2, g3);
+    for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
+        Rows::template issue<T, U>(A, t, b, V);
+        Rows::template consume<T, U>(A, t, b, V, g0, g1, g2, g3);
+    }
+    lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
+    halo_fold_store<OutT, T, true>(A, t, lds);
 }
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
@@ -327,11 +390,18 @@ SweepKernel cons_kernel(int w, int waves) {
 #endif
 constexpr int kHaloLoads = MEMO_HALO_LOADS;  // 16-byte loads in flight per lane
 
-template <typename Rows, typename OutT>
+template <typename Rows, typename OutT, bool TOP8>
 static SweepKernel halo_kernel(int waves) {
-    return waves == 8   ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 512, OutT>
-           : waves == 4 ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 256, OutT>
-                        : (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 64, OutT>;
+    return waves == 8   ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 512, OutT, TOP8>
+           : waves == 4 ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 256, OutT, TOP8>
+                        : (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 64, OutT, TOP8>;
+}
+
+template <typename OutT>
+static SweepKernel halo3_kernel(int waves) {
+    return waves == 8   ? (SweepKernel)sweep_conservation_halo3_kernel<PackedRows3::kLoads, 512, OutT>
+           : waves == 4 ? (SweepKernel)sweep_conservation_halo3_kernel<PackedRows3::kLoads, 256, OutT>
+                        : (SweepKernel)sweep_conservation_halo3_kernel<PackedRows3::kLoads, 64, OutT>;
 }
 
 template <typename OutT>
@@ -416,10 +486,33 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.ls = hl + tw + hr;
             if (tune.waves == 0) waves = w >= 1024 ? 4 : 1;
             if (tune.waves == 8) waves = 8;  // (experiment: eight waves share a tile; only this kernel has that shape)
-            SweepKernel kern = fmt == 4 ? halo_kernel<PackedRows<false, false>, OutT>(waves)
-                                        : halo_kernel<PackedRows<true, false>, OutT>(waves);
+            // densest rows that can answer: 3-byte rows for k - 1 <= 63 when the level arrays stay within
+            // 2^10 cells and the order fits the result's top-byte trick; else the 4- / 6-byte rows
+            const bool top8 = num_docs <= 255;
+            const bool three = ix->p3 && !(tune.force_packed4 && ix->pk) && k - 1 <= 63 && A.ls <= 1024 && top8;
+            if (!three && fmt == 3) {
+                halo = false;  // (below: the int64 columns, or an error when they are gone too)
+            } else {
+            SweepKernel kern = three      ? halo3_kernel<OutT>(waves)
+                               : fmt == 4 ? (top8 ? halo_kernel<PackedRows<false, false>, OutT, true>(waves)
+                                                  : halo_kernel<PackedRows<false, false>, OutT, false>(waves))
+                                          : halo_kernel<PackedRows<true, false>, OutT, false>(waves);
             if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)A.nlev * A.ls * 4, st))) return rc;
+            }
         }
+    }
+    if (!halo && fmt == 3) {  // the 3-byte rows cannot answer this one (tile shape, num_docs > 255, sparse index)
+        if (!ix->has_wide)
+            return fail(MEMO_EINVAL, "this query needs the 4-byte rows or the int64 columns, which this index dropped");
+        fmt = 0;
+        w = tune.tile_w;  // tile shape for int64 rows
+        if (!w) {
+            w = 4096;
+            while ((size_t)A.nlev * w * 4 > (sparse ? 32u : 80u) * 1024 && w > 256) w >>= 1;
+            while (w > 1024 && (qe - qs) / w < 8192) w >>= 1;
+            while (w > 256 && w <= 1024 && (qe - qs) / w < 32768) w >>= 1;
+        }
+        waves = tune.waves == 1 || tune.waves == 4 ? tune.waves : (w >= 1024 ? 4 : 1);
     }
     if (!halo) {
         while ((size_t)A.nlev * (w + kLevelSkew) * 4 > 160 * 1024 && w > 256) w >>= 1;

@@ -33,11 +33,26 @@ def words(num_docs):
 
 
 class DeviceIndex:
-    def __init__(self, rows, device=0):
+    def __init__(self, rows, device=0, _handle=None):
         self._h = C.c_void_p()
         self.rows = int(rows)
         self.device = int(device)
-        check(lib().memo_index_create(self.rows, self.device, C.byref(self._h)))
+        if _handle is not None:
+            self._h = _handle
+        else:
+            check(lib().memo_index_create(self.rows, self.device, C.byref(self._h)))
+
+    @classmethod
+    def from_host_packed(cls, start, end, annot, device=0, bucket_shift=0):
+        """the packed, pinned way in (memo_builder_*): rows narrowed on the host, 4-6 B per row over PCIe,
+        an index that is finalized and packed (k <= 256).  Raises MemoUnpackable for rows that need the
+        int64 path (from_host)."""
+        s, e, o = _col(start), _col(end), _col(annot)
+        if not (len(s) == len(e) == len(o)):
+            raise ValueError("columns differ in length")
+        with IndexBuilder(len(s), device, bucket_shift) as b:
+            b.push(s, e, o)
+            return b.finish()
 
     @classmethod
     def from_host(cls, start, end, annot, device=0, bucket_shift=0, allow_sort=True):
@@ -76,6 +91,11 @@ class DeviceIndex:
     def pack(self, keep_wide=True):
         """build the 4/6-byte-per-row query format (memo_index_pack)"""
         check(lib().memo_index_pack(self._h, 1 if keep_wide else 0))
+        return self
+
+    def pack_dense(self, keep_packed=True):
+        """build the 3-byte-per-row format (memo_index_pack_dense): k <= 64, annot <= 255"""
+        check(lib().memo_index_pack_dense(self._h, 1 if keep_packed else 0))
         return self
 
     def info(self):
@@ -142,6 +162,43 @@ class DeviceIndex:
 
     def __exit__(self, *a):
         self.close()
+
+
+class IndexBuilder:
+    """memo_builder_*: start-sorted host rows -> a packed, finalized DeviceIndex, piece by piece."""
+
+    def __init__(self, max_rows, device=0, bucket_shift=0):
+        self._b = C.c_void_p()
+        self.device = int(device)
+        self.rows = 0
+        check(lib().memo_builder_create(int(max_rows), self.device, bucket_shift, C.byref(self._b)))
+
+    def push(self, start, end, annot):
+        s, e, o = _col(start), _col(end), _col(annot)
+        check(lib().memo_builder_push(self._b, s.ctypes.data, e.ctypes.data, o.ctypes.data, len(s)))
+        self.rows += len(s)
+
+    def finish(self):
+        h = C.c_void_p()
+        check(lib().memo_builder_finish(self._b, C.byref(h)))
+        return DeviceIndex(self.rows, self.device, _handle=h)
+
+    def close(self):
+        if self._b:
+            lib().memo_builder_destroy(self._b)
+            self._b = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- one-shot host API: memo_init + memo_query + reduction on host arrays ----

@@ -21,7 +21,8 @@ import os
 
 import numpy as np
 
-from .index import DeviceIndex, emit_conservation_buffer, emit_membership_buffer, words
+from ._lib import MemoUnpackable
+from .index import DeviceIndex, IndexBuilder, emit_conservation_buffer, emit_membership_buffer, words
 
 
 class RegionRows:
@@ -114,15 +115,33 @@ def region_chunks(in_file, query_record, query_start, query_end):
     return bound, chunks()
 
 
-def region_index(in_file, query_record, query_start, query_end, device=None):
+def region_index(in_file, query_record, query_start, query_end, device=None, k=None):
     """filter_pq + the upload half of memo_init in one streaming pass: the rows go from the
     Parquet file straight into a finalized DeviceIndex, row group by row group (the next one is
-    decoded by Arrow while the current one is copied to the GPU); the host never holds more than
-    two row groups.  Anything that is not a single Parquet file goes through filter_pq."""
+    decoded by Arrow while the current one is packed and copied to the GPU); the host never holds more
+    than a few row groups.  For k <= 256 (k=None: unknown, as large as it likes) the rows take the packed
+    way in (memo_builder_*: narrowed on the host into pinned memory, 4-6 B per row over PCIe, PackedRows
+    kernels); rows that cannot be packed, and larger k, go up as int64 columns.  Anything that is not a
+    single Parquet file goes through filter_pq."""
     device = _device() if device is None else device
+    packed = k is not None and 1 < k <= 256 and not os.environ.get("MEMO_QUERY_WIDE")
     if not os.path.isfile(in_file):
         rows = filter_pq(in_file, query_record, query_start, query_end)
+        if packed:
+            try:
+                return DeviceIndex.from_host_packed(rows.start, rows.end, rows.annot, device=device)
+            except MemoUnpackable:
+                pass
         return DeviceIndex.from_host(rows.start, rows.end, rows.annot, device=device)
+    if packed:
+        bound, chunks = region_chunks(in_file, query_record, query_start, query_end)
+        try:
+            with IndexBuilder(bound, device) as builder:
+                for cols in chunks:
+                    builder.push(*cols)
+                return builder.finish()
+        except MemoUnpackable:
+            pass                                  # read the slice again, as int64 columns
     bound, chunks = region_chunks(in_file, query_record, query_start, query_end)
     index = DeviceIndex(bound, device)
     written = 0
@@ -162,7 +181,14 @@ def memo_init(mem_arr, k, true_start, true_end, num_docs, membership_query):
     else:                                     # the reference's [M, 3] array
         arr = np.asarray(mem_arr)
         s, e, o = (np.ascontiguousarray(arr[:, i]) for i in range(3))
-    index = DeviceIndex.from_host(s, e, o, device=_device())
+    index = None
+    if 1 < k <= 256:
+        try:
+            index = DeviceIndex.from_host_packed(s, e, o, device=_device())
+        except MemoUnpackable:
+            pass
+    if index is None:
+        index = DeviceIndex.from_host(s, e, o, device=_device())
     return index, QueryResult(true_start, true_end, k, num_docs, membership_query)
 
 
@@ -226,7 +252,7 @@ def _main_sharded(args):
                            dtype=torch.int32 if membership_query else torch.int16, device=dev)
 
     def sweep(a, b, out):
-        ix = region_index(args.in_file, query_record, a, b + k, device=local)
+        ix = region_index(args.in_file, query_record, a, b + k, device=local, k=k)
         held.append(ix)
         if membership_query:
             ix.membership_dev(a, b, k, num_docs, out, stream.cuda_stream)
@@ -258,7 +284,7 @@ def main(args):
     query_record, start_end = args.genome_region.split(':')      # exactly one ':' and one '-'
     query_start, query_end = map(int, start_end.split('-'))
     t = [time.perf_counter()]
-    rows = region_index(args.in_file, query_record, query_start, query_end + k)     # filter_pq, :100
+    rows = region_index(args.in_file, query_record, query_start, query_end + k, k=k)     # filter_pq, :100
     t.append(time.perf_counter())
     mem_arr, rec = memo_init(rows, k, query_start, query_end, num_docs, membership_query)
     try:

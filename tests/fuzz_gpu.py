@@ -53,13 +53,15 @@ while time.time() < t_end:
         packable = not (m and s.min() < 0)
         if packable and rng.random() < 0.7:
             ix.pack(keep_wide=True)
+            if ix.info()["packed_format"] == 4 and rng.random() < 0.6:
+                ix.pack_dense(keep_packed=True)
         for _ in range(6):
             queries += 1
             k = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 21, 31, 32, 33, 64, 65, 101, 128, 129, 255, 256, 257, 1000]))
             qs = int(rng.integers(0, length))
             qe = int(rng.integers(qs, length + 200))
             tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096])), int(rng.choice([0, 1, 4, 8])),
-                    int(rng.choice([0, 2, 3, 4])), int(rng.integers(0, 2)), int(rng.integers(0, 3)))
+                    int(rng.choice([0, 2, 3, 4])), int(rng.integers(0, 3)), int(rng.integers(0, 3)))
             ix.debug_set_tuning(*tune)
             memb = rng.random() < 0.4
             if memb and (qe - qs) * n_docs > 30_000_000:

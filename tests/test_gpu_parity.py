@@ -57,6 +57,23 @@ def test_golden_one_shot(c, memo):
         assert G.sha(text) == c["sha256"]
 
 
+@pytest.mark.parametrize("c", G.cases(raises=False)[::4], ids=lambda c: c["name"])
+def test_golden_one_shot_int64_way_in(c, memo, monkeypatch):
+    """the same goldens with the packed way in switched off (MEMO_ONESHOT_WIDE): int64 columns uploaded,
+    finalized on the device, WideRows kernels -- what k > 256 and unpackable rows get"""
+    from memo_amd.index import bits_to_matrix
+    monkeypatch.setenv("MEMO_ONESHOT_WIDE", "1")
+    rec, qs, qe = G.region(c)
+    z = G.load(c)
+    rows = G.index_columns(c["index"], rec)
+    if c["membership"]:
+        got = memo.membership(*rows, qs, qe, c["k"], c["n"])
+        assert np.array_equal(bits_to_matrix(got, c["n"]), G.expected_matrix(c, z))
+    else:
+        got = memo.conservation(*rows, qs, qe, c["k"], c["n"])
+        assert np.array_equal(got.astype(np.int64), z["vec"])
+
+
 @pytest.mark.parametrize("c", G.cases(raises=True), ids=lambda c: c["name"])
 def test_golden_index_error(c, memo):
     rec, qs, qe = G.region(c)
@@ -203,6 +220,57 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle, ab):
             ix.conservation(0, length, 31, 3)
 
 
+@pytest.mark.parametrize("n_docs,bucket_shift,keep_packed,keep_wide", [(100, 0, True, True), (255, 0, False, True),
+                                                                      (30, 3, False, False), (300, 0, True, False),
+                                                                      (90, 7, True, True)])
+def test_dense_rows_equal_packed_rows(n_docs, bucket_shift, keep_packed, keep_wide, memo, oracle, ab):
+    """memo_index_pack_dense: 3 bytes per row (start mod 2^10, length saturated at 63, 8-bit annot).
+    The unclipped conservation sweep reads them for k <= 64, level arrays of <= 1024 cells and
+    num_docs <= 255; every other query falls to the 4-byte rows / int64 columns -- or is refused when
+    those were dropped.  Index longer than 2^10 and 2^16 positions: both start fields wrap inside it."""
+    rng = np.random.default_rng(n_docs + bucket_shift)
+    length = 200_000
+    s, e, o = _random_index(rng, 700_000, length, min(n_docs, 200), 80)       # annots <= 199 also when n_docs = 300
+    e[::9] = s[::9] + rng.integers(60, 300, len(s[::9]))                      # lengths that saturate 6 and 8 bits
+    with memo.DeviceIndex.from_host(s, e, o, bucket_shift=bucket_shift) as ix:
+        with pytest.raises(memo.MemoError):
+            ix.pack_dense()                                                    # needs memo_index_pack first
+        ix.pack(keep_wide=keep_wide)
+        ix.pack_dense(keep_packed=keep_packed)
+        inf = ix.info()
+        assert inf["dense_rows"] == 1 and inf["packed_format"] == 4 and inf["has_wide"] == int(keep_wide)
+        for tile_w, waves in ((0, 0), (1024, 4), (512, 1), (2048, 4), (1024, 8)):
+            for k in (2, 3, 9, 17, 31, 33, 63, 64, 65, 101):
+                qs = int(rng.integers(0, length // 2))
+                qe = int(rng.integers(qs + 1, length + 100))
+                want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                for source in (0, 2):                   # densest rows that can answer / the 4-byte rows
+                    ix.debug_set_tuning(tile_w, waves, 0, source, 0)
+                    answerable = keep_packed or keep_wide or (k <= 64 and n_docs <= 255 and tile_w in (0, 1024, 512))
+                    if not answerable:
+                        with pytest.raises(memo.MemoError):
+                            ix.conservation(qs, qe, k, n_docs)
+                        continue
+                    assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (k, qs, qe, tile_w, source)
+                    if n_docs <= 255:
+                        assert np.array_equal(ix.conservation(qs, qe, k, n_docs, dtype=np.uint8), want.astype(np.uint8)), \
+                            (k, qs, qe, tile_w, source)
+                if k in (31, 65) and (keep_packed or keep_wide):
+                    qe = min(qe, qs + 5000)
+                    wantb = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                    assert np.array_equal(ix.membership(qs, qe, k, n_docs), wantb), (k, qs, qe)
+        ix.debug_set_tuning()
+        ix.pack_dense(keep_packed=keep_packed)          # again: nothing to do
+        if keep_wide:                                   # re-finalizing drops every packed copy
+            ix.finalize(bucket_shift)
+            assert ix.info()["dense_rows"] == 0 and ix.info()["packed_format"] == 0
+    s2, e2, o2 = _random_index(rng, 50_000, 30_000, 400, 80)                  # annots > 255: 6-byte rows, no dense form
+    with memo.DeviceIndex.from_host(s2, e2, o2) as ix:
+        ix.pack()
+        with pytest.raises(memo.MemoError):
+            ix.pack_dense()
+
+
 @pytest.mark.parametrize("bucket_shift", [1, 3, 6, 8])
 def test_bucket_widths(bucket_shift, memo, oracle, ab):
     """bucket tables of 2 .. 256 positions: a tile's row slice ends at a bucket boundary, which is what
@@ -233,6 +301,116 @@ def test_bucket_widths(bucket_shift, memo, oracle, ab):
                             assert np.array_equal(ix.membership(qs, qe, k, n_docs), wantb), (packed, k, qs, qe, tile_w)
             finally:
                 ix.debug_set_tuning()
+
+
+# ---------------------------------------------------------------------------------------
+# the packed, pinned way in (memo_builder_*): host-side narrowing + bucket table
+# ---------------------------------------------------------------------------------------
+def _check_windows(ix, s, e, o, n_docs, rng, oracle, length, ks=(2, 21, 31, 64, 101, 256), windows=3):
+    for k in ks:
+        for _ in range(windows):
+            qs = int(rng.integers(0, max(length - 10, 1)))
+            qe = int(rng.integers(qs + 1, min(qs + 400_000, length + 300)))
+            rows = oracle.filter_rows(s, e, o, qs, qe, k)
+            want = oracle.conservation(*rows, qs, qe, k, n_docs, literal=False)
+            assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (k, qs, qe)
+            qe = min(qe, qs + 5000)
+            rows = oracle.filter_rows(s, e, o, qs, qe, k)
+            wantb = oracle.membership(*rows, qs, qe, k, n_docs, literal=False)
+            assert np.array_equal(ix.membership(qs, qe, k, n_docs), wantb), (k, qs, qe)
+
+
+@pytest.mark.parametrize("n_rows,n_docs,pieces", [(300_000, 90, 1), (300_000, 90, 7), (9_500_000, 200, 3),
+                                                  (9_500_000, 700, 2), (40, 5, 1)])
+def test_builder_equals_int64_upload(n_rows, n_docs, pieces, memo, oracle):
+    """rows pushed through memo_builder_* in ragged pieces (more than one pinned slot of 4 Mi rows per
+    push in the large cases) give the index memo_index_upload + _finalize + _pack give"""
+    rng = np.random.default_rng(n_rows + pieces)
+    length = max(n_rows // 4, 100)
+    s, e, o = _random_index(rng, n_rows, length, n_docs, 90)
+    e[::11] = s[::11] + rng.integers(250, 5000, len(s[::11]))      # overlaps that saturate the 8-bit length
+    cuts = [0] + sorted(int(x) for x in rng.integers(0, n_rows, pieces - 1)) + [n_rows]
+    with memo.IndexBuilder(n_rows + 1000) as b:
+        for a, z in zip(cuts[:-1], cuts[1:]):
+            b.push(s[a:z], e[a:z], o[a:z])
+        b.push(s[:0], e[:0], o[:0])                                 # an empty piece changes nothing
+        with b.finish() as ix:
+            inf = ix.info()
+            assert inf["rows"] == n_rows and inf["finalized"] == 1 and inf["has_wide"] == 0
+            assert inf["packed_format"] == (4 if n_docs <= 256 else 6)
+            assert inf["min_start"] == int(s[0]) and inf["max_start"] == int(s[-1])
+            with memo.DeviceIndex.from_host(s, e, o) as ref:
+                ref.pack(keep_wide=True)
+                assert ref.info()["buckets"] == inf["buckets"]
+                for k in (31, 101):
+                    assert np.array_equal(ix.conservation(0, length + 50, k, n_docs), ref.conservation(0, length + 50, k, n_docs))
+            _check_windows(ix, s, e, o, n_docs, rng, oracle, length, windows=2)
+            with pytest.raises(memo.MemoError):
+                ix.conservation(0, 1000, 300, n_docs)               # k > 256 needs the int64 columns
+
+
+def test_builder_switches_to_16_bit_annots_late(memo, oracle):
+    """the first annot > 255 arrives after 5 M rows are already on the device as 8-bit annots: they are
+    widened in place (widen_annot_kernel) and the current piece is packed again"""
+    rng = np.random.default_rng(5)
+    n_rows, length, n_docs = 6_000_000, 900_000, 1000
+    s, e, o = _random_index(rng, n_rows, length, n_docs, 70)
+    o[:5_000_000] = rng.integers(1, 200, 5_000_000)
+    with memo.IndexBuilder(n_rows) as b:
+        for a in range(0, n_rows, 1_000_000):
+            b.push(s[a:a + 1_000_000], e[a:a + 1_000_000], o[a:a + 1_000_000])
+        with b.finish() as ix:
+            assert ix.info()["packed_format"] == 6
+            _check_windows(ix, s, e, o, n_docs, rng, oracle, length, ks=(31, 101), windows=3)
+
+
+def test_builder_refuses_what_cannot_be_packed(memo, oracle):
+    rng = np.random.default_rng(6)
+    s, e, o = _random_index(rng, 50_000, 20_000, 30, 80)
+    bad = {"unsorted": (s[::-1].copy(), e[::-1].copy(), o), "negative start": (s - 30_000, e - 30_000, o),
+           "annot 70000": (s, e, np.where(np.arange(len(o)) == 777, 70_000, o)),
+           "negative annot": (s, e, np.where(np.arange(len(o)) == 40_000, -1, o))}
+    for name, (bs, be, bo) in bad.items():
+        with memo.IndexBuilder(len(bs)) as b:
+            with pytest.raises(memo.MemoUnpackable):
+                b.push(bs, be, bo)
+            with pytest.raises(memo.MemoError):
+                b.push(s, e, o)                                     # a failed builder stays failed
+        if name == "annot 70000":
+            continue                                                # (IndexError in the reference: covered elsewhere)
+        # the one-shot seam falls back to the int64 way in and still equals the reference's result
+        order = np.argsort(bs, kind="stable")
+        n_docs = 30 if name != "negative annot" else 31
+        qs, qe = (-25_000, -5_000) if name == "negative start" else (1000, 15_000)
+        want = oracle.conservation(*oracle.filter_rows(bs[order], be[order], bo[order], qs, qe, 31), qs, qe, 31, n_docs,
+                                   literal=False)
+        assert np.array_equal(memo.conservation(bs, be, bo, qs, qe, 31, n_docs), want), name
+    # sorted across pieces, too
+    with memo.IndexBuilder(len(s)) as b:
+        b.push(s[25_000:], e[25_000:], o[25_000:])
+        with pytest.raises(memo.MemoUnpackable):
+            b.push(s[:25_000], e[:25_000], o[:25_000])
+    with memo.IndexBuilder(10) as b:
+        with pytest.raises(memo.MemoError):
+            b.push(s[:11], e[:11], o[:11])                          # more rows than announced
+
+
+def test_builder_rows_with_end_before_start_and_empty(memo, oracle):
+    rng = np.random.default_rng(8)
+    s, e, o = _random_index(rng, 200_000, 60_000, 40, 70)
+    neg = rng.random(len(s)) < 0.01
+    e[neg] = s[neg] - rng.integers(1, 3000, int(neg.sum()))
+    with memo.DeviceIndex.from_host_packed(s, e, o) as ix:
+        _check_windows(ix, s, e, o, 40, rng, oracle, 60_000, ks=(3, 31, 200), windows=3)
+        for L in (1, 2, 3, 5, 7):                                   # result tails shorter than a 32-bit word
+            want = oracle.conservation(*oracle.filter_rows(s, e, o, 100, 100 + L, 31), 100, 100 + L, 31, 40, literal=False)
+            assert np.array_equal(ix.conservation(100, 100 + L, 31, 40), want)
+            assert np.array_equal(ix.conservation(100, 100 + L, 31, 40, dtype=np.uint8), want.astype(np.uint8))
+    with memo.IndexBuilder(0) as b:
+        with b.finish() as ix:
+            assert ix.info()["rows"] == 0
+            assert np.array_equal(ix.conservation(5, 50, 31, 9), np.full(45, 9, np.uint16))
+            assert np.array_equal(ix.membership(5, 8, 31, 9), np.full((3, 1), 511, np.uint32))
 
 
 def test_two_threads_two_indexes(memo, oracle):
@@ -424,8 +602,9 @@ _C3_FNV = {}
 
 @pytest.mark.parametrize("membership,pack,dtype", [
     (False, None, np.uint16), (False, "keep", np.uint16), (False, "keep", np.uint8), (False, "only", np.uint8),
-    (True, None, None), (True, "keep", None)],
-    ids=["cons-int64-u16", "cons-packed-u16", "cons-packed-u8", "cons-packedonly-u8", "memb-int64", "memb-packed"])
+    (False, "dense", np.uint8), (False, "dense", np.uint16), (True, None, None), (True, "keep", None)],
+    ids=["cons-int64-u16", "cons-packed-u16", "cons-packed-u8", "cons-packedonly-u8", "cons-dense-u8", "cons-dense-u16",
+         "memb-int64", "memb-packed"])
 def test_config3_full_size_properties(membership, pack, dtype, memo, oracle):
     """configs 3/4 at full size: 100 genomes x 100 Mbp, 500 M rows, on the int64 columns AND on the
     packed rows (the benchmarked kernels: sweep_conservation_halo_kernel<PackedRows<false,false>,..,uint8>,
@@ -441,7 +620,8 @@ def test_config3_full_size_properties(membership, pack, dtype, memo, oracle):
     with ix:
         inf = ix.info()
         assert inf["rows"] == r1 - r0 and abs((r1 - r0) - 500_000_000) < 1000
-        assert inf["packed_format"] == (4 if pack else 0) and inf["has_wide"] == (0 if pack == "only" else 1)
+        assert inf["packed_format"] == (4 if pack else 0) and inf["has_wide"] == (0 if pack in ("only", "dense") else 1)
+        assert inf["dense_rows"] == int(pack == "dense")
         full = np.empty((L, W), np.uint32) if membership else np.empty(L, dtype)
         d = C.c_void_p()
         _lib.check(_lib.lib().memo_dev_malloc(0, full.nbytes, C.byref(d)))

@@ -27,14 +27,19 @@ def main():
     ap.add_argument("--u8", action="store_true")
     ap.add_argument("--length", type=int, default=0, help="query [0, length) instead of the whole pivot")
     ap.add_argument("--density", default="5/100", help="rows per genome and position")
-    ap.add_argument("--pack", default=None, choices=[None, "keep", "only"])
+    ap.add_argument("--pack", default=None, choices=[None, "keep", "only", "dense", "both"],
+                    help="keep: int64 + 4-byte rows; only: 4-byte rows; dense: 3-byte rows only; both: 4- and 3-byte rows "
+                         "(row_source 2 in a variant then selects the 4-byte ones)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     num_docs, L, membership = WORKLOADS[a.workload]
     L = a.length or L
     from fractions import Fraction
     _lib.use_ab(True)
-    ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L, density=Fraction(a.density), pack=a.pack)
+    ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L, density=Fraction(a.density),
+                                      pack="only" if a.pack == "both" else a.pack)
+    if a.pack == "both":
+        ix.pack_dense(keep_packed=True)
     W = (num_docs + 31) // 32
     out = torch.empty((L, W) if membership else (L,), dtype=torch.int32 if membership else torch.int16, device="cuda")
     st = torch.cuda.current_stream()
@@ -60,9 +65,11 @@ def main():
             if r:                                   # round 0 = warm-up
                 times[v].append(e0.elapsed_time(e1))
     ix.check()
-    brow = 24 if not a.pack else ix.info()['packed_format']
-    b_alg = brow * (r1 - r0) + (4 * W if membership else (1 if a.u8 else 2)) * L
     for v in variants:
+        src = v[3] if len(v) > 3 else 0
+        brow = 24 if (not a.pack or src == 1) else (3 if ix.info()["dense_rows"] and src != 2 and a.k <= 64 and not membership
+                                                    else ix.info()['packed_format'])
+        b_alg = brow * (r1 - r0) + (4 * W if membership else (1 if a.u8 else 2)) * L
         t = np.array(times[v])
         print(json.dumps({"variant": v, "workload": a.workload, "k": a.k, "row_bytes": brow, "ms_median": float(np.median(t)),
                           "ms_min": float(t.min()), "ms_max": float(t.max()),
