@@ -65,7 +65,8 @@ def parse():
     ap.add_argument("--rows", default="auto", choices=["auto", "dense", "packed", "wide"],
                     help="row format the timed sweep reads: dense (memo_index_pack_dense, 3 B/row: conservation, "
                          "k <= 64, num_docs <= 255), packed (memo_index_pack, 4-6 B/row), or the int64 columns as "
-                         "uploaded (24 B/row); auto = the densest that can answer; at N=1 the others are timed too")
+                         "uploaded (24 B/row); auto = the fastest that can answer (packed for k <= 256); at N=1 the "
+                         "others are timed too")
     ap.add_argument("--plain-gather", action="store_true",
                     help="N > 1: send uint8 slices as they are (default: the densest transport coding that fits)")
     ap.add_argument("--code-own-slice", action="store_true",
@@ -160,7 +161,7 @@ def main():
         _lib.use_ab(True)                   # the PMC calibration kernel lives in libmemo_amd_ab.so only
     can_dense = (not membership) and k - 1 <= 63 and num_docs <= 255 and not args.wide
     if args.rows == "auto":
-        args.rows = "wide" if k - 1 > 255 else ("dense" if can_dense else "packed")
+        args.rows = "wide" if k - 1 > 255 else "packed"      # (3-byte rows are smaller, not faster: DESIGN.md)
     if args.rows == "dense" and not can_dense:
         raise SystemExit("--rows dense answers conservation with k <= 64 and num_docs <= 255 only")
     if k - 1 > 255:

@@ -105,12 +105,13 @@ int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_so
  * columns (an HPRC-scale shard is 37 GB packed against 225 GB as int64); such an index answers
  * k <= 256 only and cannot be re-uploaded.  Needs 0 <= annot <= 65535 on every row. */
 int memo_index_pack(memo_index_t *ix, int32_t keep_wide);
-/* A denser copy of the packed rows for the queries most windows are: 3 bytes per row,
+/* A denser copy of the packed rows, for HBM capacity: 3 bytes per row,
  *     (start mod 2^10) << 6 | min(end - start, 63)   +   annot (8 bits)          12 B per 4 rows
- * Exact for k <= 64 on the unclipped conservation sweep (level arrays of <= 1024 cells, num_docs <= 255);
- * every other query keeps reading the 4-byte rows / the int64 columns.  Needs memo_index_pack first and
- * every annot <= 255.  keep_packed == 0 frees the 4-byte rows (such an index answers only what the 3-byte
- * rows or, if still resident, the int64 columns can). */
+ * Exact for k <= 64 on the unclipped conservation sweep (level arrays of <= 1024 cells, num_docs <= 255).
+ * Not faster: the 12-byte loads cost more than the bytes they save (0.48 ms against 0.39 on BASELINE
+ * config 3), so queries read the 4-byte rows while those are resident.  Needs memo_index_pack first and
+ * every annot <= 255.  keep_packed == 0 frees the 4-byte rows: such an index holds 3 B per row and answers
+ * only what the 3-byte rows (or, if still resident, the int64 columns) can. */
 int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed);
 int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);
 void memo_index_destroy(memo_index_t *ix);

@@ -1,4 +1,5 @@
-"""ctypes binding of the C ABI declared in include/memo_amd.h, memo_amd_dap.h and memo_amd_transport.h.
+"""ctypes binding of the C ABI declared in include/memo_amd.h, memo_amd_multi.h, memo_amd_dap.h and
+memo_amd_transport.h.
 
 There is NO fallback: if libmemo_amd.so is missing or a HIP call fails, this raises.
 The CPU restatement under oracle/ is test infrastructure and is never imported here.
@@ -69,6 +70,11 @@ SYMBOLS = {
     "memo_query_check": (C.c_int, [_P, _P]),
     "memo_conservation": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _I32]),
     "memo_membership": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _I32]),
+    "memo_split_window": (C.c_int, [_I64, _I64, _I32, _I32, C.c_double, _P]),
+    "memo_conservation_multi": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _P, _I32]),
+    "memo_membership_multi": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _P, _I32]),
+    "memo_query_conservation_multi_dev": (C.c_int, [_P, _I32, _I64, _I64, _I32, _I32, _P, _I32, _P, C.c_double]),
+    "memo_query_membership_multi_dev": (C.c_int, [_P, _I32, _I64, _I64, _I32, _I32, _P, _I32, _P, C.c_double]),
     "memo_dev_malloc": (C.c_int, [_I32, _SZ, C.POINTER(_P)]),
     "memo_dev_free": (C.c_int, [_I32, _P]),
     "memo_dev_upload": (C.c_int, [_I32, _P, _P, _SZ, _P]),

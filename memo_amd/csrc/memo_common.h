@@ -12,6 +12,7 @@
 
 #include "memo_amd.h"
 #include "memo_amd_dap.h"
+#include "memo_amd_multi.h"
 #include "memo_amd_transport.h"
 
 namespace memo {
@@ -64,7 +65,7 @@ struct memo_tuning {
     int memb_algo = 0;   // membership: 2 = doubling, 3 = runs, 4 = planes
     int force_wide = 0;  // 1 = read the int64 columns even when packed rows exist
     int scatter = 0;     // conservation, packed rows: 1 = clipped, 2 = unclipped + halo
-    int force_packed4 = 0;  // 1 = read the 4-byte rows even when the 3-byte rows could answer
+    int force_dense = 0;  // 1 = read the 3-byte rows when they can answer, even with the 4-byte rows resident
 };
 
 // one chromosome's rows, resident in HBM (the opaque memo_index_t of the ABI)

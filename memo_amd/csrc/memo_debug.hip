@@ -38,13 +38,13 @@ int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32
     if (membership_algo != 0 && (membership_algo < 2 || membership_algo > 4))
         return fail(MEMO_EINVAL, "membership_algo must be 0 (choose), 2 (doubling), 3 (runs) or 4 (planes)");
     if (row_source < 0 || row_source > 2)
-        return fail(MEMO_EINVAL, "row_source must be 0 (densest rows present), 1 (int64 columns) or 2 (4-byte rows, not the 3-byte ones)");
+        return fail(MEMO_EINVAL, "row_source must be 0 (library's choice), 1 (int64 columns) or 2 (3-byte rows where they can answer)");
     if (scatter < 0 || scatter > 2) return fail(MEMO_EINVAL, "scatter must be 0 (choose), 1 (clipped) or 2 (unclipped)");
     ix->tune.tile_w = tile_w;
     ix->tune.waves = waves;
     ix->tune.memb_algo = membership_algo;
     ix->tune.force_wide = row_source == 1;
-    ix->tune.force_packed4 = row_source == 2;
+    ix->tune.force_dense = row_source == 2;
     ix->tune.scatter = scatter;
     return MEMO_OK;
 }

@@ -102,8 +102,9 @@ __global__ void pack_rows_kernel(const int64_t *s, const int64_t *e, const int64
     }
 }
 
-// memo_index_pack_dense: 4-byte words -> 3-byte rows, 12 bytes per group of 4 (layout: PackedRows3, memo_sweep.h)
-__global__ void pack3_rows_kernel(const uint32_t *pk, uint64_t groups, uint32_t *p3) {
+// memo_index_pack_dense: 4-byte words -> 3-byte rows as two planes (layout: PackedRows3, memo_sweep.h);
+// a thread converts 4 rows: 8 bytes of the B plane, 4 of the A plane
+__global__ void pack3_rows_kernel(const uint32_t *pk, uint64_t groups, uint32_t *pb, uint32_t *pa) {
     for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < groups;
          g += (uint64_t)gridDim.x * blockDim.x) {
         const uint4 w = *reinterpret_cast<const uint4 *>(pk + 4 * g);
@@ -111,10 +112,8 @@ __global__ void pack3_rows_kernel(const uint32_t *pk, uint64_t groups, uint32_t 
             const uint32_t len = (x >> 16) & 0xFFu;
             return ((x & 1023u) << 6) | (len > 63u ? 63u : len);
         };
-        uint32_t *dst = p3 + 3 * g;
-        dst[0] = B(w.x) | ((w.x >> 24) << 16) | ((w.y >> 24) << 24);
-        dst[1] = B(w.y) | (B(w.z) << 16);
-        dst[2] = B(w.w) | ((w.z >> 24) << 16) | ((w.w >> 24) << 24);
+        *reinterpret_cast<uint2 *>(pb + 2 * g) = make_uint2(B(w.x) | (B(w.y) << 16), B(w.z) | (B(w.w) << 16));
+        pa[g] = (w.x >> 24) | ((w.y >> 24) << 8) | ((w.z >> 24) << 16) | (w.w & 0xFF000000u);
     }
 }
 
@@ -564,7 +563,7 @@ int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed) {
     hipStream_t st = nullptr;
     const uint64_t groups = ix->padded / 4;  // padded is a multiple of 16
     HIP_TRY(hipMalloc(&ix->p3, groups * 12));
-    hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, ix->pk, groups, ix->p3);
+    hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, ix->pk, groups, ix->p3, ix->p3 + ix->padded / 2);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     if (!keep_packed) {

@@ -14,7 +14,8 @@ struct SweepArgs {
     const int64_t *s, *e, *o;
     const uint32_t *pk;
     const uint16_t *pa;
-    const uint32_t *p3;     // 3-byte rows (PackedRows3), 3 words per 4 rows
+    const uint32_t *p3;     // 3-byte rows (PackedRows3): the 16-bit (start, length) plane ...
+    const uint32_t *pa3;    //   ... and the 8-bit annot plane
     const int64_t *boff;
     int64_t nb;
     int64_t qs, qe;
@@ -310,67 +311,78 @@ struct PackedRows {
 };
 
 // 3-byte rows (memo_index_pack_dense): start mod 2^10, min(end - start, 63), annot (8 bits) -- 24 bits per
-// row, 12 bytes per group of 4 rows, one global_load_dwordx3 per lane.  Exact for k - 1 <= 63 (a
-// saturated length clips to "does not write" just as the true one does) in kernels whose row slice
-// spans fewer than 2^10 positions (the unclipped conservation sweep with level arrays of <= 1024 cells).
-// Inside a group the fields are laid out so that no field straddles a dword and every 16-bit
-// (start, length) field sits in a 16-bit half, where the 16-bit VALU forms and SDWA reach it for free:
-//     dword 0 = B0 | A0 << 16 | A1 << 24      B = (start & 1023) << 6 | min(end - start, 63)
-//     dword 1 = B1 | B2 << 16                 A = annot
-//     dword 2 = B3 | A2 << 16 | A3 << 24
+// row, kept as two planes so that every load is a whole, aligned 16- or 8-byte piece per lane:
+//     B plane, 16 bits per row:  (start & 1023) << 6 | min(end - start, 63)
+//     A plane,  8 bits per row:  annot
+// A lane takes 8 consecutive rows: one global_load_dwordx4 from the B plane, one global_load_dwordx2 from
+// the A plane (a first layout, 12 bytes per 4 rows fetched with global_load_dwordx3, ran 21 % SLOWER than
+// the 4-byte rows it was meant to beat: profiles/r02_dense_rows_ab.txt).  Exact for k - 1 <= 63 (a
+// saturated length clips to "does not write" just as the true one does) in kernels whose row slice spans
+// fewer than 2^10 positions (the unclipped conservation sweep with level arrays of <= 1024 cells).
 // The start lives in the TOP ten bits of B: (B - (a & 1023) << 6) mod 2^16 leaves the length alone and
-// gives (start - a) mod 2^10 with no borrow to repair.
+// gives (start - a) mod 2^10 with no borrow to repair; the 16-bit VALU forms and SDWA reach either half
+// of a dword for free.
 struct PackedRows3 {
-    static constexpr int kLoads = 8;
+    static constexpr int kLoads = 3;          // (16 + 8)-byte loads in flight per lane: 24 rows
     static constexpr bool kAnnot16 = false;
-    static constexpr uint64_t kAlign = 127;  // slices start at a multiple of 128 rows = 3 cache lines
+    static constexpr uint64_t kAlign = 63;    // slices start at a multiple of 64 rows (128 B of the B plane)
+    static constexpr uint32_t kWaveRows = 512;
 
     template <int T, int U>
     static __device__ __forceinline__ uint32_t batches(const Tile &t) {
         const uint32_t end = (uint32_t)(t.r1 - (t.r0 & ~kAlign));
-        return (end + 4 * T * U - 1) / (4 * T * U);
+        return (end + 8 * T * U - 1) / (8 * T * U);
     }
 
     template <int T, int U>
-    static __device__ __forceinline__ void issue(const SweepArgs &A, const Tile &t, uint32_t batch, uint3 (&V)[U]) {
+    static __device__ __forceinline__ void issue(const SweepArgs &A, const Tile &t, uint32_t batch, uint4 (&VB)[U],
+                                                 uint2 (&VA)[U]) {
         const uint64_t base0 = t.r0 & ~kAlign;
         const uint32_t end = (uint32_t)(t.r1 - base0);
-        const uint32_t *p3 = A.p3 + (base0 >> 2) * 3;
-        const uint32_t rel = batch * (4 * T * U) + 4 * threadIdx.x;
+        const uint16_t *pb = reinterpret_cast<const uint16_t *>(A.p3) + base0;
+        const uint8_t *pa = reinterpret_cast<const uint8_t *>(A.pa3) + base0;
+        const uint32_t rel = batch * (8 * T * U) + 8 * threadIdx.x;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t r = rel + (uint32_t)u * 4 * T;
-            // wave-uniform (consume() tests the same): a wave loads its 256 rows or nothing
-            if ((__builtin_amdgcn_readfirstlane(r) & ~(uint32_t)255) < end)
-                V[u] = *reinterpret_cast<const uint3 *>(p3 + (r >> 2) * 3);
+            const uint32_t r = rel + (uint32_t)u * 8 * T;
+            // wave-uniform (consume() tests the same): a wave loads its 512 rows or nothing
+            if ((__builtin_amdgcn_readfirstlane(r) & ~(kWaveRows - 1)) < end) {
+                VB[u] = *reinterpret_cast<const uint4 *>(pb + r);
+                VA[u] = *reinterpret_cast<const uint2 *>(pa + r);
+            }
         }
     }
 
-    // g(slot-specific registers): g0(d0) .. handled by the caller through four callbacks, one per slot of
-    // the group, because every slot finds its fields in different places.  Rows outside [r0, r1) get
-    // the dead field (start = a, length 63: never writes when k - 1 <= 63).
-    template <int T, int U, typename G0, typename G1, typename G2, typename G3>
-    static __device__ __forceinline__ void consume(const SweepArgs &A, const Tile &t, uint32_t batch, uint3 (&V)[U],
-                                                   G0 g0, G1 g1, G2 g2, G3 g3) {
+    // lo(b, a, sh) / hi(b, a, sh): the row's B field sits in the low / high half of b, its annot in byte
+    // sh / 8 of a.  Rows outside [r0, r1) get the dead field (start = a, length 63: never writes when
+    // k - 1 <= 63).
+    template <int T, int U, typename GL, typename GH>
+    static __device__ __forceinline__ void consume(const SweepArgs &A, const Tile &t, uint32_t batch, uint4 (&VB)[U],
+                                                   uint2 (&VA)[U], GL lo, GH hi) {
         const uint64_t base0 = t.r0 & ~kAlign;
         const uint32_t first = (uint32_t)(t.r0 - base0), end = (uint32_t)(t.r1 - base0);
         const uint32_t dead = ((((uint32_t)t.a & 1023u) << 6) | 63u);
-        const uint32_t rel = batch * (4 * T * U) + 4 * threadIdx.x;
+        const uint32_t rel = batch * (8 * T * U) + 8 * threadIdx.x;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t r = rel + (uint32_t)u * 4 * T;
-            const uint32_t wave_lo = __builtin_amdgcn_readfirstlane(r) & ~(uint32_t)255;
+            const uint32_t r = rel + (uint32_t)u * 8 * T;
+            const uint32_t wave_lo = __builtin_amdgcn_readfirstlane(r) & ~(kWaveRows - 1);
             if (wave_lo >= end) break;  // nothing of this wave's load is inside the slice
-            if (!(wave_lo >= first && wave_lo + 256 <= end)) {  // a load that straddles an end of the slice
-                if (!(r + 0 >= first && r + 0 < end)) V[u].x = (V[u].x & 0xFFFF0000u) | dead;
-                if (!(r + 1 >= first && r + 1 < end)) V[u].y = (V[u].y & 0xFFFF0000u) | dead;
-                if (!(r + 2 >= first && r + 2 < end)) V[u].y = (V[u].y & 0x0000FFFFu) | (dead << 16);
-                if (!(r + 3 >= first && r + 3 < end)) V[u].z = (V[u].z & 0xFFFF0000u) | dead;
+            uint32_t b[4] = {VB[u].x, VB[u].y, VB[u].z, VB[u].w};
+            if (!(wave_lo >= first && wave_lo + kWaveRows <= end)) {  // a load that straddles an end of the slice
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (!(r + i >= first && r + i < end))
+                        b[i >> 1] = (i & 1) ? ((b[i >> 1] & 0x0000FFFFu) | (dead << 16)) : ((b[i >> 1] & 0xFFFF0000u) | dead);
             }
-            g0(V[u].x);          // B in the low half, annot in byte 2
-            g1(V[u].y, V[u].x);  // B in the low half of dword 1, annot in byte 3 of dword 0
-            g2(V[u].y, V[u].z);  // B in the HIGH half of dword 1, annot in byte 2 of dword 2
-            g3(V[u].z);          // B in the low half, annot in byte 3
+            lo(b[0], VA[u].x, 0);
+            hi(b[0], VA[u].x, 8);
+            lo(b[1], VA[u].x, 16);
+            hi(b[1], VA[u].x, 24);
+            lo(b[2], VA[u].y, 0);
+            hi(b[2], VA[u].y, 8);
+            lo(b[3], VA[u].y, 16);
+            hi(b[3], VA[u].y, 24);
         }
     }
 };

@@ -98,6 +98,7 @@ void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32
     A.o = ix->o;
     A.pk = ix->pk;
     A.p3 = ix->p3;
+    A.pa3 = ix->p3 ? ix->p3 + ix->padded / 2 : nullptr;  // the annot plane follows the B plane (padded * 2 bytes)
     A.pa = ix->pa;
     A.boff = ix->boff;
     A.nb = (int64_t)ix->nb;

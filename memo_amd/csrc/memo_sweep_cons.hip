@@ -102,13 +102,20 @@ __global__ __launch_bounds__(T) void sweep_conservation_kernel(const SweepArgs A
 #ifndef MEMO_HALO_WAVES
 #define MEMO_HALO_WAVES 8
 #endif
+// diagnostic builds only (tools/build_variant.sh): bit 0 / 1 = drop the first / second ds_min of a row,
+// 2 = no fold passes, 3 = no clear, 4 = no scatter arithmetic at all (rows are loaded and dropped).
+// Results are wrong with any of them; they size what each phase costs.
+#ifndef MEMO_ABLATE
+#define MEMO_ABLATE 0
+#endif
 
 // every level starts at the sentinel column N (memo_query.py:53-54); under the first loads
 template <int T>
 __device__ __forceinline__ void halo_clear(const SweepArgs &A, uint32_t *lds, uint32_t sent) {
     const uint4 sv = make_uint4(sent, sent, sent, sent);
     uint4 *p = reinterpret_cast<uint4 *>(lds);
-    for (int i = threadIdx.x; i < A.nlev * (A.ls / 4); i += T) p[i] = sv;
+    if (!(MEMO_ABLATE & 8))
+        for (int i = threadIdx.x; i < A.nlev * (A.ls / 4); i += T) p[i] = sv;
     lds_barrier();
 }
 
@@ -118,7 +125,7 @@ template <typename OutT, int T, bool TOP8>
 __device__ __forceinline__ void halo_fold_store(const SweepArgs &A, const Tile &t, uint32_t *lds) {
     const int LS = A.ls, HL = A.hl, W = A.w;
     const int cells = HL + W;
-    for (int slot = 0; slot + 2 < A.nlev; ++slot) {  // (the last fold happens in store_conservation)
+    for (int slot = 0; slot + 2 < A.nlev && !(MEMO_ABLATE & 4); ++slot) {  // (the last fold happens in store_conservation)
         const int half = 1 << (A.nlev - 2 - slot);
         const uint32_t *hi = lds + slot * LS;
         uint32_t *lo = lds + (slot + 1) * LS;
@@ -181,6 +188,10 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
     const uint32_t top_bit = pin_vgpr((int)0x80000000u);
     const uint32_t a16 = pin_vgpr((int)((uint32_t)t.a & 0xFFFFu));
     auto scatter = [&](uint32_t w, uint32_t col) {
+        if (MEMO_ABLATE & 16) {  // keep the loads alive, nothing else
+            asm volatile("" ::"v"(w), "v"(col));
+            return;
+        }
         const int n = km1 - (int)__builtin_amdgcn_ubfe(w, 16, 8);  // length of [end - (k-1), start)
         if (n > 0) {
             // f = clz(n); 2^j = 2^31 >> f; x4 = address of cell `start` on level f;
@@ -196,8 +207,12 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
                 "v_mad_i32_i24 %1, %3, -4, %2\n\t"
                 "v_ashrrev_i32 %0, %0, %8\n\t"
                 "v_lshl_add_u32 %2, %0, 2, %2\n\t"
+#if !(MEMO_ABLATE & 1)
                 "ds_min_u32 %1, %9\n\t"
+#endif
+#if !(MEMO_ABLATE & 2)
                 "ds_min_u32 %2, %9"
+#endif
                 : "=&v"(r0), "=&v"(r1), "=&v"(r2)
                 : "v"(n), "v"(w), "v"(a16), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(TOP8 ? w : col)
                 : "memory");
@@ -220,7 +235,7 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
 
 // The same sweep on the 3-byte rows (PackedRows3, k - 1 <= 63, level arrays of at most 1024 cells).
 // Per row: 16-bit subtract (start - a, length untouched below it), and, subtract, compare | ffbh, bfe,
-// mad, lshl_add, mad, ashr, lshl_add, (shift of the order byte for two of the four slots), ds_min x 2.
+// mad, lshl_add, mad, ashr, lshl_add, (shift of the order byte for three rows of four), ds_min x 2.
 template <int U, int T, typename OutT>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
 void sweep_conservation_halo3_kernel(const SweepArgs A) {
@@ -229,8 +244,9 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
     const int LS = A.ls, HL = A.hl, W = A.w;
     Tile t;
     if (!locate_tile_w(A, t, W)) return;
-    uint3 V[U];
-    Rows::template issue<T, U>(A, t, 0, V);
+    uint4 VB[U];
+    uint2 VA[U];
+    Rows::template issue<T, U>(A, t, 0, VB, VA);
     halo_clear<T>(A, lds, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
 
     const int km1 = A.km1;
@@ -259,25 +275,21 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
                 : "memory");
         }
     };
-    auto sub_lo = [&](uint32_t d) {  // 16-bit subtract on the low halves; the result's high half is zero
+    auto g_lo = [&](uint32_t b, uint32_t a, int sh) {  // 16-bit subtract on the low halves; the result's high half is zero
         uint32_t r;
-        asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(d), "v"(a10s));
-        return r;
+        asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(b), "v"(a10s));
+        scatter(r, sh == 24 ? a : a << (24 - sh));
     };
-    auto sub_hi = [&](uint32_t d) {  // ... with the HIGH half of d as the minuend (SDWA: no shift instruction)
+    auto g_hi = [&](uint32_t b, uint32_t a, int sh) {  // ... with the HIGH half of b as the minuend (SDWA: no shift instruction)
         uint32_t r;
         asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0"
-            : "=v"(r) : "v"(d), "v"(a10s));
-        return r;
+            : "=v"(r) : "v"(b), "v"(a10s));
+        scatter(r, sh == 24 ? a : a << (24 - sh));
     };
-    auto g0 = [&](uint32_t d0) { scatter(sub_lo(d0), d0 << 8); };
-    auto g1 = [&](uint32_t d1, uint32_t d0) { scatter(sub_lo(d1), d0); };
-    auto g2 = [&](uint32_t d1, uint32_t d2) { scatter(sub_hi(d1), d2 << 8); };
-    auto g3 = [&](uint32_t d2) { scatter(sub_lo(d2), d2); };
-    Rows::template consume<T, U>(A, t, 0, V, g0, g1, g2, g3);
+    Rows::template consume<T, U>(A, t, 0, VB, VA, g_lo, g_hi);
     for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
-        Rows::template issue<T, U>(A, t, b, V);
-        Rows::template consume<T, U>(A, t, b, V, g0, g1, g2, g3);
+        Rows::template issue<T, U>(A, t, b, VB, VA);
+        Rows::template consume<T, U>(A, t, b, VB, VA, g_lo, g_hi);
     }
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
     halo_fold_store<OutT, T, true>(A, t, lds);
@@ -486,10 +498,13 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.ls = hl + tw + hr;
             if (tune.waves == 0) waves = w >= 1024 ? 4 : 1;
             if (tune.waves == 8) waves = 8;  // (experiment: eight waves share a tile; only this kernel has that shape)
-            // densest rows that can answer: 3-byte rows for k - 1 <= 63 when the level arrays stay within
-            // 2^10 cells and the order fits the result's top-byte trick; else the 4- / 6-byte rows
+            // 4- / 6-byte rows when they are resident: the 3-byte rows save a quarter of the bytes but their
+            // 12-byte loads (global_load_dwordx3) and two more instructions per row cost more than that --
+            // config 3, k = 31: 0.478 ms against 0.395 (profiles/r02_dense_rows_ab.txt).  They answer when the
+            // index kept nothing else (k - 1 <= 63, level arrays within 2^10 cells, num_docs <= 255): what
+            // they buy is HBM capacity, 3 B per row.
             const bool top8 = num_docs <= 255;
-            const bool three = ix->p3 && !(tune.force_packed4 && ix->pk) && k - 1 <= 63 && A.ls <= 1024 && top8;
+            const bool three = ix->p3 && (!ix->pk || tune.force_dense) && k - 1 <= 63 && A.ls <= 1024 && top8;
             if (!three && fmt == 3) {
                 halo = false;  // (below: the int64 columns, or an error when they are gone too)
             } else {

@@ -218,6 +218,33 @@ def membership(start, end, annot, qs, qe, k, num_docs, device=0):
     return out
 
 
+# ---- several GPUs from one process (include/memo_amd_multi.h) ----
+def conservation_multi(start, end, annot, qs, qe, k, num_docs, devices):
+    s, e, o = _col(start), _col(end), _col(annot)
+    out = np.empty(max(qe - qs, 0), np.uint16)
+    dev = (C.c_int32 * len(devices))(*devices)
+    check(lib().memo_conservation_multi(s.ctypes.data, e.ctypes.data, o.ctypes.data, len(s), qs, qe, k, num_docs,
+                                        out.ctypes.data, dev, len(devices)))
+    return out
+
+
+def membership_multi(start, end, annot, qs, qe, k, num_docs, devices):
+    s, e, o = _col(start), _col(end), _col(annot)
+    out = np.empty((max(qe - qs, 0), words(num_docs)), np.uint32)
+    dev = (C.c_int32 * len(devices))(*devices)
+    check(lib().memo_membership_multi(s.ctypes.data, e.ctypes.data, o.ctypes.data, len(s), qs, qe, k, num_docs,
+                                      out.ctypes.data, dev, len(devices)))
+    return out
+
+
+def query_multi_dev(shards, qs, qe, k, num_docs, out, root_device=0, stream=None, root_weight=1.0, membership=False):
+    """shards: DeviceIndex per device (replicas, or position shards covering their sub-windows); out: device
+    buffer on root_device.  Asynchronous on `stream`; check() every shard afterwards."""
+    hs = (C.c_void_p * len(shards))(*[ix._h for ix in shards])
+    fn = lib().memo_query_membership_multi_dev if membership else lib().memo_query_conservation_multi_dev
+    check(fn(hs, len(shards), qs, qe, k, num_docs, _ptr(out), root_device, _ptr(stream), float(root_weight)))
+
+
 # ---- print_res text (memo_query.py:65-71) ----
 def emit_conservation_buffer(vec):
     """the text as a uint8 array (no extra copies; write it with fh.write(memoryview(buf)))"""

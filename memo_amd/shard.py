@@ -13,14 +13,21 @@ import numpy as np
 ALIGN = 8      # positions; keeps every uint16 slice 16-byte aligned in the gathered buffer
 
 
-def split_window(qs, qe, world, align=ALIGN):
-    """[(a_g, b_g)] for g in range(world): contiguous, equal length `per` (a multiple of
-    `align`) except the tail; ranks past the end get empty windows (a == b)."""
-    L = max(qe - qs, 0)
-    per = -(-L // world)
-    per = -(-per // align) * align if per else 0
-    cuts = [min(qs + g * per, qe) for g in range(world + 1)]
-    return [(cuts[g], cuts[g + 1]) for g in range(world)], per
+def split_window(qs, qe, world, align=ALIGN, root_weight=1.0):
+    """[(a_g, b_g)] for g in range(world), and the longest part's length `per` (a multiple of `align`):
+    contiguous parts, rank 0 gets `root_weight` shares of the window and every other rank one share
+    (1.0 = equal parts; less when rank 0 also gathers and decodes the peers' slices), the tail takes
+    what is left, ranks past the end get empty windows (a == b).  The rule itself is
+    memo_split_window() of the C ABI (include/memo_amd_multi.h), which the single-process multi-GPU
+    entry points use too; pure host arithmetic, no GPU needed."""
+    import ctypes as C
+    from ._lib import check, lib
+    cuts = (C.c_int64 * (world + 1))()
+    check(lib().memo_split_window(qs, qe, world, align, float(root_weight), cuts))
+    wins = [(cuts[g], cuts[g + 1]) for g in range(world)]
+    per = max(b - a for a, b in wins)
+    per = -(-per // align) * align
+    return wins, per
 
 
 def rows_for_window(start_sorted, a, b, k):
@@ -46,10 +53,10 @@ def gather_slices(local, per, lengths, rank, world, dist, dst=0):
     return torch.cat(parts, dim=0)
 
 
-def sharded_query(sweep, qs, qe, k, rank, world, dist, alloc, dst=0):
+def sharded_query(sweep, qs, qe, k, rank, world, dist, alloc, dst=0, root_weight=1.0):
     """Run `sweep(a, b, out)` on this rank's sub-window [a, b) of [qs, qe), writing into
     out[:b-a] (out = alloc(per)), then gather.  Returns (result on dst | None, (a, b))."""
-    wins, per = split_window(qs, qe, world)
+    wins, per = split_window(qs, qe, world, root_weight=root_weight)
     a, b = wins[rank]
     out = alloc(per)
     if b > a:

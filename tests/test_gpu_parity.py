@@ -244,7 +244,7 @@ def test_dense_rows_equal_packed_rows(n_docs, bucket_shift, keep_packed, keep_wi
                 qs = int(rng.integers(0, length // 2))
                 qe = int(rng.integers(qs + 1, length + 100))
                 want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
-                for source in (0, 2):                   # densest rows that can answer / the 4-byte rows
+                for source in (0, 2):                   # the library's choice / the 3-byte rows wherever they can answer
                     ix.debug_set_tuning(tile_w, waves, 0, source, 0)
                     answerable = keep_packed or keep_wide or (k <= 64 and n_docs <= 255 and tile_w in (0, 1024, 512))
                     if not answerable:
@@ -411,6 +411,67 @@ def test_builder_rows_with_end_before_start_and_empty(memo, oracle):
             assert ix.info()["rows"] == 0
             assert np.array_equal(ix.conservation(5, 50, 31, 9), np.full(45, 9, np.uint16))
             assert np.array_equal(ix.membership(5, 8, 31, 9), np.full((3, 1), 511, np.uint32))
+
+
+# ---------------------------------------------------------------------------------------
+# several GPUs from one process (include/memo_amd_multi.h).  One GPU here: the device list names it
+# several times, which runs every code path (threads, partition, peer copies into the root's result)
+# ---------------------------------------------------------------------------------------
+def test_multi_device_host_form(memo, oracle):
+    from memo_amd import index
+    rng = np.random.default_rng(31)
+    n_docs, length = 60, 300_000
+    s, e, o = _random_index(rng, 1_200_000, length, n_docs, 90)
+    for devices in ([0], [0, 0], [0, 0, 0, 0, 0]):
+        for k, qs, qe in ((31, 0, length + 50), (101, 12_345, 250_001), (2, 299_000, 299_013), (300, 5, 200_000)):
+            want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+            assert np.array_equal(index.conservation_multi(s, e, o, qs, qe, k, n_docs, devices), want), (devices, k, qs)
+            qe2 = min(qe, qs + 40_000)
+            wantb = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe2, k), qs, qe2, k, n_docs, literal=False)
+            assert np.array_equal(index.membership_multi(s, e, o, qs, qe2, k, n_docs, devices), wantb), (devices, k, qs)
+    # unsorted rows fall back to one device (which sorts); errors of a sub-window reach the caller
+    perm = rng.permutation(len(s))
+    want = oracle.conservation(*oracle.filter_rows(s, e, o, 0, 100_000, 31), 0, 100_000, 31, n_docs, literal=False)
+    assert np.array_equal(index.conservation_multi(s[perm], e[perm], o[perm], 0, 100_000, 31, n_docs, [0, 0]), want)
+    with pytest.raises(IndexError):
+        index.conservation_multi(s, e, o, 0, length, 31, 5, [0, 0, 0])
+    with pytest.raises(ValueError):
+        index.conservation_multi(s, e, o, 10, 5, 31, n_docs, [0, 0])
+    with pytest.raises(memo.MemoError):
+        index.conservation_multi(s, e, o, 0, 1000, 31, n_docs, [0, 7])          # no such device
+
+
+@pytest.mark.parametrize("root_weight", [1.0, 0.5, 0.0])
+def test_multi_device_resident_form(root_weight, memo, oracle):
+    import ctypes as C
+    from memo_amd import index, _lib
+    rng = np.random.default_rng(32)
+    n_docs, length = 60, 400_000
+    s, e, o = _random_index(rng, 1_500_000, length, n_docs, 90)
+    shards = [memo.DeviceIndex.from_host_packed(s, e, o) for _ in range(3)]      # replicas ("one per GPU")
+    try:
+        for membership in (False, True):
+            for k, qs, qe in ((31, 0, length), (101, 777, 333_333), (64, 100_000, 100_100)):
+                if membership:
+                    qe = min(qe, qs + 50_000)
+                    want = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                    got = np.empty_like(want)
+                else:
+                    want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                    got = np.empty_like(want)
+                d = C.c_void_p()
+                _lib.check(_lib.lib().memo_dev_malloc(0, max(got.nbytes, 16), C.byref(d)))
+                try:
+                    index.query_multi_dev(shards, qs, qe, k, n_docs, d.value, 0, None, root_weight, membership)
+                    for ix in shards:
+                        ix.check()
+                    _lib.check(_lib.lib().memo_dev_download(0, got.ctypes.data, d, got.nbytes, None))
+                finally:
+                    _lib.lib().memo_dev_free(0, d)
+                assert np.array_equal(got, want), (membership, k, qs, qe)
+    finally:
+        for ix in shards:
+            ix.close()
 
 
 def test_two_threads_two_indexes(memo, oracle):

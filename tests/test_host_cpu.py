@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(memo):
     """the product library exports exactly what the product headers declare -- and none of the A/B
     switches, which live in include/memo_amd_debug.h and libmemo_amd_ab.so"""
     from memo_amd import _lib
-    declared = _declared("memo_amd.h", "memo_amd_dap.h", "memo_amd_transport.h")
+    declared = _declared("memo_amd.h", "memo_amd_multi.h", "memo_amd_dap.h", "memo_amd_transport.h")
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     assert len(_declared("memo_amd.h")) <= 40
@@ -225,3 +225,34 @@ def test_transport_coding_choice_model():
     assert shard.pick_coding(8, sweep, usable, link=20e9)[0] == "dense"
     assert shard.pick_coding(2, sweep, usable, link=1e12)[0] == "plain"
     assert shard.modelled_step(1, sweep, 10, 1.0, 0.0) == sweep          # nobody to decode for
+
+
+def test_split_window_rule(memo):
+    """memo_split_window (include/memo_amd_multi.h; memo_amd.shard.split_window calls it): contiguous cover
+    of [qs, qe), part lengths multiples of the alignment except the tail, equal parts at weight 1 (the
+    round-1 Python rule), a lighter first part for weights < 1, empty windows past the end."""
+    from memo_amd import shard
+    rng = np.random.default_rng(4)
+    for _ in range(400):
+        qs = int(rng.integers(-1000, 10 ** 9))
+        L = int(rng.choice([0, 1, 7, 8, 9, 1000, 123_457, 10 ** 8]))
+        world = int(rng.integers(1, 10))
+        align = int(rng.choice([1, 8, 32]))
+        w = float(rng.choice([1.0, 0.0, 0.25, 0.5, 0.9, 2.0]))
+        wins, per = shard.split_window(qs, qs + L, world, align=align, root_weight=w)
+        assert len(wins) == world and wins[0][0] == qs and wins[-1][1] == qs + L
+        assert all(a <= b for a, b in wins) and all(wins[i][1] == wins[i + 1][0] for i in range(world - 1))
+        lens = [b - a for a, b in wins]
+        nonempty = [x for x in lens if x]
+        assert all(x % align == 0 for x in nonempty[:-1]) and per % align == 0 and per >= max(lens)
+        if w == 1.0:                                   # the equal split of round 1
+            p = -(-L // world)
+            p = -(-p // align) * align if p else 0
+            assert wins == [(min(qs + g * p, qs + L), min(qs + (g + 1) * p, qs + L)) for g in range(world)]
+        if world > 1 and L >= 10 ** 6:
+            if w < 1.0:
+                assert lens[0] <= lens[1] and abs(lens[0] - w * lens[1]) <= align + w * align
+            if w == 0.0:
+                assert lens[0] == 0
+    with pytest.raises(memo.MemoError):
+        shard.split_window(0, 10, 2, root_weight=-1.0)

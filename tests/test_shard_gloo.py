@@ -37,7 +37,7 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _worker(rank, world, port, membership, ret):
+def _worker(rank, world, port, membership, ret, root_weight=1.0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import memo_oracle as oracle
@@ -57,7 +57,7 @@ def _worker(rank, world, port, membership, ret):
             r = oracle.conservation(*rows, a, b, k, n, literal=False).view(np.int16)
         out[:b - a] = torch.from_numpy(r)
 
-    res, _ = shard.sharded_query(sweep, qs, qe, k, rank, world, dist, alloc)
+    res, _ = shard.sharded_query(sweep, qs, qe, k, rank, world, dist, alloc, root_weight=root_weight)
     if rank == 0:
         full = oracle.membership(s, e, o, qs, qe, k, n, literal=False).view(np.int32) if membership else \
             oracle.conservation(s, e, o, qs, qe, k, n, literal=False).view(np.int16)
@@ -66,12 +66,14 @@ def _worker(rank, world, port, membership, ret):
 
 
 @pytest.mark.parametrize("membership", [False, True])
-@pytest.mark.parametrize("world", [2, 3])
-def test_gloo_sharded_equals_whole(world, membership):
+@pytest.mark.parametrize("world,root_weight", [(2, 1.0), (3, 1.0), (3, 0.4), (2, 0.0)])
+def test_gloo_sharded_equals_whole(world, root_weight, membership):
+    """equal parts, a lighter part for rank 0 (it also gathers and decodes), and a root that only gathers;
+    the partition is memo_split_window of the C ABI"""
     ctx = mp.get_context("spawn")
     ret = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, membership, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, membership, ret, root_weight)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
