@@ -68,6 +68,9 @@ typedef struct memo_index_info {
     float pack_ms;          /* device time of the last memo_index_pack: annot census + packing kernel,
                                HIP events on its stream (the narrowing pass, timed apart) */
     int32_t dense_rows;     /* 1 while the 3-byte rows of memo_index_pack_dense are resident */
+    uint64_t long_rows;     /* rows with end < start, kept aside (see above) */
+    uint64_t max_annot;     /* largest annot of the packed rows (valid when packed_format != 0) */
+    int64_t bucket_base;    /* the bucket table starts at this bucket (a region slice of memo_index_import_packed) */
 } memo_index_info_t;
 
 const char *memo_last_error(void);
@@ -114,6 +117,19 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide);
  * only what the 3-byte rows (or, if still resident, the int64 columns) can. */
 int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed);
 int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);
+/* A packed index to host memory and back: what the CLI's sidecar cache (memo_amd/cache.py) stores next to
+ * the Parquet file, so that a repeat query uploads packed rows from the page cache instead of decoding ZSTD
+ * pages.  _export copies the packed rows (rows x uint32; rows x uint16 more when packed_format == 6), the
+ * bucket table (info.buckets x int64) and the rows with end < start (3 x info.long_rows int64: starts, ends,
+ * annots) into caller buffers.  _import builds a finalized, packed index from such arrays -- or from a SLICE
+ * of them: rows [r0, r1) with the table entries of buckets [bucket_base, bucket_base + buckets) rebased to
+ * r0 (first entry 0, last entry = rows).  Host memory may be pageable (a memory-mapped file): it goes through
+ * the pinned ring. */
+int memo_index_export_packed(memo_index_t *ix, uint32_t *pk, uint16_t *pa, int64_t *boff, int64_t *long_rows);
+int memo_index_import_packed(uint64_t rows, int32_t device, int32_t bucket_shift, int64_t bucket_base,
+                             const uint32_t *pk, const uint16_t *pa, const int64_t *boff, uint64_t buckets,
+                             int64_t min_start, int64_t max_start, uint64_t max_annot, const int64_t *long_rows,
+                             uint64_t n_long, memo_index_t **out);
 void memo_index_destroy(memo_index_t *ix);
 
 /* ---- packed upload: the fast way in for host rows ------------------------------------------

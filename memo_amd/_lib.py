@@ -41,7 +41,8 @@ class IndexInfo(C.Structure):
                 ("device", C.c_int32), ("bucket_shift", C.c_int32), ("buckets", C.c_uint64),
                 ("was_sorted", C.c_int32), ("finalized", C.c_int32), ("device_bytes", C.c_uint64),
                 ("packed_format", C.c_int32), ("has_wide", C.c_int32), ("pack_ms", C.c_float),
-                ("dense_rows", C.c_int32)]
+                ("dense_rows", C.c_int32), ("long_rows", C.c_uint64), ("max_annot", C.c_uint64),
+                ("bucket_base", C.c_int64)]
 
 
 # every symbol the product headers declare: name -> (restype, argtypes)
@@ -59,6 +60,8 @@ SYMBOLS = {
     "memo_index_pack": (C.c_int, [_P, _I32]),
     "memo_index_pack_dense": (C.c_int, [_P, _I32]),
     "memo_index_get_info": (C.c_int, [_P, C.POINTER(IndexInfo)]),
+    "memo_index_export_packed": (C.c_int, [_P, _P, _P, _P, _P]),
+    "memo_index_import_packed": (C.c_int, [_U64, _I32, _I32, _I64, _P, _P, _P, _U64, _I64, _I64, _U64, _P, _U64, C.POINTER(_P)]),
     "memo_index_destroy": (None, [_P]),
     "memo_builder_create": (C.c_int, [_U64, _I32, _I32, C.POINTER(_P)]),
     "memo_builder_push": (C.c_int, [_P, _P, _P, _P, _U64]),

@@ -24,6 +24,7 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // device -> pageable host memory through the pinned ring of memo_hostpack.hip (DMA of piece i+1 under
 // the worker threads' copy of piece i); work already queued on `producer` finishes first
 int download_pipelined(int device, void *host, const void *dev, size_t bytes, hipStream_t producer);
+int upload_pipelined(int device, void *dev, const void *host, size_t bytes);
 
 struct DeviceGuard {  // the caller (e.g. torch) keeps its own notion of the current device
     int prev = -1;
@@ -78,6 +79,7 @@ struct memo_index {
     int64_t *boff = nullptr;  // boff[b] = first row with start >= (b << bshift); boff[nb-1] == rows
     uint64_t nb = 0;
     int bshift = 0;
+    int64_t bbase = 0;        // boff[0] belongs to bucket `bbase` (a region slice imported from the CLI's cache; else 0)
     int64_t min_s = 0, max_s = -1;
     int finalized = 0;
     int was_sorted = 0;

@@ -231,6 +231,43 @@ int download_pipelined(int device, void *host, const void *dev, size_t bytes, hi
     return rc;
 }
 
+// pageable host memory (a memory-mapped cache file, a NumPy array) -> device through the ring: the worker
+// threads copy piece i + 1 into a pinned slot while piece i crosses PCIe
+int upload_pipelined(int device, void *dev, const void *host, size_t bytes) {
+    DeviceGuard guard(device);
+    if (!bytes) return MEMO_OK;
+    if (bytes < ((size_t)1 << 20)) {
+        HIP_TRY(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+        return MEMO_OK;
+    }
+    PinnedRing *ring = nullptr;
+    int rc = acquire_ring(device, &ring);
+    if (rc) return rc;
+    const size_t piece = PinnedRing::kSlotBytes / 2;  // 12 MiB pieces: the first one leaves early
+    const size_t n = (bytes + piece - 1) / piece;
+    HostPool &pool = HostPool::get();
+    for (size_t i = 0; i < n && rc == MEMO_OK; ++i) {
+        const int s = (int)(i % PinnedRing::kSlots);
+        if ((rc = ring->wait(s))) break;
+        const size_t sz = i + 1 < n ? piece : bytes - i * piece;
+        const char *src = static_cast<const char *>(host) + i * piece;
+        char *dst = ring->slot[s];
+        const int tasks = (int)((sz + ((size_t)1 << 20) - 1) >> 20);
+        pool.run(tasks, [&](int t) {
+            const size_t b = (size_t)t << 20, e = b + ((size_t)1 << 20) < sz ? b + ((size_t)1 << 20) : sz;
+            memcpy(dst + b, src + b, e - b);
+        });
+        hipError_t err = hipMemcpyAsync(static_cast<char *>(dev) + i * piece, dst, sz, hipMemcpyHostToDevice, ring->stream);
+        if (err != hipSuccess) {
+            rc = fail(MEMO_EHIP, "hipMemcpyAsync H2D: %s", hipGetErrorString(err));
+            break;
+        }
+        rc = ring->mark(s);
+    }
+    release_ring(ring);  // synchronises the copy stream
+    return rc;
+}
+
 }  // namespace memo
 
 // ------------------------------------------------------------------------------------------
@@ -530,6 +567,92 @@ int memo_builder_finish(memo_builder_t *b, memo_index_t **out) {
     ix->packed_fmt = b->annot16 ? 6 : 4;
     ix->finalized = 1;
     b->failed = MEMO_EINVAL;  // a builder finishes once
+    *out = ix;
+    return MEMO_OK;
+}
+
+// ---- a packed index to host memory and back (the CLI's sidecar cache, memo_amd/cache.py) ----------------
+int memo_index_export_packed(memo_index_t *ix, uint32_t *pk, uint16_t *pa, int64_t *boff, int64_t *long_rows) {
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (!ix->finalized || !ix->packed_fmt || !ix->pk) return fail(MEMO_ENOTREADY, "the index has no packed rows (memo_index_pack)");
+    if ((ix->rows && !pk) || (ix->packed_fmt == 6 && ix->rows && !pa) || !boff || (ix->n_long && !long_rows))
+        return fail(MEMO_EINVAL, "output pointer is NULL");
+    int rc;
+    if ((rc = download_pipelined(ix->device, pk, ix->pk, ix->rows * 4, nullptr))) return rc;
+    if (ix->packed_fmt == 6 && (rc = download_pipelined(ix->device, pa, ix->pa, ix->rows * 2, nullptr))) return rc;
+    if ((rc = download_pipelined(ix->device, boff, ix->boff, ix->nb * 8, nullptr))) return rc;
+    if (ix->n_long) {
+        DeviceGuard guard(ix->device);
+        HIP_TRY(hipMemcpy(long_rows, ix->ls, ix->n_long * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(long_rows + ix->n_long, ix->le, ix->n_long * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(long_rows + 2 * ix->n_long, ix->lo, ix->n_long * 8, hipMemcpyDeviceToHost));
+    }
+    return MEMO_OK;
+}
+
+int memo_index_import_packed(uint64_t rows, int32_t device, int32_t bucket_shift, int64_t bucket_base,
+                             const uint32_t *pk, const uint16_t *pa, const int64_t *boff, uint64_t buckets,
+                             int64_t min_start, int64_t max_start, uint64_t max_annot, const int64_t *long_rows,
+                             uint64_t n_long, memo_index_t **out) {
+    if (!out) return fail(MEMO_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (rows > ((uint64_t)1 << 40) || bucket_shift < 1 || bucket_shift > 8 || bucket_base < 0 || buckets < 2 ||
+        (rows && !pk) || !boff || (n_long && !long_rows) || n_long > kMaxLongRows || max_annot > 65535)
+        return fail(MEMO_EINVAL, "bad packed-index arguments");
+    if (boff[0] != 0 || boff[buckets - 1] != (int64_t)rows)
+        return fail(MEMO_EINVAL, "bucket table does not span the rows (first %lld, last %lld, rows %llu)", (long long)boff[0],
+                    (long long)boff[buckets - 1], (unsigned long long)rows);
+    const int ndev = memo_device_count();
+    if (device < 0 || device >= ndev) return fail(MEMO_EHIP, "HIP device %d not available (%d visible)", device, ndev);
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(MEMO_EHIP, "cannot select HIP device %d", device);
+    memo_index *ix = new (std::nothrow) memo_index();
+    if (!ix) return fail(MEMO_EHIP, "out of host memory");
+    ix->device = device;
+    ix->rows = rows;
+    ix->padded = ((rows + 15) & ~(uint64_t)15) + kPadRows;
+    ix->packed_rows = ix->padded;
+    ix->has_wide = 0;
+    ix->was_sorted = 1;
+    ix->bshift = bucket_shift;
+    ix->bbase = bucket_base;
+    ix->nb = buckets;
+    ix->min_s = min_start;
+    ix->max_s = max_start;
+    ix->max_annot = max_annot;
+    int rc = MEMO_OK;
+    do {
+        hipError_t err = hipMalloc(&ix->pk, ix->padded * 4);
+        if (err == hipSuccess && pa) err = hipMalloc(&ix->pa, ix->padded * 2);
+        if (err == hipSuccess) err = hipMalloc(&ix->boff, buckets * 8);
+        if (err == hipSuccess) err = hipMalloc(&ix->d_status, 64);
+        if (err == hipSuccess) err = hipMalloc(&ix->d_scratch, 64);
+        if (err == hipSuccess) err = hipMemset(ix->d_status, 0, 64);
+        if (err == hipSuccess) err = hipMemset(ix->pk + rows, 0, (ix->padded - rows) * 4);
+        if (err == hipSuccess && pa) err = hipMemset(ix->pa + rows, 0, (ix->padded - rows) * 2);
+        if (err == hipSuccess && n_long) {
+            err = hipMalloc(&ix->ls, n_long * 8);
+            if (err == hipSuccess) err = hipMalloc(&ix->le, n_long * 8);
+            if (err == hipSuccess) err = hipMalloc(&ix->lo, n_long * 8);
+            if (err == hipSuccess) err = hipMemcpy(ix->ls, long_rows, n_long * 8, hipMemcpyHostToDevice);
+            if (err == hipSuccess) err = hipMemcpy(ix->le, long_rows + n_long, n_long * 8, hipMemcpyHostToDevice);
+            if (err == hipSuccess) err = hipMemcpy(ix->lo, long_rows + 2 * n_long, n_long * 8, hipMemcpyHostToDevice);
+            ix->n_long = n_long;
+        }
+        if (err != hipSuccess) {
+            rc = fail(MEMO_EHIP, "importing a packed index: %s", hipGetErrorString(err));
+            break;
+        }
+        if ((rc = upload_pipelined(device, ix->pk, pk, rows * 4))) break;
+        if (pa && (rc = upload_pipelined(device, ix->pa, pa, rows * 2))) break;
+        if ((rc = upload_pipelined(device, ix->boff, boff, buckets * 8))) break;
+    } while (0);
+    if (rc) {
+        memo_index_destroy(ix);
+        return rc;
+    }
+    ix->packed_fmt = pa ? 6 : 4;
+    ix->finalized = 1;
     *out = ix;
     return MEMO_OK;
 }

@@ -588,6 +588,9 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     info->has_wide = ix->has_wide;
     info->pack_ms = ix->pack_ms;
     info->dense_rows = ix->p3 ? 1 : 0;
+    info->long_rows = ix->n_long;
+    info->max_annot = ix->max_annot;
+    info->bucket_base = ix->bbase;
     info->device_bytes = (ix->has_wide ? ix->padded * 3 * sizeof(int64_t) : 0) + ix->nb * sizeof(int64_t) + 128 +
                          (ix->pk ? ix->padded * 4 : 0) + (ix->pa ? ix->padded * 2 : 0) + (ix->p3 ? ix->padded * 3 : 0);
     return MEMO_OK;

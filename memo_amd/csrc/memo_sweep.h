@@ -18,6 +18,7 @@ struct SweepArgs {
     const uint32_t *pa3;    //   ... and the 8-bit annot plane
     const int64_t *boff;
     int64_t nb;
+    int64_t bbase;          // bucket of boff[0]
     int64_t qs, qe;
     int64_t tile0;          // pivot position of tile 0 (multiple of the tile width, <= qs)
     int64_t ntiles;
@@ -69,12 +70,12 @@ __device__ __forceinline__ int64_t tile_of_block(const SweepArgs &A) {
 __device__ __forceinline__ void row_slice(const SweepArgs &A, int64_t a, int64_t hi_abs,
                                           uint64_t &r0, uint64_t &r1) {
     const int64_t last = A.nb - 1;
-    int64_t b0 = a <= 0 ? 0 : (a >> A.bshift);
-    const int64_t lim = hi_abs + A.km1;  // rows with start >= lim cannot reach the tile
-    int64_t b1 = lim <= 0 ? 0 : ((lim + ((int64_t)1 << A.bshift) - 1) >> A.bshift);
-    b0 = b0 > last ? last : b0;
-    b1 = b1 > last ? last : b1;
-    r0 = a <= 0 ? 0 : (uint64_t)A.boff[b0];
+    int64_t b0 = a <= 0 ? 0 : (a >> A.bshift) - A.bbase;  // (the table of a region slice starts at bucket bbase:
+    const int64_t lim = hi_abs + A.km1;  // rows with start >= lim cannot reach the tile        nothing lies before it)
+    int64_t b1 = lim <= 0 ? 0 : ((lim + ((int64_t)1 << A.bshift) - 1) >> A.bshift) - A.bbase;
+    b0 = b0 < 0 ? 0 : (b0 > last ? last : b0);
+    b1 = b1 < 0 ? 0 : (b1 > last ? last : b1);
+    r0 = a <= 0 ? 0 : (uint64_t)A.boff[b0];  // (rows with a negative start lie before bucket 0)
     r1 = (uint64_t)A.boff[b1];
 }
 

@@ -102,6 +102,7 @@ void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32
     A.pa = ix->pa;
     A.boff = ix->boff;
     A.nb = (int64_t)ix->nb;
+    A.bbase = ix->bbase;
     A.qs = qs;
     A.qe = qe;
     A.out = d_out;

@@ -156,6 +156,91 @@ __device__ __forceinline__ void halo_fold_store(const SweepArgs &A, const Tile &
                                       A.nlev > 1 ? lds + (A.nlev - 2) * LS + HL : nullptr, -HL);
 }
 
+// The same folds, in registers.  Every level is read ONCE (one conflict-free ds_read_b128 per lane and
+// level) and the cascade  M_top = L_top,  M_(j-1)[x] = min(L_(j-1)[x], M_j[x], M_j[x - 2^(j-1)])  runs on a
+// lane's four cells with the shifted operand fetched from the lanes to its left (DPP wave_shr for one lane,
+// ds_bpermute -- the LDS crossbar, no bank access -- for more); the result goes straight to the output.  No
+// intermediate level is written back and no barrier separates the passes: at k = 101 the five LDS passes
+// this replaces were 0.11 of 0.63 ms (profiles/r02_ablation.txt).  A wave covers 256 cells of which the
+// leftmost ceil((2^(nlev-1) - 1) / 4) lanes only supply context (their own results would need cells of the
+// previous wave), so consecutive waves overlap by that much.  Needs the tile grid aligned with the output
+// (t.a - qs a multiple of 4: the lanes' cells are aligned in the level arrays); the caller falls back to
+// halo_fold_store otherwise.
+__device__ __forceinline__ uint32_t lane_shr1(uint32_t v) {  // lane l <- lane l - 1 (lane 0: unchanged)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+
+template <typename OutT, int T, bool TOP8>
+__device__ __forceinline__ void halo_fold_store_reg(const SweepArgs &A, const Tile &t, const uint32_t *lds) {
+    const int LS = A.ls, HL = A.hl, W = A.w, nlev = A.nlev;
+    const int cells = HL + W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = T / 64;
+    const int ctx = nlev <= 1 ? 0 : (nlev <= 3 ? 1 : 1 << (nlev - 3));  // context lanes at the left of a wave
+    const int valid = 64 - ctx;
+    OutT *out = static_cast<OutT *>(A.out);
+    const int64_t ob = t.a - A.qs - HL;  // output index of cell 0 (a multiple of 4 here)
+    const int64_t o_lo = t.a - A.qs + t.x_lo, o_hi = t.a - A.qs + t.x_hi;
+    for (int base = wave * 4 * valid; base < cells; base += NW * 4 * valid) {
+        const int x0 = base + 4 * (lane - ctx);  // this lane's cells x0 .. x0 + 3
+        const bool have = x0 >= 0 && x0 + 4 <= LS;
+        uint4 M = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (have) M = *reinterpret_cast<const uint4 *>(lds + x0);
+        for (int slot = 1; slot < nlev; ++slot) {
+            const int half = 1 << (nlev - 1 - slot);  // the level being folded in has blocks of `half`
+            uint4 S;  // M shifted right by `half` cells
+            if (half >= 4) {
+                const int lanes = half >> 2;
+                if (lanes == 1) {
+                    S = make_uint4(lane_shr1(M.x), lane_shr1(M.y), lane_shr1(M.z), lane_shr1(M.w));
+                } else {
+                    const int src = (lane - lanes) << 2;  // (negative: context lanes, whose result is dropped)
+                    S.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.x);
+                    S.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.y);
+                    S.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.z);
+                    S.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.w);
+                }
+            } else if (half == 2) {
+                S = make_uint4(lane_shr1(M.z), lane_shr1(M.w), M.x, M.y);
+            } else {
+                S = make_uint4(lane_shr1(M.w), M.x, M.y, M.z);
+            }
+            uint4 L = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (have) L = *reinterpret_cast<const uint4 *>(lds + slot * LS + x0);
+            M.x = min(L.x, min(M.x, S.x));
+            M.y = min(L.y, min(M.y, S.y));
+            M.z = min(L.z, min(M.z, S.z));
+            M.w = min(L.w, min(M.w, S.w));
+        }
+        if (lane < ctx || x0 >= cells) continue;
+        const int64_t g = ob + x0;
+        if (TOP8) M = make_uint4(M.x >> 24, M.y >> 24, M.z >> 24, M.w >> 24);
+        if (g >= o_lo && g + 4 <= o_hi) {
+            if (sizeof(OutT) == 1)
+                *reinterpret_cast<uint32_t *>(out + g) = M.x | (M.y << 8) | (M.z << 16) | (M.w << 24);
+            else
+                *reinterpret_cast<uint2 *>(out + g) = make_uint2(M.x | (M.y << 16), M.z | (M.w << 16));
+        } else {
+            const uint32_t v[4] = {M.x, M.y, M.z, M.w};
+            for (int i = 0; i < 4; ++i)
+                if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)v[i];
+        }
+    }
+}
+
+#ifndef MEMO_FOLD_REG
+#define MEMO_FOLD_REG 1
+#endif
+template <typename OutT, int T, bool TOP8>
+__device__ __forceinline__ void halo_finish(const SweepArgs &A, const Tile &t, uint32_t *lds) {
+    // A/B on config 3 (profiles/r02_fold_in_registers.txt): -5 % at k = 21 and 31, +1 % at k = 64, +5 % at k = 101
+    // (16 context lanes per wave and twelve ds_bpermute per lane there): registers up to five levels
+    if (MEMO_FOLD_REG && A.nlev <= 5 && ((t.a - A.qs) & 3) == 0)
+        halo_fold_store_reg<OutT, T, TOP8>(A, t, lds);
+    else
+        halo_fold_store<OutT, T, TOP8>(A, t, lds);
+}
+
 // 4- and 6-byte rows.  The 4-byte rows carry their order in the top byte of the word, and the cells
 // take the WORD (ds_min_u32 of the row as it was loaded: the min of the words has the min order on
 // top, the junk below it only breaks ties) -- one VALU instruction per row less than extracting it;
@@ -226,7 +311,7 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
     MEMO_STAMP(2);  // waiting for rows + scatter
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
     MEMO_STAMP(3);  // barrier after the scatter
-    halo_fold_store<OutT, T, TOP8>(A, t, lds);
+    halo_finish<OutT, T, TOP8>(A, t, lds);
     MEMO_STAMP(5);  // folds + store
 #ifdef MEMO_STAMPS
     if (threadIdx.x == 0 && A.stamps) A.stamps[8ull * blockIdx.x + 7] = 1;
@@ -292,7 +377,7 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
         Rows::template consume<T, U>(A, t, b, VB, VA, g_lo, g_hi);
     }
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
-    halo_fold_store<OutT, T, true>(A, t, lds);
+    halo_finish<OutT, T, true>(A, t, lds);
 }
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value

@@ -115,7 +115,7 @@ def region_chunks(in_file, query_record, query_start, query_end):
     return bound, chunks()
 
 
-def region_index(in_file, query_record, query_start, query_end, device=None, k=None):
+def region_index(in_file, query_record, query_start, query_end, device=None, k=None, use_cache=True):
     """filter_pq + the upload half of memo_init in one streaming pass: the rows go from the
     Parquet file straight into a finalized DeviceIndex, row group by row group (the next one is
     decoded by Arrow while the current one is packed and copied to the GPU); the host never holds more
@@ -125,6 +125,21 @@ def region_index(in_file, query_record, query_start, query_end, device=None, k=N
     single Parquet file goes through filter_pq."""
     device = _device() if device is None else device
     packed = k is not None and 1 < k <= 256 and not os.environ.get("MEMO_QUERY_WIDE")
+    miss = None
+    if packed and use_cache and os.path.isfile(in_file):
+        from . import cache                       # sidecar cache of the packed rows (memo_amd/cache.py)
+        if cache.mode() != "off":
+            index = cache.load_region(in_file, query_record, query_start, query_end, device)
+            if index is not None:
+                index.cache = "hit"
+                return index
+            miss = (in_file, query_record)
+    index = _region_index_from_parquet(in_file, query_record, query_start, query_end, device, packed)
+    index.cache = miss                            # main() builds the cache after the answer is written
+    return index
+
+
+def _region_index_from_parquet(in_file, query_record, query_start, query_end, device, packed):
     if not os.path.isfile(in_file):
         rows = filter_pq(in_file, query_record, query_start, query_end)
         if packed:
@@ -294,9 +309,17 @@ def main(args):
     t.append(time.perf_counter())
     print_res(rec, args.out_file, membership_query)
     t.append(time.perf_counter())
+    miss = getattr(rows, "cache", None)
+    if isinstance(miss, tuple) and mem_arr.rows:          # answered from the Parquet file: leave a cache for next time
+        from . import cache
+        if cache.mode() == "sync":
+            cache.build(*miss, device=_device())
+        elif cache.mode() == "on":
+            cache.build_in_background(*miss)
     if os.environ.get("MEMO_TIMING"):          # stderr only: stdout stays the reference's
-        sys.stderr.write("memo_query timing: region slice+upload %.3f s, sweep+download %.3f s, text+write %.3f s "
-                         "(%d rows, %d positions)\n" % (t[1] - t[0], t[2] - t[1], t[3] - t[2], mem_arr.rows,
+        sys.stderr.write("memo_query timing: region slice+upload %.3f s%s, sweep+download %.3f s, text+write %.3f s "
+                         "(%d rows, %d positions)\n" % (t[1] - t[0], " (from the sidecar cache)" if miss == "hit" else "",
+                                                       t[2] - t[1], t[3] - t[2], mem_arr.rows,
                                                        max(query_end - query_start, 0)))
 
 

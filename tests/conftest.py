@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# `memo query` leaves a sidecar cache next to the index it read and builds it in a detached process; the tests
+# that are about the cache switch it on themselves
+os.environ.setdefault("MEMO_CACHE", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -414,6 +414,72 @@ def test_builder_rows_with_end_before_start_and_empty(memo, oracle):
 
 
 # ---------------------------------------------------------------------------------------
+# the CLI's sidecar cache of packed rows (memo_amd/cache.py, memo_index_export_packed / _import_packed)
+# ---------------------------------------------------------------------------------------
+def test_sidecar_cache_round_trip(memo, oracle, tmp_path, monkeypatch):
+    import subprocess
+    import sys
+    import time
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from memo_amd import cache, memo_query as mq
+    rng = np.random.default_rng(12)
+    tabs, cols = [], {}
+    for name, n, n_docs in (("chrA", 400_000, 60), ("chr B/2", 250_000, 700)):         # 4-byte and 6-byte rows
+        s, e, o = _random_index(rng, n, 150_000, n_docs, 80)
+        neg = rng.random(n) < 0.001
+        e[neg] = s[neg] - rng.integers(1, 500, int(neg.sum()))                        # a few rows with end < start
+        cols[name] = (s, e, o, n_docs)
+        tabs.append(pa.table({"f0": pa.array([name] * n, pa.utf8()), "f1": s, "f2": e, "f3": o}))
+    path = str(tmp_path / "idx.parquet")
+    pq.write_table(pa.concat_tables(tabs), path, row_group_size=50_000, compression="ZSTD")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bin", "memo")
+
+    def query(record, qs, qe, k, n_docs, mode, extra=()):
+        out = tmp_path / "out.txt"
+        r = subprocess.run([sys.executable, exe, "query", "-b", path, "-k", str(k), "-n", str(n_docs), "-r",
+                            f"{record}:{qs}-{qe}", "-o", str(out), *extra], capture_output=True,
+                           env=dict(os.environ, MEMO_CACHE=mode, MEMO_TIMING="1"))
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        return out.read_bytes(), r.stderr.decode()
+
+    for record, (s, e, o, n_docs) in cols.items():
+        assert not os.path.exists(cache.cache_path(path, record))
+        text0, _ = query(record, 1000, 60_000, 31, n_docs, "0")                     # no cache read or written
+        assert not os.path.exists(cache.cache_path(path, record))
+        text1, err1 = query(record, 1000, 60_000, 31, n_docs, "sync")               # miss: answered from Parquet, cache written
+        assert text1 == text0 and "sidecar cache" not in err1
+        assert os.path.exists(cache.cache_path(path, record))
+        text2, err2 = query(record, 1000, 60_000, 31, n_docs, "1")                  # hit
+        assert text2 == text0 and "from the sidecar cache" in err2
+        textm, errm = query(record, 70_000, 71_000, 21, n_docs, "read", ("-m",))    # membership from the cache, too
+        assert "from the sidecar cache" in errm
+        assert textm == memo.emit_membership(oracle.membership(*oracle.filter_rows(s, e, o, 70_000, 71_000, 21), 70_000,
+                                                               71_000, 21, n_docs, literal=False), n_docs)
+        monkeypatch.setenv("MEMO_CACHE", "read")
+        for qs, qe, k in ((0, 150_100, 31), (149_000, 160_000, 101), (77_777, 77_778, 2), (5, 6, 256), (200_000, 200_010, 31),
+                          (31, 64, 31), (32, 95, 3)):
+            with mq.region_index(path, record, qs, qe + k, k=k) as ix:
+                assert ix.cache == "hit"
+                want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (record, qs, qe, k)
+        with mq.region_index(path, record, 10, 5000 + 300, k=300) as ix:            # k > 256: int64 columns, not the cache
+            assert ix.cache is None and ix.info()["has_wide"] == 1
+    # a changed index file invalidates its caches
+    time.sleep(0.01)
+    pq.write_table(tabs[0].slice(0, 200_000), path, row_group_size=50_000, compression="ZSTD")
+    s, e, o, n_docs = cols["chrA"]
+    with mq.region_index(path, "chrA", 0, 50_000 + 31, k=31) as ix:
+        assert ix.cache == (path, "chrA")                                          # stale: ignored
+        want = oracle.conservation(*oracle.filter_rows(s[:200_000], e[:200_000], o[:200_000], 0, 50_000, 31), 0, 50_000, 31,
+                                   n_docs, literal=False)
+        assert np.array_equal(ix.conservation(0, 50_000, 31, n_docs), want)
+    assert cache.build(path, "chrA") and cache.build(path, "nochr") is None
+    with mq.region_index(path, "chrA", 0, 50_000 + 31, k=31) as ix:
+        assert ix.cache == "hit" and np.array_equal(ix.conservation(0, 50_000, 31, n_docs), want)
+
+
+# ---------------------------------------------------------------------------------------
 # several GPUs from one process (include/memo_amd_multi.h).  One GPU here: the device list names it
 # several times, which runs every code path (threads, partition, peer copies into the root's result)
 # ---------------------------------------------------------------------------------------
