@@ -376,6 +376,8 @@ def main():
             return ("sweep_membership_planes_kernel<" if num_docs <= 512 else "sweep_membership_runs_kernel<") + rows_t + ", ...>"
         # packed rows on an index with >= 1 row per position: the unclipped scatter (memo_sweep_cons.hip)
         halo = which != "wide" and rows >= L
+        if halo and k - 1 >= 64:
+            return "sweep_conservation_r4_kernel<" + rows_t + ", ...>"
         return ("sweep_conservation_halo_kernel<" if halo else "sweep_conservation_kernel<") + rows_t + ", ...>"
 
     def per_step(fn, n):

@@ -32,14 +32,15 @@ extern "C" {
 int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32_t membership_algo,
                           int32_t row_source, int32_t scatter) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
-    if (tile_w != 0 && tile_w != 256 && tile_w != 512 && tile_w != 1024 && tile_w != 2048 && tile_w != 4096)
-        return fail(MEMO_EINVAL, "tile_w must be 0, 256, 512, 1024, 2048 or 4096");
+    if (tile_w != 0 && (tile_w < 256 || tile_w > 8192 || tile_w % 64))
+        return fail(MEMO_EINVAL, "tile_w must be 0 or a multiple of 64 in [256, 8192] (powers of two for the clipped kernels)");
     if (waves != 0 && waves != 1 && waves != 4 && waves != 8) return fail(MEMO_EINVAL, "waves must be 0, 1, 4 or 8");
     if (membership_algo != 0 && (membership_algo < 2 || membership_algo > 4))
         return fail(MEMO_EINVAL, "membership_algo must be 0 (choose), 2 (doubling), 3 (runs) or 4 (planes)");
     if (row_source < 0 || row_source > 2)
         return fail(MEMO_EINVAL, "row_source must be 0 (library's choice), 1 (int64 columns) or 2 (3-byte rows where they can answer)");
-    if (scatter < 0 || scatter > 2) return fail(MEMO_EINVAL, "scatter must be 0 (choose), 1 (clipped) or 2 (unclipped)");
+    if (scatter < 0 || scatter > 3)
+        return fail(MEMO_EINVAL, "scatter must be 0 (choose), 1 (clipped), 2 (unclipped, doubling levels) or 3 (unclipped, radix-4 levels)");
     ix->tune.tile_w = tile_w;
     ix->tune.waves = waves;
     ix->tune.memb_algo = membership_algo;

@@ -380,6 +380,144 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
     halo_finish<OutT, T, true>(A, t, lds);
 }
 
+// ------------------------------------------------------------------------------------------
+// conservation, unclipped, RADIX-4 levels: blocks of 1, 4, 16, 64 positions.
+//
+// Doubling levels cost 4 bytes of LDS per position and level -- 28 B at k = 101, 32 B at k = 256 -- and one
+// fold step per level; at large k those folds and the k-1 halo of short tiles are what the sweep spends its
+// time on (profiles/r02_ablation.txt: fold passes 0.11 of 0.63 ms at k = 101).  With levels a factor FOUR
+// apart there are four arrays for any k <= 256: an interval of n positions, 4^i <= n < 4^(i+1), is covered
+// by blocks of S = 4^i at start - n and start - S, plus one at start - n + S when n > 2S and one at
+// start - n + 2S when n > 3S (2 - 4 ds_min per row instead of 2), and a block of 4S folds into the four
+// blocks of S under it.  Tiles are twice as long in the same LDS, the halo's share of the array shrinks with
+// them, and three fold steps replace six or seven: 64 -> 16 as one LDS pass, 16 -> 4 and 4 -> 1 in registers
+// (DPP shifts only).  Used from k = 65 up; below that the doubling arrays are faster (see the launcher).
+// ------------------------------------------------------------------------------------------
+template <typename OutT, int T, bool TOP8>
+__device__ __forceinline__ void r4_fold_store(const SweepArgs &A, const Tile &t, uint32_t *lds) {
+    const int LS = A.ls, HL = A.hl, W = A.w, m = A.nlev;
+    const int cells = HL + W;
+    // levels above 16 fold down through LDS (shifts of 16 cells and more are not a DPP's reach): slot s holds
+    // blocks of 4^(m-1-s); after this loop slot m-3 (blocks of 16) has everything above it folded in
+    for (int slot = 0; slot + 3 < m; ++slot) {
+        const int S = 1 << (2 * (m - 2 - slot));  // size of the blocks being folded INTO (>= 16)
+        const uint32_t *hi = lds + slot * LS;
+        uint32_t *lo = lds + (slot + 1) * LS;
+        for (int x = 4 * threadIdx.x; x < cells; x += 4 * T) {
+            uint4 r = *reinterpret_cast<const uint4 *>(lo + x);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (x >= q * S) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(hi + x - q * S);
+                    r.x = min(r.x, v.x);
+                    r.y = min(r.y, v.y);
+                    r.z = min(r.z, v.z);
+                    r.w = min(r.w, v.w);
+                }
+            }
+            *reinterpret_cast<uint4 *>(lo + x) = r;
+        }
+        lds_barrier();
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = T / 64;
+    const int ctx = m >= 3 ? 4 : (m == 2 ? 1 : 0);  // context lanes: 15 / 3 / 0 cells to the left
+    const int valid = 64 - ctx;
+    const uint32_t *l16 = m >= 3 ? lds + (m - 3) * LS : nullptr;
+    const uint32_t *l4 = m >= 2 ? lds + (m - 2) * LS : nullptr;
+    const uint32_t *l1 = lds + (m - 1) * LS;
+    OutT *out = static_cast<OutT *>(A.out);
+    const int64_t ob = t.a - A.qs - HL;  // output index of cell 0
+    const int64_t o_lo = t.a - A.qs + t.x_lo, o_hi = t.a - A.qs + t.x_hi;
+    const bool aligned = (ob & 3) == 0;
+    for (int base = wave * 4 * valid; base < cells; base += NW * 4 * valid) {
+        const int x0 = base + 4 * (lane - ctx);  // this lane's cells x0 .. x0 + 3
+        const bool have = x0 >= 0 && x0 + 4 <= LS;
+        const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
+        uint4 M = none;
+        if (m >= 3) {  // blocks of 16 -> blocks of 4: cells x - 4, x - 8, x - 12 are the same component 1, 2, 3 lanes left
+            if (have) M = *reinterpret_cast<const uint4 *>(l16 + x0);
+            uint4 L = none;
+            if (have) L = *reinterpret_cast<const uint4 *>(l4 + x0);
+            uint4 S1 = make_uint4(lane_shr1(M.x), lane_shr1(M.y), lane_shr1(M.z), lane_shr1(M.w));
+            uint4 S2 = make_uint4(lane_shr1(S1.x), lane_shr1(S1.y), lane_shr1(S1.z), lane_shr1(S1.w));
+            uint4 S3 = make_uint4(lane_shr1(S2.x), lane_shr1(S2.y), lane_shr1(S2.z), lane_shr1(S2.w));
+            M.x = min(min(L.x, M.x), min(S1.x, min(S2.x, S3.x)));
+            M.y = min(min(L.y, M.y), min(S1.y, min(S2.y, S3.y)));
+            M.z = min(min(L.z, M.z), min(S1.z, min(S2.z, S3.z)));
+            M.w = min(min(L.w, M.w), min(S1.w, min(S2.w, S3.w)));
+        } else if (m == 2) {
+            if (have) M = *reinterpret_cast<const uint4 *>(l4 + x0);
+        }
+        uint4 R = none;
+        if (have) R = *reinterpret_cast<const uint4 *>(l1 + x0);
+        if (m >= 2) {  // blocks of 4 -> positions: cells x - 1, x - 2, x - 3
+            const uint32_t p1 = lane_shr1(M.y), p2 = lane_shr1(M.z), p3 = lane_shr1(M.w);  // cells x0 - 3, x0 - 2, x0 - 1
+            R.x = min(min(R.x, M.x), min(p3, min(p2, p1)));
+            R.y = min(min(R.y, M.y), min(M.x, min(p3, p2)));
+            R.z = min(min(R.z, M.z), min(M.y, min(M.x, p3)));
+            R.w = min(min(R.w, M.w), min(M.z, min(M.y, M.x)));
+        }
+        if (lane < ctx || x0 >= cells) continue;
+        const int64_t g = ob + x0;
+        if (TOP8) R = make_uint4(R.x >> 24, R.y >> 24, R.z >> 24, R.w >> 24);
+        if (aligned && g >= o_lo && g + 4 <= o_hi) {
+            if (sizeof(OutT) == 1)
+                *reinterpret_cast<uint32_t *>(out + g) = R.x | (R.y << 8) | (R.z << 16) | (R.w << 24);
+            else
+                *reinterpret_cast<uint2 *>(out + g) = make_uint2(R.x | (R.y << 16), R.z | (R.w << 16));
+        } else {  // window edges, and windows that do not start on the tile grid's 4-position raster
+            const uint32_t v[4] = {R.x, R.y, R.z, R.w};
+            for (int i = 0; i < 4; ++i)
+                if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)v[i];
+        }
+    }
+}
+
+template <typename Rows, int U, int T, typename OutT, bool TOP8>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
+void sweep_conservation_r4_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    static_assert(!(TOP8 && Rows::kAnnot16), "the order byte rides in the word only in the 4-byte format");
+    const int LS = A.ls, HL = A.hl, W = A.w;
+    Tile t;
+    if (!locate_tile_w(A, t, W)) return;
+    uint4 V[U];
+    uint2 N[U];
+    Rows::template issue<T, U>(A, t, 0, V, N);
+    const uint32_t sent = (uint32_t)(A.ncols - 1);
+    halo_clear<T>(A, lds, TOP8 ? (sent << 24) | 0x00FFFFFFu : sent);
+
+    const int km1 = A.km1;
+    uint32_t *level0 = lds + (A.nlev - 1) * LS + HL;  // tile slot 0 on the level of single positions
+    const uint32_t a16 = pin_vgpr((int)((uint32_t)t.a & 0xFFFFu));
+    auto scatter = [&](uint32_t w, uint32_t col) {
+        const int n = km1 - (int)__builtin_amdgcn_ubfe(w, 16, 8);  // length of [end - (k-1), start)
+        if (n > 0) {
+            uint32_t d;  // start - a (gfx9 16-bit VALU results have a zero high half)
+            asm("v_sub_u16 %0, %1, %2" : "=v"(d) : "v"(w), "v"(a16));
+            const int i2 = (31 - __builtin_clz((unsigned)n)) & ~1;  // 2 i, 4^i <= n < 4^(i+1)
+            const int S = 1 << i2;
+            uint32_t *lv = level0 - (i2 >> 1) * LS + (int)d;  // cell `start` on level i
+            const uint32_t data = TOP8 ? w : col;
+            uint32_t *first = lv - n;
+            atomicMin(first, data);   // [start - n, start - n + S)
+            atomicMin(lv - S, data);  // [start - S, start)
+            if (n > 2 * S) {
+                atomicMin(first + S, data);
+                if (n > 3 * S) atomicMin(first + 2 * S, data);
+            }
+        }
+    };
+    Rows::template consume<T, U>(A, t, 0, V, N, scatter);
+    for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
+        Rows::template issue<T, U>(A, t, b, V, N);
+        Rows::template consume<T, U>(A, t, b, V, N, scatter);
+    }
+    __syncthreads();
+    r4_fold_store<OutT, T, TOP8>(A, t, lds);
+}
+
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
 template <typename OutT>
 __global__ void fill_conservation_kernel(OutT *out, int64_t n, OutT v) {
@@ -494,6 +632,13 @@ static SweepKernel halo_kernel(int waves) {
                         : (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 64, OutT, TOP8>;
 }
 
+template <typename Rows, typename OutT, bool TOP8>
+static SweepKernel r4_kernel(int waves) {
+    return waves == 8   ? (SweepKernel)sweep_conservation_r4_kernel<Rows, kHaloLoads, 512, OutT, TOP8>
+           : waves == 4 ? (SweepKernel)sweep_conservation_r4_kernel<Rows, kHaloLoads, 256, OutT, TOP8>
+                        : (SweepKernel)sweep_conservation_r4_kernel<Rows, kHaloLoads, 64, OutT, TOP8>;
+}
+
 template <typename OutT>
 static SweepKernel halo3_kernel(int waves) {
     return waves == 8   ? (SweepKernel)sweep_conservation_halo3_kernel<PackedRows3::kLoads, 512, OutT>
@@ -546,6 +691,8 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // Short windows want many small tiles either way.
     const memo_tuning &tune = ix->tune;
     int w = tune.tile_w, waves = tune.waves == 1 || tune.waves == 4 ? tune.waves : 0;
+    while (w & (w - 1)) w &= w - 1;  // (the clipped kernels and the doubling arrays come in powers of two)
+    if (w > 4096) w = 4096;
     // int64 rows on a sparse index (< 2 rows per position: profiles/r01_sparse_index_tiles.txt) are
     // no longer HBM-bound per tile; they want the packed rows' shape (more workgroups per CU)
     const double span = (double)(ix->max_s - ix->min_s) + 1.0;
@@ -563,13 +710,41 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // HL + tile + HR cells (start - a <= tile + k + 30 inside a slice); the tile is what is left
     // after the halo, rounded down to whole buckets
     // (below one row per position the halo's extra clear and fold cost more than the scatter saves)
-    bool halo = fmt && !checked && (tune.scatter == 2 || (tune.scatter == 0 && (double)ix->rows >= span));
+    bool halo = fmt && !checked && (tune.scatter >= 2 || (tune.scatter == 0 && (double)ix->rows >= span));
+    // Radix-4 levels (sweep_conservation_r4_kernel) from k = 65 up: four arrays where doubling needs seven or
+    // eight.  Interleaved A/B on config 3 (profiles/r02_radix4_levels.txt; doubling -> radix-4, ms): k = 101
+    // 0.564 -> 0.514, k = 256 0.951 -> 0.668, with arrays of 2560 cells shared by eight waves (40 KiB, four
+    // workgroups per CU); at k = 21 / 31 / 64 the doubling arrays stay ahead (0.375 vs 0.40, 0.46 vs 0.50: there
+    // the third and fourth block of a row cost more than the two fold steps save).
+    if (halo && fmt != 3 && (tune.scatter == 3 || (tune.scatter == 0 && k - 1 >= 64))) {
+        const int bw = 1 << ix->bshift;
+        const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + bw - 1 + 3) & ~3;
+        const int m = (floor_log2((uint32_t)(k - 1)) >> 1) + 1;
+        int ls = tune.tile_w ? tune.tile_w : 2560;
+        if (ls > 8192) ls = 8192;
+        // short windows: enough tiles to fill the chip (a few thousand of them)
+        while (!tune.tile_w && ls > 640 && (qe - qs) / (ls - hl - hr > bw ? ls - hl - hr : bw) < 4096) ls = (ls / 2) & ~3;
+        const int tw = (ls - hl - hr) / bw * bw;
+        if (tw >= bw && 2 * tw >= hl + hr && (size_t)m * (hl + tw + hr) * 4 <= 160 * 1024) {
+            A.nlev = m;
+            A.hl = hl;
+            A.w = tw;
+            A.ls = hl + tw + hr;
+            waves = tune.waves == 1 || tune.waves == 4 || tune.waves == 8 ? tune.waves : (ls >= 2048 ? 8 : 4);
+            const bool top8 = num_docs <= 255;
+            SweepKernel kern = fmt == 4 ? (top8 ? r4_kernel<PackedRows<false, false>, OutT, true>(waves)
+                                                : r4_kernel<PackedRows<false, false>, OutT, false>(waves))
+                                        : r4_kernel<PackedRows<true, false>, OutT, false>(waves);
+            if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)m * A.ls * 4, st))) return rc;
+            return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
+        }
+    }
     if (halo) {
         // A/B (profiles/r01_unclipped_scatter.txt): arrays of 1024 cells x 4 waves win at every window
         // length from 10^6 positions up and at k = 21 .. 101
         const int bw = 1 << ix->bshift;  // a slice ends at a bucket boundary: start - a <= tile + k - 1 + bw - 2
         const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + bw - 1 + 3) & ~3;
-        if (!tune.tile_w) w = 1024;
+        if (!w) w = 1024;
         int tw = 0;
         for (;; w <<= 1) {
             tw = (w - hl - hr) / bw * bw;
@@ -606,6 +781,8 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             return fail(MEMO_EINVAL, "this query needs the 4-byte rows or the int64 columns, which this index dropped");
         fmt = 0;
         w = tune.tile_w;  // tile shape for int64 rows
+        while (w & (w - 1)) w &= w - 1;
+        if (w > 4096) w = 4096;
         if (!w) {
             w = 4096;
             while ((size_t)A.nlev * w * 4 > (sparse ? 32u : 80u) * 1024 && w > 256) w >>= 1;

@@ -406,6 +406,8 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     if (algo == 2 && (per_pos_doubling * 256 > 128 * 1024 || nw > 64)) algo = 3;
     const bool checked = ix->max_annot >= (uint64_t)A.ncols;
     int w = tune.tile_w, waves = tune.waves == 1 || tune.waves == 4 ? tune.waves : 0;
+    while (w & (w - 1)) w &= w - 1;  // (tile widths are powers of two here; the debug switch also takes other array sizes)
+    if (w > 4096) w = 4096;
     A.word_base = 0;
     A.out_words = nw;
     // 4 = unclipped bit planes + staged result: packed rows with every annot inside the matrix, at most

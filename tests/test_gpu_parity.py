@@ -197,7 +197,7 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle, ab):
                     qs = int(rng.integers(0, length // 2))
                     qe = int(rng.integers(qs + 1, length + 100))
                     want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
-                    for scatter in (1, 2):              # clipped to the tile / unclipped with a halo
+                    for scatter in (1, 2, 3):           # clipped to the tile / unclipped: doubling levels, radix-4 levels
                         ix.debug_set_tuning(tile_w, waves, algo, 0, scatter)
                         assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (k, qs, qe, tile_w, scatter)
                         if n_docs <= 255:
@@ -291,7 +291,7 @@ def test_bucket_widths(bucket_shift, memo, oracle, ab):
                         qe = int(rng.integers(qs + 1, length + 100))
                         rows = oracle.filter_rows(s, e, o, qs, qe, k)
                         want = oracle.conservation(*rows, qs, qe, k, n_docs, literal=False)
-                        for scatter in (1, 2):
+                        for scatter in (1, 2, 3):
                             ix.debug_set_tuning(tile_w, waves, algo, 0, scatter)
                             assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (packed, k, qs, qe, tile_w, scatter)
                         if k in (17, 31, 32, 101):
