@@ -159,7 +159,8 @@ def main():
     from memo_amd import _lib
     if args.calibrate:
         _lib.use_ab(True)                   # the PMC calibration kernel lives in libmemo_amd_ab.so only
-    can_dense = (not membership) and k - 1 <= 63 and num_docs <= 255 and not args.wide
+    # the 3-byte rows answer the unclipped conservation sweep only: k <= 64, num_docs <= 255, >= 1 row per position
+    can_dense = (not membership) and k - 1 <= 63 and num_docs <= 255 and not args.wide and num_docs >= 20
     if args.rows == "auto":
         args.rows = "wide" if k - 1 > 255 else "packed"      # (3-byte rows are smaller, not faster: DESIGN.md)
     if args.rows == "dense" and not can_dense:

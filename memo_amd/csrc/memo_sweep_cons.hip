@@ -489,23 +489,55 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
     halo_clear<T>(A, lds, TOP8 ? (sent << 24) | 0x00FFFFFFu : sent);
 
     const int km1 = A.km1;
-    uint32_t *level0 = lds + (A.nlev - 1) * LS + HL;  // tile slot 0 on the level of single positions
+    // LDS byte address of tile slot x on level i (blocks of 4^i):  level0 - i * 4 LS + 4 x
+    const uint32_t ls4 = 4u * (uint32_t)LS;
+    const int neg_ls4 = -(int)ls4;
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
+    const uint32_t level0 = pin_vgpr((int)(lds_base + (uint32_t)(A.nlev - 1) * ls4 + 4u * (uint32_t)HL));
     const uint32_t a16 = pin_vgpr((int)((uint32_t)t.a & 0xFFFFu));
     auto scatter = [&](uint32_t w, uint32_t col) {
         const int n = km1 - (int)__builtin_amdgcn_ubfe(w, 16, 8);  // length of [end - (k-1), start)
         if (n > 0) {
-            uint32_t d;  // start - a (gfx9 16-bit VALU results have a zero high half)
-            asm("v_sub_u16 %0, %1, %2" : "=v"(d) : "v"(w), "v"(a16));
-            const int i2 = (31 - __builtin_clz((unsigned)n)) & ~1;  // 2 i, 4^i <= n < 4^(i+1)
-            const int S = 1 << i2;
-            uint32_t *lv = level0 - (i2 >> 1) * LS + (int)d;  // cell `start` on level i
+            // i = floor(log4 n), S = 4^i.  Blocks [start - n, +S) and [start - S, start); r = n - 2S > 0: one more at
+            // start - n + S; r > S: and one at start - n + 2S.  By hand: the compiler's rendering takes 24 VALU
+            // instructions per row, one of them a quarter-rate 32-bit multiply.
             const uint32_t data = TOP8 ? w : col;
-            uint32_t *first = lv - n;
-            atomicMin(first, data);   // [start - n, start - n + S)
-            atomicMin(lv - S, data);  // [start - S, start)
-            if (n > 2 * S) {
-                atomicMin(first + S, data);
-                if (n > 3 * S) atomicMin(first + 2 * S, data);
+            uint32_t t31, a1, a2, s4;
+            int r;
+            asm volatile(
+                "v_ffbh_u32 %0, %5\n\t"
+                "v_sub_u32 %0, 31, %0\n\t"            // floor(log2 n)
+                "v_lshrrev_b32 %1, 1, %0\n\t"         // i
+                "v_mad_i32_i24 %1, %1, %8, %9\n\t"    // level i
+                "v_sub_u16 %2, %6, %7\n\t"            // start - a  (gfx9 16-bit VALU results have a zero high half)
+                "v_lshl_add_u32 %2, %2, 2, %1\n\t"    // cell `start` on level i
+                "v_mad_i32_i24 %1, %5, -4, %2\n\t"    // a1: cell start - n
+                "v_and_b32 %0, 30, %0\n\t"            // 2 i
+                "v_lshlrev_b32 %3, %0, 4\n\t"         // 4 S (bytes)
+                "v_sub_u32 %2, %2, %3\n\t"            // a2: cell start - S
+                "ds_min_u32 %1, %10\n\t"
+                "ds_min_u32 %2, %10\n\t"
+                "v_lshrrev_b32 %0, 1, %3\n\t"         // 2 S
+                "v_sub_u32 %4, %5, %0"                // r = n - 2 S
+                : "=&v"(t31), "=&v"(a1), "=&v"(a2), "=&v"(s4), "=&v"(r)
+                : "v"(n), "v"(w), "v"(a16), "s"(neg_ls4), "v"(level0), "v"(data)
+                : "memory");
+            if (r > 0) {
+                uint32_t a3, a4;
+                asm volatile(
+                    "v_add_u32 %0, %1, %2\n\t"        // a3 = a1 + 4 S
+                    "ds_min_u32 %0, %3"
+                    : "=&v"(a3)
+                    : "v"(a1), "v"(s4), "v"(data)
+                    : "memory");
+                if ((uint32_t)r > (s4 >> 2)) {
+                    asm volatile(
+                        "v_add_u32 %0, %1, %2\n\t"    // a4 = a3 + 4 S
+                        "ds_min_u32 %0, %3"
+                        : "=&v"(a4)
+                        : "v"(a3), "v"(s4), "v"(data)
+                        : "memory");
+                }
             }
         }
     };
@@ -514,6 +546,7 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
         Rows::template issue<T, U>(A, t, b, V, N);
         Rows::template consume<T, U>(A, t, b, V, N, scatter);
     }
+    lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
     __syncthreads();
     r4_fold_store<OutT, T, TOP8>(A, t, lds);
 }

@@ -23,13 +23,29 @@ t = time.time()
 rows = synth.write_parquet(pq_path, a.num_docs, a.pivot)
 print(f"wrote {rows} rows, {os.path.getsize(pq_path) / 1e6:.0f} MB parquet in {time.time() - t:.1f} s", flush=True)
 exe = os.path.join(ROOT, "bin", "memo")
-for region, memb in ((f"chr1:0-{a.pivot}", False), (f"chr1:{a.pivot // 4}-{a.pivot // 2}", False),
-                     (f"chr1:0-{min(a.pivot, 2_000_000)}", True)):
-    out = os.path.join(a.out, "out.txt")
-    argv = [sys.executable, exe, "query", "-b", pq_path, "-n", str(a.num_docs), "-r", region, "-o", out] + (["-m"] if memb else [])
-    t = time.time()
-    r = subprocess.run(argv, capture_output=True, env=dict(os.environ, MEMO_TIMING="1"))
-    wall = time.time() - t
-    sz = os.path.getsize(out) if os.path.exists(out) else -1
-    print(f"{region} {'membership' if memb else 'conservation'}: wall {wall:.2f} s, rc {r.returncode}, output {sz / 1e6:.0f} MB")
-    print("   ", r.stderr.decode().strip().splitlines()[-1] if r.stderr else "")
+import shutil
+shutil.rmtree(pq_path + ".memo", ignore_errors=True)
+# three passes over the same queries: no sidecar cache at all; a miss that builds the cache in-process after the
+# answer is written (MEMO_CACHE=sync: its wall clock includes the build; the default builds in a detached process);
+# hits.  Output bytes must not change.
+digests = {}
+for mode, what in (("0", "no cache (Parquet decode)"), ("sync", "cache miss + in-process build of the cache"), ("read", "cache hit"),
+                   ("read", "cache hit, again")):
+    print(f"-- MEMO_CACHE={mode}: {what}")
+    for region, memb in ((f"chr1:0-{a.pivot}", False), (f"chr1:{a.pivot // 4}-{a.pivot // 2}", False),
+                         (f"chr1:0-{min(a.pivot, 2_000_000)}", True)):
+        out = os.path.join(a.out, "out.txt")
+        argv = [sys.executable, exe, "query", "-b", pq_path, "-n", str(a.num_docs), "-r", region, "-o", out] + (["-m"] if memb else [])
+        t = time.time()
+        r = subprocess.run(argv, capture_output=True, env=dict(os.environ, MEMO_TIMING="1", MEMO_CACHE=mode))
+        wall = time.time() - t
+        sz = os.path.getsize(out) if os.path.exists(out) else -1
+        h = hashlib.sha256(open(out, "rb").read()).hexdigest()[:16] if sz >= 0 else None
+        same = digests.setdefault((region, memb), h) == h
+        print(f"{region} {'membership' if memb else 'conservation'}: wall {wall:.2f} s, rc {r.returncode}, output {sz / 1e6:.0f} MB, "
+              f"sha256 {h}{'' if same else '  <-- DIFFERS'}")
+        lines = [ln for ln in r.stderr.decode().strip().splitlines() if "memo_query timing" in ln]
+        print("   ", lines[-1] if lines else r.stderr.decode()[-300:])
+cache_dir = pq_path + ".memo"
+if os.path.isdir(cache_dir):
+    print("cache files:", {f: os.path.getsize(os.path.join(cache_dir, f)) for f in os.listdir(cache_dir)})
