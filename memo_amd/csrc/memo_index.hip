@@ -170,45 +170,52 @@ __global__ __launch_bounds__(256) void bin_conservation_kernel(const uint16_t *v
 __global__ __launch_bounds__(256) void nibble_pack_kernel(const uint8_t *in, int64_t n, uint32_t *nib,
                                                           unsigned long long *exc, unsigned int *count,
                                                           unsigned int cap) {
-    // exceptions are collected per workgroup in LDS and appended with ONE global atomic per flush:
-    // a quarter of a million same-address atomics would cost milliseconds
-    __shared__ unsigned long long held[4096];
+    // A workgroup codes 32768 consecutive positions (16 rounds of 256 threads x 8 positions).  Exceptions
+    // are collected in LDS -- no barrier between the rounds, LDS atomics order themselves -- and appended
+    // with ONE global atomic per workgroup: a quarter of a million same-address atomics would cost
+    // milliseconds, and round 1's version, which met at three barriers per round, ran at a fifth of its
+    // memory bound.  More than 4096 exceptions in 32768 positions (an eighth of them >= 15) is not data this
+    // coding is for: the count is saturated so that the receiver sees an incomplete slice.
+    constexpr int kRounds = 16, kHeld = 4096;
+    __shared__ unsigned long long held[kHeld];
     __shared__ unsigned int n_held, base;
     if (threadIdx.x == 0) n_held = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) count[1] = cap;  // header word 1
     __syncthreads();
     const int64_t groups = (n + 7) / 8;
-    const int64_t rounds = (groups + (int64_t)gridDim.x * 256 - 1) / ((int64_t)gridDim.x * 256);
-    for (int64_t r = 0; r < rounds; ++r) {  // every thread of the workgroup makes every round (barriers inside)
-        const int64_t g = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-        if (g < groups) {
-            unsigned long long eight = 0;  // 8 results in one load (the tail group byte by byte)
-            if (g * 8 + 8 <= n) {
-                eight = *reinterpret_cast<const unsigned long long *>(in + g * 8);
-            } else {
-                for (int i = 0; g * 8 + i < n; ++i) eight |= (unsigned long long)in[g * 8 + i] << (8 * i);
-            }
-            uint32_t word = 0;
+#pragma unroll 4
+    for (int r = 0; r < kRounds; ++r) {
+        const int64_t g = ((int64_t)blockIdx.x * kRounds + r) * 256 + threadIdx.x;
+        if (g >= groups) break;
+        unsigned long long eight = 0;  // 8 results in one load (the tail group byte by byte)
+        if (g * 8 + 8 <= n) {
+            eight = *reinterpret_cast<const unsigned long long *>(in + g * 8);
+        } else {
+            for (int i = 0; g * 8 + i < n; ++i) eight |= (unsigned long long)in[g * 8 + i] << (8 * i);
+        }
+        uint32_t word = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t v = (uint32_t)(eight >> (8 * i)) & 0xFFu;
-                if (v >= 15u) held[atomicAdd(&n_held, 1u)] = ((unsigned long long)(g * 8 + i) << 8) | v;
-                word |= (v < 15u ? v : 15u) << (4 * i);
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t v = (uint32_t)(eight >> (8 * i)) & 0xFFu;
+            if (v >= 15u) {
+                const unsigned int slot = atomicAdd(&n_held, 1u);
+                if (slot < (unsigned)kHeld) held[slot] = ((unsigned long long)(g * 8 + i) << 8) | v;
             }
-            nib[g] = word;
+            word |= (v < 15u ? v : 15u) << (4 * i);
         }
-        __syncthreads();
-        const unsigned int mine = n_held;
-        if (mine && (r + 1 == rounds || mine > 2048)) {  // a round adds at most 2048: flush before it could overflow
-            if (threadIdx.x == 0) base = atomicAdd(count, mine);
-            __syncthreads();
-            for (unsigned int i = threadIdx.x; i < mine; i += 256)
-                if (base + i < cap) exc[base + i] = held[i];
-            __syncthreads();
-            if (threadIdx.x == 0) n_held = 0;
-        }
-        __syncthreads();
+        nib[g] = word;
     }
+    __syncthreads();
+    const unsigned int mine = n_held;
+    if (!mine) return;
+    if (mine > (unsigned)kHeld) {
+        if (threadIdx.x == 0) count[2] = 1;  // header word 2: overflow -- the slice is incomplete, whatever the capacity
+        return;
+    }
+    if (threadIdx.x == 0) base = atomicAdd(count, mine);
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < mine; i += 256)
+        if (base + i < cap) exc[base + i] = held[i];
 }
 
 __global__ void nibble_unpack_kernel(const uint32_t *nib, int64_t n, uint8_t *out) {
@@ -757,7 +764,7 @@ int memo_bin_conservation_dev(const uint16_t *d_vec, int64_t L, const int64_t *e
     return MEMO_OK;
 }
 
-// wire layout: [count u32, cap u32, 8 B pad][nibbles: 4 * ceil(n / 8) B][exceptions: cap * 8 B]
+// wire layout: [count u32, cap u32, overflow u32, 4 B pad][nibbles: 4 * ceil(n / 8) B][exceptions: cap * 8 B]
 size_t memo_transport_bytes(int64_t n, uint32_t cap) {
     return 16 + (size_t)((n + 7) / 8) * 4 + (size_t)cap * 8;
 }
@@ -772,7 +779,9 @@ int memo_transport_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t cap, void 
     HIP_TRY(hipMemsetAsync(w, 0, 16, st));  // count = 0; the kernel fills in the capacity (no host staging)
     const int64_t groups = (n + 7) / 8;
     {
-        const unsigned grid = (unsigned)(groups / 256 + 1 < 8192 ? groups / 256 + 1 : 8192);
+        const int64_t blocks = (groups + 256 * 16 - 1) / (256 * 16);  // 32768 positions per workgroup
+        if (blocks >= ((int64_t)1 << 31)) return fail(MEMO_EINVAL, "slice too long for one launch");
+        const unsigned grid = (unsigned)blocks;
         hipLaunchKernelGGL(nibble_pack_kernel, dim3(grid), dim3(256), 0, st, d_vec, n,
                            reinterpret_cast<uint32_t *>(w + 16),
                            reinterpret_cast<unsigned long long *>(w + 16 + groups * 4),
@@ -810,7 +819,7 @@ int memo_transport_exceptions(const void *d_wire, int32_t device, void *stream, 
     uint32_t head[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(head, d_wire, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    *found = head[0];
+    *found = head[2] ? 0xFFFFFFFFu : head[0];  // word 2: a workgroup overflowed its staging (more than an eighth exceptions)
     *cap = head[1];
     return MEMO_OK;
 }
