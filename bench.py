@@ -545,7 +545,7 @@ def main():
                 whole &= bool(torch.equal(own, outs[last].reshape(-1)))
                 for g2 in range(1 if skip_own else 0, world):
                     head = roots[last][g2][:16].cpu().numpy().view(np.uint32)
-                    whole &= bool(head[0] <= head[1]) and (bool(head[2] <= head[3]) if coding == "dense" else head[2] == 0)
+                    whole &= bool(head[0] <= head[1]) and bool(head[2] <= head[3] if coding == "dense" else head[2] == 0)
                 res["gather_parity_sample"]["every_slice_complete"] = whole
             res["config"]["gather_payload"] = (
                 f"dense coding: 2 bits per position + {b_cap} B of escape nibbles + {cap} exception slots "

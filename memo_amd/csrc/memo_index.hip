@@ -781,7 +781,7 @@ int memo_transport_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t cap, void 
     {
         const int64_t blocks = (groups + 256 * 16 - 1) / (256 * 16);  // 32768 positions per workgroup
         if (blocks >= ((int64_t)1 << 31)) return fail(MEMO_EINVAL, "slice too long for one launch");
-        const unsigned grid = (unsigned)blocks;
+        const unsigned grid = (unsigned)(blocks ? blocks : 1);  // (an empty slice still gets its header)
         hipLaunchKernelGGL(nibble_pack_kernel, dim3(grid), dim3(256), 0, st, d_vec, n,
                            reinterpret_cast<uint32_t *>(w + 16),
                            reinterpret_cast<unsigned long long *>(w + 16 + groups * 4),

@@ -75,8 +75,21 @@ __device__ __forceinline__ void row_slice(const SweepArgs &A, int64_t a, int64_t
     int64_t b1 = lim <= 0 ? 0 : ((lim + ((int64_t)1 << A.bshift) - 1) >> A.bshift) - A.bbase;
     b0 = b0 < 0 ? 0 : (b0 > last ? last : b0);
     b1 = b1 < 0 ? 0 : (b1 > last ? last : b1);
+#ifdef MEMO_SYNTH_LOCATE
+    // diagnostic build only: the bucket table of the synthetic config-3 index in closed form (5 rows per
+    // position, start_i = 1 + i / 5) -- what would the sweep gain if a tile's row slice cost no memory access?
+    (void)last;
+    auto first_row = [&](int64_t pos) { return pos <= 1 ? (int64_t)0 : 5 * (pos - 1); };
+    const int64_t rows_total = A.boff ? (int64_t)MEMO_SYNTH_LOCATE : 0;
+    int64_t q0 = first_row((b0 + A.bbase) << A.bshift), q1 = first_row((b1 + A.bbase) << A.bshift);
+    q0 = q0 > rows_total ? rows_total : q0;
+    q1 = q1 > rows_total ? rows_total : q1;
+    r0 = a <= 0 ? 0 : (uint64_t)q0;
+    r1 = (uint64_t)q1;
+#else
     r0 = a <= 0 ? 0 : (uint64_t)A.boff[b0];  // (rows with a negative start lie before bucket 0)
     r1 = (uint64_t)A.boff[b1];
+#endif
 }
 
 __device__ __forceinline__ int clamp_to_tile(int64_t v, int lo, int hi) {

@@ -30,3 +30,31 @@ for n, L in ((10, 10_000_000), (100, 20_000_000), (100, 100_000_000)):
     print(f"N={n} L={L}: {r1 - r0} rows ({gb:.2f} GB of int64 columns + result): one-shot {dt * 1e3:.1f} ms -> "
           f"{L / dt:.3g} positions/s (packed way in); int64 way in {dt_w * 1e3:.1f} ms -> {L / dt_w:.3g} positions/s",
           flush=True)
+
+# ---- the pinned ring by itself: a packed index to host memory and back (memo_index_export_packed /
+# memo_index_import_packed: pageable host arrays on both sides, worker threads + pinned slots + async copies)
+import ctypes as C
+from memo_amd import _lib
+n, L = 100, 100_000_000
+num, den = synth.rows_per_position(n)
+r0, r1 = synth.shard_rows(0, L, 31, num, den, L)
+ix, _ = synth.device_index(0, L, 31, n, L, pack="only")
+inf = ix.info()
+pk = np.empty(inf["rows"], np.uint32)
+boff = np.empty(inf["buckets"], np.int64)
+for rep in range(3):
+    t = time.perf_counter()
+    _lib.check(_lib.lib().memo_index_export_packed(ix._h, pk.ctypes.data, None, boff.ctypes.data, None))
+    dt = time.perf_counter() - t
+print(f"export (D2H through the pinned ring): {(pk.nbytes + boff.nbytes) / 1e9:.2f} GB in {dt * 1e3:.1f} ms = "
+      f"{(pk.nbytes + boff.nbytes) / dt / 1e9:.1f} GB/s", flush=True)
+for rep in range(3):
+    h = C.c_void_p()
+    t = time.perf_counter()
+    _lib.check(_lib.lib().memo_index_import_packed(inf["rows"], 0, inf["bucket_shift"], 0, pk.ctypes.data, None, boff.ctypes.data,
+                                                   len(boff), inf["min_start"], inf["max_start"], inf["max_annot"], None, 0, C.byref(h)))
+    dt = time.perf_counter() - t
+    _lib.lib().memo_index_destroy(h)
+print(f"import (H2D through the pinned ring, incl. hipMalloc of the index): {(pk.nbytes + boff.nbytes) / 1e9:.2f} GB in "
+      f"{dt * 1e3:.1f} ms = {(pk.nbytes + boff.nbytes) / dt / 1e9:.1f} GB/s", flush=True)
+ix.close()
