@@ -159,16 +159,16 @@ def main():
     from memo_amd import _lib
     if args.calibrate:
         _lib.use_ab(True)                   # the PMC calibration kernel lives in libmemo_amd_ab.so only
-    # the 3-byte rows answer the unclipped conservation sweep only: k <= 64, num_docs <= 255, >= 1 row per position
+    # the dense rows answer the unclipped conservation sweep only: k <= 64, num_docs <= 255, >= 1 row per position
     can_dense = (not membership) and k - 1 <= 63 and num_docs <= 255 and not args.wide and num_docs >= 20
     if args.rows == "auto":
-        args.rows = "wide" if k - 1 > 255 else "packed"      # (3-byte rows are smaller, not faster: DESIGN.md)
+        args.rows = "wide" if k - 1 > 255 else "packed"      # (dense rows are smaller, not faster: DESIGN.md)
     if args.rows == "dense" and not can_dense:
         raise SystemExit("--rows dense answers conservation with k <= 64 and num_docs <= 255 only")
     if k - 1 > 255:
         args.rows = "wide"                  # packed rows answer k <= 256 only
     # Resident indexes of the same rows, one per row format: the int64 columns as uploaded (24 B/row), the
-    # packed query format (memo_index_pack: 4 / 6 B/row, int64 columns dropped) and the 3-byte rows
+    # packed query format (memo_index_pack: 4 / 6 B/row, int64 columns dropped) and the dense rows
     # (memo_index_pack_dense, everything else dropped).  SURVEY.md 8(d): the passes that narrow the rows are
     # timed apart from the query -- on the device (HIP event pair around the annot census and the packing
     # kernel inside memo_index_pack, buffers allocated by the first call and reused by the second; an event
@@ -202,13 +202,13 @@ def main():
             e1.record(null_stream)
             torch.cuda.synchronize()
             dms = e0.elapsed_time(e1)
-            dense_pass = {"what": "memo_index_pack_dense: 4-byte rows -> 3-byte rows (reads 4 B, writes 3 B per row; "
-                                  "includes the hipMalloc of the 3-byte rows), once per index",
-                          "ms": dms, "rows": nrows, "bytes": 7 * nrows, "GBs": 7 * nrows / (dms * 1e-3) / 1e9}
+            dense_pass = {"what": "memo_index_pack_dense: 4-byte rows -> dense rows, five per 16 bytes (reads 4 B, writes "
+                                  "3.2 B per row; includes the hipMalloc of the dense rows), once per index",
+                          "ms": dms, "rows": nrows, "bytes": 7.2 * nrows, "GBs": 7.2 * nrows / (dms * 1e-3) / 1e9}
         indexes[f] = ixf
     rows = r1 - r0
     ix = indexes[args.rows]
-    fmt_bytes = {"wide": 24, "packed": packed_fmt, "dense": 3}
+    fmt_bytes = {"wide": 24, "packed": packed_fmt, "dense": 3.2}
     row_bytes = fmt_bytes[args.rows]
     W = (num_docs + 31) // 32
     # result element: membership = W uint32 words; conservation = uint8 when num_docs <= 255 (the
@@ -369,7 +369,7 @@ def main():
 
     def kernel_name(which):
         if which == "dense":
-            return "sweep_conservation_halo3_kernel<...> (PackedRows3)"
+            return "sweep_conservation_halo3_kernel<...> (PackedRows3: five rows per 16 bytes)"
         rows_t = "WideRows" if which == "wide" else f"PackedRows<{'true' if packed_fmt == 6 else 'false'}, false>"
         if membership:      # packed rows: per-genome bit planes (unclipped + staged up to 512 genomes,
             if which == "wide":                                      # else the clipped "runs"); int64 rows: doubling
@@ -482,8 +482,8 @@ def main():
                        "query": "membership" if membership else "conservation",
                        "row_format": "3 x int64 per row as uploaded (24 B)" if args.rows == "wide" else
                                      f"packed {packed_fmt} B/row built once per index by memo_index_pack" if args.rows == "packed"
-                                     else "3 B/row (start mod 2^10, length saturated at 63, 8-bit order) built once per "
-                                          "index by memo_index_pack + memo_index_pack_dense",
+                                     else "3.2 B/row (five 24-bit rows per 16 bytes: start mod 2^10, length saturated at 63, 8-bit "
+                                          "order) built once per index by memo_index_pack + memo_index_pack_dense",
                        "row_bytes": row_bytes, "result_bytes_per_position": b_out,
                        "row_format_pass": pack_pass, "dense_format_pass": dense_pass,
                        "clock_ramp": {"what": "untimed headline launches before the warm-up steps, until a batch "

@@ -67,7 +67,7 @@ typedef struct memo_index_info {
     int32_t has_wide;       /* 1 while the three int64 columns are resident */
     float pack_ms;          /* device time of the last memo_index_pack: annot census + packing kernel,
                                HIP events on its stream (the narrowing pass, timed apart) */
-    int32_t dense_rows;     /* 1 while the 3-byte rows of memo_index_pack_dense are resident */
+    int32_t dense_rows;     /* 1 while the dense rows of memo_index_pack_dense are resident */
     uint64_t long_rows;     /* rows with end < start, kept aside (see above) */
     uint64_t max_annot;     /* largest annot of the packed rows (valid when packed_format != 0) */
     int64_t bucket_base;    /* the bucket table starts at this bucket (a region slice of memo_index_import_packed) */
@@ -108,13 +108,14 @@ int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_so
  * columns (an HPRC-scale shard is 37 GB packed against 225 GB as int64); such an index answers
  * k <= 256 only and cannot be re-uploaded.  Needs 0 <= annot <= 65535 on every row. */
 int memo_index_pack(memo_index_t *ix, int32_t keep_wide);
-/* A denser copy of the packed rows, for HBM capacity: 3 bytes per row,
- *     (start mod 2^10) << 6 | min(end - start, 63)   +   annot (8 bits)          12 B per 4 rows
+/* A denser copy of the packed rows, for HBM capacity: 24 bits per row, five rows per 16 bytes (3.2 B per row),
+ *     (start mod 2^10) << 6 | min(end - start, 63)   +   annot (8 bits)
  * Exact for k <= 64 on the unclipped conservation sweep (level arrays of <= 1024 cells, num_docs <= 255).
- * Not faster: the 12-byte loads cost more than the bytes they save (0.48 ms against 0.39 on BASELINE
- * config 3), so queries read the 4-byte rows while those are resident.  Needs memo_index_pack first and
- * every annot <= 255.  keep_packed == 0 frees the 4-byte rows: such an index holds 3 B per row and answers
- * only what the 3-byte rows (or, if still resident, the int64 columns) can. */
+ * Not faster: its kernel is bound by what it executes per row, not by the bytes it loads (0.39 ms against
+ * 0.38 on BASELINE config 3 although its memory floor is 0.30), so queries read the 4-byte rows while those
+ * are resident.  Needs memo_index_pack first and every annot <= 255.  keep_packed == 0 frees the 4-byte rows:
+ * such an index holds 3.2 B per row and answers only what the dense rows (or, if still resident, the int64
+ * columns) can. */
 int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed);
 int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);
 /* A packed index to host memory and back: what the CLI's sidecar cache (memo_amd/cache.py) stores next to

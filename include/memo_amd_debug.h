@@ -18,7 +18,7 @@ extern "C" {
  * waves: 1 or 4 waves share a tile (8: the unclipped conservation kernel only);
  * membership_algo: 2 = doubling, 3 = runs (clipped bit planes per genome + register transpose),
  *   4 = planes (unclipped, result staged through LDS; packed rows, <= 512 genomes; else 3);
- * row_source: 1 = read the int64 columns even when packed rows exist, 2 = the 3-byte rows (where they can
+ * row_source: 1 = read the int64 columns even when packed rows exist, 2 = the dense rows (where they can
  *   answer) even when the 4-byte rows are resident;
  * scatter (conservation, packed rows): 1 = clip every interval to the tile, 2 = unclipped into doubling
  *   level arrays with a halo, 3 = unclipped into radix-4 level arrays (2 and 3 only when every annot of the

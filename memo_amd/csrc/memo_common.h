@@ -66,7 +66,7 @@ struct memo_tuning {
     int memb_algo = 0;   // membership: 2 = doubling, 3 = runs, 4 = planes
     int force_wide = 0;  // 1 = read the int64 columns even when packed rows exist
     int scatter = 0;     // conservation, packed rows: 1 = clipped, 2 = unclipped + halo
-    int force_dense = 0;  // 1 = read the 3-byte rows when they can answer, even with the 4-byte rows resident
+    int force_dense = 0;  // 1 = read the dense rows when they can answer, even with the 4-byte rows resident
 };
 
 // one chromosome's rows, resident in HBM (the opaque memo_index_t of the ABI)
@@ -89,7 +89,7 @@ struct memo_index {
     int packed_fmt = 0;        // 0 = none, 4 = word only (annot <= 255), 6 = word + 16-bit annot
     uint64_t packed_rows = 0;  // rows the pk (pa) allocation holds (reused by the next memo_index_pack)
     float pack_ms = 0.f;       // device time of the last memo_index_pack (census + packing kernel)
-    uint32_t *p3 = nullptr;    // 3-byte rows (memo_index_pack_dense): 3 words per 4 rows; annot <= 255 only
+    uint32_t *p3 = nullptr;    // dense rows (memo_index_pack_dense): 16 bytes per 5 rows; annot <= 255 only
     uint64_t max_annot = 0;    // largest annot of the packed rows
     int has_wide = 1;          // the three int64 columns are still resident
     // rows with end < start (never written by the reference's index builder, but legal input to

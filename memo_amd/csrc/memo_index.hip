@@ -102,18 +102,20 @@ __global__ void pack_rows_kernel(const int64_t *s, const int64_t *e, const int64
     }
 }
 
-// memo_index_pack_dense: 4-byte words -> 3-byte rows as two planes (layout: PackedRows3, memo_sweep.h);
-// a thread converts 4 rows: 8 bytes of the B plane, 4 of the A plane
-__global__ void pack3_rows_kernel(const uint32_t *pk, uint64_t groups, uint32_t *pb, uint32_t *pa) {
+// memo_index_pack_dense: 4-byte words -> dense rows, five per 16-byte group (layout: PackedRows3, memo_sweep.h)
+__global__ void pack3_rows_kernel(const uint32_t *pk, uint64_t padded, uint64_t groups, uint4 *p3) {
     for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < groups;
          g += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4 w = *reinterpret_cast<const uint4 *>(pk + 4 * g);
+        uint32_t w[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) w[i] = 5 * g + i < padded ? pk[5 * g + i] : 0u;
         auto B = [](uint32_t x) {  // (start & 1023) << 6 | min(length, 63)
             const uint32_t len = (x >> 16) & 0xFFu;
             return ((x & 1023u) << 6) | (len > 63u ? 63u : len);
         };
-        *reinterpret_cast<uint2 *>(pb + 2 * g) = make_uint2(B(w.x) | (B(w.y) << 16), B(w.z) | (B(w.w) << 16));
-        pa[g] = (w.x >> 24) | ((w.y >> 24) << 8) | ((w.z >> 24) << 16) | (w.w & 0xFF000000u);
+        p3[g] = make_uint4(B(w[0]) | (B(w[1]) << 16), B(w[2]) | (B(w[3]) << 16),
+                           B(w[4]) | ((w[0] >> 24) << 16) | ((w[1] >> 24) << 24),
+                           (w[2] >> 24) | ((w[3] >> 24) << 8) | ((w[4] >> 24) << 16));
     }
 }
 
@@ -565,12 +567,13 @@ int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed) {
         return MEMO_OK;
     }
     if (ix->packed_fmt != 4 || !ix->pk)
-        return fail(MEMO_EINVAL, "3-byte rows are built from the 4-byte rows: memo_index_pack first, and every annot <= 255");
+        return fail(MEMO_EINVAL, "dense rows are built from the 4-byte rows: memo_index_pack first, and every annot <= 255");
     DeviceGuard guard(ix->device);
     hipStream_t st = nullptr;
-    const uint64_t groups = ix->padded / 4;  // padded is a multiple of 16
-    HIP_TRY(hipMalloc(&ix->p3, groups * 12));
-    hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, ix->pk, groups, ix->p3, ix->p3 + ix->padded / 2);
+    const uint64_t groups = (ix->padded + 4) / 5 + 64;  // (+ one wave-load of slack: a wave reads its 64 groups whole)
+    HIP_TRY(hipMalloc(&ix->p3, groups * 16));
+    hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, ix->pk, ix->padded, groups,
+                       reinterpret_cast<uint4 *>(ix->p3));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     if (!keep_packed) {
@@ -599,7 +602,7 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     info->max_annot = ix->max_annot;
     info->bucket_base = ix->bbase;
     info->device_bytes = (ix->has_wide ? ix->padded * 3 * sizeof(int64_t) : 0) + ix->nb * sizeof(int64_t) + 128 +
-                         (ix->pk ? ix->padded * 4 : 0) + (ix->pa ? ix->padded * 2 : 0) + (ix->p3 ? ix->padded * 3 : 0);
+                         (ix->pk ? ix->padded * 4 : 0) + (ix->pa ? ix->padded * 2 : 0) + (ix->p3 ? ((ix->padded + 4) / 5 + 64) * 16 : 0);
     return MEMO_OK;
 }
 

@@ -14,8 +14,7 @@ struct SweepArgs {
     const int64_t *s, *e, *o;
     const uint32_t *pk;
     const uint16_t *pa;
-    const uint32_t *p3;     // 3-byte rows (PackedRows3): the 16-bit (start, length) plane ...
-    const uint32_t *pa3;    //   ... and the 8-bit annot plane
+    const uint32_t *p3;     // dense rows (PackedRows3): 16 bytes per 5 rows
     const int64_t *boff;
     int64_t nb;
     int64_t bbase;          // bucket of boff[0]
@@ -324,79 +323,89 @@ struct PackedRows {
     }
 };
 
-// 3-byte rows (memo_index_pack_dense): start mod 2^10, min(end - start, 63), annot (8 bits) -- 24 bits per
-// row, kept as two planes so that every load is a whole, aligned 16- or 8-byte piece per lane:
-//     B plane, 16 bits per row:  (start & 1023) << 6 | min(end - start, 63)
-//     A plane,  8 bits per row:  annot
-// A lane takes 8 consecutive rows: one global_load_dwordx4 from the B plane, one global_load_dwordx2 from
-// the A plane (a first layout, 12 bytes per 4 rows fetched with global_load_dwordx3, ran 21 % SLOWER than
-// the 4-byte rows it was meant to beat: profiles/r02_dense_rows_ab.txt).  Exact for k - 1 <= 63 (a
-// saturated length clips to "does not write" just as the true one does) in kernels whose row slice spans
-// fewer than 2^10 positions (the unclipped conservation sweep with level arrays of <= 1024 cells).
-// The start lives in the TOP ten bits of B: (B - (a & 1023) << 6) mod 2^16 leaves the length alone and
-// gives (start - a) mod 2^10 with no borrow to repair; the 16-bit VALU forms and SDWA reach either half
-// of a dword for free.
+// Dense rows (memo_index_pack_dense): start mod 2^10, min(end - start, 63), annot (8 bits) -- 24 bits per
+// row, FIVE rows per 16-byte group (3.2 B per row), one aligned global_load_dwordx4 per lane and group:
+//     dword 0 = B0 | B1 << 16                       B = (start & 1023) << 6 | min(end - start, 63)
+//     dword 1 = B2 | B3 << 16                       A = annot
+//     dword 2 = B4 | A0 << 16 | A1 << 24
+//     dword 3 = A2 | A3 << 8 | A4 << 16             (top byte unused)
+// No field straddles a dword; every 16-bit (start, length) field sits in a 16-bit half, where the 16-bit
+// VALU forms and SDWA reach it for free.  The start lives in the TOP ten bits of B: (B - (a & 1023) << 6)
+// mod 2^16 leaves the length alone and gives (start - a) mod 2^10 with no borrow to repair.
+// Exact for k - 1 <= 63 (a saturated length clips to "does not write" just as the true one does) in kernels
+// whose row slice spans fewer than 2^10 positions (the unclipped conservation sweep, level arrays <= 1024 cells).
+// History (profiles/r02_dense_rows_ab.txt): 12 bytes per 4 rows fetched with global_load_dwordx3 ran 21 %
+// slower than the 4-byte rows; two planes (16 + 8 bytes per 8 rows, two loads) ran at the same speed -- the
+// sweep follows the number of load instructions per row, not the bytes; this layout has 4/5 of them.
 struct PackedRows3 {
-    static constexpr int kLoads = 3;          // (16 + 8)-byte loads in flight per lane: 24 rows
+    static constexpr int kLoads = 6;          // 16-byte loads in flight per lane: 30 rows
     static constexpr bool kAnnot16 = false;
-    static constexpr uint64_t kAlign = 63;    // slices start at a multiple of 64 rows (128 B of the B plane)
-    static constexpr uint32_t kWaveRows = 512;
+    static constexpr uint32_t kWaveRows = 320;
+
+    // the slice in units of groups: [g0, g1), g0 a multiple of 8 (128 bytes)
+    static __device__ __forceinline__ void span(const Tile &t, uint64_t &g0, uint32_t &ngroups, uint32_t &first,
+                                                uint32_t &end) {
+        g0 = (t.r0 / 5) & ~(uint64_t)7;
+        const uint64_t g1 = (t.r1 + 4) / 5;
+        ngroups = (uint32_t)(g1 - g0);
+        first = (uint32_t)(t.r0 - 5 * g0);
+        end = (uint32_t)(t.r1 - 5 * g0);
+    }
 
     template <int T, int U>
     static __device__ __forceinline__ uint32_t batches(const Tile &t) {
-        const uint32_t end = (uint32_t)(t.r1 - (t.r0 & ~kAlign));
-        return (end + 8 * T * U - 1) / (8 * T * U);
+        uint64_t g0;
+        uint32_t ng, first, end;
+        span(t, g0, ng, first, end);
+        return (ng + T * U - 1) / (T * U);
     }
 
     template <int T, int U>
-    static __device__ __forceinline__ void issue(const SweepArgs &A, const Tile &t, uint32_t batch, uint4 (&VB)[U],
-                                                 uint2 (&VA)[U]) {
-        const uint64_t base0 = t.r0 & ~kAlign;
-        const uint32_t end = (uint32_t)(t.r1 - base0);
-        const uint16_t *pb = reinterpret_cast<const uint16_t *>(A.p3) + base0;
-        const uint8_t *pa = reinterpret_cast<const uint8_t *>(A.pa3) + base0;
-        const uint32_t rel = batch * (8 * T * U) + 8 * threadIdx.x;
+    static __device__ __forceinline__ void issue(const SweepArgs &A, const Tile &t, uint32_t batch, uint4 (&V)[U]) {
+        uint64_t g0;
+        uint32_t ng, first, end;
+        span(t, g0, ng, first, end);
+        const uint4 *p = reinterpret_cast<const uint4 *>(A.p3) + g0;
+        const uint32_t q0 = batch * (T * U) + threadIdx.x;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t r = rel + (uint32_t)u * 8 * T;
-            // wave-uniform (consume() tests the same): a wave loads its 512 rows or nothing
-            if ((__builtin_amdgcn_readfirstlane(r) & ~(kWaveRows - 1)) < end) {
-                VB[u] = *reinterpret_cast<const uint4 *>(pb + r);
-                VA[u] = *reinterpret_cast<const uint2 *>(pa + r);
-            }
+            const uint32_t q = q0 + (uint32_t)u * T;
+            // wave-uniform (consume() tests the same): a wave loads its 64 groups or nothing
+            if ((__builtin_amdgcn_readfirstlane(q) & ~(uint32_t)63) < ng) V[u] = p[q];
         }
     }
 
-    // lo(b, a, sh) / hi(b, a, sh): the row's B field sits in the low / high half of b, its annot in byte
-    // sh / 8 of a.  Rows outside [r0, r1) get the dead field (start = a, length 63: never writes when
+    // g(b, hi, a, sh): the row's B field is the low (hi = 0) or high (hi = 1) half of b, its annot the byte
+    // at bit `sh` of a.  Rows outside [r0, r1) get the dead field (start = a, length 63: never writes when
     // k - 1 <= 63).
     template <int T, int U, typename GL, typename GH>
-    static __device__ __forceinline__ void consume(const SweepArgs &A, const Tile &t, uint32_t batch, uint4 (&VB)[U],
-                                                   uint2 (&VA)[U], GL lo, GH hi) {
-        const uint64_t base0 = t.r0 & ~kAlign;
-        const uint32_t first = (uint32_t)(t.r0 - base0), end = (uint32_t)(t.r1 - base0);
+    static __device__ __forceinline__ void consume(const SweepArgs &A, const Tile &t, uint32_t batch, uint4 (&V)[U],
+                                                   GL lo, GH hi) {
+        uint64_t g0;
+        uint32_t ng, first, end;
+        span(t, g0, ng, first, end);
         const uint32_t dead = ((((uint32_t)t.a & 1023u) << 6) | 63u);
-        const uint32_t rel = batch * (8 * T * U) + 8 * threadIdx.x;
+        const uint32_t q0 = batch * (T * U) + threadIdx.x;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t r = rel + (uint32_t)u * 8 * T;
-            const uint32_t wave_lo = __builtin_amdgcn_readfirstlane(r) & ~(kWaveRows - 1);
-            if (wave_lo >= end) break;  // nothing of this wave's load is inside the slice
-            uint32_t b[4] = {VB[u].x, VB[u].y, VB[u].z, VB[u].w};
-            if (!(wave_lo >= first && wave_lo + kWaveRows <= end)) {  // a load that straddles an end of the slice
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (!(r + i >= first && r + i < end))
-                        b[i >> 1] = (i & 1) ? ((b[i >> 1] & 0x0000FFFFu) | (dead << 16)) : ((b[i >> 1] & 0xFFFF0000u) | dead);
+            const uint32_t q = q0 + (uint32_t)u * T;
+            const uint32_t wave_q = __builtin_amdgcn_readfirstlane(q) & ~(uint32_t)63;
+            if (wave_q >= ng) break;  // nothing of this wave's load is inside the slice
+            uint32_t b0 = V[u].x, b1 = V[u].y, b2 = V[u].z;
+            if (!(5 * wave_q >= first && 5 * wave_q + kWaveRows <= end)) {  // a load that straddles an end of the slice
+                const uint32_t r = 5 * q;
+                auto in = [&](uint32_t i) { return r + i >= first && r + i < end; };
+                if (!in(0)) b0 = (b0 & 0xFFFF0000u) | dead;
+                if (!in(1)) b0 = (b0 & 0x0000FFFFu) | (dead << 16);
+                if (!in(2)) b1 = (b1 & 0xFFFF0000u) | dead;
+                if (!in(3)) b1 = (b1 & 0x0000FFFFu) | (dead << 16);
+                if (!in(4)) b2 = (b2 & 0xFFFF0000u) | dead;
             }
-            lo(b[0], VA[u].x, 0);
-            hi(b[0], VA[u].x, 8);
-            lo(b[1], VA[u].x, 16);
-            hi(b[1], VA[u].x, 24);
-            lo(b[2], VA[u].y, 0);
-            hi(b[2], VA[u].y, 8);
-            lo(b[3], VA[u].y, 16);
-            hi(b[3], VA[u].y, 24);
+            lo(b0, V[u].z, 16);
+            hi(b0, V[u].z, 24);
+            lo(b1, V[u].w, 0);
+            hi(b1, V[u].w, 8);
+            lo(b2, V[u].w, 16);
         }
     }
 };

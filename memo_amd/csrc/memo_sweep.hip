@@ -64,7 +64,7 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
 }
 
 // which row source a query reads: packed when the index has it and k - 1 <= 255, else the int64 columns.
-// fmt: 0 = int64 columns, 4 / 6 = packed words (+ 16-bit order column), 3 = only the 3-byte rows are left
+// fmt: 0 = int64 columns, 4 / 6 = packed words (+ 16-bit order column), 3 = only the dense rows are left
 // (memo_index_pack_dense dropped the words): k - 1 <= 63, and only kernels that read PackedRows3
 int pick_rows(const memo_index *ix, int32_t k, int &fmt) {
     fmt = 0;
@@ -98,7 +98,6 @@ void fill_args(const memo_index *ix, SweepArgs &A, int64_t qs, int64_t qe, int32
     A.o = ix->o;
     A.pk = ix->pk;
     A.p3 = ix->p3;
-    A.pa3 = ix->p3 ? ix->p3 + ix->padded / 2 : nullptr;  // the annot plane follows the B plane (padded * 2 bytes)
     A.pa = ix->pa;
     A.boff = ix->boff;
     A.nb = (int64_t)ix->nb;

@@ -318,9 +318,14 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
 #endif
 }
 
-// The same sweep on the 3-byte rows (PackedRows3, k - 1 <= 63, level arrays of at most 1024 cells).
-// Per row: 16-bit subtract (start - a, length untouched below it), and, subtract, compare | ffbh, bfe,
-// mad, lshl_add, mad, ashr, lshl_add, (shift of the order byte for three rows of four), ds_min x 2.
+// The same sweep on the dense rows (PackedRows3: five rows per 16 bytes; k - 1 <= 63, level arrays of at most
+// 1024 cells).  Per row: 16-bit subtract (start - a, length untouched below it), and, subtract, compare | ffbh,
+// bfe, mad, lshl_add, mad, ashr, lshl_add, (shift of the order byte for four rows of five), ds_min x 2.
+// Where it stands (profiles/r02_dense_rows_ab.txt): the 4-byte kernel runs at its memory floor (rows loaded and
+// dropped 0.374 ms, whole kernel 0.383); this kernel's floor is 0.304 ms but the whole kernel takes 0.39 -- with
+// 24 % fewer bytes it is bound by what it executes per row, not by what it loads.  Moving the arithmetic out of
+// the row loop into a per-tile table indexed by the length (64 entries of two LDS offsets: 4 VALU per row
+// fewer, one ds_read_b64 more) made it slower still (0.46 ms: every row then waits for an LDS round trip).
 template <int U, int T, typename OutT>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
 void sweep_conservation_halo3_kernel(const SweepArgs A) {
@@ -329,9 +334,8 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
     const int LS = A.ls, HL = A.hl, W = A.w;
     Tile t;
     if (!locate_tile_w(A, t, W)) return;
-    uint4 VB[U];
-    uint2 VA[U];
-    Rows::template issue<T, U>(A, t, 0, VB, VA);
+    uint4 V[U];
+    Rows::template issue<T, U>(A, t, 0, V);
     halo_clear<T>(A, lds, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
 
     const int km1 = A.km1;
@@ -342,6 +346,10 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
     const uint32_t a10s = pin_vgpr((int)(((uint32_t)t.a & 1023u) << 6));
     // r = (start - a) mod 2^10 << 6 | length;  data = a word with the row's order in its top byte
     auto scatter = [&](uint32_t r, uint32_t data) {
+        if (MEMO_ABLATE & 16) {  // keep the loads alive, nothing else
+            asm volatile("" ::"v"(r), "v"(data));
+            return;
+        }
         const int n = km1 - (int)(r & 63u);
         if (n > 0) {
             uint32_t r0, r1, r2;
@@ -371,10 +379,10 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
             : "=v"(r) : "v"(b), "v"(a10s));
         scatter(r, sh == 24 ? a : a << (24 - sh));
     };
-    Rows::template consume<T, U>(A, t, 0, VB, VA, g_lo, g_hi);
+    Rows::template consume<T, U>(A, t, 0, V, g_lo, g_hi);
     for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
-        Rows::template issue<T, U>(A, t, b, VB, VA);
-        Rows::template consume<T, U>(A, t, b, VB, VA, g_lo, g_hi);
+        Rows::template issue<T, U>(A, t, b, V);
+        Rows::template consume<T, U>(A, t, b, V, g_lo, g_hi);
     }
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
     halo_finish<OutT, T, true>(A, t, lds);
@@ -791,11 +799,11 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.ls = hl + tw + hr;
             if (tune.waves == 0) waves = w >= 1024 ? 4 : 1;
             if (tune.waves == 8) waves = 8;  // (experiment: eight waves share a tile; only this kernel has that shape)
-            // 4- / 6-byte rows when they are resident: the 3-byte rows save a quarter of the bytes but their
-            // 12-byte loads (global_load_dwordx3) and two more instructions per row cost more than that --
-            // config 3, k = 31: 0.478 ms against 0.395 (profiles/r02_dense_rows_ab.txt).  They answer when the
+            // 4- / 6-byte rows when they are resident: the dense rows load a fifth fewer bytes but take three
+            // more instructions per row, and the sweep is bound by the latter (profiles/r02_dense_rows_ab.txt:
+            // 0.39 ms against 0.383 on config 3 although their memory floor is 0.304).  They answer when the
             // index kept nothing else (k - 1 <= 63, level arrays within 2^10 cells, num_docs <= 255): what
-            // they buy is HBM capacity, 3 B per row.
+            // they buy is HBM capacity, 3.2 B per row.
             const bool top8 = num_docs <= 255;
             const bool three = ix->p3 && (!ix->pk || tune.force_dense) && k - 1 <= 63 && A.ls <= 1024 && top8;
             if (!three && fmt == 3) {
@@ -809,7 +817,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             }
         }
     }
-    if (!halo && fmt == 3) {  // the 3-byte rows cannot answer this one (tile shape, num_docs > 255, sparse index)
+    if (!halo && fmt == 3) {  // the dense rows cannot answer this one (tile shape, num_docs > 255, sparse index)
         if (!ix->has_wide)
             return fail(MEMO_EINVAL, "this query needs the 4-byte rows or the int64 columns, which this index dropped");
         fmt = 0;

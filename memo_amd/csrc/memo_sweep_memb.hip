@@ -389,7 +389,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     A.nwords = nw;
     int fmt;
     if ((rc = pick_rows(ix, k, fmt))) return rc;
-    if (fmt == 3) {  // only the 3-byte rows are left, and no membership kernel reads them
+    if (fmt == 3) {  // only the dense rows are left, and no membership kernel reads them
         if (!ix->has_wide)
             return fail(MEMO_EINVAL, "membership needs the 4-byte rows or the int64 columns, which this index dropped");
         fmt = 0;

@@ -94,7 +94,7 @@ class DeviceIndex:
         return self
 
     def pack_dense(self, keep_packed=True):
-        """build the 3-byte-per-row format (memo_index_pack_dense): k <= 64, annot <= 255"""
+        """build the dense rows (memo_index_pack_dense: five 24-bit rows per 16 bytes): k <= 64, annot <= 255"""
         check(lib().memo_index_pack_dense(self._h, 1 if keep_packed else 0))
         return self
 

@@ -45,7 +45,7 @@ def shard_rows(qs, qe, k, num, den, pivot):
 def device_index(qs, qe, k, num_docs, pivot, density=Fraction(5, 100), device=0, seed=SEED, pack=None):
     """DeviceIndex holding exactly the rows window [qs, qe) needs (generated in HBM).
     pack: None = int64 columns only; "keep" = also the packed rows; "only" = packed rows only;
-    "dense" = the 3-byte rows only (memo_index_pack_dense; int64 columns and 4-byte rows dropped)."""
+    "dense" = the dense rows only (memo_index_pack_dense; int64 columns and 4-byte rows dropped)."""
     num, den = rows_per_position(num_docs, density)
     r0, r1 = shard_rows(qs, qe, k, num, den, pivot)
     ix = DeviceIndex.synthetic(r1 - r0, r0, num, den, num_docs, seed=seed, device=device)

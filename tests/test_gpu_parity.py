@@ -244,7 +244,7 @@ def test_dense_rows_equal_packed_rows(n_docs, bucket_shift, keep_packed, keep_wi
                 qs = int(rng.integers(0, length // 2))
                 qe = int(rng.integers(qs + 1, length + 100))
                 want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
-                for source in (0, 2):                   # the library's choice / the 3-byte rows wherever they can answer
+                for source in (0, 2):                   # the library's choice / the dense rows wherever they can answer
                     ix.debug_set_tuning(tile_w, waves, 0, source, 0)
                     answerable = keep_packed or keep_wide or (k <= 64 and n_docs <= 255 and tile_w in (0, 1024, 512))
                     if not answerable:

@@ -28,8 +28,8 @@ def main():
     ap.add_argument("--length", type=int, default=0, help="query [0, length) instead of the whole pivot")
     ap.add_argument("--density", default="5/100", help="rows per genome and position")
     ap.add_argument("--pack", default=None, choices=[None, "keep", "only", "dense", "both"],
-                    help="keep: int64 + 4-byte rows; only: 4-byte rows; dense: 3-byte rows only; both: 4- and 3-byte rows "
-                         "(row_source 2 in a variant then selects the 3-byte ones)")
+                    help="keep: int64 + 4-byte rows; only: 4-byte rows; dense: dense rows only; both: 4- and dense rows "
+                         "(row_source 2 in a variant then selects the dense ones)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     num_docs, L, membership = WORKLOADS[a.workload]
@@ -67,7 +67,7 @@ def main():
     ix.check()
     for v in variants:
         src = v[3] if len(v) > 3 else 0
-        brow = 24 if (not a.pack or src == 1) else (3 if ix.info()["dense_rows"] and (src == 2 or a.pack == "dense") and a.k <= 64 and not membership
+        brow = 24 if (not a.pack or src == 1) else (3.2 if ix.info()["dense_rows"] and (src == 2 or a.pack == "dense") and a.k <= 64 and not membership
                                                     else ix.info()['packed_format'])
         b_alg = brow * (r1 - r0) + (4 * W if membership else (1 if a.u8 else 2)) * L
         t = np.array(times[v])
