@@ -73,6 +73,9 @@ def parse():
                     help="N > 1: rank 0 packs and unpacks its own slice too (exercises the coded path on one GPU)")
     ap.add_argument("--nibble-gather", action="store_true",
                     help="N > 1: skip the dense transport coding (nibble coding when it fits, else plain)")
+    ap.add_argument("--root-weight", default="auto",
+                    help="N > 1: the share of a window rank 0 sweeps (it also decodes the peers' slices): a number in "
+                         "(0, 1], or auto = what the step model says (1 when the slices travel as plain bytes)")
     ap.add_argument("--calibrate", action="store_true",
                     help="also run the read-once calibration kernel (for the FETCH_SIZE PMC pass)")
     ap.add_argument("--force-dist", action="store_true",
@@ -226,13 +229,15 @@ def main():
     stream = torch.cuda.current_stream()
     lib = _lib.lib()
 
+    qe_mine = qe                             # (N > 1: rank 0 may sweep less than its whole window, see below)
+
     def launch(out, ix=ix):
         if membership:
-            ix.membership_dev(qs, qe, k, num_docs, out, stream.cuda_stream)
+            ix.membership_dev(qs, qe_mine, k, num_docs, out, stream.cuda_stream)
         elif narrow:
-            ix.conservation_u8_dev(qs, qe, k, num_docs, out, stream.cuda_stream)
+            ix.conservation_u8_dev(qs, qe_mine, k, num_docs, out, stream.cuda_stream)
         else:
-            ix.conservation_dev(qs, qe, k, num_docs, out, stream.cuda_stream)
+            ix.conservation_dev(qs, qe_mine, k, num_docs, out, stream.cuda_stream)
 
     # What travels to rank 0.  A slice's own xGMI link is what bounds N > 1, so uint8
     # conservation slices go in a lossless transport coding: "dense" (2 bits per position + a nibble per
@@ -246,6 +251,7 @@ def main():
     coding, b_cap = "plain", 0
     cap = max(L // 256, 1024)
     choice = None
+    root_weight = 1.0 if args.root_weight == "auto" else min(max(float(args.root_weight), 0.01), 1.0)
     if multi and narrow and not args.plain_gather:
         found, have, taken, room = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
 
@@ -294,18 +300,31 @@ def main():
             usable["nibble"] = (lib.memo_transport_bytes(L, nibble_cap), t, tp)
         del probe, scratch
         best, model = shard.pick_coding(world, t_sweep, usable)
+        w_best = 1.0
+        if args.root_weight == "auto":
+            best, w_best, _ = shard.pick_plan(world, t_sweep, usable)
+        else:
+            w_best = min(max(float(args.root_weight), 0.01), 1.0)
         names = sorted(usable)
-        pick = torch.tensor([names.index(best)], device=dev)
+        pick = torch.tensor([names.index(best), int(round(w_best * 1000))], device=dev)
         dist.broadcast(pick, src=0)                                        # rank 0's timings decide for everybody
-        coding = names[int(pick.item())]
+        coding = names[int(pick[0].item())]
+        root_weight = int(pick[1].item()) / 1000.0
         if coding == "dense":
             cap = dense_cap
         elif coding == "nibble":
             cap = nibble_cap
-        choice = {"picked": coding, "sweep_ms": t_sweep * 1e3, "link_bytes_per_s_assumed": shard.XGMI_LINK_BYTES_PER_S,
+        choice = {"picked": coding, "root_weight": root_weight, "sweep_ms": t_sweep * 1e3,
+                  "link_bytes_per_s_assumed": shard.XGMI_LINK_BYTES_PER_S,
                   "candidates": {c: {"wire_bytes": int(usable[c][0]), "decode_ms_per_slice": usable[c][1] * 1e3, "encode_ms": usable[c][2] * 1e3,
                                      "modelled_step_ms": model[c] * 1e3} for c in names}}
     nibble = coding != "plain"              # (name kept: "the slices travel coded")
+    # rank 0 sweeps the first root_weight of its window (a multiple of 8 positions); everybody else all of it
+    L_mine = L if rank != 0 else max(8, int(L * root_weight) // 8 * 8)
+    for o in outs:                          # (every result buffer holds a whole-window result behind L_mine)
+        launch(o)
+    qe_mine = qs + L_mine
+    positions_per_step = L * (world - 1) + (max(8, int(L * root_weight) // 8 * 8) if multi else L)
 
     def pack(src, wire):
         if coding == "dense":
@@ -469,7 +488,7 @@ def main():
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         res = {
             "metric": "query-positions/sec (chr window, k=%d)" % k,
-            "value": L * world * args.steps / dt,
+            "value": positions_per_step * args.steps / dt,
             "unit": "query-positions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -489,7 +508,8 @@ def main():
                        "clock_ramp": {"what": "untimed headline launches before the warm-up steps, until a batch "
                                               "of 20 is no faster than the one before", **ramp},
                        "sharding": f"window split into {world} contiguous sub-windows, slices gathered to rank 0 "
-                                   f"over RCCL (double-buffered: gather i overlaps sweep i+1)"
+                                   f"over RCCL (double-buffered: gather i overlaps sweep i+1); rank 0 sweeps "
+                                   f"{root_weight:g} of a share ({positions_per_step} positions per step in all)"
                                    if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
@@ -510,7 +530,7 @@ def main():
         if multi:
             # what the same run delivers when the result slices stay on their GPUs (no root):
             # every rank's sweep time from its own HIP events, slowest rank counts
-            res["without_gather"] = {"value": L * world / (kern_ms * 1e-3), "unit": "query-positions/s",
+            res["without_gather"] = {"value": positions_per_step / (kern_ms * 1e-3), "unit": "query-positions/s",
                                      "note": "aggregate of the per-rank sweeps alone (max kernel_ms over ranks); "
                                              "`value` above includes delivering every slice to rank 0, which is "
                                              f"bound by {wires[0].numel() / 1e6:.0f} MB per peer link per step"}

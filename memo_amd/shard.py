@@ -69,11 +69,14 @@ def sharded_query(sweep, qs, qe, k, rank, world, dist, alloc, dst=0, root_weight
 XGMI_LINK_BYTES_PER_S = 75e9   # one direction of one xGMI link (7 links x ~153 GB/s per GPU, both directions summed)
 
 
-def modelled_step(world, t_sweep, wire_bytes, t_decode, t_encode, link=XGMI_LINK_BYTES_PER_S):
+def modelled_step(world, t_sweep, wire_bytes, t_decode, t_encode, link=XGMI_LINK_BYTES_PER_S, root_weight=1.0):
     """seconds per step when every peer's slice goes to rank 0 coded: the slowest of a peer (sweep +
-    encode), rank 0 (its own sweep + decoding the world - 1 slices it received; its own slice never
-    travels) and a peer's link to rank 0 (each peer has its own; gather i overlaps sweep i + 1)."""
-    return max(t_sweep + t_encode, t_sweep + (world - 1) * t_decode, wire_bytes / link)
+    encode), rank 0 (its own sweep of `root_weight` of a share + decoding the world - 1 slices it received;
+    its own slice never travels) and a peer's link to rank 0 (each peer has its own; gather i overlaps
+    sweep i + 1)."""
+    if world == 1:
+        return t_sweep
+    return max(t_sweep + t_encode, root_weight * t_sweep + (world - 1) * t_decode, wire_bytes / link)
 
 
 def pick_coding(world, t_sweep, usable, link=XGMI_LINK_BYTES_PER_S):
@@ -81,3 +84,18 @@ def pick_coding(world, t_sweep, usable, link=XGMI_LINK_BYTES_PER_S):
     with the shortest modelled step (ties: alphabetical, so that every rank would agree) and the model."""
     model = {c: modelled_step(world, t_sweep, *usable[c], link=link) for c in usable}
     return min(sorted(model), key=model.get), model
+
+
+def pick_plan(world, t_sweep, usable, link=XGMI_LINK_BYTES_PER_S, weights=(1.0, 0.75, 0.5, 0.25)):
+    """Coding AND root weight: rank 0 may sweep a smaller share of positions than its peers (it also decodes
+    world - 1 slices per step).  Returns (coding, root_weight, modelled positions-per-second in units of one
+    peer's window per second) for the plan with the highest modelled throughput (world - 1 + w) / step; ties go
+    to the larger weight, then alphabetically, so that every rank would agree."""
+    best = None
+    for w in weights:
+        for c in sorted(usable):
+            step = modelled_step(world, t_sweep, *usable[c], link=link, root_weight=w)
+            rate = (world - 1 + w) / step
+            if best is None or rate > best[2] * (1 + 1e-9):
+                best = (c, w, rate)
+    return best

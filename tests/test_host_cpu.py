@@ -225,6 +225,12 @@ def test_transport_coding_choice_model():
     assert shard.pick_coding(8, sweep, usable, link=20e9)[0] == "dense"
     assert shard.pick_coding(2, sweep, usable, link=1e12)[0] == "plain"
     assert shard.modelled_step(1, sweep, 10, 1.0, 0.0) == sweep          # nobody to decode for
+    # coding and root weight together: at 8 GPUs the dense coding pays once rank 0 sweeps less than a full share
+    coding, w, rate = shard.pick_plan(8, sweep, usable)
+    assert coding == "dense" and w < 1.0
+    assert abs(rate - (7 + w) / max(sweep + 0.153e-3, w * sweep + 7 * 0.058e-3, 41_250_080 / 75e9)) < 1e-6
+    assert shard.pick_plan(2, sweep, usable)[:2] == ("dense", 1.0)       # one slice to decode: nothing to give up
+    assert shard.pick_plan(1, sweep, usable)[1] == 1.0
 
 
 def test_split_window_rule(memo):
@@ -256,3 +262,41 @@ def test_split_window_rule(memo):
                 assert lens[0] == 0
     with pytest.raises(memo.MemoError):
         shard.split_window(0, 10, 2, root_weight=-1.0)
+
+
+def test_sidecar_cache_file_validation(memo, tmp_path, monkeypatch):
+    """memo_amd.cache: a cache file is visible only while its header matches the index file it was made from
+    (size + mtime_ns), its own size, its format version and its record; anything else reads as "no cache".
+    (Reading rows out of a valid file needs the GPU: tests/test_gpu_parity.py::test_sidecar_cache_round_trip.)"""
+    import json
+    from memo_amd import cache
+    index = tmp_path / "idx.parquet"
+    index.write_bytes(b"not really parquet")
+    path = cache.cache_path(str(index), "chr 1/x")
+    assert path.startswith(str(index) + ".memo" + os.sep) and "/" not in os.path.basename(path) and " " not in os.path.basename(path)
+    assert cache._open(str(index), "chr 1/x") is None                        # no file
+    os.makedirs(os.path.dirname(path))
+
+    def write(head, body=b"\0" * 100):
+        blob = cache.MAGIC + json.dumps(head).encode()
+        with open(path, "wb") as fh:
+            fh.write(blob.ljust(cache.HEADER_BYTES, b"\0") + body)
+    good = {"version": cache.VERSION, "record": "chr 1/x", "source": cache._source_key(str(index)),
+            "bytes": cache.HEADER_BYTES + 100}
+    write(good)
+    assert cache._open(str(index), "chr 1/x") is not None
+    assert cache._open(str(index), "chr2") is None                           # another record's name
+    for bad in (dict(good, version=cache.VERSION + 1), dict(good, record="other"), dict(good, bytes=5),
+                dict(good, source={"size": 1, "mtime_ns": 2})):
+        write(bad)
+        assert cache._open(str(index), "chr 1/x") is None
+    write(good)
+    with open(path, "r+b") as fh:
+        fh.write(b"XXXXXXXX")                                                # magic gone
+    assert cache._open(str(index), "chr 1/x") is None
+    write(good)
+    index.write_bytes(b"the index file changed")                            # size / mtime differ now
+    assert cache._open(str(index), "chr 1/x") is None
+    for v, want in (("0", "off"), ("off", "off"), ("read", "read"), ("sync", "sync"), ("1", "on"), ("", "on")):
+        monkeypatch.setenv("MEMO_CACHE", v)
+        assert cache.mode() == want
