@@ -188,10 +188,11 @@ def main():
             ixf.pack(keep_wide=True)            # the timed pass: same buffers
             info = ixf.info()
             packed_fmt = info["packed_format"]
-            pack_bytes = (24 + packed_fmt) * nrows + 8 * nrows      # census reads the annot column once more
+            pk_bytes = 6 if packed_fmt == 6 else 4
+            pack_bytes = (24 + pk_bytes) * nrows + 8 * nrows        # census reads the annot column once more
             pack_pass = {"what": "memo_index_pack: int64 columns -> packed rows, once per index, not part of a query "
                                  "(annot_census_kernel reads 8 B/row; pack_rows_kernel reads 24 B and writes "
-                                 "%d B per row)" % packed_fmt,
+                                 "%d B per row, format %d)" % (pk_bytes, packed_fmt),
                          "ms": info["pack_ms"], "rows": nrows, "bytes": pack_bytes,
                          "GBs": pack_bytes / (info["pack_ms"] * 1e-3) / 1e9 if info["pack_ms"] > 0 else None,
                          "timed_with": "HIP event pair inside memo_index_pack (memo_index_info.pack_ms), second call "
@@ -211,7 +212,7 @@ def main():
         indexes[f] = ixf
     rows = r1 - r0
     ix = indexes[args.rows]
-    fmt_bytes = {"wide": 24, "packed": packed_fmt, "dense": 3.2}
+    fmt_bytes = {"wide": 24, "packed": 6 if packed_fmt == 6 else 4, "dense": 3.2}
     row_bytes = fmt_bytes[args.rows]
     W = (num_docs + 31) // 32
     # result element: membership = W uint32 words; conservation = uint8 when num_docs <= 255 (the
@@ -389,14 +390,15 @@ def main():
     def kernel_name(which):
         if which == "dense":
             return "sweep_conservation_halo3_kernel<...> (PackedRows3: five rows per 16 bytes)"
-        rows_t = "WideRows" if which == "wide" else f"PackedRows<{'true' if packed_fmt == 6 else 'false'}, false>"
+        rows_t = "WideRows" if which == "wide" else ("PackedRows<true, false>" if packed_fmt == 6 else
+                                                     "PackedRows<false, false, true>" if packed_fmt == 12 else "PackedRows<false, false>")
         if membership:      # packed rows: per-genome bit planes (unclipped + staged up to 512 genomes,
             if which == "wide":                                      # else the clipped "runs"); int64 rows: doubling
                 return "sweep_membership_kernel<" + rows_t + ", ...>"
             return ("sweep_membership_planes_kernel<" if num_docs <= 512 else "sweep_membership_runs_kernel<") + rows_t + ", ...>"
         # packed rows on an index with >= 1 row per position: the unclipped scatter (memo_sweep_cons.hip)
         halo = which != "wide" and rows >= L
-        if halo and k - 1 >= 64:
+        if halo and k - 1 >= 64 and rows < 12 * L:      # (dense indexes keep the doubling arrays at every k)
             return "sweep_conservation_r4_kernel<" + rows_t + ", ...>"
         return ("sweep_conservation_halo_kernel<" if halo else "sweep_conservation_kernel<") + rows_t + ", ...>"
 
@@ -500,7 +502,7 @@ def main():
                        "num_docs": num_docs, "window_per_gpu": L, "rows_per_gpu": rows, "k": k,
                        "query": "membership" if membership else "conservation",
                        "row_format": "3 x int64 per row as uploaded (24 B)" if args.rows == "wide" else
-                                     f"packed {packed_fmt} B/row built once per index by memo_index_pack" if args.rows == "packed"
+                                     f"packed {6 if packed_fmt == 6 else 4} B/row (format {packed_fmt}) built once per index by memo_index_pack" if args.rows == "packed"
                                      else "3.2 B/row (five 24-bit rows per 16 bytes: start mod 2^10, length saturated at 63, 8-bit "
                                           "order) built once per index by memo_index_pack + memo_index_pack_dense",
                        "row_bytes": row_bytes, "result_bytes_per_position": b_out,

@@ -49,7 +49,7 @@ extern "C" {
 #define MEMO_ELONGROW (-5)  /* more than 2^22 rows have end < start.  dap_to_bed.py:93-98 never emits
                                such a row; a few are accepted and applied by a side pass */
 #define MEMO_EUNPACKABLE (-6) /* memo_builder_*: these rows cannot take the packed way in (unsorted, negative
-                               start, annot outside [0, 65535]); use memo_index_upload + _finalize */
+                               start, annot outside [0, 4095]); use memo_index_upload + _finalize */
 
 typedef struct memo_index memo_index_t; /* one chromosome's rows, resident in HBM */
 
@@ -63,7 +63,7 @@ typedef struct memo_index_info {
     int32_t was_sorted;     /* 1 if the rows arrived start-sorted */
     int32_t finalized;
     uint64_t device_bytes;  /* HBM held by this index (columns + padding + bucket table) */
-    int32_t packed_format;  /* 0 = none, 4 = 4 B/row, 6 = 6 B/row (memo_index_pack) */
+    int32_t packed_format;  /* 0 = none; 4, 12 = 4 B/row (8- / 12-bit annot); 6 = 6 B/row (memo_index_pack) */
     int32_t has_wide;       /* 1 while the three int64 columns are resident */
     float pack_ms;          /* device time of the last memo_index_pack: annot census + packing kernel,
                                HIP events on its stream (the narrowing pass, timed apart) */
@@ -99,10 +99,11 @@ int memo_index_columns(memo_index_t *ix, int64_t **d_start, int64_t **d_end, int
 /* check start-sortedness and end >= start, sort by start on the device if needed
  * (allow_sort != 0), build the start-bucket table.  bucket_shift <= 0 picks the default. */
 int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_sort);
-/* Build the query-time row format: one 32-bit word per row
- *     start mod 2^16 | min(end - start, 255) << 16 | annot << 24
- * (4 B/row; when some annot > 255 the annot moves to a separate uint16 column, 6 B/row).
- * Exact for every query with k <= 256: inside a tile's row slice starts span far less than 2^16
+/* Build the query-time row format: one 32-bit word per row, laid out by the largest annot of the index
+ *     annot <= 255    start mod 2^16 | min(end - start, 255) << 16 | annot << 24              format 4, 4 B/row
+ *     annot <= 4095   min(end - start, 255) | (start mod 2^12) << 8 | annot << 20            format 12, 4 B/row
+ *     else            the first word with annot 0 + the annot in a separate uint16 column    format 6, 6 B/row
+ * Exact for every query with k <= 256: inside a tile's row slice starts span far less than 2^12
  * positions, and an overlap of >= 255 never writes when k - 1 <= 255.  Queries then read the packed
  * rows (6x / 4x fewer bytes); k > 256 keeps using the int64 columns.  keep_wide == 0 frees the int64
  * columns (an HPRC-scale shard is 37 GB packed against 225 GB as int64); such an index answers
@@ -124,8 +125,9 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);
  * bucket table (info.buckets x int64) and the rows with end < start (3 x info.long_rows int64: starts, ends,
  * annots) into caller buffers.  _import builds a finalized, packed index from such arrays -- or from a SLICE
  * of them: rows [r0, r1) with the table entries of buckets [bucket_base, bucket_base + buckets) rebased to
- * r0 (first entry 0, last entry = rows).  Host memory may be pageable (a memory-mapped file): it goes through
- * the pinned ring. */
+ * r0 (first entry 0, last entry = rows).  The word layout follows from the arguments as it does in the
+ * packers: pa != NULL: format 6; else max_annot > 255: format 12; else format 4.  Host memory may be pageable
+ * (a memory-mapped file): it goes through the pinned ring. */
 int memo_index_export_packed(memo_index_t *ix, uint32_t *pk, uint16_t *pa, int64_t *boff, int64_t *long_rows);
 int memo_index_import_packed(uint64_t rows, int32_t device, int32_t bucket_shift, int64_t bucket_base,
                              const uint32_t *pk, const uint16_t *pa, const int64_t *boff, uint64_t buckets,
@@ -141,7 +143,8 @@ void memo_index_destroy(memo_index_t *ix);
  * the next one is being packed: 4-6 B per row on the link instead of 24, from pinned memory.  The same
  * pass validates the rows and builds the start-bucket table, so memo_builder_finish() returns an index
  * that is finalized and packed (int64 columns never reach the GPU; it answers k <= 256).
- * Rows that cannot be packed make _push return MEMO_EUNPACKABLE: start over with memo_index_upload.
+ * Rows that cannot be packed into one word (unsorted, negative start, annot outside [0, 4095]) make _push
+ * return MEMO_EUNPACKABLE: start over with memo_index_upload (+ _finalize, _pack: the 6-byte format).
  * Nothing of the caller's memory is referenced after _push returns.  One builder per thread. */
 typedef struct memo_builder memo_builder_t;
 int memo_builder_create(uint64_t max_rows, int32_t device, int32_t bucket_shift, memo_builder_t **out);

@@ -3,7 +3,7 @@
 `memo query` spends its wall clock decoding ZSTD Parquet pages (0.59 s of 0.93 s for a 2 * 10^7-position
 window of a 10^8-row index, profiles/r01_cli_timing_16decoders.txt); the sweep is 2 % of it.  The Parquet
 file stays the source of truth.  Beside it, `<index>.parquet.memo/<record>.v1.pk` keeps, per record
-(chromosome), exactly what the GPU wants: the packed rows (4 B per row; + 2 B when an annot exceeds 255),
+(chromosome), exactly what the GPU wants: the packed rows (4 B per row; + 2 B when an annot exceeds 4095),
 the start-bucket table and the few rows with end < start -- as produced by the library itself
 (memo_builder_* + memo_index_export_packed).  A repeat query maps the file, cuts the window's rows out with
 two lookups in the bucket table and uploads them through the pinned ring (memo_index_import_packed): no
@@ -54,7 +54,7 @@ def write(in_file, record, ix):
     """ix: a packed DeviceIndex holding EVERY row of `record`.  Writes the cache file atomically."""
     inf = ix.info()
     rows, nb, n_long, fmt = inf["rows"], inf["buckets"], inf["long_rows"], inf["packed_format"]
-    if fmt not in (4, 6) or inf["bucket_base"] != 0:
+    if fmt not in (4, 6, 12) or inf["bucket_base"] != 0:
         raise ValueError("only a whole, packed chromosome can be cached")
     pk = np.empty(rows, np.uint32)
     pa = np.empty(rows if fmt == 6 else 0, np.uint16)
@@ -146,7 +146,7 @@ def build(in_file, record, device=0):
     ix = region_index(in_file, record, -1, hi, device=device, k=2, use_cache=False)
     with ix:
         inf = ix.info()
-        if inf["packed_format"] not in (4, 6) or inf["rows"] == 0:
+        if inf["packed_format"] not in (4, 6, 12) or inf["rows"] == 0:
             return None                     # unpackable rows (or none): nothing worth caching
         return write(in_file, record, ix)
 

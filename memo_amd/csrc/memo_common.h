@@ -83,10 +83,11 @@ struct memo_index {
     int64_t min_s = 0, max_s = -1;
     int finalized = 0;
     int was_sorted = 0;
-    // packed rows (memo_index_pack): word = start & 0xFFFF | min(end - start, 255) << 16 | annot8 << 24
+    // packed rows (memo_index_pack): one word per row, layout by the largest annot (PackedRows, memo_sweep.h)
     uint32_t *pk = nullptr;
     uint16_t *pa = nullptr;    // format 6 only: 16-bit annot per row (the word's top byte is 0)
-    int packed_fmt = 0;        // 0 = none, 4 = word only (annot <= 255), 6 = word + 16-bit annot
+    int packed_fmt = 0;        // 0 = none, 4 = word with 8-bit annot, 12 = word with 12-bit annot and 12-bit start,
+                               //   6 = word + 16-bit annot column
     uint64_t packed_rows = 0;  // rows the pk (pa) allocation holds (reused by the next memo_index_pack)
     float pack_ms = 0.f;       // device time of the last memo_index_pack (census + packing kernel)
     uint32_t *p3 = nullptr;    // dense rows (memo_index_pack_dense): 16 bytes per 5 rows; annot <= 255 only

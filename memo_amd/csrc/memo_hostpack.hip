@@ -9,9 +9,10 @@
 // coordinate range, the rows with end < start (set aside for long_rows_*_kernel), the largest annot, and
 // the start-bucket table -- built from the sorted starts as they stream by, no search.
 //
-// Rows that cannot be packed (unsorted, negative start, annot outside [0, 65535], coordinates beyond
-// +-2^61) make the builder return MEMO_EUNPACKABLE; the caller then takes the int64 path
-// (memo_index_upload + memo_index_finalize), which sorts on the device and handles every legal input.
+// Rows that cannot be packed into one word (unsorted, negative start, annot outside [0, 4095], coordinates
+// beyond +-2^61) make the builder return MEMO_EUNPACKABLE; the caller then takes the int64 path
+// (memo_index_upload + memo_index_finalize + memo_index_pack), which sorts on the device, knows the 6-byte
+// format for larger annots and handles every legal input.
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -275,24 +276,23 @@ int upload_pipelined(int device, void *dev, const void *host, size_t bytes) {
 // ------------------------------------------------------------------------------------------
 namespace {
 
-// rows uploaded as 8-bit annots when the first annot > 255 shows up: move the top byte of every word
-// into the 16-bit column
-__global__ void widen_annot_kernel(uint32_t *pk, uint16_t *pa, uint64_t rows) {
+// rows uploaded in format 4 (8-bit annots) when the first annot > 255 shows up: rewrite them in format 12
+// (start16 | len8 << 16 | annot8 << 24  ->  len8 | start12 << 8 | annot12 << 20)
+__global__ void widen_annot_kernel(uint32_t *pk, uint64_t rows) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < rows;
          i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t w = pk[i];
-        pa[i] = (uint16_t)(w >> 24);
-        pk[i] = w & 0x00FFFFFFu;
+        pk[i] = ((w >> 16) & 0xFFu) | ((w & 0xFFFu) << 8) | ((w >> 24) << 20);
     }
 }
 
-constexpr uint64_t kChunkRows = PinnedRing::kSlotBytes / 6;  // rows per pinned slot (4 + 2 B each)
+constexpr uint64_t kChunkRows = PinnedRing::kSlotBytes / 4;  // rows per pinned slot
 constexpr uint64_t kBlockRows = 1 << 16;                     // rows per worker task
 constexpr uint64_t kMaxLongRows = (uint64_t)1 << 22;
 
 struct BlockResult {  // what one worker task found in its rows
     uint64_t max_annot = 0;
-    int bad = 0;  // 1 unsorted, 2 negative start, 4 annot outside [0, 65535], 8 wild coordinate
+    int bad = 0;  // 1 unsorted, 2 negative start, 4 annot outside [0, 4095], 8 wild coordinate
     int wide_annot = 0;
     std::vector<int64_t> long_rows;  // (start, end, annot) triples with end < start
 };
@@ -304,8 +304,7 @@ struct memo_builder {
     int bshift = kDefaultBucketShift;
     uint64_t cap = 0, padded = 0, rows = 0;
     uint32_t *d_pk = nullptr;
-    uint16_t *d_pa = nullptr;
-    bool annot16 = false;
+    int fmt = 4;  // 4 until the first annot > 255 arrives, then 12 (PackedRows, memo_sweep.h)
     bool any = false;
     int64_t first_start = 0, last_start = 0;
     int64_t last_bucket = -1;       // bucket of the last row seen; boff[0 .. last_bucket] are final
@@ -321,7 +320,7 @@ namespace {
 // rows [i0, i1) of this push -> words (and 16-bit annots) at the same offsets of the slot
 void pack_block(const memo_builder *b, const int64_t *start, const int64_t *end, const int64_t *annot,
                 uint64_t i0, uint64_t i1, uint64_t global0, int64_t prev_start, int64_t prev_bucket,
-                int64_t *boff, int64_t boff_size, uint32_t *pk, uint16_t *pa, bool annot16, BlockResult &res) {
+                int64_t *boff, int64_t boff_size, uint32_t *pk, int fmt, BlockResult &res) {
     const int shift = b->bshift;
     uint64_t top = 0;
     int bad = 0, wide = 0;
@@ -330,7 +329,7 @@ void pack_block(const memo_builder *b, const int64_t *start, const int64_t *end,
         const int64_t s = start[i], e = end[i], a = annot[i];
         bad |= (s < ps) ? 1 : 0;
         bad |= (s < 0) ? 2 : 0;
-        bad |= ((uint64_t)a > 65535u) ? 4 : 0;
+        bad |= ((uint64_t)a > 4095u) ? 4 : 0;
         bad |= (s >= kCoordLimit || e <= -kCoordLimit || e >= kCoordLimit) ? 8 : 0;
         ps = s;
         const int64_t len = e - s;
@@ -341,12 +340,10 @@ void pack_block(const memo_builder *b, const int64_t *start, const int64_t *end,
         }
         // end < start (handled by long_rows_*_kernel) packs as "never writes", like len >= 255
         const uint32_t l8 = (uint64_t)len > 255u ? 255u : (uint32_t)len;
-        const uint32_t a16 = (uint32_t)a & 0xFFFFu;
-        top = a16 > top ? a16 : top;
-        wide |= a16 > 255u;
-        uint32_t w = ((uint32_t)s & 0xFFFFu) | (l8 << 16);
-        if (annot16) pa[i] = (uint16_t)a16; else w |= a16 << 24;
-        pk[i] = w;
+        const uint32_t a12 = (uint32_t)a & 0xFFFu;
+        top = a12 > top ? a12 : top;
+        wide |= a12 > 255u;
+        pk[i] = fmt == 12 ? l8 | (((uint32_t)s & 0xFFFu) << 8) | (a12 << 20) : ((uint32_t)s & 0xFFFFu) | (l8 << 16) | (a12 << 24);
         const int64_t bk = s >> shift;
         if (bk != pb) {  // first row of its bucket(s): boff[b] = lower_bound(start, b << shift)
             if (bk > pb && !bad && bk < boff_size)
@@ -405,7 +402,6 @@ void memo_builder_destroy(memo_builder_t *b) {
     DeviceGuard guard(b->device);
     release_ring(b->ring);
     (void)hipFree(b->d_pk);
-    (void)hipFree(b->d_pa);
     delete b;
 }
 
@@ -437,11 +433,10 @@ int memo_builder_push(memo_builder_t *b, const int64_t *start, const int64_t *en
         int rc = ring->wait(s);
         if (rc) return rc;
         uint32_t *pk = reinterpret_cast<uint32_t *>(ring->slot[s]);
-        uint16_t *pa = reinterpret_cast<uint16_t *>(ring->slot[s] + kChunkRows * 4);
         const int tasks = (int)((cn + kBlockRows - 1) / kBlockRows);
         std::vector<BlockResult> res((size_t)tasks);
         for (int pass = 0; pass < 2; ++pass) {  // a second pass only when this chunk is the first with an annot > 255
-            const bool annot16 = b->annot16;
+            const int fmt = b->fmt;
             pool.run(tasks, [&](int t) {
                 const uint64_t i0 = c0 + (uint64_t)t * kBlockRows;
                 const uint64_t i1 = i0 + kBlockRows < c0 + cn ? i0 + kBlockRows : c0 + cn;
@@ -450,7 +445,7 @@ int memo_builder_push(memo_builder_t *b, const int64_t *start, const int64_t *en
                 const int64_t prev_bucket = first ? b->last_bucket : (start[i0 - 1] >> b->bshift);
                 res[(size_t)t].long_rows.clear();
                 pack_block(b, start, end, annot, i0, i1, b->rows, prev_start, prev_bucket, b->boff.data(),
-                           (int64_t)b->boff.size(), pk - c0, pa - c0, annot16, res[(size_t)t]);
+                           (int64_t)b->boff.size(), pk - c0, fmt, res[(size_t)t]);
             });
             int bad = 0, wide = 0;
             for (const BlockResult &r : res) {
@@ -461,17 +456,15 @@ int memo_builder_push(memo_builder_t *b, const int64_t *start, const int64_t *en
                 return builder_fail(b, MEMO_EUNPACKABLE,
                                     bad & 1   ? "rows are not sorted by start: not packable on the host"
                                     : bad & 2 ? "rows with a negative start cannot be packed"
-                                    : bad & 4 ? "rows with an annot outside [0, 65535] cannot be packed"
+                                    : bad & 4 ? "rows with an annot outside [0, 4095] do not fit the one-word formats"
                                               : "rows have coordinates beyond +-2^61");
-            if (wide && !annot16) {  // switch the index to 16-bit annots: widen what is on the device, redo this chunk
-                HIP_TRY(hipMalloc(&b->d_pa, b->padded * sizeof(uint16_t)));
+            if (wide && fmt == 4) {  // switch the index to 12-bit annots: rewrite what is on the device, redo this chunk
                 HIP_TRY(hipStreamSynchronize(ring->stream));
                 if (b->rows + c0) {
-                    hipLaunchKernelGGL(widen_annot_kernel, dim3(2048), dim3(256), 0, ring->stream, b->d_pk, b->d_pa,
-                                       b->rows + c0);
+                    hipLaunchKernelGGL(widen_annot_kernel, dim3(2048), dim3(256), 0, ring->stream, b->d_pk, b->rows + c0);
                     HIP_TRY(hipGetLastError());
                 }
-                b->annot16 = true;
+                b->fmt = 12;
                 continue;
             }
             break;
@@ -485,8 +478,6 @@ int memo_builder_push(memo_builder_t *b, const int64_t *start, const int64_t *en
             }
         }
         HIP_TRY(hipMemcpyAsync(b->d_pk + b->rows + c0, pk, cn * 4, hipMemcpyHostToDevice, ring->stream));
-        if (b->annot16)
-            HIP_TRY(hipMemcpyAsync(b->d_pa + b->rows + c0, pa, cn * 2, hipMemcpyHostToDevice, ring->stream));
         if ((rc = ring->mark(s))) return rc;
     }
     if (!b->any) b->first_start = start[0];
@@ -530,7 +521,7 @@ int memo_builder_finish(memo_builder_t *b, memo_index_t **out) {
             err = hipMemcpyAsync(ix->boff, b->boff.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, st);
         // the rows behind the last one are read (never used) by whole-wave loads: keep them defined
         if (err == hipSuccess) err = hipMemsetAsync(b->d_pk + b->rows, 0, (b->padded - b->rows) * 4, st);
-        if (err == hipSuccess && b->d_pa) err = hipMemsetAsync(b->d_pa + b->rows, 0, (b->padded - b->rows) * 2, st);
+
         const uint64_t n_long = b->long_rows.size() / 3;
         std::vector<int64_t> cols;
         if (err == hipSuccess && n_long) {
@@ -561,10 +552,8 @@ int memo_builder_finish(memo_builder_t *b, memo_index_t **out) {
     for (int s = 0; s < PinnedRing::kSlots; ++s) b->ring->in_flight[s] = false;
     ix->nb = nb;
     ix->pk = b->d_pk;
-    ix->pa = b->d_pa;
     b->d_pk = nullptr;  // the index owns them now
-    b->d_pa = nullptr;
-    ix->packed_fmt = b->annot16 ? 6 : 4;
+    ix->packed_fmt = b->fmt;
     ix->finalized = 1;
     b->failed = MEMO_EINVAL;  // a builder finishes once
     *out = ix;
@@ -651,7 +640,7 @@ int memo_index_import_packed(uint64_t rows, int32_t device, int32_t bucket_shift
         memo_index_destroy(ix);
         return rc;
     }
-    ix->packed_fmt = pa ? 6 : 4;
+    ix->packed_fmt = pa ? 6 : (max_annot > 255 ? 12 : 4);  // the rule both packers follow: by the largest annot
     ix->finalized = 1;
     *out = ix;
     return MEMO_OK;

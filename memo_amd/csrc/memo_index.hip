@@ -86,18 +86,21 @@ __global__ void annot_census_kernel(const int64_t *o, uint64_t rows, uint64_t *s
     if (top) atomicMax((unsigned long long *)&scratch[5], (unsigned long long)top);
 }
 
+// fmt: 4 = start16 | len8 << 16 | annot8 << 24;  12 = len8 | start12 << 8 | annot12 << 20;  6 = the first word with
+// annot 0 + a 16-bit annot column  (PackedRows, memo_sweep.h)
 __global__ void pack_rows_kernel(const int64_t *s, const int64_t *e, const int64_t *o, uint64_t rows,
-                                 uint64_t padded, uint32_t *pk, uint16_t *pa) {
+                                 uint64_t padded, uint32_t *pk, uint16_t *pa, int fmt) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < padded;
          i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t w = 0, a = 0;
         if (i < rows) {
             const int64_t len = e[i] - s[i];
             // end < start (handled by long_rows_kernel) packs as "never writes", like len >= 255
-            w = ((uint32_t)s[i] & 0xFFFFu) | ((uint32_t)(len > 255 || len < 0 ? 255 : len) << 16);
+            const uint32_t l8 = (uint32_t)(len > 255 || len < 0 ? 255 : len);
             a = (uint32_t)o[i];
+            w = fmt == 12 ? l8 | (((uint32_t)s[i] & 0xFFFu) << 8) | (a << 20) : ((uint32_t)s[i] & 0xFFFFu) | (l8 << 16);
         }
-        if (pa) pa[i] = (uint16_t)a; else w |= a << 24;
+        if (fmt == 6) pa[i] = (uint16_t)a; else if (fmt == 4) w |= a << 24;
         pk[i] = w;
     }
 }
@@ -528,15 +531,15 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
             return fail(MEMO_EINVAL, "%llu rows have an annot outside [0, 65535]: cannot be packed",
                         (unsigned long long)h[3]);
     }
-    const int fmt = h[4] ? 6 : 4;
+    const int fmt = h[5] <= 255 ? 4 : (h[5] <= 4095 ? 12 : 6);  // by the largest annot
     ix->max_annot = h[5];
     if (fmt == 6 && !ix->pa) HIP_TRY(hipMalloc(&ix->pa, ix->padded * sizeof(uint16_t)));
-    if (fmt == 4 && had_pa) {
+    if (fmt != 6 && had_pa) {
         (void)hipFree(ix->pa);
         ix->pa = nullptr;
     }
     hipLaunchKernelGGL(pack_rows_kernel, dim3(4096), dim3(256), 0, st, ix->s, ix->e, ix->o, ix->rows,
-                       ix->padded, ix->pk, fmt == 6 ? ix->pa : nullptr);
+                       ix->padded, ix->pk, fmt == 6 ? ix->pa : nullptr, fmt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -220,30 +220,53 @@ __device__ __forceinline__ int pin_vgpr(int uniform) {
     return r;
 }
 
-// packed rows (memo_index_pack): one 32-bit word per row -- start mod 2^16, min(end - start,
-// 255), annot (8 bits; ANNOT16: in a second 16-bit column).  Inside a row slice every start
-// lies in [a, a + W + k + 32), far less than 2^16 from the tile start, so the low 16 bits
-// give the tile-relative start exactly; rows outside [r0, r1) are masked by index.  Exact
-// for k - 1 <= 255: a saturated length clips to "does not write" just as the true one does.
-// 4 rows per lane per load (16 B / lane).
+// packed rows (memo_index_pack): one 32-bit word per row, in one of three layouts
+//     annot <= 255   start mod 2^16 | min(end - start, 255) << 16 | annot << 24                  (format 4)
+//     annot <= 4095  min(end - start, 255) | (start mod 2^12) << 8 | annot << 20      W12       (format 12)
+//     else           the first word with annot 0, the annot in a second, 16-bit column  ANNOT16  (format 6)
+// Inside a row slice every start lies in [a, a + W + k + 32), far less than 2^12 from the tile start
+// (tiles of at most 2048 positions with W12), so the start field gives the tile-relative start exactly;
+// rows outside [r0, r1) are masked by index.  Exact for k - 1 <= 255: a saturated length clips to "does
+// not write" just as the true one does.  4 rows per lane per load (16 B / lane).  The byte-aligned fields
+// of format 4 cost one instruction each (16-bit subtract, SDWA byte operand); format 12 keeps the length
+// in byte 0 and pays one more for the start (subtract + bit-field extract) -- against format 6's second
+// load per four rows it is 33 % fewer bytes (BASELINE config 5: 500 genomes).
 // CHECKED = false is chosen by the host when the largest annot of the index (known since
 // memo_index_pack) is inside the result matrix, so that no row can raise the reference's
 // IndexError; the column test then leaves the loop.
-template <bool ANNOT16, bool CHECKED>
+template <bool ANNOT16, bool CHECKED, bool W12 = false>
 struct PackedRows {
+    static_assert(!(ANNOT16 && W12), "a 12-bit annot rides in the word");
     static constexpr int kLoads = 2 * MEMO_KU;  // A/B: 8 x 16 B in flight per lane, 5 % over 4
     static constexpr bool kAnnot16 = ANNOT16;
+    static constexpr bool kW12 = W12;
+    static constexpr int kTopShift = W12 ? 20 : 24;  // where the annot sits when it rides in the word
+    // what a tile subtracts from a row's start field
+    static __device__ __forceinline__ uint32_t tile_key(int64_t a) {
+        return W12 ? ((uint32_t)a & 0xFFFu) << 8 : (uint32_t)a & 0xFFFFu;
+    }
+    // start - a, for a row of the tile's slice (key = tile_key(a), in a VGPR)
+    static __device__ __forceinline__ uint32_t rel_start(uint32_t w, uint32_t key) {
+        if (W12) return __builtin_amdgcn_ubfe(w - key, 8, 12);  // (a borrow into the annot field does not reach the 12 bits)
+        uint32_t d;  // gfx9 16-bit VALU results have a zero high half
+        asm("v_sub_u16 %0, %1, %2" : "=v"(d) : "v"(w), "v"(key));
+        return d;
+    }
+    static __device__ __forceinline__ int len(uint32_t w) {  // min(end - start, 255)
+        return W12 ? (int)(w & 0xFFu) : (int)__builtin_amdgcn_ubfe(w, 16, 8);
+    }
+    static __device__ __forceinline__ uint32_t word_annot(uint32_t w) { return W12 ? w >> 20 : w >> 24; }
     // f(c, h, col): the clipped interval, as WideRows hands it out
     template <int T, int U, typename B, typename F>
     static __device__ __forceinline__ void for_each(const SweepArgs &A, const Tile &t, B between, F f) {
-        const uint32_t a16 = (uint32_t)t.a & 0xFFFFu;
+        const uint32_t key = (uint32_t)pin_vgpr((int)tile_key(t.a));
         const int x_lo = pin_vgpr(t.x_lo), x_hi = t.x_hi, km1 = A.km1;
         const uint32_t ncols = (uint32_t)A.ncols;
         uint32_t bad = 0;
         for_each_raw<T, U>(A, t, between, [&](uint32_t w, uint32_t annot) {
-            const int d = (int)((w - a16) & 0xFFFFu);  // start - a
+            const int d = (int)rel_start(w, key);  // start - a
             int h = med3(d, x_lo, x_hi);
-            const int c = med3(d + (int)__builtin_amdgcn_ubfe(w, 16, 8) - km1, x_lo, x_hi);
+            const int c = med3(d + len(w) - km1, x_lo, x_hi);
             if (CHECKED && annot >= ncols) {
                 bad |= (uint32_t)(h > c);
                 h = c;
@@ -301,7 +324,7 @@ struct PackedRows {
                                                    uint2 (&N)[U], G g) {
         const uint64_t base0 = t.r0 & ~(uint64_t)31;
         const uint32_t first = (uint32_t)(t.r0 - base0), end = (uint32_t)(t.r1 - base0);
-        const uint32_t dead = ((uint32_t)t.a & 0xFFFFu) | 0x00FF0000u;
+        const uint32_t dead = tile_key(t.a) | (W12 ? 0x000000FFu : 0x00FF0000u);  // start = a, length 255: never writes
         const uint32_t rel = batch * (4 * T * U) + 4 * threadIdx.x;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -315,10 +338,10 @@ struct PackedRows {
                 V[u].z = (r + 2 >= first && r + 2 < end) ? V[u].z : dead;
                 V[u].w = (r + 3 >= first && r + 3 < end) ? V[u].w : dead;
             }
-            g(V[u].x, ANNOT16 ? (N[u].x & 0xFFFFu) : (V[u].x >> 24));
-            g(V[u].y, ANNOT16 ? (N[u].x >> 16) : (V[u].y >> 24));
-            g(V[u].z, ANNOT16 ? (N[u].y & 0xFFFFu) : (V[u].z >> 24));
-            g(V[u].w, ANNOT16 ? (N[u].y >> 16) : (V[u].w >> 24));
+            g(V[u].x, ANNOT16 ? (N[u].x & 0xFFFFu) : word_annot(V[u].x));
+            g(V[u].y, ANNOT16 ? (N[u].x >> 16) : word_annot(V[u].y));
+            g(V[u].z, ANNOT16 ? (N[u].y & 0xFFFFu) : word_annot(V[u].z));
+            g(V[u].w, ANNOT16 ? (N[u].y >> 16) : word_annot(V[u].w));
         }
     }
 };
@@ -419,9 +442,9 @@ struct PackedRows3 {
 // wave-instruction.  Pieces are aligned in the OUTPUT (the tile grid is aligned in pivot
 // coordinates, the output starts at qs); when that leaves the LDS side unaligned the cells are read
 // one by one.
-// TOP8: the cells hold whole row words whose top byte is the order (the unclipped kernels min the words
-// as they are -- the junk below the order only breaks ties); the result is that byte.
-template <typename OutT, int T, bool TOP8 = false>
+// TOP != 0: the cells hold whole row words whose top bits (from bit TOP: 24 or 20) are the order (the unclipped
+// kernels min the words as they are -- the junk below the order only breaks ties); the result is those bits.
+template <typename OutT, int T, int TOP = 0>
 __device__ __forceinline__ void store_conservation(const SweepArgs &A, const Tile &t, const uint32_t *lv0,
                                                    const uint32_t *lv1, int x_min) {
     OutT *out = static_cast<OutT *>(A.out);
@@ -434,7 +457,7 @@ __device__ __forceinline__ void store_conservation(const SweepArgs &A, const Til
             r = min(r, lv1[x]);
             if (x > x_min) r = min(r, lv1[x - 1]);
         }
-        return TOP8 ? r >> 24 : r;
+        return TOP ? r >> TOP : r;
     };
     for (int64_t g = (o_lo & ~(int64_t)3) + 4 * threadIdx.x; g < o_hi; g += 4 * T) {
         const int x = (int)(g - ob);
@@ -450,7 +473,8 @@ __device__ __forceinline__ void store_conservation(const SweepArgs &A, const Til
                     v.z = min(v.z, min(u.z, u.y));
                     v.w = min(v.w, min(u.w, u.z));
                 }
-                if (TOP8) {  // byte 3 of each word -> the packed result, one v_perm_b32 per two words
+                if (TOP && TOP != 24) v = make_uint4(v.x >> TOP, v.y >> TOP, v.z >> TOP, v.w >> TOP);
+                if (TOP == 24) {  // byte 3 of each word -> the packed result, one v_perm_b32 per two words
                     if (sizeof(OutT) == 1) {
                         const uint32_t lo = __builtin_amdgcn_perm(v.y, v.x, 0x0C0C0703u);  // [x3, y3, 0, 0]
                         const uint32_t hi = __builtin_amdgcn_perm(v.w, v.z, 0x07030C0Cu);  // [0, 0, z3, w3]

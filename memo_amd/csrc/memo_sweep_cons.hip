@@ -121,7 +121,7 @@ __device__ __forceinline__ void halo_clear(const SweepArgs &A, uint32_t *lds, ui
 
 // fold: a block of 2^j at x covers the blocks of 2^(j-1) at x and x + 2^(j-1); the left halo too.
 // Then the last fold + store (store_conservation).
-template <typename OutT, int T, bool TOP8>
+template <typename OutT, int T, int TOP>
 __device__ __forceinline__ void halo_fold_store(const SweepArgs &A, const Tile &t, uint32_t *lds) {
     const int LS = A.ls, HL = A.hl, W = A.w;
     const int cells = HL + W;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void halo_fold_store(const SweepArgs &A, const Tile &
         }
         lds_barrier();
     }
-    store_conservation<OutT, T, TOP8>(A, t, lds + (A.nlev - 1) * LS + HL,
+    store_conservation<OutT, T, TOP>(A, t, lds + (A.nlev - 1) * LS + HL,
                                       A.nlev > 1 ? lds + (A.nlev - 2) * LS + HL : nullptr, -HL);
 }
 
@@ -170,7 +170,7 @@ __device__ __forceinline__ uint32_t lane_shr1(uint32_t v) {  // lane l <- lane l
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
 }
 
-template <typename OutT, int T, bool TOP8>
+template <typename OutT, int T, int TOP>
 __device__ __forceinline__ void halo_fold_store_reg(const SweepArgs &A, const Tile &t, const uint32_t *lds) {
     const int LS = A.ls, HL = A.hl, W = A.w, nlev = A.nlev;
     const int cells = HL + W;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void halo_fold_store_reg(const SweepArgs &A, const Ti
         }
         if (lane < ctx || x0 >= cells) continue;
         const int64_t g = ob + x0;
-        if (TOP8) M = make_uint4(M.x >> 24, M.y >> 24, M.z >> 24, M.w >> 24);
+        if (TOP) M = make_uint4(M.x >> TOP, M.y >> TOP, M.z >> TOP, M.w >> TOP);
         if (g >= o_lo && g + 4 <= o_hi) {
             if (sizeof(OutT) == 1)
                 *reinterpret_cast<uint32_t *>(out + g) = M.x | (M.y << 8) | (M.z << 16) | (M.w << 24);
@@ -231,26 +231,26 @@ __device__ __forceinline__ void halo_fold_store_reg(const SweepArgs &A, const Ti
 #ifndef MEMO_FOLD_REG
 #define MEMO_FOLD_REG 1
 #endif
-template <typename OutT, int T, bool TOP8>
+template <typename OutT, int T, int TOP>
 __device__ __forceinline__ void halo_finish(const SweepArgs &A, const Tile &t, uint32_t *lds) {
     // A/B on config 3 (profiles/r02_fold_in_registers.txt): -5 % at k = 21 and 31, +1 % at k = 64, +5 % at k = 101
     // (16 context lanes per wave and twelve ds_bpermute per lane there): registers up to five levels
     if (MEMO_FOLD_REG && A.nlev <= 5 && ((t.a - A.qs) & 3) == 0)
-        halo_fold_store_reg<OutT, T, TOP8>(A, t, lds);
+        halo_fold_store_reg<OutT, T, TOP>(A, t, lds);
     else
-        halo_fold_store<OutT, T, TOP8>(A, t, lds);
+        halo_fold_store<OutT, T, TOP>(A, t, lds);
 }
 
 // 4- and 6-byte rows.  The 4-byte rows carry their order in the top byte of the word, and the cells
 // take the WORD (ds_min_u32 of the row as it was loaded: the min of the words has the min order on
 // top, the junk below it only breaks ties) -- one VALU instruction per row less than extracting it;
-// the store keeps the top byte (TOP8; needs num_docs <= 255 for the sentinel).  Otherwise the cells
+// the store keeps the top bits (TOP = 24 / 20; needs num_docs to fit the field for the sentinel).  Otherwise the cells
 // hold the order itself: the word's top byte shifted down, or the 16-bit order column.
-template <typename Rows, int U, int T, typename OutT, bool TOP8>
+template <typename Rows, int U, int T, typename OutT, int TOP>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
 void sweep_conservation_halo_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    static_assert(!(TOP8 && Rows::kAnnot16), "the order byte rides in the word only in the 4-byte format");
+    static_assert(TOP == 0 || (!Rows::kAnnot16 && TOP == Rows::kTopShift), "the order rides in the word only in the 4-byte formats");
     const int LS = A.ls, HL = A.hl, W = A.w;
     Tile t;
 #ifdef MEMO_STAMPS
@@ -262,7 +262,7 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
     uint2 N[U];
     Rows::template issue<T, U>(A, t, 0, V, N);
     const uint32_t sent = (uint32_t)(A.ncols - 1);
-    halo_clear<T>(A, lds, TOP8 ? (sent << 24) | 0x00FFFFFFu : sent);
+    halo_clear<T>(A, lds, TOP ? (sent << TOP) | ((1u << TOP) - 1u) : sent);
     MEMO_STAMP(1);  // issue of the loads + LDS clear + barrier
 
     const int km1 = A.km1;
@@ -271,35 +271,35 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
     const uint32_t bias4 = pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)(32 - A.nlev) * ls4));
     const uint32_t top_bit = pin_vgpr((int)0x80000000u);
-    const uint32_t a16 = pin_vgpr((int)((uint32_t)t.a & 0xFFFFu));
+    const uint32_t key = pin_vgpr((int)Rows::tile_key(t.a));
     auto scatter = [&](uint32_t w, uint32_t col) {
         if (MEMO_ABLATE & 16) {  // keep the loads alive, nothing else
             asm volatile("" ::"v"(w), "v"(col));
             return;
         }
-        const int n = km1 - (int)__builtin_amdgcn_ubfe(w, 16, 8);  // length of [end - (k-1), start)
+        const int n = km1 - Rows::len(w);  // length of [end - (k-1), start)
         if (n > 0) {
             // f = clz(n); 2^j = 2^31 >> f; x4 = address of cell `start` on level f;
             // ds_min into the cells of blocks [start - n, .. + 2^j) and [start - 2^j, start).
-            // (v_sub_u16: gfx9 16-bit VALU results have a zero high half.)  The compiler's own
-            // rendering of this needs 13 VALU instructions, one of them a quarter-rate multiply.
+            // The compiler's own rendering of this needs 13 VALU instructions, one of them a
+            // quarter-rate multiply.
+            const uint32_t d = Rows::rel_start(w, key);  // start - a: v_sub_u16, or subtract + bit-field extract (12-bit form)
             uint32_t r0, r1, r2;
             asm volatile(
                 "v_ffbh_u32 %0, %3\n\t"
-                "v_sub_u16 %1, %4, %5\n\t"
-                "v_mad_u32_u24 %2, %0, %6, %7\n\t"
-                "v_lshl_add_u32 %2, %1, 2, %2\n\t"
+                "v_mad_u32_u24 %2, %0, %5, %6\n\t"
+                "v_lshl_add_u32 %2, %4, 2, %2\n\t"
                 "v_mad_i32_i24 %1, %3, -4, %2\n\t"
-                "v_ashrrev_i32 %0, %0, %8\n\t"
+                "v_ashrrev_i32 %0, %0, %7\n\t"
                 "v_lshl_add_u32 %2, %0, 2, %2\n\t"
 #if !(MEMO_ABLATE & 1)
-                "ds_min_u32 %1, %9\n\t"
+                "ds_min_u32 %1, %8\n\t"
 #endif
 #if !(MEMO_ABLATE & 2)
-                "ds_min_u32 %2, %9"
+                "ds_min_u32 %2, %8"
 #endif
                 : "=&v"(r0), "=&v"(r1), "=&v"(r2)
-                : "v"(n), "v"(w), "v"(a16), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(TOP8 ? w : col)
+                : "v"(n), "v"(d), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(TOP ? w : col)
                 : "memory");
         }
     };
@@ -311,7 +311,7 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
     MEMO_STAMP(2);  // waiting for rows + scatter
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
     MEMO_STAMP(3);  // barrier after the scatter
-    halo_finish<OutT, T, TOP8>(A, t, lds);
+    halo_finish<OutT, T, TOP>(A, t, lds);
     MEMO_STAMP(5);  // folds + store
 #ifdef MEMO_STAMPS
     if (threadIdx.x == 0 && A.stamps) A.stamps[8ull * blockIdx.x + 7] = 1;
@@ -385,7 +385,7 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
         Rows::template consume<T, U>(A, t, b, V, g_lo, g_hi);
     }
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
-    halo_finish<OutT, T, true>(A, t, lds);
+    halo_finish<OutT, T, 24>(A, t, lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -401,7 +401,7 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
 // them, and three fold steps replace six or seven: 64 -> 16 as one LDS pass, 16 -> 4 and 4 -> 1 in registers
 // (DPP shifts only).  Used from k = 65 up; below that the doubling arrays are faster (see the launcher).
 // ------------------------------------------------------------------------------------------
-template <typename OutT, int T, bool TOP8>
+template <typename OutT, int T, int TOP>
 __device__ __forceinline__ void r4_fold_store(const SweepArgs &A, const Tile &t, uint32_t *lds) {
     const int LS = A.ls, HL = A.hl, W = A.w, m = A.nlev;
     const int cells = HL + W;
@@ -468,7 +468,7 @@ __device__ __forceinline__ void r4_fold_store(const SweepArgs &A, const Tile &t,
         }
         if (lane < ctx || x0 >= cells) continue;
         const int64_t g = ob + x0;
-        if (TOP8) R = make_uint4(R.x >> 24, R.y >> 24, R.z >> 24, R.w >> 24);
+        if (TOP) R = make_uint4(R.x >> TOP, R.y >> TOP, R.z >> TOP, R.w >> TOP);
         if (aligned && g >= o_lo && g + 4 <= o_hi) {
             if (sizeof(OutT) == 1)
                 *reinterpret_cast<uint32_t *>(out + g) = R.x | (R.y << 8) | (R.z << 16) | (R.w << 24);
@@ -482,11 +482,11 @@ __device__ __forceinline__ void r4_fold_store(const SweepArgs &A, const Tile &t,
     }
 }
 
-template <typename Rows, int U, int T, typename OutT, bool TOP8>
+template <typename Rows, int U, int T, typename OutT, int TOP>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
 void sweep_conservation_r4_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    static_assert(!(TOP8 && Rows::kAnnot16), "the order byte rides in the word only in the 4-byte format");
+    static_assert(TOP == 0 || (!Rows::kAnnot16 && TOP == Rows::kTopShift), "the order rides in the word only in the 4-byte formats");
     const int LS = A.ls, HL = A.hl, W = A.w;
     Tile t;
     if (!locate_tile_w(A, t, W)) return;
@@ -494,7 +494,7 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
     uint2 N[U];
     Rows::template issue<T, U>(A, t, 0, V, N);
     const uint32_t sent = (uint32_t)(A.ncols - 1);
-    halo_clear<T>(A, lds, TOP8 ? (sent << 24) | 0x00FFFFFFu : sent);
+    halo_clear<T>(A, lds, TOP ? (sent << TOP) | ((1u << TOP) - 1u) : sent);
 
     const int km1 = A.km1;
     // LDS byte address of tile slot x on level i (blocks of 4^i):  level0 - i * 4 LS + 4 x
@@ -502,33 +502,33 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
     const int neg_ls4 = -(int)ls4;
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
     const uint32_t level0 = pin_vgpr((int)(lds_base + (uint32_t)(A.nlev - 1) * ls4 + 4u * (uint32_t)HL));
-    const uint32_t a16 = pin_vgpr((int)((uint32_t)t.a & 0xFFFFu));
+    const uint32_t key = pin_vgpr((int)Rows::tile_key(t.a));
     auto scatter = [&](uint32_t w, uint32_t col) {
-        const int n = km1 - (int)__builtin_amdgcn_ubfe(w, 16, 8);  // length of [end - (k-1), start)
+        const int n = km1 - Rows::len(w);  // length of [end - (k-1), start)
         if (n > 0) {
             // i = floor(log4 n), S = 4^i.  Blocks [start - n, +S) and [start - S, start); r = n - 2S > 0: one more at
             // start - n + S; r > S: and one at start - n + 2S.  By hand: the compiler's rendering takes 24 VALU
             // instructions per row, one of them a quarter-rate 32-bit multiply.
-            const uint32_t data = TOP8 ? w : col;
+            const uint32_t data = TOP ? w : col;
+            const uint32_t d = Rows::rel_start(w, key);  // start - a
             uint32_t t31, a1, a2, s4;
             int r;
             asm volatile(
                 "v_ffbh_u32 %0, %5\n\t"
                 "v_sub_u32 %0, 31, %0\n\t"            // floor(log2 n)
                 "v_lshrrev_b32 %1, 1, %0\n\t"         // i
-                "v_mad_i32_i24 %1, %1, %8, %9\n\t"    // level i
-                "v_sub_u16 %2, %6, %7\n\t"            // start - a  (gfx9 16-bit VALU results have a zero high half)
-                "v_lshl_add_u32 %2, %2, 2, %1\n\t"    // cell `start` on level i
+                "v_mad_i32_i24 %1, %1, %7, %8\n\t"    // level i
+                "v_lshl_add_u32 %2, %6, 2, %1\n\t"    // cell `start` on level i
                 "v_mad_i32_i24 %1, %5, -4, %2\n\t"    // a1: cell start - n
                 "v_and_b32 %0, 30, %0\n\t"            // 2 i
                 "v_lshlrev_b32 %3, %0, 4\n\t"         // 4 S (bytes)
                 "v_sub_u32 %2, %2, %3\n\t"            // a2: cell start - S
-                "ds_min_u32 %1, %10\n\t"
-                "ds_min_u32 %2, %10\n\t"
+                "ds_min_u32 %1, %9\n\t"
+                "ds_min_u32 %2, %9\n\t"
                 "v_lshrrev_b32 %0, 1, %3\n\t"         // 2 S
                 "v_sub_u32 %4, %5, %0"                // r = n - 2 S
                 : "=&v"(t31), "=&v"(a1), "=&v"(a2), "=&v"(s4), "=&v"(r)
-                : "v"(n), "v"(w), "v"(a16), "s"(neg_ls4), "v"(level0), "v"(data)
+                : "v"(n), "v"(d), "s"(neg_ls4), "v"(level0), "v"(data)
                 : "memory");
             if (r > 0) {
                 uint32_t a3, a4;
@@ -556,7 +556,7 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
     }
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
     __syncthreads();
-    r4_fold_store<OutT, T, TOP8>(A, t, lds);
+    r4_fold_store<OutT, T, TOP>(A, t, lds);
 }
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
@@ -666,18 +666,18 @@ SweepKernel cons_kernel(int w, int waves) {
 #endif
 constexpr int kHaloLoads = MEMO_HALO_LOADS;  // 16-byte loads in flight per lane
 
-template <typename Rows, typename OutT, bool TOP8>
+template <typename Rows, typename OutT, int TOP>
 static SweepKernel halo_kernel(int waves) {
-    return waves == 8   ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 512, OutT, TOP8>
-           : waves == 4 ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 256, OutT, TOP8>
-                        : (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 64, OutT, TOP8>;
+    return waves == 8   ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 512, OutT, TOP>
+           : waves == 4 ? (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 256, OutT, TOP>
+                        : (SweepKernel)sweep_conservation_halo_kernel<Rows, kHaloLoads, 64, OutT, TOP>;
 }
 
-template <typename Rows, typename OutT, bool TOP8>
+template <typename Rows, typename OutT, int TOP>
 static SweepKernel r4_kernel(int waves) {
-    return waves == 8   ? (SweepKernel)sweep_conservation_r4_kernel<Rows, kHaloLoads, 512, OutT, TOP8>
-           : waves == 4 ? (SweepKernel)sweep_conservation_r4_kernel<Rows, kHaloLoads, 256, OutT, TOP8>
-                        : (SweepKernel)sweep_conservation_r4_kernel<Rows, kHaloLoads, 64, OutT, TOP8>;
+    return waves == 8   ? (SweepKernel)sweep_conservation_r4_kernel<Rows, kHaloLoads, 512, OutT, TOP>
+           : waves == 4 ? (SweepKernel)sweep_conservation_r4_kernel<Rows, kHaloLoads, 256, OutT, TOP>
+                        : (SweepKernel)sweep_conservation_r4_kernel<Rows, kHaloLoads, 64, OutT, TOP>;
 }
 
 template <typename OutT>
@@ -752,17 +752,21 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // after the halo, rounded down to whole buckets
     // (below one row per position the halo's extra clear and fold cost more than the scatter saves)
     bool halo = fmt && !checked && (tune.scatter >= 2 || (tune.scatter == 0 && (double)ix->rows >= span));
-    // Radix-4 levels (sweep_conservation_r4_kernel) from k = 65 up: four arrays where doubling needs seven or
-    // eight.  Interleaved A/B on config 3 (profiles/r02_radix4_levels.txt; doubling -> radix-4, ms): k = 101
-    // 0.564 -> 0.514, k = 256 0.951 -> 0.668, with arrays of 2560 cells shared by eight waves (40 KiB, four
-    // workgroups per CU); at k = 21 / 31 / 64 the doubling arrays stay ahead (0.375 vs 0.40, 0.46 vs 0.50: there
-    // the third and fourth block of a row cost more than the two fold steps save).
-    if (halo && fmt != 3 && (tune.scatter == 3 || (tune.scatter == 0 && k - 1 >= 64))) {
+    // Radix-4 levels (sweep_conservation_r4_kernel) from k = 65 up on indexes of moderate density: four arrays
+    // where doubling needs seven or eight.  Interleaved A/B (profiles/r02_radix4_levels.txt; doubling -> radix-4,
+    // ms): config 3 (5 rows per position) k = 101 0.564 -> 0.514, k = 256 0.951 -> 0.668, with arrays of 2560
+    // cells shared by eight waves (40 KiB, four workgroups per CU).  At k = 21 / 31 / 64 the doubling arrays stay
+    // ahead (0.375 vs 0.40, 0.46 vs 0.50), and so they do at any k on a dense index -- config 5, 25 rows per
+    // position: k = 101 0.89 vs 1.08, k = 256 1.14 vs 1.55 -- where a row's third and fourth block cost more LDS
+    // atomics than the fold steps save.
+    const bool moderate = (double)ix->rows < 12.0 * span;
+    if (halo && fmt != 3 && (tune.scatter == 3 || (tune.scatter == 0 && k - 1 >= 64 && moderate))) {
         const int bw = 1 << ix->bshift;
         const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + bw - 1 + 3) & ~3;
         const int m = (floor_log2((uint32_t)(k - 1)) >> 1) + 1;
         int ls = tune.tile_w ? tune.tile_w : 2560;
         if (ls > 8192) ls = 8192;
+        if (fmt == 12 && ls > 4096) ls = 4096;  // (12-bit start field: start - a < array size <= 2^12)
         // short windows: enough tiles to fill the chip (a few thousand of them)
         while (!tune.tile_w && ls > 640 && (qe - qs) / (ls - hl - hr > bw ? ls - hl - hr : bw) < 4096) ls = (ls / 2) & ~3;
         const int tw = (ls - hl - hr) / bw * bw;
@@ -772,10 +776,12 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.w = tw;
             A.ls = hl + tw + hr;
             waves = tune.waves == 1 || tune.waves == 4 || tune.waves == 8 ? tune.waves : (ls >= 2048 ? 8 : 4);
-            const bool top8 = num_docs <= 255;
-            SweepKernel kern = fmt == 4 ? (top8 ? r4_kernel<PackedRows<false, false>, OutT, true>(waves)
-                                                : r4_kernel<PackedRows<false, false>, OutT, false>(waves))
-                                        : r4_kernel<PackedRows<true, false>, OutT, false>(waves);
+            // the order rides in the row word when the sentinel num_docs fits its field (8 / 12 bits)
+            SweepKernel kern = fmt == 4    ? (num_docs <= 255 ? r4_kernel<PackedRows<false, false>, OutT, 24>(waves)
+                                                              : r4_kernel<PackedRows<false, false>, OutT, 0>(waves))
+                               : fmt == 12 ? (num_docs <= 4095 ? r4_kernel<PackedRows<false, false, true>, OutT, 20>(waves)
+                                                               : r4_kernel<PackedRows<false, false, true>, OutT, 0>(waves))
+                                           : r4_kernel<PackedRows<true, false>, OutT, 0>(waves);
             if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)m * A.ls * 4, st))) return rc;
             return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
         }
@@ -785,7 +791,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         // length from 10^6 positions up and at k = 21 .. 101
         const int bw = 1 << ix->bshift;  // a slice ends at a bucket boundary: start - a <= tile + k - 1 + bw - 2
         const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + bw - 1 + 3) & ~3;
-        if (!w) w = 1024;
+        if (!tune.tile_w) w = k - 1 >= 128 ? 2048 : 1024;  // (k = 256 on config 5: 1.40 ms with 1024 cells x 4 waves, 1.14 with 2048 x 8)
         int tw = 0;
         for (;; w <<= 1) {
             tw = (w - hl - hr) / bw * bw;
@@ -797,8 +803,8 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.hl = hl;
             A.w = tw;
             A.ls = hl + tw + hr;
-            if (tune.waves == 0) waves = w >= 1024 ? 4 : 1;
-            if (tune.waves == 8) waves = 8;  // (experiment: eight waves share a tile; only this kernel has that shape)
+            if (tune.waves == 0) waves = w >= 2048 ? 8 : (w >= 1024 ? 4 : 1);
+            if (tune.waves == 8) waves = 8;
             // 4- / 6-byte rows when they are resident: the dense rows load a fifth fewer bytes but take three
             // more instructions per row, and the sweep is bound by the latter (profiles/r02_dense_rows_ab.txt:
             // 0.39 ms against 0.383 on config 3 although their memory floor is 0.304).  They answer when the
@@ -810,9 +816,11 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                 halo = false;  // (below: the int64 columns, or an error when they are gone too)
             } else {
             SweepKernel kern = three      ? halo3_kernel<OutT>(waves)
-                               : fmt == 4 ? (top8 ? halo_kernel<PackedRows<false, false>, OutT, true>(waves)
-                                                  : halo_kernel<PackedRows<false, false>, OutT, false>(waves))
-                                          : halo_kernel<PackedRows<true, false>, OutT, false>(waves);
+                               : fmt == 4 ? (top8 ? halo_kernel<PackedRows<false, false>, OutT, 24>(waves)
+                                                  : halo_kernel<PackedRows<false, false>, OutT, 0>(waves))
+                               : fmt == 12 ? (num_docs <= 4095 ? halo_kernel<PackedRows<false, false, true>, OutT, 20>(waves)
+                                                               : halo_kernel<PackedRows<false, false, true>, OutT, 0>(waves))
+                                          : halo_kernel<PackedRows<true, false>, OutT, 0>(waves);
             if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)A.nlev * A.ls * 4, st))) return rc;
             }
         }
@@ -833,12 +841,15 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         waves = tune.waves == 1 || tune.waves == 4 ? tune.waves : (w >= 1024 ? 4 : 1);
     }
     if (!halo) {
+        if (fmt == 12 && w > 2048) w = 2048;  // a 12-bit start field: the slice of a tile spans less than 2^12 positions
         while ((size_t)A.nlev * (w + kLevelSkew) * 4 > 160 * 1024 && w > 256) w >>= 1;
         A.hl = 0;
         A.w = w;
         A.ls = w + kLevelSkew;
         SweepKernel kern = fmt == 4   ? (checked ? cons_kernel<PackedRows<false, true>, OutT>(w, waves)
                                                  : cons_kernel<PackedRows<false, false>, OutT>(w, waves))
+                           : fmt == 12 ? (checked ? cons_kernel<PackedRows<false, true, true>, OutT>(w, waves)
+                                                  : cons_kernel<PackedRows<false, false, true>, OutT>(w, waves))
                            : fmt == 6 ? (checked ? cons_kernel<PackedRows<true, true>, OutT>(w, waves)
                                                  : cons_kernel<PackedRows<true, false>, OutT>(w, waves))
                                       : cons_kernel<WideRows, OutT>(w, waves);

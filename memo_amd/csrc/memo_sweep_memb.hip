@@ -219,12 +219,11 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
 
     const int km1 = A.km1;
     const int HLW = A.nlev;  // words of halo left of the tile: ceil((k - 1) / 32)
-    const uint32_t a16m = pin_vgpr((int)((uint32_t)(t.a - 32 * HLW) & 0xFFFFu));  // bit 32 * HLW of a plane row = tile slot 0
+    const uint32_t keym = pin_vgpr((int)Rows::tile_key(t.a - 32 * HLW));  // bit 32 * HLW of a plane row = tile slot 0
     auto scatter = [&](uint32_t w, uint32_t col) {
-        const int n = km1 - (int)__builtin_amdgcn_ubfe(w, 16, 8);  // bits of the run [end - (k-1), start)
+        const int n = km1 - Rows::len(w);  // bits of the run [end - (k-1), start)
         if (n > 0) {
-            uint32_t d;  // start - a + 32 * HLW (gfx9 16-bit VALU results have a zero high half)
-            asm("v_sub_u16 %0, %1, %2" : "=v"(d) : "v"(w), "v"(a16m));
+            const uint32_t d = Rows::rel_start(w, keym);  // start - a + 32 * HLW
             const uint32_t first = d - (uint32_t)n;
             uint32_t *cell = lds + (__umul24(col, (uint32_t)PITCH) + __umul24(col >> 5, (uint32_t)SKEW) + (first >> 5));
             if (km1 <= 31) {  // (uniform) the run fits two words: no branches
@@ -433,6 +432,8 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             const size_t staged = ((size_t)pw * (32 * nw + nw) + 4) * 4;
             SweepKernel kern = fmt == 4 ? (T == 64 ? (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false>, 6, 64>
                                                    : (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false>, 6, 256>)
+                               : fmt == 12 ? (T == 64 ? (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false, true>, 6, 64>
+                                                      : (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false, true>, 6, 256>)
                                         : (T == 64 ? (SweepKernel)sweep_membership_planes_kernel<PackedRows<true, false>, 6, 64>
                                                    : (SweepKernel)sweep_membership_planes_kernel<PackedRows<true, false>, 6, 256>);
             if ((rc = launch_tiles(kern, A, tw, T, planes > staged ? planes : staged, st))) return rc;
@@ -455,10 +456,13 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         while (skew * 2 * slice <= 32) skew *= 2;  // largest power of two <= 32 / nw (1 when nw > 16)
         A.nlev = skew;
         auto lds_bytes = [&](int ww) { return ((size_t)32 * slice * (ww / 32 + 1) + (size_t)slice * skew) * 4; };
+        if (fmt == 12 && w > 2048) w = 2048;  // (12-bit start field)
         while (lds_bytes(w) > 160 * 1024 && w > 256) w >>= 1;
         const size_t lds = lds_bytes(w);
         SweepKernel kern = fmt == 4   ? (checked ? memb_runs_kernel<PackedRows<false, true>>(w, waves)
                                                  : memb_runs_kernel<PackedRows<false, false>>(w, waves))
+                           : fmt == 12 ? (checked ? memb_runs_kernel<PackedRows<false, true, true>>(w, waves)
+                                                  : memb_runs_kernel<PackedRows<false, false, true>>(w, waves))
                            : fmt == 6 ? (checked ? memb_runs_kernel<PackedRows<true, true>>(w, waves)
                                                  : memb_runs_kernel<PackedRows<true, false>>(w, waves))
                                       : memb_runs_kernel<WideRows>(w, waves);
@@ -479,8 +483,11 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         while (w > 256 && (qe - qs) / w < 16384) w >>= 1;
     }
     while (per_pos * w > 160 * 1024 && w > 256) w >>= 1;
+    if (fmt == 12 && w > 2048) w = 2048;  // (12-bit start field)
     SweepKernel kern = fmt == 4   ? (checked ? memb_kernel<PackedRows<false, true>>(w, waves)
                                              : memb_kernel<PackedRows<false, false>>(w, waves))
+                       : fmt == 12 ? (checked ? memb_kernel<PackedRows<false, true, true>>(w, waves)
+                                              : memb_kernel<PackedRows<false, false, true>>(w, waves))
                        : fmt == 6 ? (checked ? memb_kernel<PackedRows<true, true>>(w, waves)
                                              : memb_kernel<PackedRows<true, false>>(w, waves))
                                   : memb_kernel<WideRows>(w, waves);

@@ -175,10 +175,17 @@ def test_resident_index_windows(tile_w, waves, algo, memo, oracle, ab):
                     assert np.array_equal(ix.membership(qs, qe, k, n_docs), want), (k, qs, qe)
 
 
-@pytest.mark.parametrize("n_docs,keep_wide", [(70, True), (70, False), (256, True), (257, True), (500, False)])
+def _fmt(n_docs):
+    """the packed layout memo_index_pack / memo_builder_* choose for annots 1 .. n_docs - 1"""
+    return 4 if n_docs <= 256 else (12 if n_docs <= 4096 else 6)
+
+
+@pytest.mark.parametrize("n_docs,keep_wide", [(70, True), (70, False), (256, True), (257, True), (500, False), (4096, True),
+                                              (4097, True), (6000, False)])
 def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle, ab):
-    """memo_index_pack: 4 B/row (annot <= 255) and 6 B/row formats, every tile shape, k up to 256;
-    k > 256 falls back to the int64 columns, or is refused when they were dropped."""
+    """memo_index_pack: 4 B/row with 8-bit annots (format 4), 4 B/row with 12-bit annots and a 12-bit start
+    (format 12) and 6 B/row (format 6), every tile shape, k up to 256; k > 256 falls back to the int64
+    columns, or is refused when they were dropped."""
     from memo_amd import _lib
     rng = np.random.default_rng(n_docs)
     length = 150_000                                    # > 2^16: the 16-bit start wraps inside the index
@@ -187,7 +194,7 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle, ab):
     with memo.DeviceIndex.from_host(s, e, o) as ix:
         ix.pack(keep_wide=keep_wide)
         inf = ix.info()
-        assert inf["packed_format"] == (4 if n_docs <= 256 else 6) and inf["has_wide"] == int(keep_wide)
+        assert inf["packed_format"] == _fmt(n_docs) and inf["has_wide"] == int(keep_wide)
         try:
             for tile_w, waves, algo in [(0, 0, 0), (256, 1, 2), (512, 4, 2), (1024, 1, 2), (2048, 4, 2), (4096, 4, 0),
                                         (256, 4, 3), (2048, 4, 3), (1024, 1, 3), (0, 0, 4), (256, 1, 4), (512, 4, 4),
@@ -354,7 +361,7 @@ def test_builder_equals_int64_upload(n_rows, n_docs, pieces, memo, oracle):
         with b.finish() as ix:
             inf = ix.info()
             assert inf["rows"] == n_rows and inf["finalized"] == 1 and inf["has_wide"] == 0
-            assert inf["packed_format"] == (4 if n_docs <= 256 else 6)
+            assert inf["packed_format"] == _fmt(n_docs)
             assert inf["min_start"] == int(s[0]) and inf["max_start"] == int(s[-1])
             with memo.DeviceIndex.from_host(s, e, o) as ref:
                 ref.pack(keep_wide=True)
@@ -369,9 +376,9 @@ def test_builder_equals_int64_upload(n_rows, n_docs, pieces, memo, oracle):
                 ix.conservation(0, 1000, 300, n_docs)               # k > 256 needs the int64 columns
 
 
-def test_builder_switches_to_16_bit_annots_late(memo, oracle):
-    """the first annot > 255 arrives after 5 M rows are already on the device as 8-bit annots: they are
-    widened in place (widen_annot_kernel) and the current piece is packed again"""
+def test_builder_switches_to_12_bit_annots_late(memo, oracle):
+    """the first annot > 255 arrives after 5 M rows are already on the device in format 4: they are rewritten
+    in format 12 in place (widen_annot_kernel) and the current piece is packed again"""
     rng = np.random.default_rng(5)
     n_rows, length, n_docs = 6_000_000, 900_000, 1000
     s, e, o = _random_index(rng, n_rows, length, n_docs, 70)
@@ -380,8 +387,11 @@ def test_builder_switches_to_16_bit_annots_late(memo, oracle):
         for a in range(0, n_rows, 1_000_000):
             b.push(s[a:a + 1_000_000], e[a:a + 1_000_000], o[a:a + 1_000_000])
         with b.finish() as ix:
-            assert ix.info()["packed_format"] == 6
+            assert ix.info()["packed_format"] == 12
             _check_windows(ix, s, e, o, n_docs, rng, oracle, length, ks=(31, 101), windows=3)
+            with memo.DeviceIndex.from_host(s, e, o) as ref:        # the device's format-12 words are the same words
+                ref.pack()
+                assert all(np.array_equal(x, y) for x, y in zip(_export(ix), _export(ref)))
 
 
 def test_builder_refuses_what_cannot_be_packed(memo, oracle):
@@ -389,6 +399,7 @@ def test_builder_refuses_what_cannot_be_packed(memo, oracle):
     s, e, o = _random_index(rng, 50_000, 20_000, 30, 80)
     bad = {"unsorted": (s[::-1].copy(), e[::-1].copy(), o), "negative start": (s - 30_000, e - 30_000, o),
            "annot 70000": (s, e, np.where(np.arange(len(o)) == 777, 70_000, o)),
+           "annot 5000": (s, e, np.where(np.arange(len(o)) == 777, 5000, o)),
            "negative annot": (s, e, np.where(np.arange(len(o)) == 40_000, -1, o))}
     for name, (bs, be, bo) in bad.items():
         with memo.IndexBuilder(len(bs)) as b:
@@ -400,7 +411,7 @@ def test_builder_refuses_what_cannot_be_packed(memo, oracle):
             continue                                                # (IndexError in the reference: covered elsewhere)
         # the one-shot seam falls back to the int64 way in and still equals the reference's result
         order = np.argsort(bs, kind="stable")
-        n_docs = 30 if name != "negative annot" else 31
+        n_docs = 30 if name not in ("negative annot", "annot 5000") else (31 if name == "negative annot" else 5001)
         qs, qe = (-25_000, -5_000) if name == "negative start" else (1000, 15_000)
         want = oracle.conservation(*oracle.filter_rows(bs[order], be[order], bo[order], qs, qe, 31), qs, qe, 31, n_docs,
                                    literal=False)
@@ -449,7 +460,7 @@ def test_sidecar_cache_round_trip(memo, oracle, tmp_path, monkeypatch):
     from memo_amd import cache, memo_query as mq
     rng = np.random.default_rng(12)
     tabs, cols = [], {}
-    for name, n, n_docs in (("chrA", 400_000, 60), ("chr B/2", 250_000, 700)):         # 4-byte and 6-byte rows
+    for name, n, n_docs in (("chrA", 400_000, 60), ("chr B/2", 250_000, 700)):         # formats 4 and 12
         s, e, o = _random_index(rng, n, 150_000, n_docs, 80)
         neg = rng.random(n) < 0.001
         e[neg] = s[neg] - rng.integers(1, 500, int(neg.sum()))                        # a few rows with end < start
@@ -1050,9 +1061,9 @@ def test_config2_size_numpy_rng_index(memo, oracle):
         assert np.array_equal(ix.membership(4_000_000, 5_000_000, k, n), wantb)
 
 
-def test_config5_shard_packed_6_bytes(memo, oracle):
+def test_config5_shard_packed_rows(memo, oracle):
     """one shard of config 5 (500 genomes, 25 rows per position, 2^25 positions, 8.4e8 rows): packed
-    6-byte rows only (the int64 columns dropped, as an HPRC-scale deployment would), k in {21, 31, 101},
+    4-byte rows with 12-bit annots only (the int64 columns dropped, as an HPRC-scale deployment would), k in {21, 31, 101},
     sampled sub-windows against the oracle + the split-window property"""
     from memo_amd import synth
     n, L = 500, 1 << 25
@@ -1062,8 +1073,8 @@ def test_config5_shard_packed_6_bytes(memo, oracle):
     ix, (r0, r1) = synth.device_index(qs, qe, 101, n, pivot, pack="only")
     with ix:
         inf = ix.info()
-        assert inf["packed_format"] == 6 and inf["has_wide"] == 0 and inf["rows"] == r1 - r0
-        assert inf["device_bytes"] < 7 * (r1 - r0)
+        assert inf["packed_format"] == 12 and inf["has_wide"] == 0 and inf["rows"] == r1 - r0
+        assert inf["device_bytes"] < 5 * (r1 - r0)
         rng = np.random.default_rng(9)
         for k in (21, 31, 101):
             full = ix.conservation(qs, qe, k, n)

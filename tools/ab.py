@@ -68,7 +68,7 @@ def main():
     for v in variants:
         src = v[3] if len(v) > 3 else 0
         brow = 24 if (not a.pack or src == 1) else (3.2 if ix.info()["dense_rows"] and (src == 2 or a.pack == "dense") and a.k <= 64 and not membership
-                                                    else ix.info()['packed_format'])
+                                                    else (6 if ix.info()['packed_format'] == 6 else 4))
         b_alg = brow * (r1 - r0) + (4 * W if membership else (1 if a.u8 else 2)) * L
         t = np.array(times[v])
         print(json.dumps({"variant": v, "workload": a.workload, "k": a.k, "row_bytes": brow, "ms_median": float(np.median(t)),
