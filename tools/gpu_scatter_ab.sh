@@ -10,7 +10,7 @@ for wl in "c3 31 0" "c3 21 0" "c3 101 0" "c3 31 1000000" "c3 31 10000000" "c3 31
 done
 for lib in w8u8 w8u5; do
   echo "== lib $lib c3 k=31 packed u8" >> $OUT/ab.txt
-  MEMO_AMD_LIB=$PWD/memo_amd/libmemo_$lib.so python tools/ab.py --workload c3 --k 31 --pack only --u8 --rounds 12 "0,0,0,0,1" "0,0,0,0,2" 2>>$OUT/err.txt >> $OUT/ab.txt
+  MEMO_AMD_AB_LIB=$PWD/memo_amd/libmemo_$lib.so python tools/ab.py --workload c3 --k 31 --pack only --u8 --rounds 12 "0,0,0,0,1" "0,0,0,0,2" 2>>$OUT/err.txt >> $OUT/ab.txt
 done
 python - <<'PY' $OUT/ab.txt
 import json,sys
