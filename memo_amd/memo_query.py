@@ -312,10 +312,14 @@ def main(args):
     miss = getattr(rows, "cache", None)
     if isinstance(miss, tuple) and mem_arr.rows:          # answered from the Parquet file: leave a cache for next time
         from . import cache
-        if cache.mode() == "sync":
-            cache.build(*miss, device=_device())
-        elif cache.mode() == "on":
-            cache.build_in_background(*miss)
+        try:                                              # the answer is written: a cache that cannot be left
+            if cache.mode() == "sync":                    # (read-only directory, full disk) is not an error
+                cache.build(*miss, device=_device())
+            elif cache.mode() == "on":
+                cache.build_in_background(*miss)
+        except (OSError, RuntimeError) as exc:
+            if os.environ.get("MEMO_TIMING"):
+                sys.stderr.write("memo_query: no sidecar cache written (%s)\n" % exc)
     if os.environ.get("MEMO_TIMING"):          # stderr only: stdout stays the reference's
         sys.stderr.write("memo_query timing: region slice+upload %.3f s%s, sweep+download %.3f s, text+write %.3f s "
                          "(%d rows, %d positions)\n" % (t[1] - t[0], " (from the sidecar cache)" if miss == "hit" else "",
