@@ -317,7 +317,8 @@ struct memo_builder {
 
 namespace {
 
-// rows [i0, i1) of this push -> words (and 16-bit annots) at the same offsets of the slot
+// rows [i0, i1) of this push -> words (format 4 or 12) at the same offsets of the slot; the buckets these
+// rows open get their first row number
 void pack_block(const memo_builder *b, const int64_t *start, const int64_t *end, const int64_t *annot,
                 uint64_t i0, uint64_t i1, uint64_t global0, int64_t prev_start, int64_t prev_bucket,
                 int64_t *boff, int64_t boff_size, uint32_t *pk, int fmt, BlockResult &res) {
@@ -382,10 +383,11 @@ int memo_builder_create(uint64_t max_rows, int32_t device, int32_t bucket_shift,
     b->bshift = bucket_shift;
     b->cap = max_rows;
     b->padded = ((max_rows + 15) & ~(uint64_t)15) + kPadRows;
-    hipError_t err = hipMalloc(&b->d_pk, b->padded * sizeof(uint32_t));
+    const size_t bytes = (size_t)b->padded * sizeof(uint32_t);
+    hipError_t err = hipMalloc(&b->d_pk, bytes);
     if (err != hipSuccess) {
         delete b;
-        return fail(MEMO_EHIP, "hipMalloc of %zu bytes failed: %s", (size_t)(b->padded * 4), hipGetErrorString(err));
+        return fail(MEMO_EHIP, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(err));
     }
     int rc = acquire_ring(device, &b->ring);
     if (rc) {

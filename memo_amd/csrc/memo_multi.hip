@@ -153,6 +153,19 @@ int dev_multi(memo_index_t *const *shards, int32_t n, int64_t qs, int64_t qe, in
     thread_local std::vector<PeerLane> lanes;
     if (lanes.size() < (size_t)n) lanes.resize((size_t)n);
     hipStream_t rs = static_cast<hipStream_t>(root_stream);
+    // whatever the root's stream still has to do with d_out (readers of the previous result) comes first:
+    // the peers' copies into it wait for this point of root_stream
+    thread_local hipEvent_t root_ready[64] = {};
+    hipEvent_t ready = nullptr;
+    if (root_device >= 0 && root_device < 64) {
+        DeviceGuard root(root_device);
+        if (!root.ok) return fail(MEMO_EHIP, "cannot select HIP device %d", root_device);
+        if (!root_ready[root_device]) HIP_TRY(hipEventCreateWithFlags(&root_ready[root_device], hipEventDisableTiming));
+        ready = root_ready[root_device];
+        HIP_TRY(hipEventRecord(ready, rs));
+    } else {
+        return fail(MEMO_EINVAL, "root device %d out of range", root_device);
+    }
     for (int32_t g = 0; g < n; ++g) {
         const int64_t a = cuts[(size_t)g], b = cuts[(size_t)g + 1];
         if (b <= a) continue;
@@ -193,6 +206,7 @@ int dev_multi(memo_index_t *const *shards, int32_t n, int64_t qs, int64_t qe, in
         rc = membership ? memo_query_membership_dev(shards[g], a, b, k, num_docs, (uint32_t *)ln.buf, ln.stream)
                         : memo_query_conservation_dev(shards[g], a, b, k, num_docs, (uint16_t *)ln.buf, ln.stream);
         if (rc) return rc;
+        HIP_TRY(hipStreamWaitEvent(ln.stream, ready, 0));
         HIP_TRY(hipMemcpyPeerAsync(dst, root_device, ln.buf, dev, bytes, ln.stream));
         HIP_TRY(hipEventRecord(ln.done, ln.stream));
         {
