@@ -124,15 +124,17 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);
  * pages.  _export copies the packed rows (rows x uint32; rows x uint16 more when packed_format == 6), the
  * bucket table (info.buckets x int64) and the rows with end < start (3 x info.long_rows int64: starts, ends,
  * annots) into caller buffers.  _import builds a finalized, packed index from such arrays -- or from a SLICE
- * of them: rows [r0, r1) with the table entries of buckets [bucket_base, bucket_base + buckets) rebased to
- * r0 (first entry 0, last entry = rows).  The word layout follows from the arguments as it does in the
+ * of them: rows [row_base, row_base + rows) and, as `boff`, the buckets - 1 table entries of buckets
+ * [bucket_base, bucket_base + buckets - 1) AS THEY ARE in the exported table (absolute row numbers: the first
+ * must equal row_base, the last must not exceed row_base + rows); the library rebases them and appends the entry
+ * pinned to `rows`.  A whole exported index: row_base 0, bucket_base 0, buckets = info.buckets.  The word layout follows from the arguments as it does in the
  * packers: pa != NULL: format 6; else max_annot > 255: format 12; else format 4.  Host memory may be pageable
  * (a memory-mapped file): it goes through the pinned ring. */
 int memo_index_export_packed(memo_index_t *ix, uint32_t *pk, uint16_t *pa, int64_t *boff, int64_t *long_rows);
 int memo_index_import_packed(uint64_t rows, int32_t device, int32_t bucket_shift, int64_t bucket_base,
                              const uint32_t *pk, const uint16_t *pa, const int64_t *boff, uint64_t buckets,
-                             int64_t min_start, int64_t max_start, uint64_t max_annot, const int64_t *long_rows,
-                             uint64_t n_long, memo_index_t **out);
+                             int64_t row_base, int64_t min_start, int64_t max_start, uint64_t max_annot,
+                             const int64_t *long_rows, uint64_t n_long, memo_index_t **out);
 void memo_index_destroy(memo_index_t *ix);
 
 /* ---- packed upload: the fast way in for host rows ------------------------------------------

@@ -1,0 +1,132 @@
+"""`memo query` answered from the sidecar cache with nothing but ctypes.
+
+A repeat query of a cached record needs no Parquet, no Arrow and no NumPy: the packed rows are a memory-mapped
+file (memo_amd/cache.py), the window's slice is two lookups in its bucket table, and everything else happens
+behind the C ABI (memo_index_import_packed, memo_query_*_dev, memo_emit_*).  Importing NumPy alone costs as much
+as all of that together, so this module imports only the standard library and memo_amd._lib; bin/memo tries it
+first and falls back to memo_amd.memo_query.main (same results, same errors) whenever it does not apply: no valid
+cache, k > 256, MEMO_CACHE=0, a sharded run, unparsable arguments.
+
+Same output bytes as the reference's print_res (/root/reference/src/memo_query.py:65-71): the text comes from the
+same C emitters the regular path uses.
+"""
+import ctypes as C
+import json
+import mmap
+import os
+import struct
+import sys
+import time
+
+from . import _lib
+
+VERSION = 1
+HEADER_BYTES = 4096
+MAGIC = b"MEMOPK01"
+
+
+def _cache_path(in_file, record):       # (= memo_amd.cache.cache_path; restated here to keep NumPy out)
+    safe = "".join(ch if (ch.isalnum() or ch in "._-") else "_%02x" % ord(ch) for ch in record) or "_"
+    return os.path.join(in_file + ".memo", safe + ".v%d.pk" % VERSION)
+
+
+def _open(in_file, record):
+    """(header, writable-copy memory map, file size) of a valid cache file, else None"""
+    path = _cache_path(in_file, record)
+    try:
+        st = os.stat(in_file)
+        with open(path, "rb") as fh:
+            raw = fh.read(HEADER_BYTES)
+            if not raw.startswith(MAGIC):
+                return None
+            head = json.loads(raw[len(MAGIC):].rstrip(b"\0"))
+            if head.get("version") != VERSION or head.get("record") != record:
+                return None
+            if head.get("source") != {"size": st.st_size, "mtime_ns": st.st_mtime_ns}:
+                return None
+            if os.fstat(fh.fileno()).st_size != head["bytes"]:
+                return None
+            # ACCESS_COPY: private, copy-on-write -- never written to, but ctypes wants a writable buffer
+            return head, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_COPY)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def try_query(in_file, region, k, num_docs, out_file, membership):
+    """True when the query was answered (out_file written) from the cache; False when this path does not
+    apply and the caller should run the regular one.  Errors of the query itself (the reference's IndexError /
+    ValueError cases) are raised exactly as the regular path raises them."""
+    mode = os.environ.get("MEMO_CACHE", "1").lower()
+    if mode in ("0", "off", "no") or os.environ.get("MEMO_QUERY_WIDE") or os.environ.get("MEMO_FORCE_SHARDED"):
+        return False
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return False
+    try:
+        num_docs, k = int(num_docs), int(k)
+        record, start_end = region.split(":")
+        qs, qe = map(int, start_end.split("-"))
+    except (ValueError, TypeError, AttributeError):
+        return False                              # the regular path raises what the reference raises
+    if not (1 < k <= 256) or not os.path.isfile(in_file):
+        return False
+    t0 = time.perf_counter()
+    got = _open(in_file, record)
+    if got is None:
+        return False
+    head, mm = got
+    lib = _lib.lib()
+    device = int(os.environ.get("MEMO_DEVICE", "0"))
+    nb, shift = head["buckets"], head["bucket_shift"]
+
+    def entry(b):
+        return struct.unpack_from("<q", mm, head["off_boff"] + 8 * b)[0]
+    q_end = qe + k                                # filter_pq's upper bound (memo_query.py:100)
+    b_lo = min(max(qs, 0) >> shift, nb - 1)
+    b_hi = min(max((max(q_end, 0) >> shift) + 1, b_lo), nb - 1)
+    r0, r1 = entry(b_lo), entry(b_hi)
+    n = r1 - r0
+    base = C.addressof(C.c_char.from_buffer(mm))
+    n_long = head["long_rows"]
+    lo = max(b_lo << shift, head["min_start"]) if n else 0
+    hi = min(((b_hi + 1) << shift) - 1, head["max_start"]) if n else -1
+    ix = C.c_void_p()
+    d_out = C.c_void_p()
+    try:
+        _lib.check(lib.memo_index_import_packed(
+            n, device, shift, b_lo, base + head["off_pk"] + 4 * r0,
+            (base + head["off_pa"] + 2 * r0) if head["format"] == 6 else None,
+            base + head["off_boff"] + 8 * b_lo, b_hi - b_lo + 2, r0, lo, hi, head["max_annot"],
+            (base + head["off_long"]) if n_long else None, n_long, C.byref(ix)))
+        t1 = time.perf_counter()
+        L = max(qe - qs, 0)
+        words = (num_docs + 31) // 32
+        host = (C.c_uint32 * (L * words))() if membership else (C.c_uint16 * L)()
+        nbytes = C.sizeof(host)
+        _lib.check(lib.memo_dev_malloc(device, max(nbytes, 16), C.byref(d_out)))
+        fn = lib.memo_query_membership_dev if membership else lib.memo_query_conservation_dev
+        _lib.check(fn(ix, qs, qe, k, num_docs, d_out, None))        # (qe < qs: the reference's ValueError)
+        _lib.check(lib.memo_query_check(ix, None))                  # (annot outside the matrix: its IndexError)
+        _lib.check(lib.memo_dev_download(device, host, d_out, nbytes, None))
+        t2 = time.perf_counter()
+        if membership:
+            need = lib.memo_emit_membership(host, L, num_docs, None, 0)
+        else:
+            need = lib.memo_emit_conservation(host, L, None, 0)
+        text = (C.c_char * max(need, 1))()
+        if membership:
+            lib.memo_emit_membership(host, L, num_docs, text, need)
+        else:
+            lib.memo_emit_conservation(host, L, text, need)
+        with open(out_file, "wb") as fh:
+            fh.write(memoryview(text)[:need])
+        t3 = time.perf_counter()
+    finally:
+        if d_out:
+            lib.memo_dev_free(device, d_out)
+        if ix:
+            lib.memo_index_destroy(ix)
+    if os.environ.get("MEMO_TIMING"):
+        sys.stderr.write("memo_query timing: region slice+upload %.3f s (from the sidecar cache, ctypes-only path), "
+                         "sweep+download %.3f s, text+write %.3f s (%d rows, %d positions)\n"
+                         % (t1 - t0, t2 - t1, t3 - t2, n, L))
+    return True

@@ -61,7 +61,8 @@ SYMBOLS = {
     "memo_index_pack_dense": (C.c_int, [_P, _I32]),
     "memo_index_get_info": (C.c_int, [_P, C.POINTER(IndexInfo)]),
     "memo_index_export_packed": (C.c_int, [_P, _P, _P, _P, _P]),
-    "memo_index_import_packed": (C.c_int, [_U64, _I32, _I32, _I64, _P, _P, _P, _U64, _I64, _I64, _U64, _P, _U64, C.POINTER(_P)]),
+    "memo_index_import_packed": (C.c_int, [_U64, _I32, _I32, _I64, _P, _P, _P, _U64, _I64, _I64, _I64, _U64, _P, _U64,
+                                           C.POINTER(_P)]),
     "memo_index_destroy": (None, [_P]),
     "memo_builder_create": (C.c_int, [_U64, _I32, _I32, C.POINTER(_P)]),
     "memo_builder_push": (C.c_int, [_P, _P, _P, _P, _U64]),

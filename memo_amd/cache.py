@@ -118,25 +118,29 @@ def load_region(in_file, record, query_start, query_end, device=0):
     b_lo = min(max(query_start, 0) >> shift, nb - 1)
     b_hi = min(max((max(query_end, 0) >> shift) + 1, b_lo), nb - 1)
     r0, r1 = int(boff[b_lo]), int(boff[b_hi])
-    # the slice's table: buckets b_lo .. b_hi rebased to r0, then one more entry pinned to its row count
-    table = np.empty(b_hi - b_lo + 2, np.int64)
-    np.subtract(boff[b_lo:b_hi + 1], r0, out=table[:-1])
-    table[-1] = r1 - r0
+    table = boff[b_lo:b_hi + 1]                      # absolute entries: the library rebases them to r0
     pk = mm[head["off_pk"] + 4 * r0:head["off_pk"] + 4 * r1]
     pa = mm[head["off_pa"] + 2 * r0:head["off_pa"] + 2 * r1] if head["format"] == 6 else None
     n_long = head["long_rows"]
     longs = np.array(mm[head["off_long"]:head["off_long"] + 24 * n_long].view(np.int64)) if n_long else None
     h = C.c_void_p()
     n = r1 - r0
-    # min / max start of the slice are only used to tell dense from sparse indexes: the edges of the slice's buckets do
-    lo = max(b_lo << shift, head["min_start"]) if n else 0
-    hi = min(((b_hi + 1) << shift) - 1, head["max_start"]) if n else -1
+    lo, hi = slice_extent(head, b_lo, b_hi, n)
     check(lib().memo_index_import_packed(n, device, shift, b_lo, pk.ctypes.data if n else None,
                                          pa.ctypes.data if (pa is not None and n) else (np.zeros(1, np.uint16).ctypes.data
                                                                                           if pa is not None else None),
-                                         table.ctypes.data, len(table), lo, hi, head["max_annot"],
+                                         table.ctypes.data, len(table) + 1, r0, lo, hi, head["max_annot"],
                                          longs.ctypes.data if n_long else None, n_long, C.byref(h)))
     return DeviceIndex(n, device, _handle=h)
+
+
+def slice_extent(head, b_lo, b_hi, n):
+    """min / max start to give a slice of buckets b_lo .. b_hi (they are only used to tell dense from sparse
+    indexes: the edges of the slice's buckets do)"""
+    shift = head["bucket_shift"]
+    if not n:
+        return 0, -1
+    return max(b_lo << shift, head["min_start"]), min(((b_hi + 1) << shift) - 1, head["max_start"])
 
 
 def build(in_file, record, device=0):

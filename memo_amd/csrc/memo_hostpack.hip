@@ -276,6 +276,14 @@ int upload_pipelined(int device, void *dev, const void *host, size_t bytes) {
 // ------------------------------------------------------------------------------------------
 namespace {
 
+// memo_index_import_packed: the uploaded slice of an absolute bucket table -> this index's table: entries rebased
+// to the slice's first row, one more entry pinned to its row count
+__global__ void rebase_table_kernel(int64_t *boff, uint64_t buckets, int64_t row_base, int64_t rows) {
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i + 1 < buckets) boff[i] -= row_base;
+    else if (i + 1 == buckets) boff[i] = rows;
+}
+
 // rows uploaded in format 4 (8-bit annots) when the first annot > 255 shows up: rewrite them in format 12
 // (start16 | len8 << 16 | annot8 << 24  ->  len8 | start12 << 8 | annot12 << 20)
 __global__ void widen_annot_kernel(uint32_t *pk, uint64_t rows) {
@@ -583,16 +591,18 @@ int memo_index_export_packed(memo_index_t *ix, uint32_t *pk, uint16_t *pa, int64
 
 int memo_index_import_packed(uint64_t rows, int32_t device, int32_t bucket_shift, int64_t bucket_base,
                              const uint32_t *pk, const uint16_t *pa, const int64_t *boff, uint64_t buckets,
-                             int64_t min_start, int64_t max_start, uint64_t max_annot, const int64_t *long_rows,
-                             uint64_t n_long, memo_index_t **out) {
+                             int64_t row_base, int64_t min_start, int64_t max_start, uint64_t max_annot,
+                             const int64_t *long_rows, uint64_t n_long, memo_index_t **out) {
     if (!out) return fail(MEMO_EINVAL, "out is NULL");
     *out = nullptr;
     if (rows > ((uint64_t)1 << 40) || bucket_shift < 1 || bucket_shift > 8 || bucket_base < 0 || buckets < 2 ||
         (rows && !pk) || !boff || (n_long && !long_rows) || n_long > kMaxLongRows || max_annot > 65535)
         return fail(MEMO_EINVAL, "bad packed-index arguments");
-    if (boff[0] != 0 || boff[buckets - 1] != (int64_t)rows)
-        return fail(MEMO_EINVAL, "bucket table does not span the rows (first %lld, last %lld, rows %llu)", (long long)boff[0],
-                    (long long)boff[buckets - 1], (unsigned long long)rows);
+    // boff: buckets - 1 entries of the (absolute) table the rows were cut from; the index's table is those minus
+    // row_base, plus one entry pinned to `rows`
+    if (boff[0] != row_base || boff[buckets - 2] - row_base > (int64_t)rows || boff[buckets - 2] < row_base)
+        return fail(MEMO_EINVAL, "bucket table does not match the rows (first %lld, last %lld, row base %lld, rows %llu)",
+                    (long long)boff[0], (long long)boff[buckets - 2], (long long)row_base, (unsigned long long)rows);
     const int ndev = memo_device_count();
     if (device < 0 || device >= ndev) return fail(MEMO_EHIP, "HIP device %d not available (%d visible)", device, ndev);
     DeviceGuard guard(device);
@@ -636,7 +646,12 @@ int memo_index_import_packed(uint64_t rows, int32_t device, int32_t bucket_shift
         }
         if ((rc = upload_pipelined(device, ix->pk, pk, rows * 4))) break;
         if (pa && (rc = upload_pipelined(device, ix->pa, pa, rows * 2))) break;
-        if ((rc = upload_pipelined(device, ix->boff, boff, buckets * 8))) break;
+        if ((rc = upload_pipelined(device, ix->boff, boff, (buckets - 1) * 8))) break;
+        hipLaunchKernelGGL(rebase_table_kernel, dim3((unsigned)((buckets + 255) / 256)), dim3(256), 0, nullptr, ix->boff,
+                           buckets, row_base, (int64_t)rows);
+        err = hipGetLastError();
+        if (err == hipSuccess) err = hipStreamSynchronize(nullptr);
+        if (err != hipSuccess) rc = fail(MEMO_EHIP, "importing a packed index: %s", hipGetErrorString(err));
     } while (0);
     if (rc) {
         memo_index_destroy(ix);

@@ -49,15 +49,31 @@ while time.time() < t_end:
         e[neg] = s[neg] - rng.integers(1, 2000, int(neg.sum()))
     hi_annot = n_docs if rng.random() < 0.9 else n_docs + 3          # sometimes outside the matrix
     o = rng.integers(0 if rng.random() < 0.1 else 1, max(hi_annot, 2), m).astype(np.int64)
-    with memo_amd.DeviceIndex.from_host(s, e, o, bucket_shift=int(rng.choice([0, 0, 0, 1, 3, 6, 8]))) as ix:
-        packable = not (m and s.min() < 0)
-        if packable and rng.random() < 0.7:
+    bshift = int(rng.choice([0, 0, 0, 1, 3, 6, 8]))
+    packable = not (m and s.min() < 0)
+    # a third of the packable indexes come in the packed, pinned way (memo_builder_*: host packer + bucket table
+    # built on the host), in ragged pieces; the rest as int64 columns
+    via_builder = packable and m > 0 and int(o.max()) <= 4095 and int(o.min()) >= 0 and rng.random() < 0.33
+    if via_builder:
+        cuts = [0] + sorted(int(x) for x in rng.integers(0, m, int(rng.integers(0, 4)))) + [m]
+        with memo_amd.IndexBuilder(m + int(rng.integers(0, 100)), bucket_shift=bshift) as b:
+            for a_, z_ in zip(cuts[:-1], cuts[1:]):
+                b.push(s[a_:z_], e[a_:z_], o[a_:z_])
+            made = b.finish()
+    else:
+        made = memo_amd.DeviceIndex.from_host(s, e, o, bucket_shift=bshift)
+    with made as ix:
+        if via_builder:
+            if ix.info()["packed_format"] == 4 and rng.random() < 0.5:
+                ix.pack_dense(keep_packed=True)
+        elif packable and rng.random() < 0.7:
             ix.pack(keep_wide=True)
             if ix.info()["packed_format"] == 4 and rng.random() < 0.6:
                 ix.pack_dense(keep_packed=True)
         for _ in range(6):
             queries += 1
-            k = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 21, 31, 32, 33, 64, 65, 101, 128, 129, 255, 256, 257, 1000]))
+            k = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 21, 31, 32, 33, 64, 65, 101, 128, 129, 255, 256] +
+                               ([] if via_builder else [257, 1000])))        # (a packed-only index answers k <= 256)
             qs = int(rng.integers(0, length))
             qe = int(rng.integers(qs, length + 200))
             tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096, 1472, 1728])), int(rng.choice([0, 1, 4, 8])),
@@ -79,7 +95,7 @@ while time.time() < t_end:
                 got, gerr = None, IndexError
             ok = werr == gerr and (werr is not None or np.array_equal(got, want))
             if not ok:
-                print("MISMATCH", dict(seed=a.seed, case=cases, n_docs=n_docs, length=length, m=m, mode=mode, k=k, qs=qs, qe=qe,
+                print("MISMATCH", dict(seed=a.seed, case=cases, via_builder=via_builder, n_docs=n_docs, length=length, m=m, mode=mode, k=k, qs=qs, qe=qe,
                                        tune=tune, memb=memb, info=ix.info(), werr=str(werr), gerr=str(gerr)), flush=True)
                 np.savez("/tmp/fuzz_fail.npz", s=s, e=e, o=o)
                 sys.exit(1)

@@ -486,7 +486,32 @@ def test_sidecar_cache_round_trip(memo, oracle, tmp_path, monkeypatch):
         assert text1 == text0 and "sidecar cache" not in err1
         assert os.path.exists(cache.cache_path(path, record))
         text2, err2 = query(record, 1000, 60_000, 31, n_docs, "1")                  # hit
-        assert text2 == text0 and "from the sidecar cache" in err2
+        assert text2 == text0 and "from the sidecar cache, ctypes-only path" in err2
+        text2w, err2w = query(record, 1000, 60_000, 300, n_docs, "1")               # k > 256: not the fast path, not the cache
+        assert "sidecar cache" not in err2w
+        assert text2w == memo.emit_conservation(oracle.conservation(*oracle.filter_rows(s, e, o, 1000, 60_000, 300), 1000,
+                                                                    60_000, 300, n_docs, literal=False))
+        for region, nd in ((f"{record}:500-100", n_docs), (f"{record}:0-150100", 3), (f"{record}:200000-200010", n_docs),
+                           (f"{record}:7-7", n_docs), ("nochr:5-50", n_docs)):      # errors and empty answers: the same
+            got = []                                                                 # from either path
+            for mode in ("0", "read"):
+                out = tmp_path / "out_e.txt"
+                if out.exists():
+                    out.unlink()
+                r = subprocess.run([sys.executable, exe, "query", "-b", path, "-k", "31", "-n", str(nd), "-r", region, "-o",
+                                    str(out)], capture_output=True, env=dict(os.environ, MEMO_CACHE=mode))
+                last = r.stderr.decode().strip().splitlines()[-1:] if r.returncode else []
+                got.append((r.returncode, last, out.read_bytes() if out.exists() else None))
+            assert got[0] == got[1], (region, got)
+        # the fast path imports neither NumPy nor Arrow
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        code = ("import sys; sys.path.insert(0, %r); from memo_amd import _fastquery as f; "
+                "assert f.try_query(%r, %r, '31', %r, %r, False); "
+                "assert 'numpy' not in sys.modules and 'pyarrow' not in sys.modules"
+                % (root, path, f"{record}:1000-60000", str(n_docs), str(tmp_path / "out_f.txt")))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, env=dict(os.environ, MEMO_CACHE="read"))
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        assert (tmp_path / "out_f.txt").read_bytes() == text0
         textm, errm = query(record, 70_000, 71_000, 21, n_docs, "read", ("-m",))    # membership from the cache, too
         assert "from the sidecar cache" in errm
         assert textm == memo.emit_membership(oracle.membership(*oracle.filter_rows(s, e, o, 70_000, 71_000, 21), 70_000,

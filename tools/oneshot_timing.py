@@ -52,7 +52,8 @@ for rep in range(3):
     h = C.c_void_p()
     t = time.perf_counter()
     _lib.check(_lib.lib().memo_index_import_packed(inf["rows"], 0, inf["bucket_shift"], 0, pk.ctypes.data, None, boff.ctypes.data,
-                                                   len(boff), inf["min_start"], inf["max_start"], inf["max_annot"], None, 0, C.byref(h)))
+                                                   len(boff), 0, inf["min_start"], inf["max_start"], inf["max_annot"], None, 0,
+                                                   C.byref(h)))
     dt = time.perf_counter() - t
     _lib.lib().memo_index_destroy(h)
 print(f"import (H2D through the pinned ring, incl. hipMalloc of the index): {(pk.nbytes + boff.nbytes) / 1e9:.2f} GB in "
