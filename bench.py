@@ -396,11 +396,11 @@ def main():
             if which == "wide":                                      # else the clipped "runs"); int64 rows: doubling
                 return "sweep_membership_kernel<" + rows_t + ", ...>"
             return ("sweep_membership_planes_kernel<" if num_docs <= 512 else "sweep_membership_runs_kernel<") + rows_t + ", ...>"
-        # packed rows on an index with >= 1 row per position: the unclipped scatter (memo_sweep_cons.hip)
-        halo = which != "wide" and rows >= L
-        if halo and k - 1 >= 64 and rows < 12 * L:      # (dense indexes keep the doubling arrays at every k)
-            return "sweep_conservation_r4_kernel<" + rows_t + ", ...>"
-        return ("sweep_conservation_halo_kernel<" if halo else "sweep_conservation_kernel<") + rows_t + ", ...>"
+        # the library says which kernel family answered the last conservation query on this index (it picks the
+        # level arrays per query from k and the overlap lengths of the rows: memo_sweep_cons.hip, pick_levels)
+        family = {1: "sweep_conservation_kernel<", 2: "sweep_conservation_halo_kernel<", 3: "sweep_conservation_r4_kernel<",
+                  4: "sweep_conservation_mixed_kernel<"}[indexes[which].info()["last_sweep"]]
+        return family + rows_t + ", ...>"
 
     def per_step(fn, n):
         """n launches with a HIP event pair each -> ms per launch (list)"""

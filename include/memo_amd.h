@@ -71,6 +71,12 @@ typedef struct memo_index_info {
     uint64_t long_rows;     /* rows with end < start, kept aside (see above) */
     uint64_t max_annot;     /* largest annot of the packed rows (valid when packed_format != 0) */
     int64_t bucket_base;    /* the bucket table starts at this bucket (a region slice of memo_index_import_packed) */
+    int32_t last_sweep;     /* which kernel family answered the last conservation query on this index: 0 none yet,
+                               1 clipped scatter into doubling level arrays, 2 unclipped doubling, 3 unclipped
+                               radix-4, 4 unclipped mixed (1, 4, 16, then doubling), 5 dense rows; the library picks
+                               2 / 3 / 4 per query from k and the overlap lengths of the rows it sampled when the
+                               packed rows were made */
+    int32_t reserved;
 } memo_index_info_t;
 
 const char *memo_last_error(void);

@@ -21,8 +21,9 @@ extern "C" {
  * row_source: 1 = read the int64 columns even when packed rows exist, 2 = the dense rows (where they can
  *   answer) even when the 4-byte rows are resident;
  * scatter (conservation, packed rows): 1 = clip every interval to the tile, 2 = unclipped into doubling
- *   level arrays with a halo, 3 = unclipped into radix-4 level arrays (2 and 3 only when every annot of the
- *   index is inside the result matrix, else 1). */
+ *   level arrays with a halo, 3 = unclipped into radix-4 level arrays, 4 = unclipped into mixed level arrays
+ *   (blocks of 1, 4, 16, then doubling; k - 1 >= 16) -- 2, 3 and 4 only when every annot of the index is inside
+ *   the result matrix, else 1. */
 int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32_t membership_algo,
                           int32_t row_source, int32_t scatter);
 /* one pass that reads the three int64 columns exactly once (24 B/row) with the sweep's access

@@ -92,6 +92,13 @@ struct memo_index {
     float pack_ms = 0.f;       // device time of the last memo_index_pack (census + packing kernel)
     uint32_t *p3 = nullptr;    // dense rows (memo_index_pack_dense): 16 bytes per 5 rows; annot <= 255 only
     uint64_t max_annot = 0;    // largest annot of the packed rows
+    // Sampled histogram of the packed rows' overlap field (min(end - start, 255)): with it the length n = k - 1 -
+    // overlap of a row's interval is known in distribution for any k, which is what the choice between the level
+    // arrays of the unclipped conservation sweeps turns on (memo_sweep_cons.hip, pick_levels).  Filled wherever
+    // 4- / 6-byte rows come into being: memo_index_pack, memo_builder_finish, memo_index_import_packed.
+    uint32_t len_hist[256] = {0};
+    uint64_t len_hist_rows = 0;  // rows sampled (0: no histogram)
+    int last_sweep = 0;          // level arrays of the last conservation sweep (memo_index_info_t.last_sweep)
     int has_wide = 1;          // the three int64 columns are still resident
     // rows with end < start (never written by the reference's index builder, but legal input to
     // memo_query.py): copied aside at finalize and applied by long_rows_kernel after each sweep
@@ -100,5 +107,8 @@ struct memo_index {
     int *d_status = nullptr;   // sticky flags set by the sweep kernels
     uint64_t *d_scratch = nullptr;  // finalize(): [0] unsorted pairs, [1] rows with end < start
 };
+
+// fills ix->len_hist from the resident 4- / 6-byte rows (a few thousand 1024-row blocks, evenly spread); NULL stream, synchronous
+int memo_len_census(memo_index *ix);
 
 #endif  // MEMO_COMMON_H

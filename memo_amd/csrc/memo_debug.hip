@@ -39,8 +39,9 @@ int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32
         return fail(MEMO_EINVAL, "membership_algo must be 0 (choose), 2 (doubling), 3 (runs) or 4 (planes)");
     if (row_source < 0 || row_source > 2)
         return fail(MEMO_EINVAL, "row_source must be 0 (library's choice), 1 (int64 columns) or 2 (dense rows where they can answer)");
-    if (scatter < 0 || scatter > 3)
-        return fail(MEMO_EINVAL, "scatter must be 0 (choose), 1 (clipped), 2 (unclipped, doubling levels) or 3 (unclipped, radix-4 levels)");
+    if (scatter < 0 || scatter > 4)
+        return fail(MEMO_EINVAL, "scatter must be 0 (choose), 1 (clipped), 2 (unclipped, doubling levels), 3 (unclipped, radix-4 levels) "
+                                 "or 4 (unclipped, mixed levels)");
     ix->tune.tile_w = tile_w;
     ix->tune.waves = waves;
     ix->tune.memb_algo = membership_algo;

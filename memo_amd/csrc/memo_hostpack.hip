@@ -566,6 +566,10 @@ int memo_builder_finish(memo_builder_t *b, memo_index_t **out) {
     ix->packed_fmt = b->fmt;
     ix->finalized = 1;
     b->failed = MEMO_EINVAL;  // a builder finishes once
+    if (int rc2 = memo_len_census(ix)) {
+        memo_index_destroy(ix);
+        return rc2;
+    }
     *out = ix;
     return MEMO_OK;
 }
@@ -659,6 +663,10 @@ int memo_index_import_packed(uint64_t rows, int32_t device, int32_t bucket_shift
     }
     ix->packed_fmt = pa ? 6 : (max_annot > 255 ? 12 : 4);  // the rule both packers follow: by the largest annot
     ix->finalized = 1;
+    if ((rc = memo_len_census(ix))) {
+        memo_index_destroy(ix);
+        return rc;
+    }
     *out = ix;
     return MEMO_OK;
 }

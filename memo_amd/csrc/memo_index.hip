@@ -491,6 +491,50 @@ int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_so
     return MEMO_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// one workgroup per sampled block of 1024 rows: LDS histogram of the overlap byte, then its non-empty bins to HBM
+__global__ __launch_bounds__(256) void len_census_kernel(const uint32_t *__restrict__ pk, uint64_t rows, int shift,
+                                                         uint64_t step, unsigned int *__restrict__ hist) {
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t r = ((uint64_t)blockIdx.x * step * 256 + threadIdx.x) * 4;
+    if (r < rows) {  // (pk is padded: the 16 bytes are there)
+        const uint4 v = *reinterpret_cast<const uint4 *>(pk + r);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (int i = 0; i < 4; ++i)
+            if (r + i < rows) atomicAdd(&h[(w[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+}  // namespace
+
+int memo_len_census(memo_index *ix) {
+    ix->len_hist_rows = 0;
+    for (unsigned int &c : ix->len_hist) c = 0;
+    if (!ix->pk || !ix->rows || (ix->packed_fmt != 4 && ix->packed_fmt != 6 && ix->packed_fmt != 12)) return MEMO_OK;
+    DeviceGuard guard(ix->device);
+    unsigned int *d_hist = nullptr;
+    HIP_TRY(hipMalloc(&d_hist, sizeof(ix->len_hist)));
+    const uint64_t blocks = (ix->rows + 1023) / 1024, step = blocks / 4096 + 1, grid = (blocks + step - 1) / step;
+    hipError_t err = hipMemsetAsync(d_hist, 0, sizeof(ix->len_hist), nullptr);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(len_census_kernel, dim3((unsigned)grid), dim3(256), 0, nullptr, ix->pk, ix->rows,
+                           ix->packed_fmt == 12 ? 0 : 16, step, d_hist);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpy(ix->len_hist, d_hist, sizeof(ix->len_hist), hipMemcpyDeviceToHost);
+    (void)hipFree(d_hist);
+    if (err != hipSuccess) return fail(MEMO_EHIP, "overlap census: %s", hipGetErrorString(err));
+    for (unsigned int c : ix->len_hist) ix->len_hist_rows += c;
+    return MEMO_OK;
+}
+
+extern "C" {
+
 int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
     if (!ix->finalized) return fail(MEMO_ENOTREADY, "index not finalized");
@@ -547,6 +591,7 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
     HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
     ix->pack_ms = ms;
     ix->packed_fmt = fmt;
+    if (int rc = memo_len_census(ix)) return rc;
     if (!keep_wide) {
         (void)hipFree(ix->s);
         (void)hipFree(ix->e);
@@ -600,6 +645,8 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     info->packed_format = ix->packed_fmt;
     info->has_wide = ix->has_wide;
     info->pack_ms = ix->pack_ms;
+    info->last_sweep = ix->last_sweep;
+    info->reserved = 0;
     info->dense_rows = ix->p3 ? 1 : 0;
     info->long_rows = ix->n_long;
     info->max_annot = ix->max_annot;

@@ -156,22 +156,56 @@ __device__ __forceinline__ void halo_fold_store(const SweepArgs &A, const Tile &
                                       A.nlev > 1 ? lds + (A.nlev - 2) * LS + HL : nullptr, -HL);
 }
 
-// The same folds, in registers.  Every level is read ONCE (one conflict-free ds_read_b128 per lane and
-// level) and the cascade  M_top = L_top,  M_(j-1)[x] = min(L_(j-1)[x], M_j[x], M_j[x - 2^(j-1)])  runs on a
-// lane's four cells with the shifted operand fetched from the lanes to its left (DPP wave_shr for one lane,
-// ds_bpermute -- the LDS crossbar, no bank access -- for more); the result goes straight to the output.  No
-// intermediate level is written back and no barrier separates the passes: at k = 101 the five LDS passes
-// this replaces were 0.11 of 0.63 ms (profiles/r02_ablation.txt).  A wave covers 256 cells of which the
-// leftmost ceil((2^(nlev-1) - 1) / 4) lanes only supply context (their own results would need cells of the
-// previous wave), so consecutive waves overlap by that much.  Needs the tile grid aligned with the output
-// (t.a - qs a multiple of 4: the lanes' cells are aligned in the level arrays); the caller falls back to
-// halo_fold_store otherwise.
 __device__ __forceinline__ uint32_t lane_shr1(uint32_t v) {  // lane l <- lane l - 1 (lane 0: unchanged)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
 }
 
+// The same folds, in registers.  Every level is read ONCE (one conflict-free ds_read_b128 per lane and level) and
+// the cascade  M_top = L_top,  M_(j-1)[x] = min(L_(j-1)[x], M_j[x], M_j[x - 2^(j-1)])  runs on a lane's four cells
+// with the shifted operand taken from the lanes to its left: through the DPP operand of v_min_u32 itself for one
+// lane, through ds_bpermute (the LDS crossbar, no bank access) for more; the result goes straight to the output.
+// No intermediate level is written back and no barrier separates the steps.  A wave covers 256 cells of which the
+// leftmost 2^(nlev-3) lanes only supply context (their own results would need cells of the previous wave), so
+// consecutive waves overlap by that much; wave 0's context lanes hold the first cells of the left halo, whose own
+// results nobody stores and left of which no block can start -- every lane reads real cells, no ds_read is
+// conditional.  Needs the tile grid aligned with the output (t.a - qs a multiple of 4: the lanes' cells are aligned
+// in the level arrays); the caller falls back to halo_fold_store otherwise.
+// History (profiles/r02_fold_in_registers.txt): the compiler's rendering of this fold (lane_shr1() + min3: a copy,
+// a v_mov_dpp and a share of a min3 per shifted operand, all-ones stand-ins for lanes left of the array) took
+// ~100 VALU instructions per wave at k = 31 -- 30 % of a sweep whose VALU is 70 % busy -- and lost to the LDS
+// passes from six levels up; written as below it takes ~40, is 2-5 % of the whole sweep faster at k = 21 / 31,
+// and wins up to seven levels (k = 64: 0.53 -> 0.48 ms; k = 101 / 128 on doubling arrays: -2 / -3 %).
+// M_(j-1)[x] = min(L[x], M_j[x], M_j[x - half]),  half = 2^J cells, on a lane's four cells, IN PLACE (one asm block
+// per step: the compiler, left to itself, computes into fresh registers and copies them back at the join of the
+// wave-uniform branch around the step).  The DPP operations come first -- they read the left lane's M before any
+// lane overwrites it -- and fold their operand into L; s_nop 1: a DPP source written by the instruction before
+// needs two wait states, and the compiler does not see into the string.
+#define MEMO_DPP_MIN(dst, src) "v_min_u32_dpp " dst ", " src ", " dst " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+template <int J>
+__device__ __forceinline__ void fold_step_dpp(uint4 &M, uint4 L, int lane) {
+    if (J >= 3) {
+        const int src = (lane - (1 << (J - 2))) << 2;  // (negative: context lanes, whose result is dropped)
+        const uint32_t sx = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.x), sy = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.y);
+        const uint32_t sz = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.z), sw = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.w);
+        M = make_uint4(min(L.x, min(M.x, sx)), min(L.y, min(M.y, sy)), min(L.z, min(M.z, sz)), min(L.w, min(M.w, sw)));
+    } else if (J == 2) {
+        asm("s_nop 1\n\t" MEMO_DPP_MIN("%4", "%0") MEMO_DPP_MIN("%5", "%1") MEMO_DPP_MIN("%6", "%2") MEMO_DPP_MIN("%7", "%3")
+            "v_min_u32 %0, %4, %0\n\tv_min_u32 %1, %5, %1\n\tv_min_u32 %2, %6, %2\n\tv_min_u32 %3, %7, %3"
+            : "+v"(M.x), "+v"(M.y), "+v"(M.z), "+v"(M.w), "+v"(L.x), "+v"(L.y), "+v"(L.z), "+v"(L.w));
+    } else if (J == 1) {
+        asm("s_nop 1\n\t" MEMO_DPP_MIN("%4", "%2") MEMO_DPP_MIN("%5", "%3")
+            "v_min3_u32 %2, %6, %2, %0\n\tv_min3_u32 %3, %7, %3, %1\n\tv_min_u32 %0, %4, %0\n\tv_min_u32 %1, %5, %1"
+            : "+v"(M.x), "+v"(M.y), "+v"(M.z), "+v"(M.w), "+v"(L.x), "+v"(L.y) : "v"(L.z), "v"(L.w));
+    } else {
+        asm("s_nop 1\n\t" MEMO_DPP_MIN("%4", "%3")
+            "v_min3_u32 %3, %7, %3, %2\n\tv_min3_u32 %2, %6, %2, %1\n\tv_min3_u32 %1, %5, %1, %0\n\tv_min_u32 %0, %4, %0"
+            : "+v"(M.x), "+v"(M.y), "+v"(M.z), "+v"(M.w), "+v"(L.x) : "v"(L.y), "v"(L.z), "v"(L.w));
+    }
+}
+#undef MEMO_DPP_MIN
+
 template <typename OutT, int T, int TOP>
-__device__ __forceinline__ void halo_fold_store_reg(const SweepArgs &A, const Tile &t, const uint32_t *lds) {
+__device__ __forceinline__ void halo_fold_store_dpp(const SweepArgs &A, const Tile &t, const uint32_t *lds) {
     const int LS = A.ls, HL = A.hl, W = A.w, nlev = A.nlev;
     const int cells = HL + W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -181,47 +215,32 @@ __device__ __forceinline__ void halo_fold_store_reg(const SweepArgs &A, const Ti
     OutT *out = static_cast<OutT *>(A.out);
     const int64_t ob = t.a - A.qs - HL;  // output index of cell 0 (a multiple of 4 here)
     const int64_t o_lo = t.a - A.qs + t.x_lo, o_hi = t.a - A.qs + t.x_hi;
-    for (int base = wave * 4 * valid; base < cells; base += NW * 4 * valid) {
-        const int x0 = base + 4 * (lane - ctx);  // this lane's cells x0 .. x0 + 3
-        const bool have = x0 >= 0 && x0 + 4 <= LS;
-        uint4 M = make_uint4(~0u, ~0u, ~0u, ~0u);
-        if (have) M = *reinterpret_cast<const uint4 *>(lds + x0);
-        for (int slot = 1; slot < nlev; ++slot) {
-            const int half = 1 << (nlev - 1 - slot);  // the level being folded in has blocks of `half`
-            uint4 S;  // M shifted right by `half` cells
-            if (half >= 4) {
-                const int lanes = half >> 2;
-                if (lanes == 1) {
-                    S = make_uint4(lane_shr1(M.x), lane_shr1(M.y), lane_shr1(M.z), lane_shr1(M.w));
-                } else {
-                    const int src = (lane - lanes) << 2;  // (negative: context lanes, whose result is dropped)
-                    S.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.x);
-                    S.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.y);
-                    S.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.z);
-                    S.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.w);
-                }
-            } else if (half == 2) {
-                S = make_uint4(lane_shr1(M.z), lane_shr1(M.w), M.x, M.y);
-            } else {
-                S = make_uint4(lane_shr1(M.w), M.x, M.y, M.z);
-            }
-            uint4 L = make_uint4(~0u, ~0u, ~0u, ~0u);
-            if (have) L = *reinterpret_cast<const uint4 *>(lds + slot * LS + x0);
-            M.x = min(L.x, min(M.x, S.x));
-            M.y = min(L.y, min(M.y, S.y));
-            M.z = min(L.z, min(M.z, S.z));
-            M.w = min(L.w, min(M.w, S.w));
-        }
+    for (int base = wave * 4 * valid; base + 4 * ctx < cells; base += NW * 4 * valid) {
+        const int x0 = base + 4 * lane;             // this lane's cells x0 .. x0 + 3
+        const uint32_t *p = lds + min(x0, LS - 4);  // (past the array: lanes whose results are dropped below)
+        uint4 M = *reinterpret_cast<const uint4 *>(p);
+        // blocks of 2^J fold in when that level exists (wave-uniform branches around straight-line steps)
+        if (nlev >= 7) fold_step_dpp<5>(M, *reinterpret_cast<const uint4 *>(p + (nlev - 6) * LS), lane);
+        if (nlev >= 6) fold_step_dpp<4>(M, *reinterpret_cast<const uint4 *>(p + (nlev - 5) * LS), lane);
+        if (nlev >= 5) fold_step_dpp<3>(M, *reinterpret_cast<const uint4 *>(p + (nlev - 4) * LS), lane);
+        if (nlev >= 4) fold_step_dpp<2>(M, *reinterpret_cast<const uint4 *>(p + (nlev - 3) * LS), lane);
+        if (nlev >= 3) fold_step_dpp<1>(M, *reinterpret_cast<const uint4 *>(p + (nlev - 2) * LS), lane);
+        if (nlev >= 2) fold_step_dpp<0>(M, *reinterpret_cast<const uint4 *>(p + (nlev - 1) * LS), lane);
         if (lane < ctx || x0 >= cells) continue;
         const int64_t g = ob + x0;
-        if (TOP) M = make_uint4(M.x >> TOP, M.y >> TOP, M.z >> TOP, M.w >> TOP);
         if (g >= o_lo && g + 4 <= o_hi) {
-            if (sizeof(OutT) == 1)
-                *reinterpret_cast<uint32_t *>(out + g) = M.x | (M.y << 8) | (M.z << 16) | (M.w << 24);
-            else
-                *reinterpret_cast<uint2 *>(out + g) = make_uint2(M.x | (M.y << 16), M.z | (M.w << 16));
+            if (sizeof(OutT) == 1 && TOP == 24) {  // the four top bytes, two v_perm_b32 and an or
+                *reinterpret_cast<uint32_t *>(out + g) = __builtin_amdgcn_perm(M.y, M.x, 0x0c0c0703u) |
+                                                         __builtin_amdgcn_perm(M.w, M.z, 0x07030c0cu);
+            } else {
+                if (TOP) M = make_uint4(M.x >> TOP, M.y >> TOP, M.z >> TOP, M.w >> TOP);
+                if (sizeof(OutT) == 1)
+                    *reinterpret_cast<uint32_t *>(out + g) = M.x | (M.y << 8) | (M.z << 16) | (M.w << 24);
+                else
+                    *reinterpret_cast<uint2 *>(out + g) = make_uint2(M.x | (M.y << 16), M.z | (M.w << 16));
+            }
         } else {
-            const uint32_t v[4] = {M.x, M.y, M.z, M.w};
+            const uint32_t v[4] = {M.x >> TOP, M.y >> TOP, M.z >> TOP, M.w >> TOP};
             for (int i = 0; i < 4; ++i)
                 if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)v[i];
         }
@@ -231,12 +250,13 @@ __device__ __forceinline__ void halo_fold_store_reg(const SweepArgs &A, const Ti
 #ifndef MEMO_FOLD_REG
 #define MEMO_FOLD_REG 1
 #endif
+#ifndef MEMO_FOLD_DPP_LEVELS
+#define MEMO_FOLD_DPP_LEVELS 7  // most levels folded in registers (<= 7: 2^(levels - 3) context lanes per wave)
+#endif
 template <typename OutT, int T, int TOP>
 __device__ __forceinline__ void halo_finish(const SweepArgs &A, const Tile &t, uint32_t *lds) {
-    // A/B on config 3 (profiles/r02_fold_in_registers.txt): -5 % at k = 21 and 31, +1 % at k = 64, +5 % at k = 101
-    // (16 context lanes per wave and twelve ds_bpermute per lane there): registers up to five levels
-    if (MEMO_FOLD_REG && A.nlev <= 5 && ((t.a - A.qs) & 3) == 0)
-        halo_fold_store_reg<OutT, T, TOP>(A, t, lds);
+    if (MEMO_FOLD_REG && A.nlev <= MEMO_FOLD_DPP_LEVELS && ((t.a - A.qs) & 3) == 0)
+        halo_fold_store_dpp<OutT, T, TOP>(A, t, lds);
     else
         halo_fold_store<OutT, T, TOP>(A, t, lds);
 }
@@ -401,13 +421,35 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
 // them, and three fold steps replace six or seven: 64 -> 16 as one LDS pass, 16 -> 4 and 4 -> 1 in registers
 // (DPP shifts only).  Used from k = 65 up; below that the doubling arrays are faster (see the launcher).
 // ------------------------------------------------------------------------------------------
-template <typename OutT, int T, int TOP>
+template <typename OutT, int T, int TOP, bool MIXED = false>
 __device__ __forceinline__ void r4_fold_store(const SweepArgs &A, const Tile &t, uint32_t *lds) {
     const int LS = A.ls, HL = A.hl, W = A.w, m = A.nlev;
     const int cells = HL + W;
-    // levels above 16 fold down through LDS (shifts of 16 cells and more are not a DPP's reach): slot s holds
-    // blocks of 4^(m-1-s); after this loop slot m-3 (blocks of 16) has everything above it folded in
-    for (int slot = 0; slot + 3 < m; ++slot) {
+    // levels above 16 fold down through LDS (shifts of 16 cells and more are not a DPP's reach).
+    // Mixed levels: slot s < m - 3 holds blocks of 16 * 2^(m-3-s); ONE pass takes every one of them into the blocks
+    // of 16 (slot m-3): a block of 16 * 2^e at x covers the blocks of 16 at x, x + 16, ..., x + 16 (2^e - 1).
+    if (MIXED && m > 3) {
+        uint32_t *lo = lds + (m - 3) * LS;
+        for (int x = 4 * threadIdx.x; x < cells; x += 4 * T) {
+            uint4 r = *reinterpret_cast<const uint4 *>(lo + x);
+            for (int slot = m - 4; slot >= 0; --slot) {
+                const uint32_t *hi = lds + slot * LS;
+                const int reach = 16 << (m - 3 - slot);  // the size of this level's blocks
+                for (int back = 0; back < reach && back <= x; back += 16) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(hi + x - back);
+                    r.x = min(r.x, v.x);
+                    r.y = min(r.y, v.y);
+                    r.z = min(r.z, v.z);
+                    r.w = min(r.w, v.w);
+                }
+            }
+            *reinterpret_cast<uint4 *>(lo + x) = r;
+        }
+        lds_barrier();
+    }
+    // Radix-4 levels: slot s holds blocks of 4^(m-1-s); after this loop slot m-3 (blocks of 16) has everything
+    // above it folded in
+    for (int slot = 0; !MIXED && slot + 3 < m; ++slot) {
         const int S = 1 << (2 * (m - 2 - slot));  // size of the blocks being folded INTO (>= 16)
         const uint32_t *hi = lds + slot * LS;
         uint32_t *lo = lds + (slot + 1) * LS;
@@ -427,59 +469,67 @@ __device__ __forceinline__ void r4_fold_store(const SweepArgs &A, const Tile &t,
         }
         lds_barrier();
     }
+    // 16 -> 4 and 4 -> 1 in registers, as in halo_fold_store_dpp: four cells per lane, lane 0 of a wave on cell
+    // `base` (wave 0's context lanes hold the first cells of the left halo), operands from the lanes to the left
+    // through DPP, one in-place asm block per step (s_nop 1: the two wait states a DPP source written by the
+    // instruction before needs).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = T / 64;
     const int ctx = m >= 3 ? 4 : (m == 2 ? 1 : 0);  // context lanes: 15 / 3 / 0 cells to the left
     const int valid = 64 - ctx;
-    const uint32_t *l16 = m >= 3 ? lds + (m - 3) * LS : nullptr;
-    const uint32_t *l4 = m >= 2 ? lds + (m - 2) * LS : nullptr;
-    const uint32_t *l1 = lds + (m - 1) * LS;
     OutT *out = static_cast<OutT *>(A.out);
     const int64_t ob = t.a - A.qs - HL;  // output index of cell 0
     const int64_t o_lo = t.a - A.qs + t.x_lo, o_hi = t.a - A.qs + t.x_hi;
     const bool aligned = (ob & 3) == 0;
-    for (int base = wave * 4 * valid; base < cells; base += NW * 4 * valid) {
-        const int x0 = base + 4 * (lane - ctx);  // this lane's cells x0 .. x0 + 3
-        const bool have = x0 >= 0 && x0 + 4 <= LS;
-        const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
-        uint4 M = none;
-        if (m >= 3) {  // blocks of 16 -> blocks of 4: cells x - 4, x - 8, x - 12 are the same component 1, 2, 3 lanes left
-            if (have) M = *reinterpret_cast<const uint4 *>(l16 + x0);
-            uint4 L = none;
-            if (have) L = *reinterpret_cast<const uint4 *>(l4 + x0);
-            uint4 S1 = make_uint4(lane_shr1(M.x), lane_shr1(M.y), lane_shr1(M.z), lane_shr1(M.w));
-            uint4 S2 = make_uint4(lane_shr1(S1.x), lane_shr1(S1.y), lane_shr1(S1.z), lane_shr1(S1.w));
-            uint4 S3 = make_uint4(lane_shr1(S2.x), lane_shr1(S2.y), lane_shr1(S2.z), lane_shr1(S2.w));
-            M.x = min(min(L.x, M.x), min(S1.x, min(S2.x, S3.x)));
-            M.y = min(min(L.y, M.y), min(S1.y, min(S2.y, S3.y)));
-            M.z = min(min(L.z, M.z), min(S1.z, min(S2.z, S3.z)));
-            M.w = min(min(L.w, M.w), min(S1.w, min(S2.w, S3.w)));
-        } else if (m == 2) {
-            if (have) M = *reinterpret_cast<const uint4 *>(l4 + x0);
-        }
-        uint4 R = none;
-        if (have) R = *reinterpret_cast<const uint4 *>(l1 + x0);
-        if (m >= 2) {  // blocks of 4 -> positions: cells x - 1, x - 2, x - 3
-            const uint32_t p1 = lane_shr1(M.y), p2 = lane_shr1(M.z), p3 = lane_shr1(M.w);  // cells x0 - 3, x0 - 2, x0 - 1
-            R.x = min(min(R.x, M.x), min(p3, min(p2, p1)));
-            R.y = min(min(R.y, M.y), min(M.x, min(p3, p2)));
-            R.z = min(min(R.z, M.z), min(M.y, min(M.x, p3)));
-            R.w = min(min(R.w, M.w), min(M.z, min(M.y, M.x)));
+#define MEMO_DPP_MIN(dst, src) "v_min_u32_dpp " dst ", " src ", " dst " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define MEMO_DPP_MOV(dst, src) "v_mov_b32_dpp " dst ", " src " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    for (int base = wave * 4 * valid; base + 4 * ctx < cells; base += NW * 4 * valid) {
+        const int x0 = base + 4 * lane;             // this lane's cells x0 .. x0 + 3
+        const uint32_t *p = lds + min(x0, LS - 4);  // (past the array: lanes whose results are dropped below)
+        uint4 R = *reinterpret_cast<const uint4 *>(p + (m - 1) * LS);  // blocks of 1
+        if (m >= 2) {
+            uint4 M = *reinterpret_cast<const uint4 *>(p + (m - 2) * LS);  // blocks of 4
+            if (m >= 3) {
+                // blocks of 16 -> blocks of 4: cells x - 4, x - 8, x - 12 are the same component 1, 2, 3 lanes left.
+                // B = min over two lanes in place, P = B one lane left; M = min(M, B, P one more lane left)
+                uint4 B = *reinterpret_cast<const uint4 *>(p + (m - 3) * LS), P;
+                asm("s_nop 1\n\t" MEMO_DPP_MIN("%4", "%4") MEMO_DPP_MIN("%5", "%5") MEMO_DPP_MIN("%6", "%6") MEMO_DPP_MIN("%7", "%7")
+                    MEMO_DPP_MOV("%8", "%4") MEMO_DPP_MOV("%9", "%5") MEMO_DPP_MOV("%10", "%6") MEMO_DPP_MOV("%11", "%7")
+                    "v_min_u32 %0, %4, %0\n\tv_min_u32 %1, %5, %1\n\tv_min_u32 %2, %6, %2\n\tv_min_u32 %3, %7, %3\n\t"
+                    MEMO_DPP_MIN("%0", "%8") MEMO_DPP_MIN("%1", "%9") MEMO_DPP_MIN("%2", "%10") MEMO_DPP_MIN("%3", "%11")
+                    : "+v"(M.x), "+v"(M.y), "+v"(M.z), "+v"(M.w), "+v"(B.x), "+v"(B.y), "+v"(B.z), "+v"(B.w),
+                      "=&v"(P.x), "=&v"(P.y), "=&v"(P.z), "=&v"(P.w));  // (P of lane 0: whatever was there; a context lane)
+            }
+            // blocks of 4 -> positions: cell x takes the blocks at x, x - 1, x - 2, x - 3 (the last ones of the lane to the left)
+            asm("s_nop 1\n\t"
+                "v_min3_u32 %3, %3, %7, %6\n\tv_min3_u32 %3, %3, %5, %4\n\t"
+                "v_min3_u32 %2, %2, %6, %5\n\tv_min_u32 %2, %2, %4\n\t"
+                "v_min3_u32 %1, %1, %5, %4\n\tv_min_u32 %0, %0, %4\n\t"
+                MEMO_DPP_MIN("%2", "%7") MEMO_DPP_MIN("%1", "%7") MEMO_DPP_MIN("%0", "%7")
+                MEMO_DPP_MIN("%1", "%6") MEMO_DPP_MIN("%0", "%6") MEMO_DPP_MIN("%0", "%5")
+                : "+v"(R.x), "+v"(R.y), "+v"(R.z), "+v"(R.w) : "v"(M.x), "v"(M.y), "v"(M.z), "v"(M.w));
         }
         if (lane < ctx || x0 >= cells) continue;
         const int64_t g = ob + x0;
-        if (TOP) R = make_uint4(R.x >> TOP, R.y >> TOP, R.z >> TOP, R.w >> TOP);
         if (aligned && g >= o_lo && g + 4 <= o_hi) {
-            if (sizeof(OutT) == 1)
-                *reinterpret_cast<uint32_t *>(out + g) = R.x | (R.y << 8) | (R.z << 16) | (R.w << 24);
-            else
-                *reinterpret_cast<uint2 *>(out + g) = make_uint2(R.x | (R.y << 16), R.z | (R.w << 16));
+            if (sizeof(OutT) == 1 && TOP == 24) {  // the four top bytes, two v_perm_b32 and an or
+                *reinterpret_cast<uint32_t *>(out + g) = __builtin_amdgcn_perm(R.y, R.x, 0x0c0c0703u) |
+                                                         __builtin_amdgcn_perm(R.w, R.z, 0x07030c0cu);
+            } else {
+                if (TOP) R = make_uint4(R.x >> TOP, R.y >> TOP, R.z >> TOP, R.w >> TOP);
+                if (sizeof(OutT) == 1)
+                    *reinterpret_cast<uint32_t *>(out + g) = R.x | (R.y << 8) | (R.z << 16) | (R.w << 24);
+                else
+                    *reinterpret_cast<uint2 *>(out + g) = make_uint2(R.x | (R.y << 16), R.z | (R.w << 16));
+            }
         } else {  // window edges, and windows that do not start on the tile grid's 4-position raster
-            const uint32_t v[4] = {R.x, R.y, R.z, R.w};
+            const uint32_t v[4] = {R.x >> TOP, R.y >> TOP, R.z >> TOP, R.w >> TOP};
             for (int i = 0; i < 4; ++i)
                 if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)v[i];
         }
     }
+#undef MEMO_DPP_MIN
+#undef MEMO_DPP_MOV
 }
 
 template <typename Rows, int U, int T, typename OutT, int TOP>
@@ -499,38 +549,38 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
     const int km1 = A.km1;
     // LDS byte address of tile slot x on level i (blocks of 4^i):  level0 - i * 4 LS + 4 x
     const uint32_t ls4 = 4u * (uint32_t)LS;
-    const int neg_ls4 = -(int)ls4;
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
-    const uint32_t level0 = pin_vgpr((int)(lds_base + (uint32_t)(A.nlev - 1) * ls4 + 4u * (uint32_t)HL));
+    // level i (blocks of 4^i) sits at level0 - i * 4 LS; with i' = clz(n) >> 1 = 15 - i:  levelK + i' * 4 LS
+    const uint32_t levelK = pin_vgpr((int)(lds_base + (uint32_t)(A.nlev - 1) * ls4 + 4u * (uint32_t)HL - 15u * ls4));
+    const uint32_t top_bit = pin_vgpr((int)0x80000000u);
     const uint32_t key = pin_vgpr((int)Rows::tile_key(t.a));
     auto scatter = [&](uint32_t w, uint32_t col) {
         const int n = km1 - Rows::len(w);  // length of [end - (k-1), start)
         if (n > 0) {
-            // i = floor(log4 n), S = 4^i.  Blocks [start - n, +S) and [start - S, start); r = n - 2S > 0: one more at
-            // start - n + S; r > S: and one at start - n + 2S.  By hand: the compiler's rendering takes 24 VALU
-            // instructions per row, one of them a quarter-rate 32-bit multiply.
+            // i = floor(log4 n), S = 4^i, q = n >> 2i (the leading base-4 digit).  Blocks [start - n, +S) and
+            // [start - S, start); q >= 2: one more at start - n + S; q = 3: and one at start - n + 2S.  By hand: 14 - 16
+            // VALU instructions per row after the length / validity / start triple (the compiler's rendering took 24,
+            // one of them a quarter-rate 32-bit multiply; the first hand-written one 16 - 19).
             const uint32_t data = TOP ? w : col;
             const uint32_t d = Rows::rel_start(w, key);  // start - a
-            uint32_t t31, a1, a2, s4;
-            int r;
+            uint32_t tmp, a1, a2, s4, q;
             asm volatile(
                 "v_ffbh_u32 %0, %5\n\t"
-                "v_sub_u32 %0, 31, %0\n\t"            // floor(log2 n)
-                "v_lshrrev_b32 %1, 1, %0\n\t"         // i
-                "v_mad_i32_i24 %1, %1, %7, %8\n\t"    // level i
-                "v_lshl_add_u32 %2, %6, 2, %1\n\t"    // cell `start` on level i
-                "v_mad_i32_i24 %1, %5, -4, %2\n\t"    // a1: cell start - n
-                "v_and_b32 %0, 30, %0\n\t"            // 2 i
-                "v_lshlrev_b32 %3, %0, 4\n\t"         // 4 S (bytes)
-                "v_sub_u32 %2, %2, %3\n\t"            // a2: cell start - S
+                "v_lshrrev_b32 %0, 1, %0\n\t"        // i' = 15 - i
+                "v_mad_u32_u24 %1, %0, %7, %8\n\t"   // level i
+                "v_lshl_add_u32 %2, %6, 2, %1\n\t"   // cell `start` on level i
+                "v_mad_i32_i24 %1, %5, -4, %2\n\t"   // a1: cell start - n
+                "v_lshl_add_u32 %0, %0, 1, -1\n\t"   // 2 i' - 1 = 29 - 2 i
+                "v_lshrrev_b32 %3, %0, %10\n\t"      // 4 S (bytes) = 2^31 >> (29 - 2 i)
+                "v_sub_u32 %2, %2, %3\n\t"           // a2: cell start - S
                 "ds_min_u32 %1, %9\n\t"
                 "ds_min_u32 %2, %9\n\t"
-                "v_lshrrev_b32 %0, 1, %3\n\t"         // 2 S
-                "v_sub_u32 %4, %5, %0"                // r = n - 2 S
-                : "=&v"(t31), "=&v"(a1), "=&v"(a2), "=&v"(s4), "=&v"(r)
-                : "v"(n), "v"(d), "s"(neg_ls4), "v"(level0), "v"(data)
+                "v_sub_u32 %0, 29, %0\n\t"           // 2 i
+                "v_lshrrev_b32 %4, %0, %5"             // q
+                : "=&v"(tmp), "=&v"(a1), "=&v"(a2), "=&v"(s4), "=&v"(q)
+                : "v"(n), "v"(d), "s"(ls4), "v"(levelK), "v"(data), "v"(top_bit)
                 : "memory");
-            if (r > 0) {
+            if (q >= 2) {
                 uint32_t a3, a4;
                 asm volatile(
                     "v_add_u32 %0, %1, %2\n\t"        // a3 = a1 + 4 S
@@ -538,7 +588,7 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
                     : "=&v"(a3)
                     : "v"(a1), "v"(s4), "v"(data)
                     : "memory");
-                if ((uint32_t)r > (s4 >> 2)) {
+                if (q == 3) {
                     asm volatile(
                         "v_add_u32 %0, %1, %2\n\t"    // a4 = a3 + 4 S
                         "ds_min_u32 %0, %3"
@@ -557,6 +607,82 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
     __syncthreads();
     r4_fold_store<OutT, T, TOP>(A, t, lds);
+}
+
+// ------------------------------------------------------------------------------------------
+// conservation, unclipped, MIXED levels: blocks of 1, 4, 16 and then doubling -- 32, 64, 128.
+//
+// What the radix-4 arrays cost is LDS atomics: an interval of n positions with 2S < n < 4S takes three or four
+// blocks of S, and the sweep's time follows the blocks per row (config 3, profiles/r02_mixed_levels.txt: k = 128,
+// where every interval has 64 <= n < 128 and takes two blocks, 0.39 ms; k = 101, 2.6 blocks per row, 0.515;
+// k = 200, 3.5 blocks, 0.545).  At k >= 65 most intervals are long, and from 16 positions up these arrays go in
+// steps of two: n >= 16 takes the two blocks of 2^floor(log2 n) of the doubling scatter, at its price (ffbh +
+// five instructions after the length / validity / start triple); only n < 16 takes the radix-4 route (blocks of 4
+// or of 1, two to four of them) under a branch that a wave full of long intervals never enters.  Five arrays at
+// k <= 128 and six at k <= 256, where doubling alone needs seven and eight; the fold is r4_fold_store's: the
+// doubling levels into the blocks of 16 in one LDS pass, 16 -> 4 -> 1 in registers.
+// ------------------------------------------------------------------------------------------
+template <typename Rows, int U, int T, typename OutT, int TOP>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
+void sweep_conservation_mixed_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    static_assert(TOP == 0 || (!Rows::kAnnot16 && TOP == Rows::kTopShift), "the order rides in the word only in the 4-byte formats");
+    const int LS = A.ls, HL = A.hl, W = A.w, m = A.nlev;
+    Tile t;
+    if (!locate_tile_w(A, t, W)) return;
+    uint4 V[U];
+    uint2 N[U];
+    Rows::template issue<T, U>(A, t, 0, V, N);
+    const uint32_t sent = (uint32_t)(A.ncols - 1);
+    halo_clear<T>(A, lds, TOP ? (sent << TOP) | ((1u << TOP) - 1u) : sent);
+
+    const int km1 = A.km1;
+    // slot of the blocks of 2^(31-f), f = clz(n) <= 27:  f - fmin, fmin = 30 - m (slot m-3 = blocks of 16 = f 27);
+    // LDS byte address of tile slot x there:  bias4 + f * 4 LS + 4 x
+    const uint32_t ls4 = 4u * (uint32_t)LS;
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
+    const uint32_t bias4 = pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)(30 - m) * ls4));
+    const uint32_t top_bit = pin_vgpr((int)0x80000000u);
+    const uint32_t key = pin_vgpr((int)Rows::tile_key(t.a));
+    uint32_t *const cells4 = lds + (m - 2) * LS + HL, *const cells1 = lds + (m - 1) * LS + HL;
+    auto scatter = [&](uint32_t w, uint32_t col) {
+        const int n = km1 - Rows::len(w);  // length of [end - (k-1), start)
+        if (n > 0) {
+            const uint32_t data = TOP ? w : col;
+            const uint32_t d = Rows::rel_start(w, key);  // start - a
+            const int f = __builtin_clz((unsigned)n);
+            if (f <= 27) {  // n >= 16: blocks [start - n, .. + 2^j) and [start - 2^j, start), j = floor(log2 n)
+                uint32_t r0, r1, r2;
+                asm volatile(
+                    "v_mad_u32_u24 %2, %5, %6, %7\n\t"
+                    "v_lshl_add_u32 %2, %4, 2, %2\n\t"
+                    "v_mad_i32_i24 %1, %3, -4, %2\n\t"
+                    "v_ashrrev_i32 %0, %5, %8\n\t"
+                    "v_lshl_add_u32 %2, %0, 2, %2\n\t"
+                    "ds_min_u32 %1, %9\n\t"
+                    "ds_min_u32 %2, %9"
+                    : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+                    : "v"(n), "v"(d), "v"(f), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(data)
+                    : "memory");
+            } else {  // n < 16: blocks of S = 4 (n >= 4) or 1 at start - n and start - S; two more while n >= 2S, 3S
+                const bool four = n >= 4;
+                uint32_t *lv = (four ? cells4 : cells1) + d;
+                const int S = four ? 4 : 1, q = four ? n >> 2 : n;
+                atomicMin(lv - n, data);
+                atomicMin(lv - S, data);
+                if (q >= 2) atomicMin(lv - n + S, data);
+                if (q == 3) atomicMin(lv - n + 2 * S, data);
+            }
+        }
+    };
+    Rows::template consume<T, U>(A, t, 0, V, N, scatter);
+    for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
+        Rows::template issue<T, U>(A, t, b, V, N);
+        Rows::template consume<T, U>(A, t, b, V, N, scatter);
+    }
+    lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
+    __syncthreads();
+    r4_fold_store<OutT, T, TOP, true>(A, t, lds);
 }
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
@@ -680,6 +806,13 @@ static SweepKernel r4_kernel(int waves) {
                         : (SweepKernel)sweep_conservation_r4_kernel<Rows, kHaloLoads, 64, OutT, TOP>;
 }
 
+template <typename Rows, typename OutT, int TOP>
+static SweepKernel mixed_kernel(int waves) {
+    return waves == 8   ? (SweepKernel)sweep_conservation_mixed_kernel<Rows, kHaloLoads, 512, OutT, TOP>
+           : waves == 4 ? (SweepKernel)sweep_conservation_mixed_kernel<Rows, kHaloLoads, 256, OutT, TOP>
+                        : (SweepKernel)sweep_conservation_mixed_kernel<Rows, kHaloLoads, 64, OutT, TOP>;
+}
+
 template <typename OutT>
 static SweepKernel halo3_kernel(int waves) {
     return waves == 8   ? (SweepKernel)sweep_conservation_halo3_kernel<PackedRows3::kLoads, 512, OutT>
@@ -698,6 +831,34 @@ static int long_rows_conservation(const memo_index *ix, int64_t qs, int64_t qe, 
                            (uint64_t)ix->n_long, qs, qe, k - 1, ncols, d_out, ix->d_status);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
+}
+
+// Which level arrays for the unclipped sweep at k - 1 >= 64: 2 = doubling, 3 = radix-4, 4 = mixed.
+// What separates them is LDS atomics per row against level arrays per tile (profiles/r02_mixed_levels.txt, config 3):
+// every row costs two blocks on doubling and mixed arrays (mixed: when its interval has 16 positions or more), two
+// to four on radix-4 arrays -- 0.39 ms at two blocks per row, +0.14 ms per extra block -- and every array beyond
+// four costs clear, fold and tile length: five arrays +0.03 ms, six +0.1, doubling's seven or eight +0.17 / +0.25.
+// The interval lengths n = k - 1 - overlap are known in distribution from the overlaps sampled when the packed rows
+// were made (memo_index.len_hist), so: many intervals under 16 positions (mixed would keep entering its slow path)
+// -> doubling up to seven levels (k <= 128; its fold runs in registers) and on dense indexes, else radix-4; radix-4
+// within 0.15 blocks per row of two (0.9 where mixed needs six arrays) -> radix-4; else mixed.
+static int pick_levels(const memo_index *ix, int k, bool moderate) {
+    const int km1 = k - 1, fallback = (km1 < 128 || !moderate) ? 2 : 3;
+    if (!ix->len_hist_rows) return fallback;
+    double rows = 0, blocks4 = 0, small = 0;
+    for (int len = 0; len < 256 && len < km1; ++len) {
+        const double w = ix->len_hist[len];
+        const int n = km1 - len;
+        const int i = floor_log2((uint32_t)n) >> 1, q = n >> (2 * i);  // radix-4: blocks of 4^i, leading digit q
+        rows += w;
+        blocks4 += w * (q == 1 ? 2 : q + 1);
+        if (n < 16) small += w;
+    }
+    if (rows <= 0) return fallback;
+    if (small > 0.03 * rows) return fallback;
+    // (six mixed arrays from k = 130 up: on indexes of moderate density radix-4 stays ahead up to ~2.9 blocks per row --
+    // config 3, k = 160: 2.5 blocks, 0.46 against 0.52 ms; k = 200: 3.1 blocks, level)
+    return blocks4 <= (km1 >= 128 && moderate ? 2.9 : 2.15) * rows ? 3 : 4;
 }
 
 template <typename OutT>
@@ -760,7 +921,8 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // position: k = 101 0.89 vs 1.08, k = 256 1.14 vs 1.55 -- where a row's third and fourth block cost more LDS
     // atomics than the fold steps save.
     const bool moderate = (double)ix->rows < 12.0 * span;
-    if (halo && fmt != 3 && (tune.scatter == 3 || (tune.scatter == 0 && k - 1 >= 64 && moderate))) {
+    const int levels = !halo || fmt == 3 ? 0 : tune.scatter >= 2 ? tune.scatter : (k - 1 >= 64 ? pick_levels(ix, k, moderate) : 2);
+    if (levels == 3) {
         const int bw = 1 << ix->bshift;
         const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + bw - 1 + 3) & ~3;
         const int m = (floor_log2((uint32_t)(k - 1)) >> 1) + 1;
@@ -783,6 +945,33 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                                                : r4_kernel<PackedRows<false, false, true>, OutT, 0>(waves))
                                            : r4_kernel<PackedRows<true, false>, OutT, 0>(waves);
             if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)m * A.ls * 4, st))) return rc;
+            ix->last_sweep = 3;
+            return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
+        }
+    }
+    // Mixed levels (sweep_conservation_mixed_kernel): 1, 4, 16, then doubling.  k - 1 >= 16 (three arrays or more).
+    if (levels == 4 && k - 1 >= 16) {
+        const int bw = 1 << ix->bshift;
+        const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + bw - 1 + 3) & ~3;
+        const int m = floor_log2((uint32_t)(k - 1)) - 1;  // blocks of 2^floor(log2(k-1)) .. 16, then 4 and 1
+        int ls = tune.tile_w ? tune.tile_w : (40 * 1024 / (4 * m)) & ~63;
+        if (ls > 8192) ls = 8192;
+        if (fmt == 12 && ls > 4096) ls = 4096;  // (12-bit start field: start - a < array size <= 2^12)
+        while (!tune.tile_w && ls > 640 && (qe - qs) / (ls - hl - hr > bw ? ls - hl - hr : bw) < 4096) ls = (ls / 2) & ~3;
+        const int tw = (ls - hl - hr) / bw * bw;
+        if (tw >= bw && 2 * tw >= hl + hr && (size_t)m * (hl + tw + hr) * 4 <= 160 * 1024) {
+            A.nlev = m;
+            A.hl = hl;
+            A.w = tw;
+            A.ls = hl + tw + hr;
+            waves = tune.waves == 1 || tune.waves == 4 || tune.waves == 8 ? tune.waves : (ls >= 1536 ? 8 : 4);
+            SweepKernel kern = fmt == 4    ? (num_docs <= 255 ? mixed_kernel<PackedRows<false, false>, OutT, 24>(waves)
+                                                              : mixed_kernel<PackedRows<false, false>, OutT, 0>(waves))
+                               : fmt == 12 ? (num_docs <= 4095 ? mixed_kernel<PackedRows<false, false, true>, OutT, 20>(waves)
+                                                               : mixed_kernel<PackedRows<false, false, true>, OutT, 0>(waves))
+                                           : mixed_kernel<PackedRows<true, false>, OutT, 0>(waves);
+            if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)m * A.ls * 4, st))) return rc;
+            ix->last_sweep = 4;
             return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
         }
     }
@@ -822,6 +1011,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                                                : halo_kernel<PackedRows<false, false, true>, OutT, 0>(waves))
                                           : halo_kernel<PackedRows<true, false>, OutT, 0>(waves);
             if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)A.nlev * A.ls * 4, st))) return rc;
+            ix->last_sweep = three ? 5 : 2;
             }
         }
     }
@@ -855,6 +1045,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                       : cons_kernel<WideRows, OutT>(w, waves);
         if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
         if ((rc = launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * A.ls * 4, st))) return rc;
+        ix->last_sweep = 1;
     }
     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
 }

@@ -15,6 +15,14 @@ os.environ.setdefault("MEMO_CACHE", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Load order: the torch wheel bundles its own ROCm runtime, libmemo_amd.so links the system's.  Whichever HIP
+    # runtime a process loads first serves both; with the system's first, torch then finds no GPU ("No HIP GPUs are
+    # available") -- seen when one GPU test module ran alone and its first torch user came after the library.  Same
+    # order as bench.py and the tools: torch first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -1113,6 +1113,39 @@ def test_config5_shard_packed_rows(memo, oracle):
                 assert np.array_equal(ix.conservation(a + 3, b - 11, k, n), want[3:-11])
 
 
+def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
+    """k >= 65, unclipped conservation sweep: the library picks doubling / radix-4 / mixed level arrays from k and the
+    overlap lengths it sampled when the packed rows were made (info.last_sweep says which ran); every choice is
+    bit-exact"""
+    rng = np.random.default_rng(77)
+    n_docs, length, m = 60, 300_000, 1_500_000                     # 5 rows per position: "moderate" density
+    s = np.sort(rng.integers(1, length, m)).astype(np.int64)
+    o = rng.integers(1, n_docs, m).astype(np.int64)
+    cases = {
+        "uniform 0..59": (rng.integers(0, 60, m), {31: 2, 64: 2, 65: 2, 80: 4, 101: 4, 128: 3, 129: 3, 160: 3, 200: 4, 256: 4}),
+        "all 0": (np.zeros(m, np.int64), {65: 3, 101: 3, 200: 4}),   # n = k - 1: one length, radix-4 unless 2S < n
+        "0..250": (rng.integers(0, 251, m), {101: 2, 200: 3, 256: 3}),  # many short intervals: doubling to k = 128, then radix-4
+    }
+    for name, (ov, want_by_k) in cases.items():
+        e = s + ov.astype(np.int64)
+        for way in ("pack", "builder"):
+            if way == "pack":
+                ix = memo.DeviceIndex.from_host(s, e, o)
+                ix.pack(keep_wide=False)
+            else:
+                ix = memo.DeviceIndex.from_host_packed(s, e, o)
+            with ix:
+                # (a window this short would get arrays so small that the k - 1 halo rules the large ones out:
+                # keep the long-window shape; the choice of the levels stays the library's)
+                ix.debug_set_tuning(tile_w=2560, waves=8)
+                for k, want in want_by_k.items():
+                    qs, qe = 1000, 250_000
+                    got = ix.conservation(qs, qe, k, n_docs)
+                    assert ix.info()["last_sweep"] == want, (name, way, k, ix.info()["last_sweep"])
+                    ref = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                    assert np.array_equal(got, ref), (name, way, k)
+
+
 def test_transport_nibble_coding_round_trip(memo):
     """uint8 results -> nibbles + exception list -> uint8, for value mixes with none, few and too
     many values >= 15"""
