@@ -300,3 +300,50 @@ def test_sidecar_cache_file_validation(memo, tmp_path, monkeypatch):
     for v, want in (("0", "off"), ("off", "off"), ("read", "read"), ("sync", "sync"), ("1", "on"), ("", "on")):
         monkeypatch.setenv("MEMO_CACHE", v)
         assert cache.mode() == want
+
+
+def test_fast_query_path_declines_what_it_cannot_answer(tmp_path, monkeypatch):
+    """memo_amd._fastquery (the ctypes-only cache-hit path of `memo query`) keeps the same file rules as memo_amd.cache
+    and answers False -- "take the regular path" -- before it touches the library for everything else: no cache,
+    a stale or foreign one, caching off, k > 256, sharded runs, arguments it cannot parse.  It must not import NumPy."""
+    import json
+    import subprocess
+    import sys
+    from memo_amd import _fastquery as fq, cache
+    assert (fq.VERSION, fq.HEADER_BYTES, fq.MAGIC) == (cache.VERSION, cache.HEADER_BYTES, cache.MAGIC)
+    index = tmp_path / "idx.parquet"
+    index.write_bytes(b"not really parquet")
+    out = str(tmp_path / "out.txt")
+    for record in ("chr1", "chr 1/x", ""):
+        assert fq._cache_path(str(index), record) == cache.cache_path(str(index), record)
+    monkeypatch.setenv("MEMO_CACHE", "read")
+    assert fq.try_query(str(index), "chr1:0-100", "31", "5", out, False) is False          # no cache file
+    path = cache.cache_path(str(index), "chr1")
+    os.makedirs(os.path.dirname(path))
+    st = os.stat(index)
+    good = {"version": cache.VERSION, "record": "chr1", "source": {"size": st.st_size, "mtime_ns": st.st_mtime_ns},
+            "bytes": cache.HEADER_BYTES + 100}
+
+    def write(head):
+        with open(path, "wb") as fh:
+            fh.write((cache.MAGIC + json.dumps(head).encode()).ljust(cache.HEADER_BYTES, b"\0") + b"\0" * 100)
+    write(good)
+    assert fq._open(str(index), "chr1") is not None
+    for bad in (dict(good, version=cache.VERSION + 1), dict(good, record="other"), dict(good, bytes=5),
+                dict(good, source={"size": 1, "mtime_ns": 2})):
+        write(bad)
+        assert fq._open(str(index), "chr1") is None
+        assert fq.try_query(str(index), "chr1:0-100", "31", "5", out, False) is False
+    write(good)
+    for region, k, n in (("chr1", "31", "5"), ("chr1:5", "31", "5"), ("chr1:a-b", "31", "5"), ("chr1:0-100", "300", "5"),
+                         ("chr1:0-100", "1", "5"), ("chr1:0-100", "x", "5"), ("chr1:0-100", "31", "many")):
+        assert fq.try_query(str(index), region, k, n, out, False) is False
+    for var, val in (("MEMO_CACHE", "0"), ("MEMO_QUERY_WIDE", "1"), ("WORLD_SIZE", "2"), ("MEMO_FORCE_SHARDED", "1")):
+        monkeypatch.setenv(var, val)
+        assert fq.try_query(str(index), "chr1:0-100", "31", "5", out, False) is False
+        monkeypatch.delenv(var)
+        monkeypatch.setenv("MEMO_CACHE", "read")
+    assert not os.path.exists(out)
+    code = "import sys; from memo_amd import _fastquery; assert 'numpy' not in sys.modules and 'pyarrow' not in sys.modules"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, "-c", code], cwd=root).returncode == 0
