@@ -156,10 +156,6 @@ __device__ __forceinline__ void halo_fold_store(const SweepArgs &A, const Tile &
                                       A.nlev > 1 ? lds + (A.nlev - 2) * LS + HL : nullptr, -HL);
 }
 
-__device__ __forceinline__ uint32_t lane_shr1(uint32_t v) {  // lane l <- lane l - 1 (lane 0: unchanged)
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-}
-
 // The same folds, in registers.  Every level is read ONCE (one conflict-free ds_read_b128 per lane and level) and
 // the cascade  M_top = L_top,  M_(j-1)[x] = min(L_(j-1)[x], M_j[x], M_j[x - 2^(j-1)])  runs on a lane's four cells
 // with the shifted operand taken from the lanes to its left: through the DPP operand of v_min_u32 itself for one
@@ -183,16 +179,16 @@ __device__ __forceinline__ uint32_t lane_shr1(uint32_t v) {  // lane l <- lane l
 #define MEMO_DPP_MIN(dst, src) "v_min_u32_dpp " dst ", " src ", " dst " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
 template <int J>
 __device__ __forceinline__ void fold_step_dpp(uint4 &M, uint4 L, int lane) {
-    if (J >= 3) {
+    if constexpr (J >= 3) {
         const int src = (lane - (1 << (J - 2))) << 2;  // (negative: context lanes, whose result is dropped)
         const uint32_t sx = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.x), sy = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.y);
         const uint32_t sz = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.z), sw = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.w);
         M = make_uint4(min(L.x, min(M.x, sx)), min(L.y, min(M.y, sy)), min(L.z, min(M.z, sz)), min(L.w, min(M.w, sw)));
-    } else if (J == 2) {
+    } else if constexpr (J == 2) {
         asm("s_nop 1\n\t" MEMO_DPP_MIN("%4", "%0") MEMO_DPP_MIN("%5", "%1") MEMO_DPP_MIN("%6", "%2") MEMO_DPP_MIN("%7", "%3")
             "v_min_u32 %0, %4, %0\n\tv_min_u32 %1, %5, %1\n\tv_min_u32 %2, %6, %2\n\tv_min_u32 %3, %7, %3"
             : "+v"(M.x), "+v"(M.y), "+v"(M.z), "+v"(M.w), "+v"(L.x), "+v"(L.y), "+v"(L.z), "+v"(L.w));
-    } else if (J == 1) {
+    } else if constexpr (J == 1) {
         asm("s_nop 1\n\t" MEMO_DPP_MIN("%4", "%2") MEMO_DPP_MIN("%5", "%3")
             "v_min3_u32 %2, %6, %2, %0\n\tv_min3_u32 %3, %7, %3, %1\n\tv_min_u32 %0, %4, %0\n\tv_min_u32 %1, %5, %1"
             : "+v"(M.x), "+v"(M.y), "+v"(M.z), "+v"(M.w), "+v"(L.x), "+v"(L.y) : "v"(L.z), "v"(L.w));
