@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--rows", default="auto", choices=["auto", "dense", "packed", "wide"],
                     help="row format the timed sweep reads: dense (memo_index_pack_dense, 3 B/row: conservation, "
                          "k <= 64, num_docs <= 255), packed (memo_index_pack, 4-6 B/row), or the int64 columns as "
-                         "uploaded (24 B/row); auto = the fastest that can answer (packed for k <= 256); at N=1 the "
+                         "uploaded (24 B/row); auto = the fastest that can answer (dense where they can, else packed for k <= 256); at N=1 the "
                          "others are timed too")
     ap.add_argument("--plain-gather", action="store_true",
                     help="N > 1: send uint8 slices as they are (default: the densest transport coding that fits)")
@@ -164,8 +164,8 @@ def main():
         _lib.use_ab(True)                   # the PMC calibration kernel lives in libmemo_amd_ab.so only
     # the dense rows answer the unclipped conservation sweep only: k <= 64, num_docs <= 255, >= 1 row per position
     can_dense = (not membership) and k - 1 <= 63 and num_docs <= 255 and not args.wide and num_docs >= 20
-    if args.rows == "auto":
-        args.rows = "wide" if k - 1 > 255 else "packed"      # (dense rows are smaller, not faster: DESIGN.md)
+    if args.rows == "auto":     # the fastest format that can answer: dense rows (back to back they are 13 % ahead of the
+        args.rows = "wide" if k - 1 > 255 else ("dense" if can_dense else "packed")     # 4-byte rows: DESIGN.md section 7)
     if args.rows == "dense" and not can_dense:
         raise SystemExit("--rows dense answers conservation with k <= 64 and num_docs <= 255 only")
     if k - 1 > 255:
@@ -417,11 +417,24 @@ def main():
 
     # (1) the same query on the OTHER row format, for the record -- and first, so that the headline's
     # timed region does not sit in the clock ramp of a cold device (the driver runs --steps 20 --warmup 5)
+    def settle(fn):
+        """untimed launches until the device has settled on this kernel -- a change of kernels sets off a swing of the
+        clocks (the sweep runs at the 1400 W power cap: fast for a few launches, then slower than its steady state,
+        then back over some thirty launches; profiles/r02_dense_rows_ab.txt): batches of 20 until two in a row are
+        within 1 % of the one before them; at least 5 batches, at most 1.5 s of them"""
+        prev, calm, n, t_ramp = None, 0, 0, time.perf_counter()
+        while True:
+            cur = float(np.mean(per_step(fn, 20)))
+            n += 20
+            calm = calm + 1 if prev is not None and abs(cur - prev) <= 0.01 * prev else 0
+            prev = cur
+            if (calm >= 2 and n >= 100) or time.perf_counter() - t_ramp > 1.5:
+                return {"launches": n, "ms": (time.perf_counter() - t_ramp) * 1e3}
+
     other = []
     for which in formats[1:]:
         ob = fmt_bytes[which]
-        for i in range(max(args.warmup, 5)):
-            launch(outs[0], indexes[which])
+        settle(lambda: launch(outs[0], indexes[which]))
         ms2 = per_step(lambda: launch(outs[0], indexes[which]), max(args.steps, 20))
         indexes[which].check(stream.cuda_stream)
         alg2 = ob * rows + b_out * L
@@ -431,19 +444,8 @@ def main():
                       "query_positions_per_s": L / (med2 * 1e-3), "algorithmic_bytes": alg2,
                       "achieved_GBs": alg2 / (med2 * 1e-3) / 1e9, "frac": alg2 / (med2 * 1e-3) / 1e9 / HBM_PEAK_GBS})
 
-    # (2) clock ramp: headline launches, untimed, until a batch of 20 is no faster than the one before
-    # (within 1 %) -- at least 3 batches, at most 1.5 s of them
-    ramp = {"launches": 0, "ms": 0.0}
-    if not multi:
-        prev, t_ramp = None, time.perf_counter()
-        while True:
-            cur = float(np.mean(per_step(lambda: launch(outs[0]), 20)))
-            ramp["launches"] += 20
-            done = prev is not None and ramp["launches"] >= 60 and cur > prev * 0.99
-            prev = cur
-            if done or time.perf_counter() - t_ramp > 1.5:
-                break
-        ramp["ms"] = (time.perf_counter() - t_ramp) * 1e3
+    # (2) settling on the headline kernel (see settle())
+    ramp = settle(lambda: launch(outs[0])) if not multi else {"launches": 0, "ms": 0.0}
 
     for i in range(args.warmup):
         step(i)
@@ -507,8 +509,8 @@ def main():
                                           "order) built once per index by memo_index_pack + memo_index_pack_dense",
                        "row_bytes": row_bytes, "result_bytes_per_position": b_out,
                        "row_format_pass": pack_pass, "dense_format_pass": dense_pass,
-                       "clock_ramp": {"what": "untimed headline launches before the warm-up steps, until a batch "
-                                              "of 20 is no faster than the one before", **ramp},
+                       "clock_ramp": {"what": "untimed headline launches before the warm-up steps, in batches of 20 until two "
+                                              "batches in a row are within 1 % of the one before them", **ramp},
                        "sharding": f"window split into {world} contiguous sub-windows, slices gathered to rank 0 "
                                    f"over RCCL (double-buffered: gather i overlaps sweep i+1); rank 0 sweeps "
                                    f"{root_weight:g} of a share ({positions_per_step} positions per step in all)"

@@ -115,13 +115,13 @@ int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_so
  * columns (an HPRC-scale shard is 37 GB packed against 225 GB as int64); such an index answers
  * k <= 256 only and cannot be re-uploaded.  Needs 0 <= annot <= 65535 on every row. */
 int memo_index_pack(memo_index_t *ix, int32_t keep_wide);
-/* A denser copy of the packed rows, for HBM capacity: 24 bits per row, five rows per 16 bytes (3.2 B per row),
+/* A denser copy of the packed rows: 24 bits per row, five rows per 16 bytes (3.2 B per row),
  *     (start mod 2^10) << 6 | min(end - start, 63)   +   annot (8 bits)
- * Exact for k <= 64 on the unclipped conservation sweep (level arrays of <= 1024 cells, num_docs <= 255).
- * Not faster: its kernel is bound by what it executes per row, not by the bytes it loads (0.39 ms against
- * 0.38 on BASELINE config 3 although its memory floor is 0.30), so queries read the 4-byte rows while those
- * are resident.  Needs memo_index_pack first and every annot <= 255.  keep_packed == 0 frees the 4-byte rows:
- * such an index holds 3.2 B per row and answers only what the dense rows (or, if still resident, the int64
+ * Exact for k <= 64 on the unclipped conservation sweep (level arrays of <= 1024 cells, num_docs <= 255), and its
+ * fastest source: conservation queries read these rows wherever they are resident and can answer (BASELINE
+ * config 3, launches back to back: 0.324 ms against 0.374 on the 4-byte rows at k = 31).  Membership and k > 64
+ * need the 4-byte rows.  Needs memo_index_pack first and every annot <= 255.  keep_packed == 0 frees the 4-byte
+ * rows: such an index holds 3.2 B per row and answers only what the dense rows (or, if still resident, the int64
  * columns) can. */
 int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed);
 int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);

@@ -18,8 +18,9 @@ extern "C" {
  * waves: 1 or 4 waves share a tile (8: the unclipped conservation kernel only);
  * membership_algo: 2 = doubling, 3 = runs (clipped bit planes per genome + register transpose),
  *   4 = planes (unclipped, result staged through LDS; packed rows, <= 512 genomes; else 3);
- * row_source: 1 = read the int64 columns even when packed rows exist, 2 = the dense rows (where they can
- *   answer) even when the 4-byte rows are resident;
+ * row_source: 0 = the library's choice (conservation: the dense rows where they are resident and can answer,
+ *   else the 4- / 6-byte rows, else the int64 columns), 1 = the int64 columns even when packed rows exist,
+ *   2 = same as 0 (kept for older scripts), 3 = the 4- / 6-byte rows even where the dense rows could answer;
  * scatter (conservation, packed rows): 1 = clip every interval to the tile, 2 = unclipped into doubling
  *   level arrays with a halo, 3 = unclipped into radix-4 level arrays, 4 = unclipped into mixed level arrays
  *   (blocks of 1, 4, 16, then doubling; k - 1 >= 16) -- 2, 3 and 4 only when every annot of the index is inside

@@ -66,7 +66,8 @@ struct memo_tuning {
     int memb_algo = 0;   // membership: 2 = doubling, 3 = runs, 4 = planes
     int force_wide = 0;  // 1 = read the int64 columns even when packed rows exist
     int scatter = 0;     // conservation, packed rows: 1 = clipped, 2 = unclipped + halo
-    int force_dense = 0;  // 1 = read the dense rows when they can answer, even with the 4-byte rows resident
+    int force_packed = 0;  // 1 = read the 4-byte rows even when the dense rows are resident and could answer (they are
+                           //     the faster source for the conservation sweep: profiles/r02_dense_rows_ab.txt)
 };
 
 // one chromosome's rows, resident in HBM (the opaque memo_index_t of the ABI)

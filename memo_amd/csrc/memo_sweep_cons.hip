@@ -337,11 +337,12 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
 // The same sweep on the dense rows (PackedRows3: five rows per 16 bytes; k - 1 <= 63, level arrays of at most
 // 1024 cells).  Per row: 16-bit subtract (start - a, length untouched below it), and, subtract, compare | ffbh,
 // bfe, mad, lshl_add, mad, ashr, lshl_add, (shift of the order byte for four rows of five), ds_min x 2.
-// Where it stands (profiles/r02_dense_rows_ab.txt): the 4-byte kernel runs at its memory floor (rows loaded and
-// dropped 0.374 ms, whole kernel 0.383); this kernel's floor is 0.304 ms but the whole kernel takes 0.39 -- with
-// 24 % fewer bytes it is bound by what it executes per row, not by what it loads.  Moving the arithmetic out of
-// the row loop into a per-tile table indexed by the length (64 entries of two LDS offsets: 4 VALU per row
-// fewer, one ds_read_b64 more) made it slower still (0.46 ms: every row then waits for an LDS round trip).
+// Where it stands (profiles/r02_dense_rows_ab.txt): back to back -- the device settled at its power cap -- this kernel
+// takes 0.324 ms on config 3 where the 4-byte kernel takes 0.374 (another device: 0.331 against 0.343): 19 % fewer bytes,
+// 13 % less time; what keeps it from the full 19 % is the power cap (1370 W of 1400 at 2.2 GHz; the 4-byte kernel
+// runs at 2.36 GHz), i.e. what it executes per row.  Moving the arithmetic out of the row loop into a per-tile table
+// indexed by the length (64 entries of two LDS offsets: 4 VALU per row fewer, one ds_read_b64 more) made it slower
+// (0.46 ms: every row then waits for an LDS round trip).
 template <int U, int T, typename OutT>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
 void sweep_conservation_halo3_kernel(const SweepArgs A) {
@@ -990,13 +991,15 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.ls = hl + tw + hr;
             if (tune.waves == 0) waves = w >= 2048 ? 8 : (w >= 1024 ? 4 : 1);
             if (tune.waves == 8) waves = 8;
-            // 4- / 6-byte rows when they are resident: the dense rows load a fifth fewer bytes but take three
-            // more instructions per row, and the sweep is bound by the latter (profiles/r02_dense_rows_ab.txt:
-            // 0.39 ms against 0.383 on config 3 although their memory floor is 0.304).  They answer when the
-            // index kept nothing else (k - 1 <= 63, level arrays within 2^10 cells, num_docs <= 255): what
-            // they buy is HBM capacity, 3.2 B per row.
+            // The dense rows where they are resident and can answer (k - 1 <= 63, level arrays within 2^10 cells,
+            // num_docs <= 255): a fifth fewer bytes for three more instructions per row.  Back to back -- thousands
+            // of launches, the device settled at its power cap (1345-1375 W of 1400) -- they are 13 % faster at
+            // k = 21 / 31 and 4-7 % at k = 48 / 64 (config 3: 0.324 against 0.374 ms on one device;
+            // profiles/r02_dense_rows_ab.txt).  Short interleaved timings had shown them level: a switch of kernels
+            // sets off a swing of the clocks that lasts some thirty launches, and the dense kernel, which draws more
+            // power per unit of time, sits on the cap at a lower clock (2.2 against 2.36 GHz).
             const bool top8 = num_docs <= 255;
-            const bool three = ix->p3 && (!ix->pk || tune.force_dense) && k - 1 <= 63 && A.ls <= 1024 && top8;
+            const bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && top8;
             if (!three && fmt == 3) {
                 halo = false;  // (below: the int64 columns, or an error when they are gone too)
             } else {

@@ -77,7 +77,7 @@ while time.time() < t_end:
             qs = int(rng.integers(0, length))
             qe = int(rng.integers(qs, length + 200))
             tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096, 1472, 1728])), int(rng.choice([0, 1, 4, 8])),
-                    int(rng.choice([0, 2, 3, 4])), int(rng.integers(0, 3)), int(rng.integers(0, 5)))
+                    int(rng.choice([0, 2, 3, 4])), int(rng.integers(0, 4)), int(rng.integers(0, 5)))
             ix.debug_set_tuning(*tune)
             memb = rng.random() < 0.4
             if memb and (qe - qs) * n_docs > 30_000_000:

@@ -251,14 +251,19 @@ def test_dense_rows_equal_packed_rows(n_docs, bucket_shift, keep_packed, keep_wi
                 qs = int(rng.integers(0, length // 2))
                 qe = int(rng.integers(qs + 1, length + 100))
                 want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
-                for source in (0, 2):                   # the library's choice / the dense rows wherever they can answer
+                for source in (0, 3):                   # the library's choice (dense where they can answer) / the 4-byte rows
                     ix.debug_set_tuning(tile_w, waves, 0, source, 0)
-                    answerable = keep_packed or keep_wide or (k <= 64 and n_docs <= 255 and tile_w in (0, 1024, 512))
+                    dense_can = k <= 64 and n_docs <= 255 and tile_w in (0, 1024, 512)
+                    answerable = keep_packed or keep_wide or dense_can
                     if not answerable:
                         with pytest.raises(memo.MemoError):
                             ix.conservation(qs, qe, k, n_docs)
                         continue
                     assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (k, qs, qe, tile_w, source)
+                    if keep_packed or dense_can:
+                        # which rows answered: the dense ones wherever they can, unless the 4-byte rows were asked for
+                        took_dense = ix.info()["last_sweep"] == 5
+                        assert took_dense == (dense_can and not (source == 3 and keep_packed)), (k, tile_w, source)
                     if n_docs <= 255:
                         assert np.array_equal(ix.conservation(qs, qe, k, n_docs, dtype=np.uint8), want.astype(np.uint8)), \
                             (k, qs, qe, tile_w, source)

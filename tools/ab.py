@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--density", default="5/100", help="rows per genome and position")
     ap.add_argument("--pack", default=None, choices=[None, "keep", "only", "dense", "both"],
                     help="keep: int64 + 4-byte rows; only: 4-byte rows; dense: dense rows only; both: 4- and dense rows "
-                         "(row_source 2 in a variant then selects the dense ones)")
+                         "(the library reads the dense ones where they can answer; row_source 3 in a variant selects the 4-byte rows)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     num_docs, L, membership = WORKLOADS[a.workload]

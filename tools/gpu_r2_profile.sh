@@ -10,6 +10,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_summary.py c3_packed $OUT/pmc "sweep_conservation_halo_kernel" r02 > $OUT/traffic_packed.txt 2>&1; tail -12 $OUT/traffic_packed.txt
 python tools/pmc_summary.py c3_wide $OUT/pmc "sweep_conservation_kernel" r02 > $OUT/traffic_wide.txt 2>&1
+python tools/pmc_summary.py c3_dense $OUT/pmc "sweep_conservation_halo3_kernel" r02 > $OUT/traffic_dense.txt 2>&1
 cp profiles/traffic.json $OUT/traffic.json
 for wl in "c2 31" "c4 31" "c5 31" "c3 21" "c3 101" "c3 256" "c5 101" "c4 101"; do read -r w k <<< "$wl"
   timeout 400 python bench.py --workload $w --k $k --steps 100 --warmup 20 --cpu-sample 0 2>>$OUT/bench.err >> $OUT/workloads.jsonl
