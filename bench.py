@@ -508,6 +508,11 @@ def main():
                                      else "3.2 B/row (five 24-bit rows per 16 bytes: start mod 2^10, length saturated at 63, 8-bit "
                                           "order) built once per index by memo_index_pack + memo_index_pack_dense",
                        "row_bytes": row_bytes, "result_bytes_per_position": b_out,
+                       "row_format_choice": "--rows auto = the format that answers this query fastest: the dense rows where they "
+                                            "can (conservation, k <= 64, num_docs <= 255), else the 4- / 6-byte rows (k <= 256), "
+                                            "else int64.  roofline is priced on the bytes of the format read (fewer bytes per row "
+                                            "lower `frac` at the same speed); the other resident formats are timed in "
+                                            "other_row_formats",
                        "row_format_pass": pack_pass, "dense_format_pass": dense_pass,
                        "clock_ramp": {"what": "untimed headline launches before the warm-up steps, in batches of 20 until two "
                                               "batches in a row are within 1 % of the one before them", **ramp},
