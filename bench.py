@@ -69,6 +69,8 @@ def parse():
                          "others are timed too")
     ap.add_argument("--plain-gather", action="store_true",
                     help="N > 1: send uint8 slices as they are (default: the densest transport coding that fits)")
+    ap.add_argument("--coding", default=None, choices=["runs", "dense", "nibble", "plain"],
+                    help="N > 1: this transport coding instead of the one the step model picks (if the slices fit it)")
     ap.add_argument("--code-own-slice", action="store_true",
                     help="N > 1: rank 0 packs and unpacks its own slice too (exercises the coded path on one GPU)")
     ap.add_argument("--nibble-gather", action="store_true",
@@ -241,9 +243,9 @@ def main():
             ix.conservation_dev(qs, qe_mine, k, num_docs, out, stream.cuda_stream)
 
     # What travels to rank 0.  A slice's own xGMI link is what bounds N > 1, so uint8
-    # conservation slices go in a lossless transport coding: "dense" (2 bits per position + a nibble per
-    # value outside 1..3, memo_transport_dense_*), "nibble" (one nibble per position, memo_transport_*), or
-    # plain bytes.  Every rank sizes the codings on its own first result (the same query runs every
+    # conservation slices go in a lossless transport coding: "runs" (one bit per position + a byte per change of
+    # value, memo_transport_runs_*), "dense" (2 bits per position + a nibble per value outside 1..3,
+    # memo_transport_dense_*), "nibble" (one nibble per position, memo_transport_*), or plain bytes.  Every rank sizes the codings on its own first result (the same query runs every
     # step); a coding is usable when every rank's slice fits it.  Fewer bytes is not all: rank 0 decodes
     # world - 1 slices per step, so among the usable codings it takes the one whose modelled step
     #     max(sweep + encode [a peer], sweep + (world - 1) * decode of one slice [rank 0],
@@ -299,6 +301,20 @@ def main():
             tp = timed(lambda: _lib.check(lib.memo_transport_pack_dev(
                 outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream)))
             usable["nibble"] = (lib.memo_transport_bytes(L, nibble_cap), t, tp)
+        # runs: one bit per position + one byte per change of value
+        trial_r = (L + 4 * (L // 32768 + 1) + 3) & ~3                      # every position a change
+        probe = torch.empty(lib.memo_transport_runs_bytes(L, trial_r), dtype=torch.uint8, device=dev)
+        _lib.check(lib.memo_transport_runs_pack_dev(outs[0].data_ptr(), L, trial_r, probe.data_ptr(), local, stream.cuda_stream))
+        _lib.check(lib.memo_transport_runs_stats(probe.data_ptr(), local, stream.cuda_stream, C.byref(taken), C.byref(room)))
+        need = torch.tensor([taken.value], dtype=torch.int64, device=dev)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        runs_cap = (int(need.item()) + int(need.item()) // 16 + 4096 + 3) & ~3       # what the ranks needed + slack
+        if not args.nibble_gather:
+            t = timed(lambda: _lib.check(lib.memo_transport_runs_unpack_dev(
+                probe.data_ptr(), L, trial_r, scratch.data_ptr(), local, stream.cuda_stream)))
+            tp = timed(lambda: _lib.check(lib.memo_transport_runs_pack_dev(
+                outs[0].data_ptr(), L, trial_r, probe.data_ptr(), local, stream.cuda_stream)))
+            usable["runs"] = (lib.memo_transport_runs_bytes(L, runs_cap), t, tp)
         del probe, scratch
         best, model = shard.pick_coding(world, t_sweep, usable)
         w_best = 1.0
@@ -306,6 +322,8 @@ def main():
             best, w_best, _ = shard.pick_plan(world, t_sweep, usable)
         else:
             w_best = min(max(float(args.root_weight), 0.01), 1.0)
+        if args.coding in usable:
+            best = args.coding
         names = sorted(usable)
         pick = torch.tensor([names.index(best), int(round(w_best * 1000))], device=dev)
         dist.broadcast(pick, src=0)                                        # rank 0's timings decide for everybody
@@ -315,6 +333,8 @@ def main():
             cap = dense_cap
         elif coding == "nibble":
             cap = nibble_cap
+        elif coding == "runs":
+            b_cap = runs_cap
         choice = {"picked": coding, "root_weight": root_weight, "sweep_ms": t_sweep * 1e3,
                   "link_bytes_per_s_assumed": shard.XGMI_LINK_BYTES_PER_S,
                   "candidates": {c: {"wire_bytes": int(usable[c][0]), "decode_ms_per_slice": usable[c][1] * 1e3, "encode_ms": usable[c][2] * 1e3,
@@ -328,20 +348,26 @@ def main():
     positions_per_step = L * (world - 1) + (max(8, int(L * root_weight) // 8 * 8) if multi else L)
 
     def pack(src, wire):
-        if coding == "dense":
+        if coding == "runs":
+            _lib.check(lib.memo_transport_runs_pack_dev(src.data_ptr(), L, b_cap, wire.data_ptr(), local, stream.cuda_stream))
+        elif coding == "dense":
             _lib.check(lib.memo_transport_dense_pack_dev(src.data_ptr(), L, b_cap, cap, wire.data_ptr(), local,
                                                          stream.cuda_stream))
         else:
             _lib.check(lib.memo_transport_pack_dev(src.data_ptr(), L, cap, wire.data_ptr(), local, stream.cuda_stream))
 
     def unpack(wire, dst):
-        if coding == "dense":
+        if coding == "runs":
+            _lib.check(lib.memo_transport_runs_unpack_dev(wire.data_ptr(), L, b_cap, dst.data_ptr(), local, stream.cuda_stream))
+        elif coding == "dense":
             _lib.check(lib.memo_transport_dense_unpack_dev(wire.data_ptr(), L, b_cap, cap, dst.data_ptr(), local,
                                                            stream.cuda_stream))
         else:
             _lib.check(lib.memo_transport_unpack_dev(wire.data_ptr(), L, dst.data_ptr(), local, stream.cuda_stream))
 
-    if coding == "dense":
+    if coding == "runs":
+        wires = [torch.empty(lib.memo_transport_runs_bytes(L, b_cap), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    elif coding == "dense":
         wires = [torch.empty(lib.memo_transport_dense_bytes(L, b_cap, cap), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     elif coding == "nibble":
         wires = [torch.empty(lib.memo_transport_bytes(L, cap), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
@@ -574,9 +600,14 @@ def main():
                 whole &= bool(torch.equal(own, outs[last].reshape(-1)))
                 for g2 in range(1 if skip_own else 0, world):
                     head = roots[last][g2][:16].cpu().numpy().view(np.uint32)
+                    # head words: runs = (B taken, B capacity, 0, 0); dense = (exceptions, their capacity, B taken, B capacity);
+                    # nibble = (exceptions, their capacity, overflow flag, -)
                     whole &= bool(head[0] <= head[1]) and bool(head[2] <= head[3] if coding == "dense" else head[2] == 0)
                 res["gather_parity_sample"]["every_slice_complete"] = whole
             res["config"]["gather_payload"] = (
+                f"runs coding: 1 bit per position + {b_cap} B for one byte per change of value "
+                f"({wires[0].numel()} B per slice, {8 * wires[0].numel() / L:.2f} bits per position)"
+                if coding == "runs" else
                 f"dense coding: 2 bits per position + {b_cap} B of escape nibbles + {cap} exception slots "
                 f"({wires[0].numel()} B per slice, {8 * wires[0].numel() / L:.2f} bits per position)"
                 if coding == "dense" else

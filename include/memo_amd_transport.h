@@ -38,6 +38,18 @@ int memo_transport_dense_unpack_dev(const void *d_wire, int64_t n, uint32_t b_ca
 int memo_transport_dense_stats(const void *d_wire, int32_t device, void *stream, uint32_t *found, uint32_t *cap,
                                uint32_t *b_taken, uint32_t *b_capacity);
 
+/* Third coding, "runs": one bit per position (1 = the value differs from the one before; the first position of
+ * every 32768 is marked always) + one byte per marked position, allocated exactly per 32768 positions from a B
+ * region of `b_capacity` bytes (a multiple of 4).  A conservation value changes at one position in ten on BASELINE
+ * config 3 (k = 31): 1.8 bits per position, no escapes, no exception list.  Buffers 16-byte aligned.  _stats
+ * (synchronising `stream`) returns the B bytes taken and the B capacity: the slice is complete iff taken <=
+ * capacity.  Pack once with a generous capacity to learn what a workload needs (at most n + 4 * ceil(n / 32768)). */
+size_t memo_transport_runs_bytes(int64_t n, uint32_t b_capacity);
+int memo_transport_runs_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t b_capacity, void *d_wire, int32_t device,
+                                 void *stream);
+int memo_transport_runs_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint8_t *d_vec, int32_t device,
+                                   void *stream);
+int memo_transport_runs_stats(const void *d_wire, int32_t device, void *stream, uint32_t *b_taken, uint32_t *b_capacity);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,10 @@ SYMBOLS = {
     "memo_dap_destroy": (None, [_P]),
     "memo_parse_ints": (C.c_int64, [_P, _SZ, _P, _SZ]),
     "memo_emit_bed": (_SZ, [_P, _P, _P, _P, _U64, _P, _I32, _P, _SZ]),
+    "memo_transport_runs_bytes": (_SZ, [_I64, C.c_uint32]),
+    "memo_transport_runs_pack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
+    "memo_transport_runs_unpack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
+    "memo_transport_runs_stats": (C.c_int, [_P, _I32, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "memo_transport_bytes": (_SZ, [_I64, C.c_uint32]),
     "memo_transport_pack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
     "memo_transport_unpack_dev": (C.c_int, [_P, _I64, _P, _I32, _P]),

@@ -228,6 +228,200 @@ __global__ void dense_exceptions_kernel(const unsigned long long *exc, const uns
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Third coding, "runs": a conservation value is the minimum over the rows that cover a position, and neighbouring
+// positions share almost all of their rows -- the value changes at one position in ten on config 3 (k = 31), at one in
+// 350 at k = 101.
+//   stream A   1 bit per position: 1 = the value differs from the one before (the first position of every
+//              block of 32768 is marked always, so a block decodes on its own)            4096 B per block
+//   stream B   one byte per marked position, in position order: the new value; a workgroup collects its bytes
+//              in LDS and takes exactly what it needs (rounded to 4) from the B region with one atomic add;
+//              the table holds every block's offset and byte count
+// 1 + 8 * 0.099 = 1.8 bits per position on config 3 (dense coding: 3.3; nibbles: 4.25), no escapes, no exception
+// list.  Same shape as the dense kernels: 256 threads own 32768 positions as 8 rounds of 4096, 16 positions per
+// thread and round; ranks inside the block from the wave prefix and the (round, wave) sums.
+// head: [0] B bytes taken, [1] B capacity
+// ------------------------------------------------------------------------------------------
+constexpr int kRunsStaged = 8192;  // bytes of a block's values staged in LDS (config 3: ~3300 per block); more: straight to / from HBM
+
+__global__ __launch_bounds__(256) void runs_pack_kernel(const uint8_t *in, int64_t n, uint16_t *A, uint8_t *B,
+                                                        uint2 *table, unsigned int *head, unsigned int b_cap) {
+    __shared__ __attribute__((aligned(16))) uint8_t vals[kRunsStaged];
+    __shared__ int wave_sum[kRounds][4];
+    __shared__ uint32_t wave_last[kRounds][4];  // the last value of every (round, wave): the next wave's "value before"
+    __shared__ unsigned int b_off;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int64_t block = blockIdx.x;
+    if (block == 0 && tid == 0) head[1] = b_cap;
+
+    uint32_t w[kRounds][4];
+    uint32_t before[kRounds];  // the value at the position before this thread's sixteen
+    int prefix[kRounds];
+    uint32_t marks[kRounds];
+#pragma unroll
+    for (int c = 0; c < kRounds; ++c) {
+        const int64_t p0 = (block * kRounds + c) * kChunk + (int64_t)tid * kPerThread;
+        w[c][0] = w[c][1] = w[c][2] = w[c][3] = 0;
+        if (p0 + kPerThread <= n) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(in + p0);
+            w[c][0] = q.x, w[c][1] = q.y, w[c][2] = q.z, w[c][3] = q.w;
+        } else {
+            for (int i = 0; i < kPerThread && p0 + i < n; ++i) w[c][i >> 2] |= (uint32_t)in[p0 + i] << (8 * (i & 3));
+        }
+    }
+    // the value before a thread's sixteen positions: its left neighbour's last one; lane 0 takes it from the wave
+    // before (through LDS), the block's first thread needs none (a block starts with a marked position)
+#pragma unroll
+    for (int c = 0; c < kRounds; ++c) {
+        const uint32_t last = w[c][3] >> 24;
+        before[c] = (uint32_t)__shfl_up((int)last, 1, 64);
+        if (lane == 63) wave_last[c][wv] = last;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kRounds; ++c) {
+        const int64_t p0 = (block * kRounds + c) * kChunk + (int64_t)tid * kPerThread;
+        if (lane == 0) before[c] = wv > 0 ? wave_last[c][wv - 1] : (c > 0 ? wave_last[c - 1][3] : 0u);
+        uint32_t m = 0, prev = before[c];
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            const uint32_t v = (w[c][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            m |= (v != prev ? 1u : 0u) << i;
+            prev = v;
+        }
+        if (c == 0 && tid == 0) m |= 1u;                                    // a block starts with a value
+        const int64_t left = n - p0;                                         // positions of mine that exist
+        m = left >= kPerThread ? m : (left <= 0 ? 0u : m & ((1u << left) - 1u));
+        marks[c] = m;
+        if (p0 < n) A[p0 / kPerThread] = (uint16_t)m;
+        const int pc = __popc(m), inc = wave_inclusive_scan(pc);
+        prefix[c] = inc - pc;
+        if (lane == 63) wave_sum[c][wv] = inc;
+    }
+    __syncthreads();
+
+    int total = 0;
+#pragma unroll
+    for (int c = 0; c < kRounds; ++c) total += wave_sum[c][0] + wave_sum[c][1] + wave_sum[c][2] + wave_sum[c][3];
+    const unsigned int bytes = (unsigned int)((total + 3) & ~3);
+    const bool staged = total <= kRunsStaged;  // (block-uniform)
+    if (tid == 0) {
+        b_off = bytes ? atomicAdd(head, bytes) : 0u;
+        table[block] = make_uint2(b_off, (unsigned int)total);
+    }
+    __syncthreads();
+    const bool fits = (uint64_t)b_off + bytes <= b_cap;  // else: head[0] > head[1] tells the caller
+    auto scatter_values = [&](auto *dst) {  // (LDS or HBM: two instantiations, no generic pointer)
+        int run = 0;  // bytes of the rounds before this one
+#pragma unroll
+        for (int c = 0; c < kRounds; ++c) {
+            const int s0 = wave_sum[c][0], s1 = wave_sum[c][1], s2 = wave_sum[c][2], s3 = wave_sum[c][3];
+            int r = run + (wv > 0 ? s0 : 0) + (wv > 1 ? s1 : 0) + (wv > 2 ? s2 : 0) + prefix[c];
+            run += s0 + s1 + s2 + s3;
+            const uint32_t m = marks[c];
+            if (m) {  // (static byte numbers: a loop over the set bits would index the registers dynamically --
+#pragma unroll        //  a chain of selects per byte, 8x the instructions of the whole kernel)
+                for (int j = 0; j < 4; ++j) {
+                    if ((m >> (4 * j)) & 0xFu) {  // (one position in ten is marked: most dwords have none)
+#pragma unroll
+                        for (int i = 4 * j; i < 4 * j + 4; ++i)
+                            if ((m >> i) & 1u) dst[r++] = (uint8_t)(w[c][j] >> (8 * (i & 3)));
+                    }
+                }
+            }
+        }
+    };
+    if (staged)
+        scatter_values(vals);
+    else if (fits)
+        scatter_values(B + b_off);
+    if (staged) {
+        __syncthreads();
+        if (bytes && fits) {
+            uint32_t *out = reinterpret_cast<uint32_t *>(B + b_off);
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(vals);
+            for (unsigned int i = tid; i < bytes / 4; i += 256) out[i] = src[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void runs_unpack_kernel(const uint16_t *A, const uint8_t *B, const uint2 *table,
+                                                          unsigned int b_cap, int64_t n, uint8_t *out) {
+    __shared__ __attribute__((aligned(16))) uint8_t vals[kRunsStaged];
+    __shared__ int wave_sum[kRounds][4];
+    const int tid = threadIdx.x, wv = tid >> 6;
+    const int64_t block = blockIdx.x;
+    const uint2 ent = table[block];
+    const unsigned int bytes = (ent.y + 3u) & ~3u;
+    if ((uint64_t)ent.x + bytes > b_cap) return;  // this block did not fit on the sender's side (stats say so)
+    const bool staged = ent.y <= (unsigned int)kRunsStaged;
+    if (staged) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(B + ent.x);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(vals);
+        for (unsigned int i = tid; i < bytes / 4; i += 256) dst[i] = src[i];
+    }
+    const uint8_t *val = staged ? vals : B + ent.x;
+    uint32_t marks[kRounds];
+    int prefix[kRounds];
+#pragma unroll
+    for (int c = 0; c < kRounds; ++c) {
+        const int64_t p0 = (block * kRounds + c) * kChunk + (int64_t)tid * kPerThread;
+        marks[c] = p0 < n ? A[p0 / kPerThread] : 0u;
+        const int pc = __popc(marks[c]), inc = wave_inclusive_scan(pc);
+        prefix[c] = inc - pc;
+        if ((tid & 63) == 63) wave_sum[c][wv] = inc;
+    }
+    __syncthreads();
+    int run = 0;
+#pragma unroll
+    for (int c = 0; c < kRounds; ++c) {
+        const int s0 = wave_sum[c][0], s1 = wave_sum[c][1], s2 = wave_sum[c][2], s3 = wave_sum[c][3];
+        int r = run + (wv > 0 ? s0 : 0) + (wv > 1 ? s1 : 0) + (wv > 2 ? s2 : 0) + prefix[c];  // marks before mine
+        run += s0 + s1 + s2 + s3;
+        const int64_t p0 = (block * kRounds + c) * kChunk + (int64_t)tid * kPerThread;
+        if (p0 >= n) continue;
+        uint32_t cur = r > 0 ? val[r - 1] : 0u;  // (r == 0 only for the block's first thread, whose first bit is set)
+        uint32_t q[4] = {0, 0, 0, 0};
+        const uint32_t m = marks[c];
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            if ((m >> i) & 1u) cur = val[r++];
+            q[i >> 2] |= cur << (8 * (i & 3));
+        }
+        if (p0 + kPerThread <= n) {
+            *reinterpret_cast<uint4 *>(out + p0) = make_uint4(q[0], q[1], q[2], q[3]);
+        } else {
+            for (int i = 0; i < kPerThread && p0 + i < n; ++i) out[p0 + i] = (uint8_t)(q[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+}
+
+struct RunsLayout {
+    int64_t blocks;
+    size_t t_off, a_off, b_off, bytes;
+};
+
+RunsLayout runs_layout(int64_t n, uint32_t b_cap) {
+    RunsLayout l;
+    l.blocks = (n + kBlock - 1) / kBlock;
+    l.t_off = 16;
+    l.a_off = l.t_off + (size_t)l.blocks * 8;
+    l.b_off = (l.a_off + (size_t)l.blocks * (kBlock / 8) + 15) & ~(size_t)15;
+    l.bytes = (l.b_off + (size_t)b_cap + 15) & ~(size_t)15;
+    return l;
+}
+
+int runs_check_args(const void *d_vec, const void *d_wire, int64_t n, uint32_t b_cap) {
+    if (n < 0 || (n > 0 && (!d_vec || !d_wire))) return fail(MEMO_EINVAL, "bad transport arguments");
+    // 32-bit offsets into the B region: the worst case -- every position marked, n bytes + 4 per block of rounding
+    if (n + 4 * ((n + kBlock - 1) / kBlock) >= ((int64_t)1 << 32) - 64)
+        return fail(MEMO_EINVAL, "slice too long for the runs coding (at most ~2^32 positions per slice)");
+    if (b_cap % 4) return fail(MEMO_EINVAL, "the B region's capacity must be a multiple of 4");
+    if (((uintptr_t)d_vec & 15) || ((uintptr_t)d_wire & 15))
+        return fail(MEMO_EINVAL, "transport buffers must be 16-byte aligned");
+    return MEMO_OK;
+}
+
 struct Layout {
     int64_t chunks, blocks;
     size_t t_off, a_off, b_off, x_off, bytes;
@@ -325,6 +519,65 @@ int memo_transport_dense_stats(const void *d_wire, int32_t device, void *stream,
     *cap = head[1];
     *b_taken = head[2];
     *b_capacity = head[3];
+    return MEMO_OK;
+}
+
+// ---- "runs" coding: wire layout [B bytes taken u32, B capacity u32, 0, 0][table: (offset in B, bytes) per 32768
+//      positions][A: one bit per position, 4096 B per block][B: b_capacity bytes]
+size_t memo_transport_runs_bytes(int64_t n, uint32_t b_capacity) {
+    return n < 0 ? 0 : runs_layout(n, b_capacity).bytes;
+}
+
+int memo_transport_runs_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t b_capacity, void *d_wire, int32_t device,
+                                 void *stream) {
+    int rc = runs_check_args(d_vec, d_wire, n, b_capacity);
+    if (rc) return rc;
+    DeviceGuard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *w = static_cast<char *>(d_wire);
+    if (!w) return MEMO_OK;
+    const RunsLayout l = runs_layout(n, b_capacity);
+    HIP_TRY(hipMemsetAsync(w, 0, 16, st));
+    if (l.blocks) {
+        if (l.blocks >= ((int64_t)1 << 31)) return fail(MEMO_EINVAL, "slice too long for one launch");
+        hipLaunchKernelGGL(runs_pack_kernel, dim3((unsigned)l.blocks), dim3(256), 0, st, d_vec, n,
+                           reinterpret_cast<uint16_t *>(w + l.a_off), reinterpret_cast<uint8_t *>(w + l.b_off),
+                           reinterpret_cast<uint2 *>(w + l.t_off), reinterpret_cast<unsigned int *>(w), b_capacity);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemcpyAsync(w + 4, &b_capacity, 4, hipMemcpyHostToDevice, st));
+    }
+    return MEMO_OK;
+}
+
+int memo_transport_runs_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint8_t *d_vec, int32_t device,
+                                   void *stream) {
+    int rc = runs_check_args(d_vec, d_wire, n, b_capacity);
+    if (rc) return rc;
+    DeviceGuard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const char *w = static_cast<const char *>(d_wire);
+    const RunsLayout l = runs_layout(n, b_capacity);
+    if (l.blocks) {
+        hipLaunchKernelGGL(runs_unpack_kernel, dim3((unsigned)l.blocks), dim3(256), 0, st,
+                           reinterpret_cast<const uint16_t *>(w + l.a_off), reinterpret_cast<const uint8_t *>(w + l.b_off),
+                           reinterpret_cast<const uint2 *>(w + l.t_off), b_capacity, n, d_vec);
+        HIP_TRY(hipGetLastError());
+    }
+    return MEMO_OK;
+}
+
+// what the sender needed (host values; synchronises `stream`): B bytes taken against the B region's capacity.
+// The slice is complete iff taken <= capacity.
+int memo_transport_runs_stats(const void *d_wire, int32_t device, void *stream, uint32_t *b_taken, uint32_t *b_capacity) {
+    if (!d_wire || !b_taken || !b_capacity) return fail(MEMO_EINVAL, "NULL argument");
+    DeviceGuard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t head[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(head, d_wire, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *b_taken = head[0];
+    *b_capacity = head[1];
     return MEMO_OK;
 }
 

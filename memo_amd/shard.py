@@ -86,7 +86,10 @@ def pick_coding(world, t_sweep, usable, link=XGMI_LINK_BYTES_PER_S):
     return min(sorted(model), key=model.get), model
 
 
-def pick_plan(world, t_sweep, usable, link=XGMI_LINK_BYTES_PER_S, weights=(1.0, 0.75, 0.5, 0.25)):
+ROOT_WEIGHTS = tuple(round(1.0 - 0.05 * i, 2) for i in range(20))     # 1.0, 0.95, ..., 0.05
+
+
+def pick_plan(world, t_sweep, usable, link=XGMI_LINK_BYTES_PER_S, weights=ROOT_WEIGHTS):
     """Coding AND root weight: rank 0 may sweep a smaller share of positions than its peers (it also decodes
     world - 1 slices per step).  Returns (coding, root_weight, modelled positions-per-second in units of one
     peer's window per second) for the plan with the highest modelled throughput (world - 1 + w) / step; ties go

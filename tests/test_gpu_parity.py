@@ -1188,6 +1188,74 @@ def test_transport_nibble_coding_round_trip(memo):
 
 
 @pytest.mark.gpu
+def test_transport_runs_coding_round_trip(memo, oracle):
+    """uint8 results -> change bitmap + one byte per change (allocated exactly per 32768 positions) -> uint8:
+    run-length-like data (what conservation looks like), data that changes at every position, constant data,
+    ragged lengths around the 16-position pieces, 4096-position rounds and 32768-position blocks, a capacity that
+    does not suffice (reported, never silent), and a real conservation result"""
+    import ctypes as C
+    import torch
+    from memo_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(26)
+
+    def round_trip(v, b_cap):
+        n = len(v)
+        src = torch.from_numpy(v).cuda() if n else torch.zeros(16, dtype=torch.uint8, device="cuda")
+        wire = torch.zeros(L.memo_transport_runs_bytes(n, b_cap), dtype=torch.uint8, device="cuda")
+        dst = torch.full((max(n, 16),), 77, dtype=torch.uint8, device="cuda")
+        _lib.check(L.memo_transport_runs_pack_dev(src.data_ptr(), n, b_cap, wire.data_ptr(), 0, None))
+        taken, room = C.c_uint32(), C.c_uint32()
+        _lib.check(L.memo_transport_runs_stats(wire.data_ptr(), 0, None, C.byref(taken), C.byref(room)))
+        _lib.check(L.memo_transport_runs_unpack_dev(wire.data_ptr(), n, b_cap, dst.data_ptr(), 0, None))
+        torch.cuda.synchronize()
+        return dst[:n].cpu().numpy(), taken.value, room.value, wire.numel()
+
+    def wanted(v):
+        n = len(v)
+        ch = np.ones(n, bool)
+        ch[1:] = v[1:] != v[:-1]
+        ch[::32768] = True
+        per_block = [int(ch[i:i + 32768].sum()) for i in range(0, n, 32768)]
+        return sum((c + 3) & ~3 for c in per_block), len(per_block)
+
+    for n in (0, 1, 15, 16, 17, 4095, 4096, 4097, 12345, 32767, 32768, 32769, 65536, 1_000_003, 3_000_000):
+        for mix in ("runs", "uniform", "constant", "zeros", "alternating"):
+            if mix == "runs":
+                v = np.repeat(np.minimum(rng.geometric(0.33, n // 3 + 1), 255), rng.integers(1, 30, n // 3 + 1))[:n].astype(np.uint8)
+                v = np.resize(v, n) if len(v) < n else v
+            elif mix == "uniform":
+                v = rng.integers(0, 256, n).astype(np.uint8)
+            elif mix == "constant":
+                v = np.full(n, 7, np.uint8)
+            elif mix == "zeros":
+                v = np.zeros(n, np.uint8)
+            else:
+                v = (np.arange(n) & 1).astype(np.uint8) * 255
+            b_want, blocks = wanted(v)
+            got, taken, room, size = round_trip(v, b_want)
+            assert (taken, room) == (b_want, b_want), (n, mix, taken, room, b_want)
+            assert np.array_equal(got, v), (n, mix)
+            assert size == ((((16 + 8 * blocks + 4096 * blocks + 15) & ~15) + b_want + 15) & ~15), (n, mix)
+            if mix == "runs" and n >= 1_000_000:
+                got, taken, room, _ = round_trip(v, (b_want // 2) & ~3)          # too small: said so, never silent
+                assert taken == b_want and room == (b_want // 2) & ~3 and taken > room
+                got, taken, room, _ = round_trip(v, b_want + 4096)               # slack is fine
+                assert taken == b_want and np.array_equal(got, v)
+    # a conservation result: about one change in ten positions at k = 31
+    from memo_amd import synth
+    n_docs, length, k = 100, 2_000_000, 31
+    ix, (r0, r1) = synth.device_index(0, length, k, n_docs, length, pack="only")
+    with ix:
+        v = ix.conservation(0, length, k, n_docs, dtype=np.uint8)
+    b_want, blocks = wanted(v)
+    got, taken, room, size = round_trip(v, b_want)
+    assert np.array_equal(got, v) and taken == b_want
+    assert size < 0.26 * length, size                                             # < 2.1 bits per position on the wire
+    with pytest.raises(memo.MemoError):
+        _lib.check(L.memo_transport_runs_pack_dev(1, 100, 6, 16, 0, None))       # capacity not a multiple of 4
+
+
 def test_transport_dense_coding_round_trip(memo):
     """uint8 results -> 2 bits + escape nibbles (allocated exactly per 32768 positions) + exception list
     -> uint8: geometric value mixes (what conservation looks like), all-escape and no-escape data,

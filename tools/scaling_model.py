@@ -17,13 +17,14 @@ from memo_amd import shard  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--L", type=int, default=100_000_000, help="positions per GPU (config 3)")
-ap.add_argument("--sweep-ms", type=float, default=0.37)
+ap.add_argument("--sweep-ms", type=float, default=0.332)
 ap.add_argument("--link-GBs", type=float, default=75.0, help="one direction of one xGMI link")
 ap.add_argument("--nibble", default="53101352,0.031,0.108", help="wire bytes, decode ms per slice, encode ms")
 ap.add_argument("--dense", default="41250080,0.058,0.153")
+ap.add_argument("--runs", default="23046320,0.036,0.064")
 a = ap.parse_args()
 codings = {"plain": (a.L, 0.0, 0.0)}
-for name in ("nibble", "dense"):
+for name in ("nibble", "dense", "runs"):
     b, d, e = getattr(a, name).split(",")
     codings[name] = (int(b), float(d) * 1e-3, float(e) * 1e-3)
 sweep, link = a.sweep_ms * 1e-3, a.link_GBs * 1e9
@@ -32,7 +33,7 @@ print(f"one GPU: {a.sweep_ms} ms per {a.L} positions = {single:.3g} positions/s;
 print("N  root_weight  coding   step_ms   positions/s   x one GPU   bound by")
 for world in (2, 4, 8):
     best = None
-    for w in (1.0, 0.75, 0.5, 0.25, 0.0):
+    for w in shard.ROOT_WEIGHTS + (0.0,):
         for name, (wire, dec, enc) in codings.items():
             peer = sweep + enc
             root = w * sweep + (world - 1) * dec
