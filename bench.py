@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--wide", action="store_true", help="uint16 conservation results even when num_docs <= 255")
     ap.add_argument("--rows", default="auto", choices=["auto", "dense", "packed", "wide"],
-                    help="row format the timed sweep reads: dense (memo_index_pack_dense, 3 B/row: conservation, "
+                    help="row format the timed sweep reads: dense (memo_index_pack_dense, 3.2 B/row: conservation, "
                          "k <= 64, num_docs <= 255), packed (memo_index_pack, 4-6 B/row), or the int64 columns as "
                          "uploaded (24 B/row); auto = the fastest that can answer (dense where they can, else packed for k <= 256); at N=1 the "
                          "others are timed too")
@@ -165,6 +165,7 @@ def main():
     if args.calibrate:
         _lib.use_ab(True)                   # the PMC calibration kernel lives in libmemo_amd_ab.so only
     # the dense rows answer the unclipped conservation sweep only: k <= 64, num_docs <= 255, >= 1 row per position
+    # (membership reads them too when an index holds nothing else, 4 % slower than the 4-byte rows: not a bench format)
     can_dense = (not membership) and k - 1 <= 63 and num_docs <= 255 and not args.wide and num_docs >= 20
     if args.rows == "auto":     # the fastest format that can answer: dense rows (back to back they are 13 % ahead of the
         args.rows = "wide" if k - 1 > 255 else ("dense" if can_dense else "packed")     # 4-byte rows: DESIGN.md section 7)
@@ -414,11 +415,13 @@ def main():
         torch.cuda.synchronize()
 
     def kernel_name(which):
-        if which == "dense":
+        if which == "dense" and not membership:
             return "sweep_conservation_halo3_kernel<...> (PackedRows3: five rows per 16 bytes)"
         rows_t = "WideRows" if which == "wide" else ("PackedRows<true, false>" if packed_fmt == 6 else
                                                      "PackedRows<false, false, true>" if packed_fmt == 12 else "PackedRows<false, false>")
         if membership:      # packed rows: per-genome bit planes (unclipped + staged up to 512 genomes,
+            if which == "dense":
+                return "sweep_membership_planes3_kernel<...> (PackedRows3: five rows per 16 bytes)"
             if which == "wide":                                      # else the clipped "runs"); int64 rows: doubling
                 return "sweep_membership_kernel<" + rows_t + ", ...>"
             return ("sweep_membership_planes_kernel<" if num_docs <= 512 else "sweep_membership_runs_kernel<") + rows_t + ", ...>"

@@ -71,11 +71,11 @@ typedef struct memo_index_info {
     uint64_t long_rows;     /* rows with end < start, kept aside (see above) */
     uint64_t max_annot;     /* largest annot of the packed rows (valid when packed_format != 0) */
     int64_t bucket_base;    /* the bucket table starts at this bucket (a region slice of memo_index_import_packed) */
-    int32_t last_sweep;     /* which kernel family answered the last conservation query on this index: 0 none yet,
+    int32_t last_sweep;     /* which kernel family answered the last query on this index: 0 none yet; conservation:
                                1 clipped scatter into doubling level arrays, 2 unclipped doubling, 3 unclipped
-                               radix-4, 4 unclipped mixed (1, 4, 16, then doubling), 5 dense rows; the library picks
+                               radix-4, 4 unclipped mixed (1, 4, 16, then doubling), 5 dense rows -- the library picks
                                2 / 3 / 4 per query from k and the overlap lengths of the rows it sampled when the
-                               packed rows were made */
+                               packed rows were made; membership: 6 bit planes on the dense rows, 7 any other */
     int32_t reserved;
 } memo_index_info_t;
 
@@ -119,8 +119,9 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide);
  *     (start mod 2^10) << 6 | min(end - start, 63)   +   annot (8 bits)
  * Exact for k <= 64 on the unclipped conservation sweep (level arrays of <= 1024 cells, num_docs <= 255), and its
  * fastest source: conservation queries read these rows wherever they are resident and can answer (BASELINE
- * config 3, launches back to back: 0.324 ms against 0.374 on the 4-byte rows at k = 31).  Membership and k > 64
- * need the 4-byte rows.  Needs memo_index_pack first and every annot <= 255.  keep_packed == 0 frees the 4-byte
+ * config 3, launches back to back: 0.324 ms against 0.374 on the 4-byte rows at k = 31).  Membership queries
+ * read them when the index holds no 4-byte rows (same limits; 4 % slower than on the 4-byte rows).  k > 64 and
+ * more than 255 genomes need the 4-byte rows.  Needs memo_index_pack first and every annot <= 255.  keep_packed == 0 frees the 4-byte
  * rows: such an index holds 3.2 B per row and answers only what the dense rows (or, if still resident, the int64
  * columns) can. */
 int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed);

@@ -181,6 +181,60 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 }
 
 
+// The second half of both planes kernels: the planes are complete (all scatters issued); transpose every 32 x 32 block
+// in registers, stage the tile position-major in LDS over the planes, copy it out in whole 16-byte pieces.
+template <int T>
+__device__ __forceinline__ void planes_transpose_store(const SweepArgs &A, const Tile &t, uint32_t *lds) {
+    const int tid = threadIdx.x;
+    const int W = A.w, nw = A.nwords, PITCH = A.ls, SKEW = A.hl, HLW = A.nlev;
+    __syncthreads();
+
+    // transpose: lane (G, p), G fastest
+    const int PW = W / 32, blocks = nw * PW;
+    const int G = tid % nw, p = tid / nw;
+    uint32_t m[32];
+    if (tid < blocks) {
+        const uint32_t *src = lds + (32 * G) * PITCH + G * SKEW + p + HLW;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) m[i] = src[i * PITCH];
+    }
+    __syncthreads();  // the planes are dead: the staged result goes over them
+    const int stride = 32 * nw + nw;  // staged words per position word (nw of padding)
+    if (tid < blocks) {
+        transpose32(m);
+        const uint32_t full = full_word(A.ncols, G);
+        uint32_t *dst = lds + p * stride + G;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) dst[j * nw] = full & ~m[j];
+    }
+    __syncthreads();
+
+    // copy: slots [x_lo, x_hi) are one contiguous run of words in the output
+    uint32_t *out = static_cast<uint32_t *>(A.out);
+    const int64_t ob = (t.a - A.qs) * nw;  // output word of tile slot 0, word 0
+    const int64_t o_lo = ob + (int64_t)t.x_lo * nw, o_hi = ob + (int64_t)t.x_hi * nw;
+    // staged word of output word q of the tile: q + (q / (32 nw)) * nw; the quotient by v_mul_hi (q < 2^15)
+    auto staged = [&](int q) { return lds[q + (int)__umulhi((uint32_t)q, A.magic) * nw]; };
+    for (int64_t g = (o_lo & ~(int64_t)3) + 4 * tid; g < o_hi; g += 4 * T) {
+        const int q = (int)(g - ob);  // may be negative by up to 3 at the window's first piece
+        if (g >= o_lo && g + 4 <= o_hi) {
+            uint4 v;
+            if ((nw & 3) == 0) {  // 4 | nw: a piece never straddles a position word, and is 16-byte aligned in LDS
+                v = *reinterpret_cast<const uint4 *>(lds + q + (int)__umulhi((uint32_t)q, A.magic) * nw);
+            } else {
+                v.x = staged(q);
+                v.y = staged(q + 1);
+                v.z = staged(q + 2);
+                v.w = staged(q + 3);
+            }
+            *reinterpret_cast<uint4 *>(out + g) = v;
+        } else {
+            for (int i = 0; i < 4; ++i)
+                if (g + i >= o_lo && g + i < o_hi) out[g + i] = staged(q + i);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // membership, bit planes per genome, unclipped, with the result staged through LDS
 // (packed rows whose annot is known to be inside the matrix, at most 16 result words).
@@ -245,52 +299,70 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
         Rows::template issue<T, U>(A, t, b, V, N);
         Rows::template consume<T, U>(A, t, b, V, N, scatter);
     }
-    __syncthreads();
+    planes_transpose_store<T>(A, t, lds);
+}
 
-    // transpose: lane (G, p), G fastest
-    const int PW = W / 32, blocks = nw * PW;
-    const int G = tid % nw, p = tid / nw;
-    uint32_t m[32];
-    if (tid < blocks) {
-        const uint32_t *src = lds + (32 * G) * PITCH + G * SKEW + p + HLW;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) m[i] = src[i * PITCH];
+// The same on the dense rows (PackedRows3: five rows per 16 bytes, a fifth fewer bytes to read; k - 1 <= 63, at most 255
+// genomes).  A row's field after the 16-bit subtract of the tile's key is (start - a + 32 HLW) << 6 | overlap, so the
+// plane row's bit numbers have to stay below 2^10: the launcher sizes the tile for that (W + k - 1 + bucket + 32 HLW <=
+// 1024).
+template <int U, int T>
+__global__ __launch_bounds__(T) void sweep_membership_planes3_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    using Rows = PackedRows3;
+    const int tid = threadIdx.x;
+    const int W = A.w, nw = A.nwords, PITCH = A.ls, SKEW = A.hl;
+    Tile t;
+    if (!locate_tile_w(A, t, W)) return;
+    uint4 V[U];
+    Rows::template issue<T, U>(A, t, 0, V);
+    {
+        const int plane_pieces = (32 * nw * PITCH + nw * SKEW + 1 + 3) / 4;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        uint4 *pz = reinterpret_cast<uint4 *>(lds);
+        for (int i = tid; i < plane_pieces; i += T) pz[i] = z;
+        lds_barrier();
     }
-    __syncthreads();  // the planes are dead: the staged result goes over them
-    const int stride = 32 * nw + nw;  // staged words per position word (nw of padding)
-    if (tid < blocks) {
-        transpose32(m);
-        const uint32_t full = full_word(A.ncols, G);
-        uint32_t *dst = lds + p * stride + G;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) dst[j * nw] = full & ~m[j];
-    }
-    __syncthreads();
-
-    // copy: slots [x_lo, x_hi) are one contiguous run of words in the output
-    uint32_t *out = static_cast<uint32_t *>(A.out);
-    const int64_t ob = (t.a - A.qs) * nw;  // output word of tile slot 0, word 0
-    const int64_t o_lo = ob + (int64_t)t.x_lo * nw, o_hi = ob + (int64_t)t.x_hi * nw;
-    // staged word of output word q of the tile: q + (q / (32 nw)) * nw; the quotient by v_mul_hi (q < 2^15)
-    auto staged = [&](int q) { return lds[q + (int)__umulhi((uint32_t)q, A.magic) * nw]; };
-    for (int64_t g = (o_lo & ~(int64_t)3) + 4 * tid; g < o_hi; g += 4 * T) {
-        const int q = (int)(g - ob);  // may be negative by up to 3 at the window's first piece
-        if (g >= o_lo && g + 4 <= o_hi) {
-            uint4 v;
-            if ((nw & 3) == 0) {  // 4 | nw: a piece never straddles a position word, and is 16-byte aligned in LDS
-                v = *reinterpret_cast<const uint4 *>(lds + q + (int)__umulhi((uint32_t)q, A.magic) * nw);
-            } else {
-                v.x = staged(q);
-                v.y = staged(q + 1);
-                v.z = staged(q + 2);
-                v.w = staged(q + 3);
+    const int km1 = A.km1;
+    const int HLW = A.nlev;  // words of halo left of the tile: ceil((k - 1) / 32)
+    const uint32_t key6 = pin_vgpr((int)((((uint32_t)(t.a - 32 * HLW)) & 1023u) << 6));  // bit 32 * HLW of a plane row = tile slot 0
+    auto put = [&](uint32_t r, uint32_t col) {  // r = (start - a + 32 HLW) << 6 | overlap
+        const int n = km1 - (int)(r & 63u);     // bits of the run [end - (k-1), start)
+        if (n > 0) {
+            const uint32_t d = r >> 6;
+            const uint32_t first = d - (uint32_t)n;
+            uint32_t *cell = lds + (__umul24(col, (uint32_t)PITCH) + __umul24(col >> 5, (uint32_t)SKEW) + (first >> 5));
+            if (km1 <= 31) {  // (uniform) the run fits two words: no branches
+                const uint64_t run = (uint64_t)((1u << n) - 1u) << (first & 31u);
+                atomicOr(cell, (uint32_t)run);
+                atomicOr(cell + 1, (uint32_t)(run >> 32));
+            } else {  // up to 63 bits: first word, a whole word, last word
+                const uint32_t last = d - 1u;
+                const int more = (int)(last >> 5) - (int)(first >> 5);
+                const uint32_t head = 0xFFFFFFFFu << (first & 31u), tail = 0xFFFFFFFFu >> (31u - (last & 31u));
+                atomicOr(cell, more ? head : head & tail);
+                for (int i = 1; i < more; ++i) atomicOr(cell + i, 0xFFFFFFFFu);
+                if (more) atomicOr(cell + more, tail);
             }
-            *reinterpret_cast<uint4 *>(out + g) = v;
-        } else {
-            for (int i = 0; i < 4; ++i)
-                if (g + i >= o_lo && g + i < o_hi) out[g + i] = staged(q + i);
         }
+    };
+    auto g_lo = [&](uint32_t b, uint32_t a, int sh) {  // 16-bit subtract on the low halves; the result's high half is zero
+        uint32_t r;
+        asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(b), "v"(key6));
+        put(r, (a >> sh) & 0xFFu);
+    };
+    auto g_hi = [&](uint32_t b, uint32_t a, int sh) {  // ... with the HIGH half of b as the minuend (SDWA: no shift instruction)
+        uint32_t r;
+        asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0"
+            : "=v"(r) : "v"(b), "v"(key6));
+        put(r, (a >> sh) & 0xFFu);
+    };
+    Rows::template consume<T, U>(A, t, 0, V, g_lo, g_hi);
+    for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
+        Rows::template issue<T, U>(A, t, b, V);
+        Rows::template consume<T, U>(A, t, b, V, g_lo, g_hi);
     }
+    planes_transpose_store<T>(A, t, lds);
 }
 
 __global__ void fill_membership_kernel(uint32_t *out, int64_t n, int nw, int ncols) {
@@ -388,9 +460,47 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     A.nwords = nw;
     int fmt;
     if ((rc = pick_rows(ix, k, fmt))) return rc;
-    if (fmt == 3) {  // only the dense rows are left, and no membership kernel reads them
+    ix->last_sweep = 7;  // a membership kernel on the 4- / 6-byte rows or the int64 columns (6: on the dense rows)
+    const memo_tuning &tune0 = ix->tune;
+    // The dense rows where an index holds no 4- / 6-byte rows and they can answer: the planes kernel on them (k - 1 <= 63,
+    // at most 255 genomes, every annot inside the matrix, an index of >= 1 row per position like the other unclipped
+    // kernels; a tile whose plane rows stay within the 10-bit start field).  What this buys is a 3.2-byte-per-row index
+    // that answers both queries; it is not faster than the 4-byte rows here (config 4, back to back: 0.658 against 0.634 ms
+    // at k = 31, 0.81 against 0.76 at k = 48 -- a membership sweep writes 1.6 GB, the 0.4 GB of rows it saves are paid
+    // for by the longer decode and the shorter tiles; profiles/r02_dense_rows_ab.txt), so resident 4-byte rows are preferred.
+    {
+        const int bw = 1 << ix->bshift, hlw = (k - 1 + 31) / 32;
+        const double span = (double)(ix->max_s - ix->min_s) + 1.0;
+        int tw = (1024 - (k - 1) - bw - 32 * hlw) / bw * bw;
+        tw = tw / 32 * 32;
+        if (tune0.tile_w && tune0.tile_w < tw) tw = tune0.tile_w / bw * bw / 32 * 32;
+        if (nw * (tw / 32) > 256) tw = 32 * (256 / nw);
+        const bool dense_ok = ix->p3 && !ix->pk && !(tune0.force_wide && ix->has_wide) && k - 1 <= 63 &&
+                              num_docs <= 255 && ix->max_annot < (uint64_t)num_docs && (double)ix->rows >= span &&
+                              (tune0.memb_algo == 0 || tune0.memb_algo == 4) && tw >= bw && tw >= 32 && tw % bw == 0;
+        if (dense_ok) {
+            const int pw = tw / 32;
+            int skew = 0;
+            for (int pow2 = 4; pow2 <= 64; pow2 <<= 1)
+                if (nw == pow2) skew = (64 / nw + 32) & 63;
+            A.w = tw;
+            A.nlev = hlw;
+            A.ls = (hlw + pw + ((k - 1 + bw - 3) >> 5) + 1) | 1;
+            A.hl = skew;
+            A.magic = (uint32_t)((((uint64_t)1 << 32) + 32 * nw - 1) / (32 * nw));
+            A.word_base = 0;
+            A.out_words = nw;
+            const size_t planes = ((size_t)32 * nw * A.ls + (size_t)nw * skew + 8) * 4;
+            const size_t staged = ((size_t)pw * (32 * nw + nw) + 4) * 4;
+            SweepKernel kern = (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256>;
+            if ((rc = launch_tiles(kern, A, tw, 256, planes > staged ? planes : staged, st))) return rc;
+            ix->last_sweep = 6;
+            return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
+        }
+    }
+    if (fmt == 3) {  // only the dense rows are left, and they cannot answer this one
         if (!ix->has_wide)
-            return fail(MEMO_EINVAL, "membership needs the 4-byte rows or the int64 columns, which this index dropped");
+            return fail(MEMO_EINVAL, "this membership query needs the 4-byte rows or the int64 columns, which this index dropped");
         fmt = 0;
     }
     // algorithm: 4 = planes (unclipped bit planes per genome, result staged), 3 = runs (clipped bit planes
