@@ -116,9 +116,9 @@ __global__ void pack3_rows_kernel(const uint32_t *pk, uint64_t padded, uint64_t 
             const uint32_t len = (x >> 16) & 0xFFu;
             return ((x & 1023u) << 6) | (len > 63u ? 63u : len);
         };
-        p3[g] = make_uint4(B(w[0]) | (B(w[1]) << 16), B(w[2]) | (B(w[3]) << 16),
-                           B(w[4]) | ((w[0] >> 24) << 16) | ((w[1] >> 24) << 24),
-                           (w[2] >> 24) | ((w[3] >> 24) << 8) | ((w[4] >> 24) << 16));
+        const uint32_t b4 = B(w[4]);
+        p3[g] = make_uint4(B(w[0]) | ((b4 & 0xFFu) << 16) | (w[0] & 0xFF000000u), B(w[1]) | ((b4 >> 8) << 16) | (w[1] & 0xFF000000u),
+                           B(w[2]) | ((w[4] >> 24) << 16) | (w[2] & 0xFF000000u), B(w[3]) | (w[3] & 0xFF000000u));
     }
 }
 

@@ -348,18 +348,21 @@ struct PackedRows {
 
 // Dense rows (memo_index_pack_dense): start mod 2^10, min(end - start, 63), annot (8 bits) -- 24 bits per
 // row, FIVE rows per 16-byte group (3.2 B per row), one aligned global_load_dwordx4 per lane and group:
-//     dword 0 = B0 | B1 << 16                       B = (start & 1023) << 6 | min(end - start, 63)
-//     dword 1 = B2 | B3 << 16                       A = annot
-//     dword 2 = B4 | A0 << 16 | A1 << 24
-//     dword 3 = A2 | A3 << 8 | A4 << 16             (top byte unused)
-// No field straddles a dword; every 16-bit (start, length) field sits in a 16-bit half, where the 16-bit
-// VALU forms and SDWA reach it for free.  The start lives in the TOP ten bits of B: (B - (a & 1023) << 6)
-// mod 2^16 leaves the length alone and gives (start - a) mod 2^10 with no borrow to repair.
+//     dword j = B_j | X_j << 16 | A_j << 24   (j = 0 .. 3)      B = (start & 1023) << 6 | min(end - start, 63)
+//     X_0 = B_4 & 255, X_1 = B_4 >> 8, X_2 = A_4, X_3 = 0         A = annot
+// Rows 0 .. 3 are used as they are loaded: the (start, length) field is the low half of the dword, where the 16-bit
+// VALU forms reach it, and the annot its top byte -- the dword itself is what ds_min_u32 takes (order in place, as
+// in the 4-byte format: what lies below the top byte only breaks ties).  Row 4 is put together from the spare
+// bytes: one v_perm_b32 for its field, one shift for its annot.  (First layout of this format: fields in both
+// halves of dwords 0 .. 2, the annots as bytes of dwords 2 and 3 -- four shifts per five rows and SDWA forms for
+// the high halves; this one takes 0.4 VALU instructions per row less.)
+// The start lives in the TOP ten bits of B: (B - (a & 1023) << 6) mod 2^16 leaves the length alone and gives
+// (start - a) mod 2^10 with no borrow to repair.
 // Exact for k - 1 <= 63 (a saturated length clips to "does not write" just as the true one does) in kernels
 // whose row slice spans fewer than 2^10 positions (the unclipped conservation sweep, level arrays <= 1024 cells).
 // History (profiles/r02_dense_rows_ab.txt): 12 bytes per 4 rows fetched with global_load_dwordx3 ran 21 %
-// slower than the 4-byte rows; two planes (16 + 8 bytes per 8 rows, two loads) ran at the same speed -- the
-// sweep follows the number of load instructions per row, not the bytes; this layout has 4/5 of them.
+// slower than the 4-byte rows; two planes (16 + 8 bytes per 8 rows, two loads) and five rows per 16 bytes are
+// 13 % faster than the 4-byte rows back to back.
 struct PackedRows3 {
     static constexpr int kLoads = 6;          // 16-byte loads in flight per lane: 30 rows
     static constexpr bool kAnnot16 = false;
@@ -398,12 +401,11 @@ struct PackedRows3 {
         }
     }
 
-    // g(b, hi, a, sh): the row's B field is the low (hi = 0) or high (hi = 1) half of b, its annot the byte
-    // at bit `sh` of a.  Rows outside [r0, r1) get the dead field (start = a, length 63: never writes when
+    // g(b, data): the row's B field is the low half of b (the high half is other rows' business), data a word with
+    // its annot in the top byte.  Rows outside [r0, r1) get the dead field (start = a, length 63: never writes when
     // k - 1 <= 63).
-    template <int T, int U, typename GL, typename GH>
-    static __device__ __forceinline__ void consume(const SweepArgs &A, const Tile &t, uint32_t batch, uint4 (&V)[U],
-                                                   GL lo, GH hi) {
+    template <int T, int U, typename G>
+    static __device__ __forceinline__ void consume(const SweepArgs &A, const Tile &t, uint32_t batch, uint4 (&V)[U], G g) {
         uint64_t g0;
         uint32_t ng, first, end;
         span(t, g0, ng, first, end);
@@ -414,21 +416,24 @@ struct PackedRows3 {
             const uint32_t q = q0 + (uint32_t)u * T;
             const uint32_t wave_q = __builtin_amdgcn_readfirstlane(q) & ~(uint32_t)63;
             if (wave_q >= ng) break;  // nothing of this wave's load is inside the slice
-            uint32_t b0 = V[u].x, b1 = V[u].y, b2 = V[u].z;
+            // (the fields are overwritten in place -- V[u] is dead after this -- so that the common path needs no copies)
             if (!(5 * wave_q >= first && 5 * wave_q + kWaveRows <= end)) {  // a load that straddles an end of the slice
                 const uint32_t r = 5 * q;
                 auto in = [&](uint32_t i) { return r + i >= first && r + i < end; };
-                if (!in(0)) b0 = (b0 & 0xFFFF0000u) | dead;
-                if (!in(1)) b0 = (b0 & 0x0000FFFFu) | (dead << 16);
-                if (!in(2)) b1 = (b1 & 0xFFFF0000u) | dead;
-                if (!in(3)) b1 = (b1 & 0x0000FFFFu) | (dead << 16);
-                if (!in(4)) b2 = (b2 & 0xFFFF0000u) | dead;
+                if (!in(4)) {  // row 4's field: byte 2 of dwords 0 and 1
+                    V[u].x = (V[u].x & 0xFF00FFFFu) | ((dead & 0xFFu) << 16);
+                    V[u].y = (V[u].y & 0xFF00FFFFu) | ((dead >> 8) << 16);
+                }
+                if (!in(0)) V[u].x = (V[u].x & 0xFFFF0000u) | dead;
+                if (!in(1)) V[u].y = (V[u].y & 0xFFFF0000u) | dead;
+                if (!in(2)) V[u].z = (V[u].z & 0xFFFF0000u) | dead;
+                if (!in(3)) V[u].w = (V[u].w & 0xFFFF0000u) | dead;
             }
-            lo(b0, V[u].z, 16);
-            hi(b0, V[u].z, 24);
-            lo(b1, V[u].w, 0);
-            hi(b1, V[u].w, 8);
-            lo(b2, V[u].w, 16);
+            g(V[u].x, V[u].x);
+            g(V[u].y, V[u].y);
+            g(V[u].z, V[u].z);
+            g(V[u].w, V[u].w);
+            g(__builtin_amdgcn_perm(V[u].y, V[u].x, 0x0c0c0602u), V[u].z << 8);  // row 4: B_4 from the spare bytes, A_4 to the top
         }
     }
 };

@@ -336,7 +336,8 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
 
 // The same sweep on the dense rows (PackedRows3: five rows per 16 bytes; k - 1 <= 63, level arrays of at most
 // 1024 cells).  Per row: 16-bit subtract (start - a, length untouched below it), and, subtract, compare | ffbh,
-// bfe, mad, lshl_add, mad, ashr, lshl_add, (shift of the order byte for four rows of five), ds_min x 2.
+// bfe, mad, lshl_add, mad, ashr, lshl_add, ds_min x 2 (four rows of five as they were loaded -- the dword is the
+// ds_min operand; the fifth after a v_perm_b32 and a shift).
 // Where it stands (profiles/r02_dense_rows_ab.txt): back to back -- the device settled at its power cap -- this kernel
 // takes 0.324 ms on config 3 where the 4-byte kernel takes 0.374 (another device: 0.331 against 0.343): 19 % fewer bytes,
 // 13 % less time; what keeps it from the full 19 % is the power cap (1370 W of 1400 at 2.2 GHz; the 4-byte kernel
@@ -385,21 +386,15 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
                 : "memory");
         }
     };
-    auto g_lo = [&](uint32_t b, uint32_t a, int sh) {  // 16-bit subtract on the low halves; the result's high half is zero
+    auto g = [&](uint32_t b, uint32_t data) {  // 16-bit subtract on the low half; the result's high half is zero
         uint32_t r;
         asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(b), "v"(a10s));
-        scatter(r, sh == 24 ? a : a << (24 - sh));
+        scatter(r, data);
     };
-    auto g_hi = [&](uint32_t b, uint32_t a, int sh) {  // ... with the HIGH half of b as the minuend (SDWA: no shift instruction)
-        uint32_t r;
-        asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0"
-            : "=v"(r) : "v"(b), "v"(a10s));
-        scatter(r, sh == 24 ? a : a << (24 - sh));
-    };
-    Rows::template consume<T, U>(A, t, 0, V, g_lo, g_hi);
+    Rows::template consume<T, U>(A, t, 0, V, g);
     for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
         Rows::template issue<T, U>(A, t, b, V);
-        Rows::template consume<T, U>(A, t, b, V, g_lo, g_hi);
+        Rows::template consume<T, U>(A, t, b, V, g);
     }
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
     halo_finish<OutT, T, 24>(A, t, lds);

@@ -346,21 +346,15 @@ __global__ __launch_bounds__(T) void sweep_membership_planes3_kernel(const Sweep
             }
         }
     };
-    auto g_lo = [&](uint32_t b, uint32_t a, int sh) {  // 16-bit subtract on the low halves; the result's high half is zero
+    auto g = [&](uint32_t b, uint32_t data) {  // 16-bit subtract on the low half; the result's high half is zero
         uint32_t r;
         asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(b), "v"(key6));
-        put(r, (a >> sh) & 0xFFu);
+        put(r, data >> 24);
     };
-    auto g_hi = [&](uint32_t b, uint32_t a, int sh) {  // ... with the HIGH half of b as the minuend (SDWA: no shift instruction)
-        uint32_t r;
-        asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0"
-            : "=v"(r) : "v"(b), "v"(key6));
-        put(r, (a >> sh) & 0xFFu);
-    };
-    Rows::template consume<T, U>(A, t, 0, V, g_lo, g_hi);
+    Rows::template consume<T, U>(A, t, 0, V, g);
     for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
         Rows::template issue<T, U>(A, t, b, V);
-        Rows::template consume<T, U>(A, t, b, V, g_lo, g_hi);
+        Rows::template consume<T, U>(A, t, b, V, g);
     }
     planes_transpose_store<T>(A, t, lds);
 }
