@@ -18,8 +18,10 @@ ap.add_argument("--workload", default="c3")
 ap.add_argument("--k", type=int, default=31)
 ap.add_argument("--pack", default=None)
 ap.add_argument("--tuning", default="0,0,0")
+ap.add_argument("--length", type=int, default=0, help="window length (default: the workload's); 10^7 positions of config 3 fit the Infinity Cache")
 a = ap.parse_args()
 num_docs, L, _ = WORKLOADS[a.workload]
+L = a.length or L
 _lib.use_ab(True)              # the stamps build is an AB build (make EXTRA=-DMEMO_STAMPS OUT_AB=...)
 ix, _ = synth.device_index(0, L, a.k, num_docs, L, pack=a.pack)
 out = torch.empty(L, dtype=torch.int16, device="cuda")
