@@ -257,6 +257,17 @@ __device__ __forceinline__ void halo_finish(const SweepArgs &A, const Tile &t, u
         halo_fold_store<OutT, T, TOP>(A, t, lds);
 }
 
+// The row loops below run every row as ONE branch-free block: v_cmpx puts "this row writes" (n > 0) into EXEC itself,
+// the address arithmetic and both ds_min run on those lanes only, and an s_mov restores EXEC (every lane of a wave
+// is active in a row loop: rows outside the slice arrive as rows that cannot write).  The compiler's form of the
+// same test -- v_cmp, s_and_saveexec, s_cbranch_execz, ..., s_or -- costs three scalar instructions and a branch
+// per row, and the CU's one scalar unit was as busy as its vector pipes (1.3e8 SALU against 1.5e8 VALU
+// wave-instructions per launch): dense rows, sustained, k = 21 / 31 / 64: 0.3218 -> 0.3133, 0.3249 -> 0.318,
+// 0.383 -> 0.374 ms (profiles/r02_dense_rows_ab.txt).  MEMO_ROW_CMPX=0 builds the branchy form for A/B.
+#ifndef MEMO_ROW_CMPX
+#define MEMO_ROW_CMPX 1
+#endif
+
 // 4- and 6-byte rows.  The 4-byte rows carry their order in the top byte of the word, and the cells
 // take the WORD (ds_min_u32 of the row as it was loaded: the min of the words has the min order on
 // top, the junk below it only breaks ties) -- one VALU instruction per row less than extracting it;
@@ -291,6 +302,45 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
     auto scatter = [&](uint32_t w, uint32_t col) {
         if (MEMO_ABLATE & 16) {  // keep the loads alive, nothing else
             asm volatile("" ::"v"(w), "v"(col));
+            return;
+        }
+        if (MEMO_ROW_CMPX && !(MEMO_ABLATE & 3)) {  // n, the test, start - a, the two cells, both ds_min: one block
+            uint32_t r0, r1, r2, nn;
+            if constexpr (!Rows::kW12)
+                asm volatile(
+                    "v_sub_u32_sdwa %3, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+                    "v_cmpx_lt_i32 vcc, 0, %3\n\t"
+                    "v_sub_u16 %1, %4, %6\n\t"
+                    "v_ffbh_u32 %0, %3\n\t"
+                    "v_mad_u32_u24 %2, %0, %7, %8\n\t"
+                    "v_lshl_add_u32 %2, %1, 2, %2\n\t"
+                    "v_mad_i32_i24 %1, %3, -4, %2\n\t"
+                    "v_ashrrev_i32 %0, %0, %9\n\t"
+                    "v_lshl_add_u32 %2, %0, 2, %2\n\t"
+                    "ds_min_u32 %1, %10\n\t"
+                    "ds_min_u32 %2, %10\n\t"
+                    "s_mov_b64 exec, -1"
+                    : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(nn)
+                    : "v"(w), "s"(km1), "v"(key), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(TOP ? w : col)
+                    : "memory", "vcc");
+            else
+                asm volatile(
+                    "v_sub_u32_sdwa %3, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                    "v_cmpx_lt_i32 vcc, 0, %3\n\t"
+                    "v_sub_u32 %1, %4, %6\n\t"
+                    "v_bfe_u32 %1, %1, 8, 12\n\t"
+                    "v_ffbh_u32 %0, %3\n\t"
+                    "v_mad_u32_u24 %2, %0, %7, %8\n\t"
+                    "v_lshl_add_u32 %2, %1, 2, %2\n\t"
+                    "v_mad_i32_i24 %1, %3, -4, %2\n\t"
+                    "v_ashrrev_i32 %0, %0, %9\n\t"
+                    "v_lshl_add_u32 %2, %0, 2, %2\n\t"
+                    "ds_min_u32 %1, %10\n\t"
+                    "ds_min_u32 %2, %10\n\t"
+                    "s_mov_b64 exec, -1"
+                    : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(nn)
+                    : "v"(w), "s"(km1), "v"(key), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(TOP ? w : col)
+                    : "memory", "vcc");
             return;
         }
         const int n = km1 - Rows::len(w);  // length of [end - (k-1), start)
@@ -387,6 +437,30 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
         }
     };
     auto g = [&](uint32_t b, uint32_t data) {  // 16-bit subtract on the low half; the result's high half is zero
+        if (MEMO_ROW_CMPX) {
+            // the whole row in one block, no branch: v_cmpx puts "this row writes" into EXEC itself, everything after it
+            // runs on those lanes only, s_mov restores EXEC (every lane of the wave is active in the row loop)
+            uint32_t r0, r1, r2, r3;
+            asm volatile(
+                "v_sub_u16 %3, %4, %5\n\t"
+                "v_and_b32 %0, 63, %3\n\t"
+                "v_sub_u32 %0, %6, %0\n\t"
+                "v_cmpx_lt_i32 vcc, 0, %0\n\t"
+                "v_ffbh_u32 %1, %0\n\t"
+                "v_bfe_u32 %3, %3, 6, 10\n\t"
+                "v_mad_u32_u24 %2, %1, %7, %8\n\t"
+                "v_lshl_add_u32 %2, %3, 2, %2\n\t"
+                "v_mad_i32_i24 %3, %0, -4, %2\n\t"
+                "v_ashrrev_i32 %1, %1, %9\n\t"
+                "v_lshl_add_u32 %2, %1, 2, %2\n\t"
+                "ds_min_u32 %3, %10\n\t"
+                "ds_min_u32 %2, %10\n\t"
+                "s_mov_b64 exec, -1"
+                : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                : "v"(b), "v"(a10s), "s"(km1), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(data)
+                : "memory", "vcc");
+            return;
+        }
         uint32_t r;
         asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(b), "v"(a10s));
         scatter(r, data);
