@@ -712,6 +712,61 @@ void sweep_conservation_mixed_kernel(const SweepArgs A) {
     const uint32_t key = pin_vgpr((int)Rows::tile_key(t.a));
     uint32_t *const cells4 = lds + (m - 2) * LS + HL, *const cells1 = lds + (m - 1) * LS + HL;
     auto scatter = [&](uint32_t w, uint32_t col) {
+        if (MEMO_ROW_CMPX) {
+            // The long intervals (n >= 16) as one branch-free block: v_cmpx narrows EXEC to "n > 0", then to "clz(n) < 28";
+            // the doubling arithmetic and both ds_min run on those lanes; EXEC restored.  What is left for the
+            // compiler's branch is the rare short interval (0 < n < 16).
+            int n;
+            uint32_t r0, r1, r2, d;
+            if constexpr (!Rows::kW12)
+                asm volatile(
+                    "v_sub_u32_sdwa %3, %6, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+                    "v_sub_u16 %4, %5, %7\n\t"
+                    "v_ffbh_u32 %0, %3\n\t"
+                    "v_cmpx_lt_i32 vcc, 0, %3\n\t"
+                    "v_cmpx_gt_u32 vcc, 28, %0\n\t"
+                    "v_mad_u32_u24 %2, %0, %8, %9\n\t"
+                    "v_lshl_add_u32 %2, %4, 2, %2\n\t"
+                    "v_mad_i32_i24 %1, %3, -4, %2\n\t"
+                    "v_ashrrev_i32 %0, %0, %10\n\t"
+                    "v_lshl_add_u32 %2, %0, 2, %2\n\t"
+                    "ds_min_u32 %1, %11\n\t"
+                    "ds_min_u32 %2, %11\n\t"
+                    "s_mov_b64 exec, -1"
+                    : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(n), "=&v"(d)
+                    : "v"(w), "s"(km1), "v"(key), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(TOP ? w : col)
+                    : "memory", "vcc");
+            else
+                asm volatile(
+                    "v_sub_u32_sdwa %3, %6, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+                    "v_sub_u32 %4, %5, %7\n\t"
+                    "v_bfe_u32 %4, %4, 8, 12\n\t"
+                    "v_ffbh_u32 %0, %3\n\t"
+                    "v_cmpx_lt_i32 vcc, 0, %3\n\t"
+                    "v_cmpx_gt_u32 vcc, 28, %0\n\t"
+                    "v_mad_u32_u24 %2, %0, %8, %9\n\t"
+                    "v_lshl_add_u32 %2, %4, 2, %2\n\t"
+                    "v_mad_i32_i24 %1, %3, -4, %2\n\t"
+                    "v_ashrrev_i32 %0, %0, %10\n\t"
+                    "v_lshl_add_u32 %2, %0, 2, %2\n\t"
+                    "ds_min_u32 %1, %11\n\t"
+                    "ds_min_u32 %2, %11\n\t"
+                    "s_mov_b64 exec, -1"
+                    : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(n), "=&v"(d)
+                    : "v"(w), "s"(km1), "v"(key), "s"(ls4), "v"(bias4), "v"(top_bit), "v"(TOP ? w : col)
+                    : "memory", "vcc");
+            if ((uint32_t)(n - 1) < 15u) {  // 0 < n < 16: blocks of S = 4 (n >= 4) or 1 at start - n and start - S; two more while n >= 2S, 3S
+                const uint32_t data = TOP ? w : col;
+                const bool four = n >= 4;
+                uint32_t *lv = (four ? cells4 : cells1) + d;
+                const int S = four ? 4 : 1, q = four ? n >> 2 : n;
+                atomicMin(lv - n, data);
+                atomicMin(lv - S, data);
+                if (q >= 2) atomicMin(lv - n + S, data);
+                if (q == 3) atomicMin(lv - n + 2 * S, data);
+            }
+            return;
+        }
         const int n = km1 - Rows::len(w);  // length of [end - (k-1), start)
         if (n > 0) {
             const uint32_t data = TOP ? w : col;
