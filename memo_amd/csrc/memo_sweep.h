@@ -307,12 +307,13 @@ struct PackedRows {
         const uint32_t *pk = A.pk + base0;
         const uint16_t *pa = ANNOT16 ? A.pa + base0 : nullptr;
         const uint32_t rel = batch * (4 * T * U) + 4 * threadIdx.x;
+        const uint32_t wave_rel = __builtin_amdgcn_readfirstlane(rel) & ~(uint32_t)255;  // once: the rest is scalar arithmetic
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t r = rel + (uint32_t)u * 4 * T;
             // wave-uniform (consume() tests the same): a wave loads its 256 rows or nothing.  The rows
             // it reads past the slice lie inside the index or its kPadRows sentinel rows.
-            if ((__builtin_amdgcn_readfirstlane(r) & ~(uint32_t)255) < end) {
+            if (wave_rel + (uint32_t)u * 4 * T < end) {
                 V[u] = *reinterpret_cast<const uint4 *>(pk + r);
                 if (ANNOT16) N[u] = *reinterpret_cast<const uint2 *>(pa + r);
             }
@@ -326,11 +327,12 @@ struct PackedRows {
         const uint32_t first = (uint32_t)(t.r0 - base0), end = (uint32_t)(t.r1 - base0);
         const uint32_t dead = tile_key(t.a) | (W12 ? 0x000000FFu : 0x00FF0000u);  // start = a, length 255: never writes
         const uint32_t rel = batch * (4 * T * U) + 4 * threadIdx.x;
+        const uint32_t wave_rel = __builtin_amdgcn_readfirstlane(rel) & ~(uint32_t)255;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t r = rel + (uint32_t)u * 4 * T;
             // wave-uniform: only a load that straddles an end of the slice masks rows by number
-            const uint32_t wave_lo = __builtin_amdgcn_readfirstlane(r) & ~(uint32_t)255;
+            const uint32_t wave_lo = wave_rel + (uint32_t)u * 4 * T;
             if (wave_lo >= end) break;  // nothing of this wave's load is inside the slice
             if (!(wave_lo >= first && wave_lo + 256 <= end)) {
                 V[u].x = (r + 0 >= first && r + 0 < end) ? V[u].x : dead;
@@ -393,11 +395,11 @@ struct PackedRows3 {
         span(t, g0, ng, first, end);
         const uint4 *p = reinterpret_cast<const uint4 *>(A.p3) + g0;
         const uint32_t q0 = batch * (T * U) + threadIdx.x;
+        const uint32_t wave_q0 = __builtin_amdgcn_readfirstlane(q0) & ~(uint32_t)63;  // once: the rest is scalar arithmetic
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t q = q0 + (uint32_t)u * T;
             // wave-uniform (consume() tests the same): a wave loads its 64 groups or nothing
-            if ((__builtin_amdgcn_readfirstlane(q) & ~(uint32_t)63) < ng) V[u] = p[q];
+            if (wave_q0 + (uint32_t)u * T < ng) V[u] = p[q0 + (uint32_t)u * T];
         }
     }
 
@@ -411,13 +413,17 @@ struct PackedRows3 {
         span(t, g0, ng, first, end);
         const uint32_t dead = ((((uint32_t)t.a & 1023u) << 6) | 63u);
         const uint32_t q0 = batch * (T * U) + threadIdx.x;
+        const uint32_t wave_q0 = __builtin_amdgcn_readfirstlane(q0) & ~(uint32_t)63;
+        // a wave's load lies wholly inside the slice iff its first group is in [in_lo, in_hi] (scalar, once per batch)
+        const uint32_t in_lo = (first + 4) / 5;
+        const int32_t in_hi = end >= kWaveRows ? (int32_t)((end - kWaveRows) / 5) : -1;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t q = q0 + (uint32_t)u * T;
-            const uint32_t wave_q = __builtin_amdgcn_readfirstlane(q) & ~(uint32_t)63;
+            const uint32_t wave_q = wave_q0 + (uint32_t)u * T;
             if (wave_q >= ng) break;  // nothing of this wave's load is inside the slice
             // (the fields are overwritten in place -- V[u] is dead after this -- so that the common path needs no copies)
-            if (!(5 * wave_q >= first && 5 * wave_q + kWaveRows <= end)) {  // a load that straddles an end of the slice
+            if (wave_q < in_lo || (int32_t)wave_q > in_hi) {  // a load that straddles an end of the slice
                 const uint32_t r = 5 * q;
                 auto in = [&](uint32_t i) { return r + i >= first && r + i < end; };
                 if (!in(4)) {  // row 4's field: byte 2 of dwords 0 and 1
