@@ -621,6 +621,58 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
     const uint32_t top_bit = pin_vgpr((int)0x80000000u);
     const uint32_t key = pin_vgpr((int)Rows::tile_key(t.a));
     auto scatter = [&](uint32_t w, uint32_t col) {
+        if (MEMO_ROW_CMPX) {
+            // the first two blocks of a row as one branch-free block (EXEC narrowed to "n > 0" by v_cmpx, restored at the end);
+            // the third and fourth stay behind the compiler's branches: where no row of a wave needs them (k = 128 on config 3)
+            // skipping them beats issuing them with no lane -- 0.395 against 0.415 ms (profiles/r02_mixed_levels.txt)
+            uint32_t tmp, a1, a2, s4, q, dd;
+#define MEMO_R4_BLOCK(LEN_SEL, REL_START)                                                                         \
+            asm volatile(                                                                                          \
+                "v_mov_b32 %4, 0\n\t"                 /* q = 0 where the row does not write */                     \
+                "v_sub_u32_sdwa %0, %7, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" LEN_SEL "\n\t" \
+                "v_cmpx_lt_i32 vcc, 0, %0\n\t"                                                                    \
+                REL_START                                                                                          \
+                "v_ffbh_u32 %4, %0\n\t"                                                                           \
+                "v_lshrrev_b32 %4, 1, %4\n\t"        /* i' = 15 - i */                                            \
+                "v_mad_u32_u24 %1, %4, %9, %10\n\t"  /* level i */                                                \
+                "v_lshl_add_u32 %2, %5, 2, %1\n\t"   /* cell `start` on level i (%5 = start - a) */               \
+                "v_mad_i32_i24 %1, %0, -4, %2\n\t"   /* a1: cell start - n */                                     \
+                "v_lshl_add_u32 %4, %4, 1, -1\n\t"   /* 2 i' - 1 = 29 - 2 i */                                    \
+                "v_lshrrev_b32 %3, %4, %12\n\t"      /* 4 S (bytes) */                                            \
+                "v_sub_u32 %2, %2, %3\n\t"           /* a2: cell start - S */                                     \
+                "ds_min_u32 %1, %11\n\t"                                                                          \
+                "ds_min_u32 %2, %11\n\t"                                                                          \
+                "v_sub_u32 %4, 29, %4\n\t"           /* 2 i */                                                    \
+                "v_lshrrev_b32 %4, %4, %0\n\t"       /* q */                                                      \
+                "s_mov_b64 exec, -1"                                                                               \
+                : "=&v"(tmp), "=&v"(a1), "=&v"(a2), "=&v"(s4), "=&v"(q), "=&v"(dd)                                 \
+                : "v"(w), "s"(km1), "v"(key), "s"(ls4), "v"(levelK), "v"(TOP ? w : col), "v"(top_bit)              \
+                : "memory", "vcc")
+            if constexpr (!Rows::kW12)
+                MEMO_R4_BLOCK("BYTE_2", "v_sub_u16 %5, %6, %8\n\t");
+            else
+                MEMO_R4_BLOCK("BYTE_0", "v_sub_u32 %5, %6, %8\n\tv_bfe_u32 %5, %5, 8, 12\n\t");
+#undef MEMO_R4_BLOCK
+            if (q >= 2) {
+                const uint32_t data = TOP ? w : col;
+                uint32_t a3, a4;
+                asm volatile(
+                    "v_add_u32 %0, %1, %2\n\t"        // a3 = a1 + 4 S
+                    "ds_min_u32 %0, %3"
+                    : "=&v"(a3)
+                    : "v"(a1), "v"(s4), "v"(data)
+                    : "memory");
+                if (q == 3) {
+                    asm volatile(
+                        "v_add_u32 %0, %1, %2\n\t"    // a4 = a3 + 4 S
+                        "ds_min_u32 %0, %3"
+                        : "=&v"(a4)
+                        : "v"(a3), "v"(s4), "v"(data)
+                        : "memory");
+                }
+            }
+            return;
+        }
         const int n = km1 - Rows::len(w);  // length of [end - (k-1), start)
         if (n > 0) {
             // i = floor(log4 n), S = 4^i, q = n >> 2i (the leading base-4 digit).  Blocks [start - n, +S) and
