@@ -2,7 +2,9 @@
 """bench.py -- query-positions/sec of the windowed k-mer conservation sweep on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 either way: `python bench.py --gpus N ...` starts its own ranks -- one child
+     `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, whose one JSON line and exit
+     code it relays -- or start it under torch.distributed.run yourself; see launch_ranks())
 
 Workload (BASELINE.json config 3 by default): synthetic pangenome, 100 genomes, 5 rows per
 pivot position (density 0.05 per genome-position), one window of 10^8 positions per GPU,
@@ -31,16 +33,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import memo_amd  # noqa: E402
-from memo_amd import shard, synth  # noqa: E402
+# numpy / torch / memo_amd are imported in main(), after launch_ranks() has had its say: the parent of a
+# self-launched N > 1 run never loads the HIP runtime or the library.
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
@@ -82,15 +80,72 @@ def parse():
                     help="also run the read-once calibration kernel (for the FETCH_SIZE PMC pass)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gather path even with one rank (validation)")
+    ap.add_argument("--launch", action="store_true",
+                    help="start the ranks as a child torch.distributed.run even when --gpus is 1 (N > 1 without "
+                         "WORLD_SIZE in the environment does so by itself)")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000,
                     help="positions of the window the 1-core CPU baseline is timed on (0 = skip)")
     return ap.parse_args()
+
+
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT initialising one (torch.cuda.device_count() reads the
+    topology only on this image; no HIP call, no memo_device_count).  MEMO_BENCH_ASSUME_DEVICES overrides
+    it (the CPU test of the launcher)."""
+    if os.environ.get("MEMO_BENCH_ASSUME_DEVICES"):
+        return int(os.environ["MEMO_BENCH_ASSUME_DEVICES"])
+    import torch
+    return torch.cuda.device_count()
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` as the driver spells it, with no WORLD_SIZE in the environment: this process
+    becomes the PARENT of one `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py <the same arguments>` -- a child process (subprocess; never os.exec*, and
+    nothing here has touched a GPU) -- relays rank 0's one JSON line on stdout and exits with the child's code.
+    Returns None when this process is itself a rank (or a plain N = 1 run)."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None                                         # already a rank of somebody's launcher
+    if args.gpus <= 1 and not args.launch:
+        return None
+    have = visible_gpus()
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but {have} GPU(s) visible on this node\n")
+        return 2
+    import socket
+    import subprocess
+    with socket.socket() as sk:                             # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    child_argv = [a for a in argv if a != "--launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + child_argv
+    if os.environ.get("MEMO_BENCH_CHILD_CMD"):              # the CPU test of this function: a stub child
+        cmd = json.loads(os.environ["MEMO_BENCH_CHILD_CMD"]) + child_argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL needs it on this pool)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)          # stderr passes through
+    out, _ = proc.communicate()
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+    for ln in out.decode(errors="replace").splitlines():   # anything else a rank printed on fd 1: to stderr
+        if ln not in lines:
+            sys.stderr.write(ln + "\n")
+    if proc.returncode == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from rank 0, got {len(lines)}\n")
+        return 3
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return proc.returncode
 
 
 def cpu_baseline(args, num_docs, L, k, membership, gpu_result_slice):
     """The oracle's literal transcription of memo_init + memo_query + argmax, one core,
     on the first `cpu_sample` positions of rank 0's window.  Also serves as the parity check
     of the benchmarked result (same positions)."""
+    import numpy as np
+    from memo_amd import synth
     from oracle import memo_oracle as oracle        # checker / baseline leg only
     S = min(args.cpu_sample, L)
     if membership:
@@ -132,6 +187,15 @@ def cpu_baseline(args, num_docs, L, k, membership, gpu_result_slice):
 
 def main():
     args = parse()
+    rc = launch_ranks(args, sys.argv[1:])
+    if rc is not None:
+        raise SystemExit(rc)
+    global np, torch, dist, memo_amd, shard, synth
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import memo_amd
+    from memo_amd import shard, synth
     # stdout carries exactly one JSON line.  RCCL and the HIP runtime sometimes print banners
     # on fd 1, so fd 1 is pointed at stderr for the run and the line goes to the saved fd.
     sys.stdout.flush()
@@ -141,7 +205,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus disagree")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     multi = world > 1 or args.force_dist
@@ -255,6 +319,38 @@ def main():
     coding, b_cap = "plain", 0
     cap = max(L // 256, 1024)
     choice = None
+    # N > 1: who is here, and what a peer's link into rank 0 delivers -- measured, not assumed: a gather of one
+    # plain slice per rank (what --plain-gather would send every step), 3 repetitions after one untimed.  Every
+    # peer sends over its own xGMI link at once, so slice bytes / gather time is the per-peer rate the step model
+    # needs (shard.XGMI_LINK_BYTES_PER_S is only the stand-in for a run with a single rank, where nothing travels).
+    link_measured, ranks_seen, link_probe = None, None, None
+    if multi:
+        props = torch.cuda.get_device_properties(local)
+        me = {"rank": rank, "device": local, "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None),
+              "uuid": str(getattr(props, "uuid", ""))}
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        ranks_seen = {"world_size": dist.get_world_size(), "ranks": seen,
+                      "distinct_devices": len({(r["device"], r["pci_bus_id"], r["uuid"]) for r in seen})}
+        launch(outs[0])
+        probe = outs[0].view(torch.uint8).reshape(-1)
+        probe = probe[:min(probe.numel(), 1 << 28)]
+        bufs = [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None
+        dist.gather(probe, bufs, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t_g0 = time.perf_counter()
+        for _ in range(3):
+            dist.gather(probe, bufs, dst=0)
+        torch.cuda.synchronize()
+        t_g = torch.tensor([(time.perf_counter() - t_g0) / 3], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_g, op=dist.ReduceOp.MAX)
+        link_probe = {"bytes_per_rank": probe.numel(), "gather_ms": float(t_g[0]) * 1e3, "reps": 3}
+        if world > 1:
+            link_measured = probe.numel() / float(t_g[0])
+        del bufs, probe
+    link = link_measured or shard.XGMI_LINK_BYTES_PER_S
     root_weight = 1.0 if args.root_weight == "auto" else min(max(float(args.root_weight), 0.01), 1.0)
     if multi and narrow and not args.plain_gather:
         found, have, taken, room = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
@@ -317,10 +413,10 @@ def main():
                 outs[0].data_ptr(), L, trial_r, probe.data_ptr(), local, stream.cuda_stream)))
             usable["runs"] = (lib.memo_transport_runs_bytes(L, runs_cap), t, tp)
         del probe, scratch
-        best, model = shard.pick_coding(world, t_sweep, usable)
+        best, model = shard.pick_coding(world, t_sweep, usable, link=link)
         w_best = 1.0
         if args.root_weight == "auto":
-            best, w_best, _ = shard.pick_plan(world, t_sweep, usable)
+            best, w_best, _ = shard.pick_plan(world, t_sweep, usable, link=link)
         else:
             w_best = min(max(float(args.root_weight), 0.01), 1.0)
         if args.coding in usable:
@@ -337,7 +433,11 @@ def main():
         elif coding == "runs":
             b_cap = runs_cap
         choice = {"picked": coding, "root_weight": root_weight, "sweep_ms": t_sweep * 1e3,
-                  "link_bytes_per_s_assumed": shard.XGMI_LINK_BYTES_PER_S,
+                  "link_GBs_used": link / 1e9,
+                  "link_source": "measured in this run (plain gather of one slice per rank)" if link_measured else
+                                 "assumed (one rank: nothing travels)",
+                  "modelled_step_ms": shard.modelled_step(world, t_sweep, *usable[coding], link=link,
+                                                          root_weight=root_weight) * 1e3,
                   "candidates": {c: {"wire_bytes": int(usable[c][0]), "decode_ms_per_slice": usable[c][1] * 1e3, "encode_ms": usable[c][2] * 1e3,
                                      "modelled_step_ms": model[c] * 1e3} for c in names}}
     nibble = coding != "plain"              # (name kept: "the slices travel coded")
@@ -396,14 +496,10 @@ def main():
             for g in range(1 if skip_own else 0, world):
                 unpack(roots[b][g], decoded[b][g])
 
-    def step(i, ev=None):
+    def step(i):
         b = i % nbuf
         finish(b)                           # buffer b is free once its previous gather is done
-        if ev:
-            ev[0].record(stream)
         launch(outs[b])
-        if ev:
-            ev[1].record(stream)
         if multi:                           # result slices -> rank 0 over xGMI (RCCL send/recv)
             if nibble and not skip_own:
                 pack(outs[b], wires[b])
@@ -474,46 +570,43 @@ def main():
                       "achieved_GBs": alg2 / (med2 * 1e-3) / 1e9, "frac": alg2 / (med2 * 1e-3) / 1e9 / HBM_PEAK_GBS})
 
     # (2) settling on the headline kernel (see settle())
-    ramp = settle(lambda: launch(outs[0])) if not multi else {"launches": 0, "ms": 0.0}
+    ramp = settle(lambda: launch(outs[0]))
 
     for i in range(args.warmup):
         step(i)
     drain()
     ix.check(stream.cuda_stream)           # raises if the kernel flagged a bad row
 
-    # HIP events on the launch stream.  N > 1: a pair around every step's sweep (pack and gather follow
-    # it on the same stream).  N = 1: the K sweeps run back to back, so ONE pair around all of them --
-    # two event packets between every two launches cost the timed region 5-7 us per step.
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps if multi else 1)]
+    # HIP events on the launch stream: ONE pair around the K timed steps at N = 1 (the sweeps run back to back;
+    # two event packets between every two launches cost the timed region 5-7 us per step) and none at all inside
+    # the timed region at N > 1 (or --force-dist): there a step is sweep + coding + gather and the wall clock
+    # between the barriers is what counts; the sweep alone is timed afterwards, K launches with a pair each.
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if multi:
-        for i in range(args.steps):
-            step(i, ev[i])
-    else:
-        ev[0][0].record(stream)
-        for i in range(args.steps):
-            step(i)
-        ev[0][1].record(stream)
+    if not multi:
+        ev[0].record(stream)
+    for i in range(args.steps):
+        step(i)
+    if not multi:
+        ev[1].record(stream)
     drain()
     if multi:
         dist.barrier()
     dt = time.perf_counter() - t0
-    per = [a.elapsed_time(b) for a, b in ev]
-    kern_ms = float(np.mean(per)) / (1 if multi else args.steps)
+    ix.check(stream.cuda_stream)
+    out = outs[(args.steps - 1) % nbuf]
+    # per-step spread (and, N > 1, the sweep's own time): K more sweeps with an event pair each, outside the
+    # timed region
+    per = per_step(lambda: launch(outs[args.steps % nbuf]), args.steps)
+    kern_ms = float(np.mean(per)) if multi else ev[0].elapsed_time(ev[1]) / args.steps
     if multi:
+        launch(outs[args.steps % nbuf])     # (leave every buffer holding a complete result)
         t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kern_ms = float(t[0]), float(t[1])
-    ix.check(stream.cuda_stream)
-    out = outs[(args.steps - 1) % nbuf]
-    # per-step spread: N = 1 re-runs the K steps with an event pair each (outside the timed region: the
-    # pairs cost 5-7 us per step); N > 1 has them already
-    if not multi:
-        per = per_step(lambda: launch(outs[0]), args.steps)
 
     if rank == 0:
         # bytes of the row layout the timed kernel reads + the result it writes
@@ -555,7 +648,9 @@ def main():
                          "kernel_ms": kern_ms, "kernel_ms_median": float(np.median(per)),
                          "kernel_ms_min": float(np.min(per)), "algorithmic_bytes": b_alg,
                          "timed_with": "HIP events on the launch stream: one pair around the K timed steps (kernel_ms "
-                                       "= mean); median / min from K further steps with a pair each"},
+                                       "= mean); median / min from K further steps with a pair each" if not multi else
+                                       "HIP events on the launch stream: K sweeps with a pair each, after the timed "
+                                       "region (kernel_ms = mean, slowest rank)"},
         }
         prof = os.path.join(ROOT, "profiles", "traffic.json")    # PMC passes are separate runs
         if os.path.exists(prof):
@@ -617,7 +712,12 @@ def main():
                 f"nibble per position + {cap} exception slots ({wires[0].numel()} B per slice)" if coding == "nibble" else
                 f"plain result bytes ({wires[0].numel()} B per slice)")
             if choice:
+                choice["measured_step_ms"] = dt / args.steps * 1e3
                 res["config"]["gather_coding_choice"] = choice
+            res["link_GBs_measured"] = link_measured / 1e9 if link_measured else None
+            res["link_GBs_assumed_when_unmeasured"] = shard.XGMI_LINK_BYTES_PER_S / 1e9
+            res["link_probe"] = link_probe
+            res["ranks_seen"] = ranks_seen
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     for x in indexes.values():
         x.close()

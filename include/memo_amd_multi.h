@@ -36,7 +36,8 @@ int memo_membership_multi(const int64_t *start, const int64_t *end, const int64_
 /* Resident form: shards[g] is an index resident on ITS device that holds (at least) the rows sub-window g
  * of memo_split_window(qs, qe, n_shards, 8, root_weight) needs -- a replica of the chromosome on every
  * GPU always does (2 GB of packed rows for 5 * 10^8 rows), a position-sharded index does for windows
- * inside its cuts.  Every device sweeps its sub-window on a stream of its own; hipMemcpyPeerAsync
+ * inside its cuts when it also holds every row of the window with end < start (those reach any distance left
+ * of their start; they are filtered by the whole window [qs, qe), not by the sub-window).  Every device sweeps its sub-window on a stream of its own; hipMemcpyPeerAsync
  * delivers the slice into d_out on `root_device` (over xGMI every peer has its own link to the root);
  * `root_stream` waits for all slices, so the result is complete in its order.  The root's own slice is
  * swept straight into d_out.  Check every shard with memo_query_check afterwards. */

@@ -105,6 +105,11 @@ struct memo_index {
     // memo_query.py): copied aside at finalize and applied by long_rows_kernel after each sweep
     int64_t *ls = nullptr, *le = nullptr, *lo = nullptr;
     uint64_t n_long = 0;
+    // memo_multi.hip (resident form) sweeps a SUB-window of the caller's window on this index.  A row with end < start
+    // can reach any distance left of its start, so it has to pass the reference's filter (memo_query.py:25-27) on the
+    // WHOLE window, not on the sub-window: while whole_set, the long-row kernels filter by [whole_qs, whole_qe).
+    int64_t whole_qs = 0, whole_qe = 0;
+    int whole_set = 0;
     int *d_status = nullptr;   // sticky flags set by the sweep kernels
     uint64_t *d_scratch = nullptr;  // finalize(): [0] unsorted pairs, [1] rows with end < start
 };

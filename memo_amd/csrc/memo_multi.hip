@@ -64,17 +64,20 @@ uint64_t lower_bound64(const int64_t *v, uint64_t n, int64_t key) {
     return lo;
 }
 
-bool sorted_by_start(const int64_t *s, uint64_t n) {
-    if (n < 2) return true;
+// rows start-sorted, and none with end < start?  Such a row (legal input to memo_query.py, never written by the
+// reference's index builder) shades [end - (k-1), start), any distance left of its start: the rule "sub-window
+// [a, b) needs the rows a < start < b + k" does not hold for it, so the split is not taken.
+bool splittable(const int64_t *s, const int64_t *e, uint64_t n) {
+    if (n < 1) return true;
     const unsigned nt = n > (1u << 22) ? 16u : 1u;
     std::vector<int> bad(nt, 0);
     std::vector<std::thread> th;
     const uint64_t per = (n + nt - 1) / nt;
     for (unsigned t = 0; t < nt; ++t)
         th.emplace_back([=, &bad] {
-            const uint64_t b = (uint64_t)t * per + 1, e = b + per < n ? b + per : n;
+            const uint64_t b = (uint64_t)t * per, en = b + per < n ? b + per : n;
             int x = 0;
-            for (uint64_t i = b; i < e; ++i) x |= s[i - 1] > s[i];
+            for (uint64_t i = b; i < en; ++i) x |= (i > 0 && s[i - 1] > s[i]) | (e[i] < s[i]);
             bad[t] = x;
         });
     for (auto &x : th) x.join();
@@ -93,10 +96,11 @@ int host_multi(const int64_t *start, const int64_t *end, const int64_t *annot, u
         return membership ? memo_membership(start, end, annot, rows, qs, qe, k, num_docs, (uint32_t *)out, dev)
                           : memo_conservation(start, end, annot, rows, qs, qe, k, num_docs, (uint16_t *)out, dev);
     };
-    // one device, nothing to cut, or rows the binary searches below cannot be trusted on: the single-GPU
-    // path (which sorts on the device and reproduces the reference's errors)
+    // one device, nothing to cut, rows the binary searches below cannot be trusted on, or rows with end < start
+    // (which reach further than k - 1 positions): the single-GPU path (which sorts on the device, applies such rows
+    // across the whole window and reproduces the reference's errors)
     if (n_devices == 1 || qe - qs < 8 * (int64_t)n_devices || k >= (1 << 30) || k <= -(1 << 30) || num_docs < 1 ||
-        !sorted_by_start(start, rows))
+        !splittable(start, end, rows))
         return single(devices[0]);
     std::vector<int64_t> cuts((size_t)n_devices + 1);
     int rc = memo_split_window(qs, qe, n_devices, 8, 1.0, cuts.data());
@@ -171,6 +175,14 @@ int dev_multi(memo_index_t *const *shards, int32_t n, int64_t qs, int64_t qe, in
         if (b <= a) continue;
         const int dev = shards[g]->device;
         char *dst = static_cast<char *>(d_out) + (size_t)(a - qs) * stride;
+        // rows with end < start pass the reference's filter on the WHOLE window (they can reach any distance left of
+        // their start, memo_common.h: whole_set); every shard holds the ones its sub-window can see as long as it
+        // holds the rows of the whole window with end < start (a replica does)
+        struct WholeWindow {
+            memo_index_t *ix;
+            WholeWindow(memo_index_t *i, int64_t s, int64_t e) : ix(i) { ix->whole_qs = s; ix->whole_qe = e; ix->whole_set = 1; }
+            ~WholeWindow() { ix->whole_set = 0; }
+        } whole(shards[g], qs, qe);
         if (g == 0 && dev == root_device) {  // the root's own slice is swept straight into the result, on the root's stream
             rc = membership ? memo_query_membership_dev(shards[g], a, b, k, num_docs, (uint32_t *)dst, root_stream)
                             : memo_query_conservation_dev(shards[g], a, b, k, num_docs, (uint16_t *)dst, root_stream);

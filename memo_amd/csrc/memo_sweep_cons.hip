@@ -874,8 +874,10 @@ __global__ void fill_conservation_kernel(OutT *out, int64_t n, OutT v) {
 // (at most 3) positions are left to long_rows_tail_kernel.
 template <typename OutT>
 __device__ __forceinline__ bool long_row_interval(int64_t s, int64_t e, int64_t o, int64_t qs, int64_t qe, int km1,
-                                                  int ncols, int *status, int64_t &c, int64_t &hi, int64_t &cc) {
-    if (!(s > qs && s < qe + km1 + 1)) return false;
+                                                  int ncols, int *status, int64_t &c, int64_t &hi, int64_t &cc,
+                                                  int64_t fqs, int64_t fqe) {
+    // [fqs, fqe) = the window the reference's filter sees (= [qs, qe) unless this sweep is a sub-window of it)
+    if (!(s > fqs && s < fqe + km1 + 1)) return false;
     const int64_t L = qe - qs;
     hi = s - qs > L ? L : s - qs;
     c = e - qs - km1;
@@ -892,9 +894,10 @@ __device__ __forceinline__ bool long_row_interval(int64_t s, int64_t e, int64_t 
 template <typename OutT>
 __global__ void long_rows_conservation_kernel(const int64_t *ls, const int64_t *le, const int64_t *lo,
                                               int64_t qs, int64_t qe, int km1, int ncols, OutT *out,
-                                              int *status) {
+                                              int *status, int64_t fqs, int64_t fqe) {
     int64_t c, hi, cc;
-    if (!long_row_interval<OutT>(ls[blockIdx.x], le[blockIdx.x], lo[blockIdx.x], qs, qe, km1, ncols, status, c, hi, cc))
+    if (!long_row_interval<OutT>(ls[blockIdx.x], le[blockIdx.x], lo[blockIdx.x], qs, qe, km1, ncols, status, c, hi, cc,
+                                 fqs, fqe))
         return;
     constexpr int PER = 4 / (int)sizeof(OutT);  // results per 32-bit word
     const int64_t whole = (qe - qs) / PER * PER;  // positions whose word lies inside the buffer
@@ -918,7 +921,8 @@ __global__ void long_rows_conservation_kernel(const int64_t *ls, const int64_t *
 template <typename OutT>
 __global__ __launch_bounds__(256) void long_rows_tail_kernel(const int64_t *ls, const int64_t *le, const int64_t *lo,
                                                              uint64_t n_long, int64_t qs, int64_t qe, int km1,
-                                                             int ncols, OutT *out, int *status) {
+                                                             int ncols, OutT *out, int *status, int64_t fqs,
+                                                             int64_t fqe) {
     constexpr int PER = 4 / (int)sizeof(OutT);
     const int64_t L = qe - qs, whole = L / PER * PER;
     __shared__ uint32_t best[4];
@@ -928,7 +932,7 @@ __global__ __launch_bounds__(256) void long_rows_tail_kernel(const int64_t *ls, 
         int64_t c, hi, cc;
         // (the bad-annot flag is raised by thread 0 of the main kernel's workgroup for this row)
         const int64_t s = ls[r], e = le[r], o = lo[r];
-        if (!(s > qs && s < qe + km1 + 1)) continue;
+        if (!(s > fqs && s < fqe + km1 + 1)) continue;
         hi = s - qs > L ? L : s - qs;
         c = e - qs - km1;
         c = c < 0 ? 0 : c;
@@ -997,11 +1001,12 @@ template <typename OutT>
 static int long_rows_conservation(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int ncols,
                                   OutT *d_out, hipStream_t st) {
     if (!ix->n_long) return MEMO_OK;
+    const int64_t fqs = ix->whole_set ? ix->whole_qs : qs, fqe = ix->whole_set ? ix->whole_qe : qe;
     hipLaunchKernelGGL((long_rows_conservation_kernel<OutT>), dim3((unsigned)ix->n_long), dim3(256), 0, st,
-                       ix->ls, ix->le, ix->lo, qs, qe, k - 1, ncols, d_out, ix->d_status);
+                       ix->ls, ix->le, ix->lo, qs, qe, k - 1, ncols, d_out, ix->d_status, fqs, fqe);
     if ((qe - qs) % (4 / (int)sizeof(OutT)))
         hipLaunchKernelGGL((long_rows_tail_kernel<OutT>), dim3(1), dim3(256), 0, st, ix->ls, ix->le, ix->lo,
-                           (uint64_t)ix->n_long, qs, qe, k - 1, ncols, d_out, ix->d_status);
+                           (uint64_t)ix->n_long, qs, qe, k - 1, ncols, d_out, ix->d_status, fqs, fqe);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }

@@ -369,9 +369,9 @@ __global__ void fill_membership_kernel(uint32_t *out, int64_t n, int nw, int nco
 
 __global__ void long_rows_membership_kernel(const int64_t *ls, const int64_t *le, const int64_t *lo,
                                             int64_t qs, int64_t qe, int km1, int ncols, int nw,
-                                            uint32_t *out, int *status) {
+                                            uint32_t *out, int *status, int64_t fqs, int64_t fqe) {
     const int64_t s = ls[blockIdx.x], e = le[blockIdx.x], o = lo[blockIdx.x];
-    if (!(s > qs && s < qe + km1 + 1)) return;
+    if (!(s > fqs && s < fqe + km1 + 1)) return;  // the reference's filter, on the whole window (memo_common.h: whole_set)
     const int64_t L = qe - qs;
     const int64_t hi = s - qs > L ? L : s - qs;
     int64_t c = e - qs - km1;
@@ -426,7 +426,8 @@ static int long_rows_membership(const memo_index *ix, int64_t qs, int64_t qe, in
                                 uint32_t *d_out, hipStream_t st) {
     if (!ix->n_long) return MEMO_OK;
     hipLaunchKernelGGL(long_rows_membership_kernel, dim3((unsigned)ix->n_long), dim3(256), 0, st, ix->ls,
-                       ix->le, ix->lo, qs, qe, k - 1, ncols, nw, d_out, ix->d_status);
+                       ix->le, ix->lo, qs, qe, k - 1, ncols, nw, d_out, ix->d_status,
+                       ix->whole_set ? ix->whole_qs : qs, ix->whole_set ? ix->whole_qe : qe);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }

@@ -613,6 +613,51 @@ def test_multi_device_resident_form(root_weight, memo, oracle):
             ix.close()
 
 
+def test_multi_device_rows_with_end_before_start(memo, oracle):
+    """A row with end < start shades [end - (k-1), start): any distance LEFT of its start, across sub-window cuts.
+    The rule 'sub-window [a, b) needs the rows a < start < b + k' does not hold for it (round-2 ADVICE): the host
+    form must not split such an index, the resident form filters those rows by the whole window."""
+    import ctypes as C
+    from memo_amd import index, _lib
+    rng = np.random.default_rng(33)
+    n_docs, length = 40, 200_000
+    s, e, o = _random_index(rng, 600_000, length, n_docs, 90)
+    # 300 rows reaching 100 .. 150 000 positions left of their start -- across one or several cuts
+    pick = rng.choice(len(s), 300, replace=False)
+    e[pick] = np.maximum(s[pick] - rng.integers(100, 150_000, 300), -5)
+    mid = length // 2
+    j = int(np.searchsorted(s, mid + 41))          # the ADVICE example: start just right of a cut + k, end far left of it
+    e[j] = s[j] - 400
+    for k, qs, qe in ((31, 0, length), (101, 1_000, 180_001), (5, 50_000, 150_000)):
+        want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+        qe2 = min(qe, qs + 60_000)
+        wantb = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe2, k), qs, qe2, k, n_docs, literal=False)
+        for devices in ([0, 0], [0, 0, 0, 0, 0, 0, 0]):
+            assert np.array_equal(index.conservation_multi(s, e, o, qs, qe, k, n_docs, devices), want), (devices, k)
+            assert np.array_equal(index.membership_multi(s, e, o, qs, qe2, k, n_docs, devices), wantb), (devices, k)
+        shards = [memo.DeviceIndex.from_host_packed(s, e, o) for _ in range(4)]
+        try:
+            assert shards[0].info()["long_rows"] >= 300
+            for membership, w, a, b in ((False, want, qs, qe), (True, wantb, qs, qe2)):
+                for root_weight in (1.0, 0.3):
+                    got = np.empty_like(w)
+                    d = C.c_void_p()
+                    _lib.check(_lib.lib().memo_dev_malloc(0, max(got.nbytes, 16), C.byref(d)))
+                    try:
+                        index.query_multi_dev(shards, a, b, k, n_docs, d.value, 0, None, root_weight, membership)
+                        for ix in shards:
+                            ix.check()
+                        _lib.check(_lib.lib().memo_dev_download(0, got.ctypes.data, d, got.nbytes, None))
+                    finally:
+                        _lib.lib().memo_dev_free(0, d)
+                    assert np.array_equal(got, w), (membership, k, root_weight)
+            # the single-window calls on the same index are untouched by the sub-window state
+            assert np.array_equal(shards[0].conservation(qs, qe, k, n_docs), want)
+        finally:
+            for ix in shards:
+                ix.close()
+
+
 def test_integration_stub_from_the_docs(memo, oracle):
     """the ctypes stub a maintainer of the reference would add, executed as it is
     printed there (only the library path filled in), against reference goldens"""

@@ -347,3 +347,71 @@ def test_fast_query_path_declines_what_it_cannot_answer(tmp_path, monkeypatch):
     code = "import sys; from memo_amd import _fastquery; assert 'numpy' not in sys.modules and 'pyarrow' not in sys.modules"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert subprocess.run([sys.executable, "-c", code], cwd=root).returncode == 0
+
+
+def _run_bench_parent(tmp_path, stub_body, extra_env=None, args=("--gpus", "8", "--steps", "20", "--warmup", "5")):
+    """`python bench.py --gpus N` with no WORLD_SIZE: the parent of bench.launch_ranks(), with a stub in the
+    place of `python -m torch.distributed.run ... bench.py` (MEMO_BENCH_CHILD_CMD)."""
+    import json
+    import subprocess
+    import sys
+    stub = tmp_path / "stub_child.py"
+    stub.write_text(stub_body)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MEMO_BENCH_CHILD_CMD"] = json.dumps([sys.executable, str(stub)])
+    env["MEMO_BENCH_ASSUME_DEVICES"] = "8"
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                          env=env, timeout=120)
+
+
+def test_bench_launches_its_own_ranks_and_relays_the_line(tmp_path):
+    """The driver spells N > 1 as `python bench.py --gpus N ...` (no torchrun in front, no WORLD_SIZE): the parent
+    starts ONE child process, hands it the same arguments, relays rank 0's single JSON line (banners a rank
+    printed on fd 1 go to stderr) and exits with the child's code.  The parent must not have loaded the HIP
+    runtime, torch.cuda or the library by then (it only counts devices)."""
+    import json
+    r = _run_bench_parent(tmp_path, (
+        "import json, os, sys\n"
+        "print('some RCCL banner on fd 1')\n"
+        "print(json.dumps({'metric': 'stub', 'argv': sys.argv[1:], 'value': 1.5, 'n_gpus': 8,\n"
+        "                  'ipc': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}))\n"))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["argv"] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and j["value"] == 1.5 and j["ipc"] == "0"
+    assert "some RCCL banner" in r.stderr and "some RCCL banner" not in r.stdout
+
+
+def test_bench_launcher_exit_codes(tmp_path):
+    # the child's failure is the parent's
+    r = _run_bench_parent(tmp_path, "import sys\nsys.stderr.write('rank 3 died\\n')\nsys.exit(7)\n")
+    assert r.returncode == 7 and r.stdout == "" and "rank 3 died" in r.stderr
+    # a child that succeeds without the line is an error too
+    r = _run_bench_parent(tmp_path, "print('no json here')\n")
+    assert r.returncode == 3 and r.stdout == ""
+    # fewer GPUs than asked for: one clear line, non-zero, no child started
+    r = _run_bench_parent(tmp_path, "raise SystemExit('the child must not run')\n", {"MEMO_BENCH_ASSUME_DEVICES": "1"})
+    assert r.returncode == 2 and "--gpus 8 but 1 GPU(s) visible" in r.stderr and "must not run" not in r.stderr
+    # --launch: the same path at N = 1 (what tools/gpu_torchrun.sh uses on the one-GPU pool); the flag itself is
+    # not handed down, or the child would launch again
+    r = _run_bench_parent(tmp_path, "import json, sys\nprint(json.dumps({'argv': sys.argv[1:]}))\n",
+                          args=("--gpus", "1", "--launch", "--force-dist"))
+    assert r.returncode == 0 and '"--launch"' not in r.stdout and '"--force-dist"' in r.stdout
+
+
+def test_bench_parent_does_not_touch_the_gpu_stack(tmp_path):
+    """launch_ranks() runs before numpy / torch / memo_amd are imported by bench.py itself."""
+    import subprocess
+    import sys
+    code = ("import sys, os\nsys.argv = ['bench.py', '--gpus', '8']\n"
+            "os.environ['MEMO_BENCH_ASSUME_DEVICES'] = '8'\n"
+            "os.environ['MEMO_BENCH_CHILD_CMD'] = '[\"%s\", \"-c\", \"print(chr(123)+chr(125))\"]'\n"
+            "os.environ.pop('WORLD_SIZE', None); os.environ.pop('RANK', None)\n"
+            "sys.path.insert(0, %r)\nimport bench\n"
+            "try:\n    bench.main()\nexcept SystemExit as e:\n    assert e.code == 0, e.code\n"
+            "bad = [m for m in ('torch', 'memo_amd', 'numpy') if m in sys.modules]\n"
+            "assert not bad, bad\n") % (sys.executable, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
