@@ -476,6 +476,9 @@ def main():
         wires = [o.view(torch.uint8).reshape(-1) for o in outs]  # RCCL has no 16-bit integer type
     roots = [[torch.empty_like(wires[0]) for _ in range(world)] if (multi and rank == 0) else None
              for _ in range(nbuf)]
+    if multi and rank == 0 and coding == "plain":
+        for b in range(nbuf):               # plain bytes: rank 0 sweeps straight into its place of the gathered result
+            roots[b][0] = wires[b]
     # rank 0: the gathered slices in result form (decoded when they travelled as nibbles)
     decoded = [[torch.empty(L, dtype=torch.uint8, device=dev) for _ in range(world)] if (nibble and rank == 0) else None
                for _ in range(nbuf)]
@@ -487,10 +490,23 @@ def main():
     if skip_own:
         outs = [decoded[b][0] for b in range(nbuf)]
 
+    def send_slices(b):
+        """every peer's wire b -> rank 0 (roots[b][g]): grouped RCCL send / recv, one per peer link; rank 0's own slice
+        never travels (dist.gather would copy it through RCCL's copy kernel, next to the sweep: 10 % of a step at
+        N = 1, gpurun r3a)."""
+        if rank == 0:
+            if nibble and args.code_own_slice:
+                roots[b][0].copy_(wires[b])     # (validation mode: rank 0's slice coded like a peer's)
+            ops = [dist.P2POp(dist.irecv, roots[b][g], g) for g in range(1, world)]
+        else:
+            ops = [dist.P2POp(dist.isend, wires[b], 0)]
+        return dist.batch_isend_irecv(ops) if ops else []
+
     def finish(b):                          # gather b done -> (root) slices back in result form
         if pending[b] is None:
             return
-        pending[b].wait()
+        for work in pending[b]:
+            work.wait()
         pending[b] = None
         if nibble and rank == 0:
             for g in range(1 if skip_own else 0, world):
@@ -503,7 +519,7 @@ def main():
         if multi:                           # result slices -> rank 0 over xGMI (RCCL send/recv)
             if nibble and not skip_own:
                 pack(outs[b], wires[b])
-            pending[b] = dist.gather(wires[b], roots[b], dst=0, async_op=True)
+            pending[b] = send_slices(b)
 
     def drain():
         for b in range(nbuf):

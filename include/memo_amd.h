@@ -76,7 +76,7 @@ typedef struct memo_index_info {
                                radix-4, 4 unclipped mixed (1, 4, 16, then doubling), 5 dense rows -- the library picks
                                2 / 3 / 4 per query from k and the overlap lengths of the rows it sampled when the
                                packed rows were made; membership: 6 bit planes on the dense rows, 7 any other */
-    int32_t reserved;
+    int32_t last_variant;   /* 1 when that sweep ran as persistent workgroups (dense rows streamed by LDS-DMA), else 0 */
 } memo_index_info_t;
 
 const char *memo_last_error(void);
@@ -138,6 +138,24 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);
  * packers: pa != NULL: format 6; else max_annot > 255: format 12; else format 4.  Host memory may be pageable
  * (a memory-mapped file): it goes through the pinned ring. */
 int memo_index_export_packed(memo_index_t *ix, uint32_t *pk, uint16_t *pa, int64_t *boff, int64_t *long_rows);
+/* The same for the DENSE rows (five per 16 bytes; memo_index_pack_dense, or a memo_builder_create_rows(...,
+ * MEMO_ROWS_DENSE) index): _export copies ceil(rows / 5) groups, the bucket table and the rows with end < start;
+ * _import builds a finalized index that holds the dense rows only (3.2 B per row: conservation, k <= 64, <= 255
+ * genomes -- memo_dense_rows_can_answer) from such arrays, or from a slice of them: `groups` points at the group
+ * that holds row `row_base` (a multiple of 5), `rows` counts from row_base, and the first table entry may lie up to
+ * 4 rows behind row_base (the bucket's first row sits inside that group).  So that `memo query` reads the
+ * benchmarked row format straight from its sidecar cache. */
+int memo_index_export_dense(memo_index_t *ix, void *groups, int64_t *boff, int64_t *long_rows);
+int memo_index_import_dense(uint64_t rows, int32_t device, int32_t bucket_shift, int64_t bucket_base,
+                            const void *groups, const int64_t *boff, uint64_t buckets, int64_t row_base,
+                            int64_t min_start, int64_t max_start, uint64_t max_annot, const int64_t *long_rows,
+                            uint64_t n_long, memo_index_t **out);
+/* 1 when an index that holds ONLY the dense rows answers this query (the unclipped conservation sweep on them:
+ * conservation, 2 <= k <= 64, num_docs <= 255, every annot <= num_docs, at least one row per pivot position between
+ * min_start and max_start), else 0.  Pure host arithmetic; the one rule the one-shot form, memo_amd/memo_query.py and
+ * the cache use to choose the row format BEFORE they build or import an index. */
+int memo_dense_rows_can_answer(uint64_t rows, int64_t min_start, int64_t max_start, uint64_t max_annot, int32_t k,
+                               int32_t num_docs, int32_t membership);
 int memo_index_import_packed(uint64_t rows, int32_t device, int32_t bucket_shift, int64_t bucket_base,
                              const uint32_t *pk, const uint16_t *pa, const int64_t *boff, uint64_t buckets,
                              int64_t row_base, int64_t min_start, int64_t max_start, uint64_t max_annot,
@@ -154,9 +172,17 @@ void memo_index_destroy(memo_index_t *ix);
  * that is finalized and packed (int64 columns never reach the GPU; it answers k <= 256).
  * Rows that cannot be packed into one word (unsorted, negative start, annot outside [0, 4095]) make _push
  * return MEMO_EUNPACKABLE: start over with memo_index_upload (+ _finalize, _pack: the 6-byte format).
- * Nothing of the caller's memory is referenced after _push returns.  One builder per thread. */
+ * Nothing of the caller's memory is referenced after _push returns.  One builder per thread.
+ * memo_builder_create_rows(..., MEMO_ROWS_DENSE) narrows the rows to the DENSE format instead (five rows per 16
+ * bytes: 3.2 B per row on the link and in HBM, the fastest source of the conservation sweep) for callers that know
+ * their queries fit it (memo_dense_rows_can_answer); a row with an annot > 255 makes _push return MEMO_EUNPACKABLE
+ * there too: start over with MEMO_ROWS_PACKED. */
 typedef struct memo_builder memo_builder_t;
+#define MEMO_ROWS_PACKED 0 /* one 32-bit word per row (formats 4 / 12): every query with k <= 256 */
+#define MEMO_ROWS_DENSE 1  /* five 24-bit rows per 16 bytes: conservation, k <= 64, <= 255 genomes */
 int memo_builder_create(uint64_t max_rows, int32_t device, int32_t bucket_shift, memo_builder_t **out);
+int memo_builder_create_rows(uint64_t max_rows, int32_t device, int32_t bucket_shift, int32_t row_format,
+                             memo_builder_t **out);
 int memo_builder_push(memo_builder_t *b, const int64_t *start, const int64_t *end, const int64_t *annot,
                       uint64_t rows);
 /* hands the index over (destroy the builder afterwards; it cannot be used again) */
@@ -182,9 +208,10 @@ int memo_query_check(memo_index_t *ix, void *stream);
 
 /* ---- one-shot host form: the drop-in for memo_query.py:103-104 + :70 ------------------
  * Host pointers in and out; uploads, queries, downloads, frees.  `device` is a HIP device ordinal.
- * For k <= 256 and packable rows (see memo_builder_*) the rows take the packed, pinned way in and the
- * sweep reads 4-6 B per row; the result comes back through the same pinned ring.  Anything else is
- * uploaded as int64 columns, validated (and sorted if need be) on the device. */
+ * For k <= 256 and packable rows (see memo_builder_*) the rows take the packed, pinned way in -- as dense rows
+ * (3.2 B per row, the benchmarked kernel) when memo_dense_rows_can_answer says so, else as 4-byte words -- and the
+ * result comes back through the same pinned ring.  Anything else is uploaded as int64 columns, validated (and
+ * sorted if need be) on the device. */
 int memo_conservation(const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows,
                       int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint16_t *out,
                       int32_t device);

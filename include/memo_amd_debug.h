@@ -20,13 +20,20 @@ extern "C" {
  *   4 = planes (unclipped, result staged through LDS; packed rows, <= 512 genomes; else 3);
  * row_source: 0 = the library's choice (conservation: the dense rows where they are resident and can answer,
  *   else the 4- / 6-byte rows, else the int64 columns), 1 = the int64 columns even when packed rows exist,
- *   2 = same as 0 (kept for older scripts), 3 = the 4- / 6-byte rows even where the dense rows could answer;
+ *   2 = same as 0 (kept for older scripts), 3 = the 4- / 6-byte rows even where the dense rows could answer,
+ *   4 = the dense rows swept by PERSISTENT workgroups with their rows streamed by LDS-DMA (memo_sweep_cons3p.hip)
+ *   wherever the query fits that kernel, 5 = the dense rows with one workgroup per tile, 6 / 7 = persistent workgroups
+ *   whose rows go into registers at the head of a tile / one tile ahead;
  * scatter (conservation, packed rows): 1 = clip every interval to the tile, 2 = unclipped into doubling
  *   level arrays with a halo, 3 = unclipped into radix-4 level arrays, 4 = unclipped into mixed level arrays
  *   (blocks of 1, 4, 16, then doubling; k - 1 >= 16) -- 2, 3 and 4 only when every annot of the index is inside
  *   the result matrix, else 1. */
 int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32_t membership_algo,
                           int32_t row_source, int32_t scatter);
+/* memo_index_info_t.last_sweep of the index this thread's last memo_conservation / memo_membership call built and
+ * swept (the one-shot forms destroy their index before they return): which kernel family -- hence which row format --
+ * answered it */
+int memo_debug_last_one_shot_sweep(void);
 /* one pass that reads the three int64 columns exactly once (24 B/row) with the sweep's access
  * shape, to calibrate the FETCH_SIZE counter on a known byte count */
 int memo_debug_stream_rows(memo_index_t *ix, void *stream);

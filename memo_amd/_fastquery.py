@@ -20,14 +20,32 @@ import time
 
 from . import _lib
 
-VERSION = 1
+VERSION = 2
 HEADER_BYTES = 4096
-MAGIC = b"MEMOPK01"
+MAGIC = b"MEMOPK02"
 
 
 def _cache_path(in_file, record):       # (= memo_amd.cache.cache_path; restated here to keep NumPy out)
-    safe = "".join(ch if (ch.isalnum() or ch in "._-") else "_%02x" % ord(ch) for ch in record) or "_"
+    safe = "".join(ch if (ch.isalnum() or ch in ".-") else "_%02x" % ord(ch) for ch in record) or "_"
     return os.path.join(in_file + ".memo", safe + ".v%d.pk" % VERSION)
+
+
+def _header_ok(head, file_bytes):       # (= memo_amd.cache.header_ok)
+    try:
+        rows, nb, n_long, fmt = int(head["rows"]), int(head["buckets"]), int(head["long_rows"]), int(head["format"])
+        total = int(head["bytes"])
+        if total != file_bytes or rows < 0 or nb < 2 or n_long < 0 or fmt not in (4, 6, 12):
+            return False
+        if not (1 <= int(head["bucket_shift"]) <= 8) or int(head["max_annot"]) < 0:
+            return False
+        need = [(int(head["off_pk"]), 4 * rows), (int(head["off_boff"]), 8 * nb), (int(head["off_long"]), 24 * n_long)]
+        if fmt == 6:
+            need.append((int(head["off_pa"]), 2 * rows))
+        if head.get("off_p3") is not None:
+            need.append((int(head["off_p3"]), 16 * ((rows + 4) // 5)))
+        return all(off >= HEADER_BYTES and size >= 0 and off + size <= total for off, size in need)
+    except (KeyError, TypeError, ValueError):
+        return False
 
 
 def _open(in_file, record):
@@ -44,7 +62,7 @@ def _open(in_file, record):
                 return None
             if head.get("source") != {"size": st.st_size, "mtime_ns": st.st_mtime_ns}:
                 return None
-            if os.fstat(fh.fileno()).st_size != head["bytes"]:
+            if not _header_ok(head, os.fstat(fh.fileno()).st_size):
                 return None
             # ACCESS_COPY: private, copy-on-write -- never written to, but ctypes wants a writable buffer
             return head, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_COPY)
@@ -84,6 +102,8 @@ def try_query(in_file, region, k, num_docs, out_file, membership):
     b_lo = min(max(qs, 0) >> shift, nb - 1)
     b_hi = min(max((max(q_end, 0) >> shift) + 1, b_lo), nb - 1)
     r0, r1 = entry(b_lo), entry(b_hi)
+    if not (0 <= r0 <= r1 <= head["rows"]):
+        return False                              # a table that does not describe these rows: the regular path answers
     n = r1 - r0
     base = C.addressof(C.c_char.from_buffer(mm))
     n_long = head["long_rows"]
@@ -91,12 +111,24 @@ def try_query(in_file, region, k, num_docs, out_file, membership):
     hi = min(((b_hi + 1) << shift) - 1, head["max_start"]) if n else -1
     ix = C.c_void_p()
     d_out = C.c_void_p()
+    dense = False
     try:
-        _lib.check(lib.memo_index_import_packed(
-            n, device, shift, b_lo, base + head["off_pk"] + 4 * r0,
-            (base + head["off_pa"] + 2 * r0) if head["format"] == 6 else None,
-            base + head["off_boff"] + 8 * b_lo, b_hi - b_lo + 2, r0, lo, hi, head["max_annot"],
-            (base + head["off_long"]) if n_long else None, n_long, C.byref(ix)))
+        # the dense rows (3.2 B per row, the benchmarked conservation kernel) when the file has them and they alone can
+        # answer this query; else the 4- / 6-byte rows
+        if head.get("off_p3") is not None and lib.memo_dense_rows_can_answer(n, lo, hi, head["max_annot"], k, num_docs,
+                                                                             1 if membership else 0):
+            row_base = r0 // 5 * 5                # the slice starts with the group that holds row r0
+            dense = True
+            _lib.check(lib.memo_index_import_dense(
+                r1 - row_base, device, shift, b_lo, base + head["off_p3"] + 16 * (row_base // 5),
+                base + head["off_boff"] + 8 * b_lo, b_hi - b_lo + 2, row_base, lo, hi, head["max_annot"],
+                (base + head["off_long"]) if n_long else None, n_long, C.byref(ix)))
+        else:
+            _lib.check(lib.memo_index_import_packed(
+                n, device, shift, b_lo, base + head["off_pk"] + 4 * r0,
+                (base + head["off_pa"] + 2 * r0) if head["format"] == 6 else None,
+                base + head["off_boff"] + 8 * b_lo, b_hi - b_lo + 2, r0, lo, hi, head["max_annot"],
+                (base + head["off_long"]) if n_long else None, n_long, C.byref(ix)))
         t1 = time.perf_counter()
         L = max(qe - qs, 0)
         words = (num_docs + 31) // 32
@@ -127,6 +159,6 @@ def try_query(in_file, region, k, num_docs, out_file, membership):
             lib.memo_index_destroy(ix)
     if os.environ.get("MEMO_TIMING"):
         sys.stderr.write("memo_query timing: region slice+upload %.3f s (from the sidecar cache, ctypes-only path), "
-                         "sweep+download %.3f s, text+write %.3f s (%d rows, %d positions)\n"
-                         % (t1 - t0, t2 - t1, t3 - t2, n, L))
+                         "sweep+download %.3f s, text+write %.3f s (%d rows as %s, %d positions)\n"
+                         % (t1 - t0, t2 - t1, t3 - t2, n, "dense rows (3.2 B)" if dense else "4-byte rows", L))
     return True

@@ -42,7 +42,7 @@ class IndexInfo(C.Structure):
                 ("was_sorted", C.c_int32), ("finalized", C.c_int32), ("device_bytes", C.c_uint64),
                 ("packed_format", C.c_int32), ("has_wide", C.c_int32), ("pack_ms", C.c_float),
                 ("dense_rows", C.c_int32), ("long_rows", C.c_uint64), ("max_annot", C.c_uint64),
-                ("bucket_base", C.c_int64), ("last_sweep", C.c_int32), ("reserved", C.c_int32)]
+                ("bucket_base", C.c_int64), ("last_sweep", C.c_int32), ("last_variant", C.c_int32)]
 
 
 # every symbol the product headers declare: name -> (restype, argtypes)
@@ -63,8 +63,13 @@ SYMBOLS = {
     "memo_index_export_packed": (C.c_int, [_P, _P, _P, _P, _P]),
     "memo_index_import_packed": (C.c_int, [_U64, _I32, _I32, _I64, _P, _P, _P, _U64, _I64, _I64, _I64, _U64, _P, _U64,
                                            C.POINTER(_P)]),
+    "memo_index_export_dense": (C.c_int, [_P, _P, _P, _P]),
+    "memo_index_import_dense": (C.c_int, [_U64, _I32, _I32, _I64, _P, _P, _U64, _I64, _I64, _I64, _U64, _P, _U64,
+                                          C.POINTER(_P)]),
+    "memo_dense_rows_can_answer": (C.c_int, [_U64, _I64, _I64, _U64, _I32, _I32, _I32]),
     "memo_index_destroy": (None, [_P]),
     "memo_builder_create": (C.c_int, [_U64, _I32, _I32, C.POINTER(_P)]),
+    "memo_builder_create_rows": (C.c_int, [_U64, _I32, _I32, _I32, C.POINTER(_P)]),
     "memo_builder_push": (C.c_int, [_P, _P, _P, _P, _U64]),
     "memo_builder_finish": (C.c_int, [_P, C.POINTER(_P)]),
     "memo_builder_destroy": (None, [_P]),
@@ -113,6 +118,7 @@ SYMBOLS = {
 DEBUG_SYMBOLS = {
     "memo_debug_set_tuning": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32]),
     "memo_debug_stream_rows": (C.c_int, [_P, _P]),
+    "memo_debug_last_one_shot_sweep": (C.c_int, []),
     "memo_debug_set_stamp_buffer": (C.c_int, [_P]),
 }
 

@@ -2,8 +2,9 @@
 
 `memo query` spends its wall clock decoding ZSTD Parquet pages (0.59 s of 0.93 s for a 2 * 10^7-position
 window of a 10^8-row index, profiles/r01_cli_timing_16decoders.txt); the sweep is 2 % of it.  The Parquet
-file stays the source of truth.  Beside it, `<index>.parquet.memo/<record>.v1.pk` keeps, per record
+file stays the source of truth.  Beside it, `<index>.parquet.memo/<record>.v2.pk` keeps, per record
 (chromosome), exactly what the GPU wants: the packed rows (4 B per row; + 2 B when an annot exceeds 4095),
+the dense rows (3.2 B per row, when every annot fits 8 bits: the benchmarked kernel's format),
 the start-bucket table and the few rows with end < start -- as produced by the library itself
 (memo_builder_* + memo_index_export_packed).  A repeat query maps the file, cuts the window's rows out with
 two lookups in the bucket table and uploads them through the pinned ring (memo_index_import_packed): no
@@ -14,21 +15,25 @@ version, or a truncated file) makes the cache invisible and it is rebuilt.  File
 temporary name and renamed, so a reader never sees a partial file.  Set MEMO_CACHE=0 to neither read nor
 write caches; MEMO_CACHE=read to read but never build.  A miss starts `python -m memo_amd.cache build`
 detached in the background (the query itself is answered from the Parquet file as before); MEMO_CACHE=sync
-builds it in-process after the answer is written instead (tests, batch jobs).
+builds it in-process after the answer is written instead (tests, batch jobs).  One builder per record at a
+time (an O_EXCL lock file); a record whose rows cannot be packed leaves a marker (`.v2.nocache`, keyed like the
+cache) so that later queries neither rebuild nor respawn.
 """
 import ctypes as C
 import json
 import os
 import sys
+import time
 
 import numpy as np
 
-from ._lib import check, lib
-from .index import DeviceIndex
+from ._lib import MemoUnpackable, check, lib
+from .index import DeviceIndex, dense_rows_can_answer
 
-VERSION = 1
+VERSION = 2
 HEADER_BYTES = 4096
-MAGIC = b"MEMOPK01"
+MAGIC = b"MEMOPK02"
+LOCK_STALE_SECONDS = 3600.0
 
 
 def mode():
@@ -36,9 +41,21 @@ def mode():
     return {"0": "off", "off": "off", "no": "off", "read": "read", "sync": "sync"}.get(v, "on")
 
 
+def _safe(record):
+    """file-name form of a record name; injective ('_' is escaped too: 'chr 1' and 'chr_201' stay apart)"""
+    return "".join(ch if (ch.isalnum() or ch in ".-") else "_%02x" % ord(ch) for ch in record) or "_"
+
+
 def cache_path(in_file, record):
-    safe = "".join(ch if (ch.isalnum() or ch in "._-") else "_%02x" % ord(ch) for ch in record) or "_"
-    return os.path.join(in_file + ".memo", safe + ".v%d.pk" % VERSION)
+    return os.path.join(in_file + ".memo", _safe(record) + ".v%d.pk" % VERSION)
+
+
+def _marker_path(in_file, record):      # "this record cannot be cached" (unpackable rows, or none)
+    return os.path.join(in_file + ".memo", _safe(record) + ".v%d.nocache" % VERSION)
+
+
+def _lock_path(in_file, record):
+    return os.path.join(in_file + ".memo", _safe(record) + ".v%d.lock" % VERSION)
 
 
 def _source_key(in_file):
@@ -50,8 +67,31 @@ def _align(x, a=4096):
     return (x + a - 1) // a * a
 
 
+def header_ok(head, file_bytes):
+    """every offset / count of a header lies inside the file it describes (a corrupt or hand-edited header must make
+    the cache invisible, not send raw pointers past the mapping)"""
+    try:
+        rows, nb, n_long, fmt = int(head["rows"]), int(head["buckets"]), int(head["long_rows"]), int(head["format"])
+        total = int(head["bytes"])
+        if total != file_bytes or rows < 0 or nb < 2 or n_long < 0 or fmt not in (4, 6, 12):
+            return False
+        if not (1 <= int(head["bucket_shift"]) <= 8) or int(head["max_annot"]) < 0:
+            return False
+        need = [(int(head["off_pk"]), 4 * rows), (int(head["off_boff"]), 8 * nb), (int(head["off_long"]), 24 * n_long)]
+        if fmt == 6:
+            need.append((int(head["off_pa"]), 2 * rows))
+        if head.get("off_p3") is not None:
+            need.append((int(head["off_p3"]), 16 * ((rows + 4) // 5)))
+        return all(off >= HEADER_BYTES and size >= 0 and off + size <= total for off, size in need)
+    except (KeyError, TypeError, ValueError):
+        return False
+
+
 def write(in_file, record, ix):
-    """ix: a packed DeviceIndex holding EVERY row of `record`.  Writes the cache file atomically."""
+    """ix: a packed DeviceIndex holding EVERY row of `record`.  Writes the cache file atomically: the 4- (6-) byte
+    rows, the bucket table, the rows with end < start and -- when every annot fits 8 bits -- the DENSE rows too (3.2 B
+    per row, memo_index_pack_dense: what the conservation sweep reads fastest, so that a cached `memo query -k 31`
+    runs the benchmarked kernel)."""
     inf = ix.info()
     rows, nb, n_long, fmt = inf["rows"], inf["buckets"], inf["long_rows"], inf["packed_format"]
     if fmt not in (4, 6, 12) or inf["bucket_base"] != 0:
@@ -62,15 +102,22 @@ def write(in_file, record, ix):
     longs = np.empty(3 * n_long, np.int64)
     check(lib().memo_index_export_packed(ix._h, pk.ctypes.data, pa.ctypes.data if fmt == 6 else None, boff.ctypes.data,
                                          longs.ctypes.data if n_long else None))
+    p3 = np.empty(0, np.uint32)
+    if fmt == 4 and rows:
+        ix.pack_dense(keep_packed=True)
+        p3 = np.empty(4 * ((rows + 4) // 5), np.uint32)
+        boff2 = np.empty(nb, np.int64)
+        check(lib().memo_index_export_dense(ix._h, p3.ctypes.data, boff2.ctypes.data, longs.ctypes.data if n_long else None))
     off_pk = HEADER_BYTES
     off_pa = _align(off_pk + pk.nbytes)
-    off_boff = _align(off_pa + pa.nbytes)
+    off_p3 = _align(off_pa + pa.nbytes)
+    off_boff = _align(off_p3 + p3.nbytes)
     off_long = _align(off_boff + boff.nbytes)
     total = off_long + longs.nbytes
     head = {"version": VERSION, "record": record, "source": _source_key(in_file), "rows": rows, "format": fmt,
             "bucket_shift": inf["bucket_shift"], "buckets": nb, "min_start": inf["min_start"], "max_start": inf["max_start"],
-            "max_annot": inf["max_annot"], "long_rows": n_long, "off_pk": off_pk, "off_pa": off_pa, "off_boff": off_boff,
-            "off_long": off_long, "bytes": total}
+            "max_annot": inf["max_annot"], "long_rows": n_long, "off_pk": off_pk, "off_pa": off_pa,
+            "off_p3": off_p3 if p3.nbytes else None, "off_boff": off_boff, "off_long": off_long, "bytes": total}
     blob = MAGIC + json.dumps(head).encode()
     if len(blob) > HEADER_BYTES:
         raise ValueError("cache header too large")
@@ -79,7 +126,7 @@ def write(in_file, record, ix):
     tmp = "%s.tmp.%d" % (path, os.getpid())
     with open(tmp, "wb") as fh:
         fh.write(blob.ljust(HEADER_BYTES, b"\0"))
-        for off, arr in ((off_pk, pk), (off_pa, pa), (off_boff, boff), (off_long, longs)):
+        for off, arr in ((off_pk, pk), (off_pa, pa), (off_p3, p3), (off_boff, boff), (off_long, longs)):
             fh.seek(off)
             fh.write(memoryview(arr).cast("B"))
         fh.truncate(total)
@@ -98,34 +145,56 @@ def _open(in_file, record):
         head = json.loads(raw[len(MAGIC):].rstrip(b"\0"))
         if head.get("version") != VERSION or head.get("record") != record or head.get("source") != _source_key(in_file):
             return None
-        if os.path.getsize(path) != head["bytes"]:
+        if not header_ok(head, os.path.getsize(path)):
             return None
         return head, np.memmap(path, dtype=np.uint8, mode="r")
     except (OSError, ValueError, KeyError):
         return None
 
 
-def load_region(in_file, record, query_start, query_end, device=0):
+def bucket_slice(head, entry, query_start, query_end):
+    """(b_lo, b_hi, r0, r1) of the rows with query_start < start < query_end (+ the rest of the two edge buckets);
+    entry(b) reads table entry b; None when the table is inconsistent"""
+    nb, shift, rows = head["buckets"], head["bucket_shift"], head["rows"]
+    b_lo = min(max(query_start, 0) >> shift, nb - 1)
+    b_hi = min(max((max(query_end, 0) >> shift) + 1, b_lo), nb - 1)
+    r0, r1 = int(entry(b_lo)), int(entry(b_hi))
+    if not (0 <= r0 <= r1 <= rows):
+        return None
+    return b_lo, b_hi, r0, r1
+
+
+def load_region(in_file, record, query_start, query_end, device=0, k=None, num_docs=None, membership=None):
     """DeviceIndex with the rows of `record` that have query_start < start < query_end (and a few more from
     the two buckets at the edges, which the sweep ignores as it ignores every row outside the window), from
-    the cache; None when there is no valid cache."""
+    the cache; None when there is no valid cache.  With the query known (k, num_docs, membership) and dense rows in
+    the file, the slice is imported as dense rows when they alone can answer it (memo_dense_rows_can_answer)."""
     got = _open(in_file, record)
     if got is None:
         return None
     head, mm = got
-    rows, nb, shift = head["rows"], head["buckets"], head["bucket_shift"]
+    nb, shift = head["buckets"], head["bucket_shift"]
     boff = mm[head["off_boff"]:head["off_boff"] + 8 * nb].view(np.int64)
-    b_lo = min(max(query_start, 0) >> shift, nb - 1)
-    b_hi = min(max((max(query_end, 0) >> shift) + 1, b_lo), nb - 1)
-    r0, r1 = int(boff[b_lo]), int(boff[b_hi])
+    cut = bucket_slice(head, lambda b: boff[b], query_start, query_end)
+    if cut is None:
+        return None
+    b_lo, b_hi, r0, r1 = cut
     table = boff[b_lo:b_hi + 1]                      # absolute entries: the library rebases them to r0
-    pk = mm[head["off_pk"] + 4 * r0:head["off_pk"] + 4 * r1]
-    pa = mm[head["off_pa"] + 2 * r0:head["off_pa"] + 2 * r1] if head["format"] == 6 else None
     n_long = head["long_rows"]
     longs = np.array(mm[head["off_long"]:head["off_long"] + 24 * n_long].view(np.int64)) if n_long else None
     h = C.c_void_p()
     n = r1 - r0
     lo, hi = slice_extent(head, b_lo, b_hi, n)
+    if (head.get("off_p3") is not None and k is not None and num_docs is not None and
+            dense_rows_can_answer(n, lo, hi, head["max_annot"], k, num_docs, membership)):
+        base = r0 // 5 * 5                           # the slice starts with the group that holds row r0
+        g = mm[head["off_p3"] + 16 * (base // 5):head["off_p3"] + 16 * ((r1 + 4) // 5)]
+        check(lib().memo_index_import_dense(r1 - base, device, shift, b_lo, g.ctypes.data, table.ctypes.data, len(table) + 1,
+                                            base, lo, hi, head["max_annot"], longs.ctypes.data if n_long else None, n_long,
+                                            C.byref(h)))
+        return DeviceIndex(r1 - base, device, _handle=h)
+    pk = mm[head["off_pk"] + 4 * r0:head["off_pk"] + 4 * r1]
+    pa = mm[head["off_pa"] + 2 * r0:head["off_pa"] + 2 * r1] if head["format"] == 6 else None
     check(lib().memo_index_import_packed(n, device, shift, b_lo, pk.ctypes.data if n else None,
                                          pa.ctypes.data if (pa is not None and n) else (np.zeros(1, np.uint16).ctypes.data
                                                                                           if pa is not None else None),
@@ -143,35 +212,104 @@ def slice_extent(head, b_lo, b_hi, n):
     return max(b_lo << shift, head["min_start"]), min(((b_hi + 1) << shift) - 1, head["max_start"])
 
 
-def build(in_file, record, device=0):
-    """decode every row of `record` from the Parquet file, pack it with the library, write the cache"""
+# ---- building: at most one builder per record at a time, and a record that cannot be cached is remembered -------
+def uncacheable(in_file, record):
+    """a marker written by an earlier build says: this record (of this very Parquet file) cannot be cached"""
+    try:
+        with open(_marker_path(in_file, record)) as fh:
+            return json.load(fh).get("source") == _source_key(in_file)
+    except (OSError, ValueError):
+        return False
+
+
+def _mark_uncacheable(in_file, record, why):
+    path = _marker_path(in_file, record)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    tmp = "%s.tmp.%d" % (path, os.getpid())
+    with open(tmp, "w") as fh:
+        json.dump({"source": _source_key(in_file), "record": record, "why": why}, fh)
+    os.replace(tmp, path)
+
+
+def take_lock(in_file, record):
+    """O_EXCL lock file: True when this process may build (or spawn the builder of) this record's cache.  A lock
+    older than an hour is a builder that died; it is replaced."""
+    path = _lock_path(in_file, record)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    for _ in range(2):
+        try:
+            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o644)
+            os.write(fd, str(os.getpid()).encode())
+            os.close(fd)
+            return True
+        except FileExistsError:
+            try:
+                if time.time() - os.stat(path).st_mtime < LOCK_STALE_SECONDS:
+                    return False
+                os.unlink(path)
+            except OSError:
+                return False
+    return False
+
+
+def release_lock(in_file, record):
+    try:
+        os.unlink(_lock_path(in_file, record))
+    except OSError:
+        pass
+
+
+def build(in_file, record, device=0, locked=False):
+    """decode every row of `record` from the Parquet file, pack it with the library (the host packer only: rows it
+    refuses are NOT uploaded as int64 columns -- 24 B per row of a whole chromosome for a cache that cannot be
+    written), write the cache; a record that cannot be cached gets a marker so that no later query tries again.
+    locked: the caller (build_in_background's parent) already holds the record's lock."""
     from .memo_query import region_index
-    hi = (1 << 61) - 1
-    ix = region_index(in_file, record, -1, hi, device=device, k=2, use_cache=False)
-    with ix:
-        inf = ix.info()
-        if inf["packed_format"] not in (4, 6, 12) or inf["rows"] == 0:
-            return None                     # unpackable rows (or none): nothing worth caching
-        return write(in_file, record, ix)
+    if not locked and not take_lock(in_file, record):
+        return None                         # somebody else is building it
+    try:
+        if _open(in_file, record) is not None:
+            return cache_path(in_file, record)
+        hi = (1 << 61) - 1
+        try:
+            ix = region_index(in_file, record, -1, hi, device=device, k=2, use_cache=False, packed_only=True)
+        except MemoUnpackable as exc:
+            _mark_uncacheable(in_file, record, str(exc))
+            return None
+        with ix:
+            inf = ix.info()
+            if inf["packed_format"] not in (4, 6, 12) or inf["rows"] == 0:
+                _mark_uncacheable(in_file, record, "no rows" if inf["rows"] == 0 else "rows are not packed")
+                return None
+            return write(in_file, record, ix)
+    finally:
+        release_lock(in_file, record)
 
 
 def build_in_background(in_file, record):
+    """a detached `python -m memo_amd.cache build` -- unless the record is known to be uncacheable or somebody
+    (this user's other queries) is already building it"""
     import subprocess
-    env = dict(os.environ, MEMO_CACHE="read")
+    if uncacheable(in_file, record) or not take_lock(in_file, record):
+        return False
+    env = dict(os.environ, MEMO_CACHE="read", MEMO_CACHE_LOCKED="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     try:
         subprocess.Popen([sys.executable, "-m", "memo_amd.cache", "build", in_file, record], env=env,
                          stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                          start_new_session=True)
+        return True
     except OSError:
-        pass
+        release_lock(in_file, record)
+        return False
 
 
 if __name__ == "__main__":
     if len(sys.argv) >= 4 and sys.argv[1] == "build":
         dev = int(os.environ.get("MEMO_DEVICE", "0"))
+        held = bool(os.environ.get("MEMO_CACHE_LOCKED")) and len(sys.argv) == 4
         for rec in sys.argv[3:]:
-            print(build(sys.argv[2], rec, dev))
+            print(build(sys.argv[2], rec, dev, locked=held))
     else:
         sys.exit("usage: python -m memo_amd.cache build INDEX.parquet RECORD [RECORD ...]")

@@ -66,6 +66,9 @@ struct memo_tuning {
     int memb_algo = 0;   // membership: 2 = doubling, 3 = runs, 4 = planes
     int force_wide = 0;  // 1 = read the int64 columns even when packed rows exist
     int scatter = 0;     // conservation, packed rows: 1 = clipped, 2 = unclipped + halo
+    int persistent = 0;  // dense rows: 0 = the library's choice, 1 = one workgroup per tile (sweep_conservation_halo3_kernel),
+                         //   2 / 3 / 4 = persistent workgroups (sweep_conservation_halo3p_kernel) wherever the query fits: rows by
+                         //   LDS-DMA / into registers at the head of a tile / into registers one tile ahead
     int force_packed = 0;  // 1 = read the 4-byte rows even when the dense rows are resident and could answer (they are
                            //     the faster source for the conservation sweep: profiles/r02_dense_rows_ab.txt)
 };
@@ -100,6 +103,7 @@ struct memo_index {
     uint32_t len_hist[256] = {0};
     uint64_t len_hist_rows = 0;  // rows sampled (0: no histogram)
     int last_sweep = 0;          // level arrays of the last conservation sweep (memo_index_info_t.last_sweep)
+    int last_variant = 0;        // ... 1 when it ran as persistent workgroups (memo_sweep_cons3p.hip)
     int has_wide = 1;          // the three int64 columns are still resident
     // rows with end < start (never written by the reference's index builder, but legal input to
     // memo_query.py): copied aside at finalize and applied by long_rows_kernel after each sweep
@@ -113,6 +117,10 @@ struct memo_index {
     int *d_status = nullptr;   // sticky flags set by the sweep kernels
     uint64_t *d_scratch = nullptr;  // finalize(): [0] unsorted pairs, [1] rows with end < start
 };
+
+namespace memo {
+extern thread_local int g_last_one_shot_sweep;  // which kernel family answered this thread's last one-shot call
+}
 
 // fills ix->len_hist from the resident 4- / 6-byte rows (a few thousand 1024-row blocks, evenly spread); NULL stream, synchronous
 int memo_len_census(memo_index *ix);

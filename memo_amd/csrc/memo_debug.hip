@@ -37,10 +37,11 @@ int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32
     if (waves != 0 && waves != 1 && waves != 4 && waves != 8) return fail(MEMO_EINVAL, "waves must be 0, 1, 4 or 8");
     if (membership_algo != 0 && (membership_algo < 2 || membership_algo > 4))
         return fail(MEMO_EINVAL, "membership_algo must be 0 (choose), 2 (doubling), 3 (runs) or 4 (planes)");
-    if (row_source < 0 || row_source > 3)
+    if (row_source < 0 || row_source > 7)
         return fail(MEMO_EINVAL, "row_source must be 0 (library's choice: dense rows where they are resident and can answer, else "
                                  "the 4- / 6-byte rows, else the int64 columns), 1 (int64 columns), 2 (same as 0) or 3 (4- / 6-byte "
-                                 "rows even where the dense rows could answer)");
+                                 "rows even where the dense rows could answer), 4 (dense rows swept by persistent workgroups with LDS-DMA where the "
+                                 "query fits) or 5 (dense rows, one workgroup per tile)");
     if (scatter < 0 || scatter > 4)
         return fail(MEMO_EINVAL, "scatter must be 0 (choose), 1 (clipped), 2 (unclipped, doubling levels), 3 (unclipped, radix-4 levels) "
                                  "or 4 (unclipped, mixed levels)");
@@ -49,6 +50,7 @@ int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32
     ix->tune.memb_algo = membership_algo;
     ix->tune.force_wide = row_source == 1;
     ix->tune.force_packed = row_source == 3;
+    ix->tune.persistent = row_source == 4 ? 2 : row_source == 5 ? 1 : row_source == 6 ? 3 : row_source == 7 ? 4 : 0;
     ix->tune.scatter = scatter;
     return MEMO_OK;
 }
@@ -63,6 +65,8 @@ int memo_debug_stream_rows(memo_index_t *ix, void *stream) {
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }
+
+int memo_debug_last_one_shot_sweep(void) { return g_last_one_shot_sweep; }
 
 int memo_debug_set_stamp_buffer(uint64_t *d_buffer) {
 #ifdef MEMO_STAMPS

@@ -11,6 +11,10 @@
 
 using namespace memo;
 
+namespace memo {
+thread_local int g_last_one_shot_sweep = 0;  // memo_index_info_t.last_sweep of this thread's last one-shot call (memo_debug.hip)
+}
+
 extern "C" __attribute__((visibility("hidden"))) int memo_sort_rows_by_start(int64_t *s, int64_t *e, int64_t *o, uint64_t rows,
                                        uint64_t padded_rows, hipStream_t stream, char *err,
                                        size_t errcap);
@@ -646,7 +650,7 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     info->has_wide = ix->has_wide;
     info->pack_ms = ix->pack_ms;
     info->last_sweep = ix->last_sweep;
-    info->reserved = 0;
+    info->last_variant = ix->last_variant;
     info->dense_rows = ix->p3 ? 1 : 0;
     info->long_rows = ix->n_long;
     info->max_annot = ix->max_annot;
@@ -674,16 +678,26 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
     };
     const auto t0 = now();
     if (rows && k > 1 && k - 1 <= 255 && !getenv("MEMO_ONESHOT_WIDE")) {
-        memo_builder_t *b = nullptr;
-        if ((rc = memo_builder_create(rows, device, 0, &b))) return rc;
-        rc = memo_builder_push(b, start, end, annot, rows);
-        if (!rc) rc = memo_builder_finish(b, &ix);
-        memo_builder_destroy(b);
-        if (rc == MEMO_EUNPACKABLE) {
-            rc = MEMO_OK;
-            ix = nullptr;
-        } else if (rc) {
-            return rc;
+        // the dense rows first (3.2 B per row over PCIe and in HBM, sweep_conservation_halo3_kernel) when they can
+        // answer THIS query -- judged from the first and last start before the rows are touched, and again from the
+        // largest annot once they have been packed; else (or when a row does not fit them) the 4-byte words
+        const bool try_dense = !getenv("MEMO_ONESHOT_PACKED") &&
+                               memo_dense_rows_can_answer(rows, start[0], start[rows - 1], 0, k, num_docs, membership);
+        for (int dense = try_dense ? 1 : 0; dense >= 0 && !ix; --dense) {
+            memo_builder_t *b = nullptr;
+            if ((rc = memo_builder_create_rows(rows, device, 0, dense ? MEMO_ROWS_DENSE : MEMO_ROWS_PACKED, &b))) return rc;
+            rc = memo_builder_push(b, start, end, annot, rows);
+            if (!rc) rc = memo_builder_finish(b, &ix);
+            memo_builder_destroy(b);
+            if (rc == MEMO_EUNPACKABLE) {
+                rc = MEMO_OK;
+                ix = nullptr;
+            } else if (rc) {
+                return rc;
+            } else if (dense && !memo_dense_rows_can_answer(ix->rows, ix->min_s, ix->max_s, ix->max_annot, k, num_docs, membership)) {
+                memo_index_destroy(ix);  // (an annot outside the result matrix: the 4-byte kernels flag the reference's IndexError)
+                ix = nullptr;
+            }
         }
     }
     if (!ix) {
@@ -713,6 +727,7 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
                         : memo_query_conservation_dev(ix, qs, qe, k, num_docs, (uint16_t *)d_out, nullptr);
         if (rc) break;
         if ((rc = memo_query_check(ix, nullptr))) break;
+        g_last_one_shot_sweep = ix->last_sweep;
         t2 = now();
         if (bytes) rc = download_pipelined(device, out, d_out, bytes, nullptr);
     } while (0);
@@ -721,7 +736,7 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
         fprintf(stderr,
                 "memo one-shot: %llu rows %s: rows in %.1f ms (%.1f GB/s of int64 columns), result alloc + sweep + check "
                 "%.1f ms, result out %.1f ms (%.1f GB/s), total %.1f ms\n",
-                (unsigned long long)rows, ix->has_wide ? "as int64 columns" : (ix->packed_fmt == 6 ? "packed to 6 B" : "packed to 4 B"),
+                (unsigned long long)rows, ix->has_wide ? "as int64 columns" : (ix->packed_fmt == 6 ? "packed to 6 B" : ix->pk ? "packed to 4 B" : "packed to 3.2 B (dense rows)"),
                 ms(t0, t1), rows * 24.0 / 1e6 / (ms(t0, t1) + 1e-9), ms(t1, t2), ms(t2, t3),
                 bytes / 1e6 / (ms(t2, t3) + 1e-9), ms(t0, t3));
     }

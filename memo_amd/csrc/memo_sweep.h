@@ -22,6 +22,8 @@ struct SweepArgs {
     int64_t tile0;          // pivot position of tile 0 (multiple of the tile width, <= qs)
     int64_t ntiles;
     int64_t tiles_per_xcd;  // ceil(ntiles / 8)
+    int64_t tiles_per_wg;   // persistent sweeps (memo_sweep_cons3p.hip): tiles per workgroup; tiles_per_xcd = runs per XCD group
+    int x_lo_first, x_hi_last;  //   ... and the window's edges inside its first / last tile
     void *out;
     int *status;
     int bshift;
@@ -528,6 +530,10 @@ using SweepKernel = void (*)(const SweepArgs);
 
 inline int floor_log2(uint32_t v) { return 31 - __builtin_clz(v); }
 int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st);
+// memo_sweep_cons3p.hip (linked into libmemo_amd_ab.so only: an experiment that lost, kept for A/B): the persistent
+// dense-row sweep registers itself here; 1 = this query does not fit it (take the tile-per-workgroup kernel)
+using PersistentLaunch = int (*)(SweepArgs &A, int tw, int elem_bytes, int device, int mode, hipStream_t st);
+extern PersistentLaunch g_persistent_launch;
 int pick_rows(const memo_index *ix, int32_t k, int &fmt);
 int check_query_args(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
                      const void *d_out);

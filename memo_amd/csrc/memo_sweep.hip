@@ -66,6 +66,8 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
 // which row source a query reads: packed when the index has it and k - 1 <= 255, else the int64 columns.
 // fmt: 0 = int64 columns, 4 / 6 = packed words (+ 16-bit order column), 3 = only the dense rows are left
 // (memo_index_pack_dense dropped the words): k - 1 <= 63, and only kernels that read PackedRows3
+PersistentLaunch g_persistent_launch = nullptr;  // set by memo_sweep_cons3p.o where it is linked in (the AB library)
+
 int pick_rows(const memo_index *ix, int32_t k, int &fmt) {
     fmt = 0;
     if (ix->packed_fmt && k - 1 <= 255 && !(ix->tune.force_wide && ix->has_wide)) fmt = ix->pk ? ix->packed_fmt : 0;

@@ -2,6 +2,7 @@
 // k <= 1 fill, the side pass for rows with end < start, tile-shape choice and the ABI entry points.
 // Replaces /root/reference/src/memo_query.py:42-63 + the argmax of :70.
 #include "memo_sweep.h"
+#include "memo_sweep_fold.h"
 
 using namespace memo;
 
@@ -171,34 +172,7 @@ __device__ __forceinline__ void halo_fold_store(const SweepArgs &A, const Tile &
 // ~100 VALU instructions per wave at k = 31 -- 30 % of a sweep whose VALU is 70 % busy -- and lost to the LDS
 // passes from six levels up; written as below it takes ~40, is 2-5 % of the whole sweep faster at k = 21 / 31,
 // and wins up to seven levels (k = 64: 0.53 -> 0.48 ms; k = 101 / 128 on doubling arrays: -2 / -3 %).
-// M_(j-1)[x] = min(L[x], M_j[x], M_j[x - half]),  half = 2^J cells, on a lane's four cells, IN PLACE (one asm block
-// per step: the compiler, left to itself, computes into fresh registers and copies them back at the join of the
-// wave-uniform branch around the step).  The DPP operations come first -- they read the left lane's M before any
-// lane overwrites it -- and fold their operand into L; s_nop 1: a DPP source written by the instruction before
-// needs two wait states, and the compiler does not see into the string.
-#define MEMO_DPP_MIN(dst, src) "v_min_u32_dpp " dst ", " src ", " dst " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-template <int J>
-__device__ __forceinline__ void fold_step_dpp(uint4 &M, uint4 L, int lane) {
-    if constexpr (J >= 3) {
-        const int src = (lane - (1 << (J - 2))) << 2;  // (negative: context lanes, whose result is dropped)
-        const uint32_t sx = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.x), sy = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.y);
-        const uint32_t sz = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.z), sw = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)M.w);
-        M = make_uint4(min(L.x, min(M.x, sx)), min(L.y, min(M.y, sy)), min(L.z, min(M.z, sz)), min(L.w, min(M.w, sw)));
-    } else if constexpr (J == 2) {
-        asm("s_nop 1\n\t" MEMO_DPP_MIN("%4", "%0") MEMO_DPP_MIN("%5", "%1") MEMO_DPP_MIN("%6", "%2") MEMO_DPP_MIN("%7", "%3")
-            "v_min_u32 %0, %4, %0\n\tv_min_u32 %1, %5, %1\n\tv_min_u32 %2, %6, %2\n\tv_min_u32 %3, %7, %3"
-            : "+v"(M.x), "+v"(M.y), "+v"(M.z), "+v"(M.w), "+v"(L.x), "+v"(L.y), "+v"(L.z), "+v"(L.w));
-    } else if constexpr (J == 1) {
-        asm("s_nop 1\n\t" MEMO_DPP_MIN("%4", "%2") MEMO_DPP_MIN("%5", "%3")
-            "v_min3_u32 %2, %6, %2, %0\n\tv_min3_u32 %3, %7, %3, %1\n\tv_min_u32 %0, %4, %0\n\tv_min_u32 %1, %5, %1"
-            : "+v"(M.x), "+v"(M.y), "+v"(M.z), "+v"(M.w), "+v"(L.x), "+v"(L.y) : "v"(L.z), "v"(L.w));
-    } else {
-        asm("s_nop 1\n\t" MEMO_DPP_MIN("%4", "%3")
-            "v_min3_u32 %3, %7, %3, %2\n\tv_min3_u32 %2, %6, %2, %1\n\tv_min3_u32 %1, %5, %1, %0\n\tv_min_u32 %0, %4, %0"
-            : "+v"(M.x), "+v"(M.y), "+v"(M.z), "+v"(M.w), "+v"(L.x) : "v"(L.y), "v"(L.z), "v"(L.w));
-    }
-}
-#undef MEMO_DPP_MIN
+// (fold_step_dpp<J>: memo_sweep_fold.h)
 
 template <typename OutT, int T, int TOP>
 __device__ __forceinline__ void halo_fold_store_dpp(const SweepArgs &A, const Tile &t, const uint32_t *lds) {
@@ -404,6 +378,22 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
     if (!locate_tile_w(A, t, W)) return;
     uint4 V[U];
     Rows::template issue<T, U>(A, t, 0, V);
+    // diagnostic builds only (tools/build_variant.sh): what is the sweep short of?  N more scalar / vector instructions
+    // per wave that do nothing -- if the time follows the scalar ones, the CU's one scalar unit is the bound
+#if defined(MEMO_EXTRA_SALU) || defined(MEMO_EXTRA_VALU)
+    {
+        uint32_t sx = (uint32_t)A.km1, vx = threadIdx.x;
+#ifdef MEMO_EXTRA_SALU
+#pragma unroll
+        for (int i = 0; i < MEMO_EXTRA_SALU; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sx)::"scc");
+#endif
+#ifdef MEMO_EXTRA_VALU
+#pragma unroll
+        for (int i = 0; i < MEMO_EXTRA_VALU; ++i) asm volatile("v_add_u32 %0, %0, 1" : "+v"(vx));
+#endif
+        if (sx + vx == 0xFFFFFFF0u) atomicOr(A.status, 64);  // (keeps them alive)
+    }
+#endif
     halo_clear<T>(A, lds, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
 
     const int km1 = A.km1;
@@ -1181,6 +1171,18 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             // power per unit of time, sits on the cap at a lower clock (2.2 against 2.36 GHz).
             const bool top8 = num_docs <= 255;
             const bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && top8;
+            ix->last_variant = 0;
+            if (three && g_persistent_launch && tune.persistent >= 2) {
+                // persistent workgroups (memo_sweep_cons3p.hip, AB library only: 17 - 50 % slower than a workgroup per tile,
+                // profiles/r03_persistent_sweep.txt); 1 = this query does not fit it
+                const int prc = g_persistent_launch(A, tw, (int)sizeof(OutT), ix->device, tune.persistent - 2, st);
+                if (prc < 0) return prc;
+                if (prc == MEMO_OK) {
+                    ix->last_sweep = 5;
+                    ix->last_variant = 1;
+                    return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
+                }
+            }
             if (!three && fmt == 3) {
                 halo = false;  // (below: the int64 columns, or an error when they are gone too)
             } else {

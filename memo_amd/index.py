@@ -32,6 +32,15 @@ def words(num_docs):
     return (num_docs + 31) // 32
 
 
+def dense_rows_can_answer(rows, min_start, max_start, max_annot, k, num_docs, membership):
+    """memo_dense_rows_can_answer: would an index holding only the dense rows (3.2 B per row) answer this query?"""
+    try:
+        return bool(lib().memo_dense_rows_can_answer(int(rows), int(min_start), int(max_start), int(max_annot), int(k),
+                                                     int(num_docs), 1 if membership else 0))
+    except (C.ArgumentError, OverflowError, ValueError, TypeError):
+        return False
+
+
 class DeviceIndex:
     def __init__(self, rows, device=0, _handle=None):
         self._h = C.c_void_p()
@@ -43,14 +52,15 @@ class DeviceIndex:
             check(lib().memo_index_create(self.rows, self.device, C.byref(self._h)))
 
     @classmethod
-    def from_host_packed(cls, start, end, annot, device=0, bucket_shift=0):
-        """the packed, pinned way in (memo_builder_*): rows narrowed on the host, 4-6 B per row over PCIe,
-        an index that is finalized and packed (k <= 256).  Raises MemoUnpackable for rows that need the
-        int64 path (from_host)."""
+    def from_host_packed(cls, start, end, annot, device=0, bucket_shift=0, dense=False):
+        """the packed, pinned way in (memo_builder_*): rows narrowed on the host, 4 B per row over PCIe -- or, with
+        dense=True, 3.2 B per row as the dense rows the benchmarked conservation kernel reads (conservation, k <= 64,
+        <= 255 genomes: dense_rows_can_answer) -- an index that is finalized and packed.  Raises MemoUnpackable
+        for rows that need the next way in (dense -> 4-byte words -> from_host)."""
         s, e, o = _col(start), _col(end), _col(annot)
         if not (len(s) == len(e) == len(o)):
             raise ValueError("columns differ in length")
-        with IndexBuilder(len(s), device, bucket_shift) as b:
+        with IndexBuilder(len(s), device, bucket_shift, dense=dense) as b:
             b.push(s, e, o)
             return b.finish()
 
@@ -167,11 +177,12 @@ class DeviceIndex:
 class IndexBuilder:
     """memo_builder_*: start-sorted host rows -> a packed, finalized DeviceIndex, piece by piece."""
 
-    def __init__(self, max_rows, device=0, bucket_shift=0):
+    def __init__(self, max_rows, device=0, bucket_shift=0, dense=False):
         self._b = C.c_void_p()
         self.device = int(device)
         self.rows = 0
-        check(lib().memo_builder_create(int(max_rows), self.device, bucket_shift, C.byref(self._b)))
+        self.dense = bool(dense)
+        check(lib().memo_builder_create_rows(int(max_rows), self.device, bucket_shift, 1 if dense else 0, C.byref(self._b)))
 
     def push(self, start, end, annot):
         s, e, o = _col(start), _col(end), _col(annot)

@@ -22,7 +22,8 @@ import os
 import numpy as np
 
 from ._lib import MemoUnpackable
-from .index import DeviceIndex, IndexBuilder, emit_conservation_buffer, emit_membership_buffer, words
+from .index import (DeviceIndex, IndexBuilder, dense_rows_can_answer, emit_conservation_buffer, emit_membership_buffer,
+                    words)
 
 
 class RegionRows:
@@ -115,48 +116,75 @@ def region_chunks(in_file, query_record, query_start, query_end):
     return bound, chunks()
 
 
-def region_index(in_file, query_record, query_start, query_end, device=None, k=None, use_cache=True):
+def region_index(in_file, query_record, query_start, query_end, device=None, k=None, use_cache=True,
+                 num_docs=None, membership=None, packed_only=False):
     """filter_pq + the upload half of memo_init in one streaming pass: the rows go from the
     Parquet file straight into a finalized DeviceIndex, row group by row group (the next one is
     decoded by Arrow while the current one is packed and copied to the GPU); the host never holds more
     than a few row groups.  For k <= 256 (k=None: unknown, as large as it likes) the rows take the packed
-    way in (memo_builder_*: narrowed on the host into pinned memory, 4-6 B per row over PCIe, PackedRows
-    kernels); rows that cannot be packed, and larger k, go up as int64 columns.  Anything that is not a
-    single Parquet file goes through filter_pq."""
+    way in (memo_builder_*: narrowed on the host into pinned memory, PackedRows kernels) -- as DENSE rows
+    (3.2 B per row, the benchmarked conservation kernel) when the query is known (num_docs, membership) and
+    the dense rows alone can answer it (memo_dense_rows_can_answer), else as 4-byte words; rows that cannot be
+    packed, and larger k, go up as int64 columns (packed_only: raise MemoUnpackable instead).  Anything that
+    is not a single Parquet file goes through filter_pq."""
     device = _device() if device is None else device
     packed = k is not None and 1 < k <= 256 and not os.environ.get("MEMO_QUERY_WIDE")
+    hint = (k, num_docs, bool(membership)) if (packed and num_docs is not None and not os.environ.get("MEMO_QUERY_PACKED")) else None
     miss = None
     if packed and use_cache and os.path.isfile(in_file):
         from . import cache                       # sidecar cache of the packed rows (memo_amd/cache.py)
         if cache.mode() != "off":
-            index = cache.load_region(in_file, query_record, query_start, query_end, device)
+            index = cache.load_region(in_file, query_record, query_start, query_end, device, *(hint or (None, None, None)))
             if index is not None:
                 index.cache = "hit"
                 return index
             miss = (in_file, query_record)
-    index = _region_index_from_parquet(in_file, query_record, query_start, query_end, device, packed)
+    index = _region_index_from_parquet(in_file, query_record, query_start, query_end, device, packed, hint, packed_only)
     index.cache = miss                            # main() builds the cache after the answer is written
     return index
 
 
-def _region_index_from_parquet(in_file, query_record, query_start, query_end, device, packed):
+def _dense_first(rows, lo, hi, max_annot, hint):
+    """[True, False] = try the dense rows, then the 4-byte words; [False] = words only"""
+    if hint is None:
+        return [False]
+    k, num_docs, membership = hint
+    return [True, False] if dense_rows_can_answer(rows, lo, hi, max_annot, k, num_docs, membership) else [False]
+
+
+def _region_index_from_parquet(in_file, query_record, query_start, query_end, device, packed, hint=None, packed_only=False):
     if not os.path.isfile(in_file):
         rows = filter_pq(in_file, query_record, query_start, query_end)
         if packed:
-            try:
-                return DeviceIndex.from_host_packed(rows.start, rows.end, rows.annot, device=device)
-            except MemoUnpackable:
-                pass
+            index = _from_host_rows(rows.start, rows.end, rows.annot, device, hint)
+            if index is not None:
+                return index
+            if packed_only:
+                raise MemoUnpackable(-6, "rows cannot be packed")
         return DeviceIndex.from_host(rows.start, rows.end, rows.annot, device=device)
     if packed:
+        # density judged from the row groups' statistics before anything is decoded: `bound` rows (an upper bound)
+        # between query_start and query_end; the finished index is asked again (it knows its rows and largest annot)
         bound, chunks = region_chunks(in_file, query_record, query_start, query_end)
-        try:
-            with IndexBuilder(bound, device) as builder:
-                for cols in chunks:
-                    builder.push(*cols)
-                return builder.finish()
-        except MemoUnpackable:
-            pass                                  # read the slice again, as int64 columns
+        for dense in _dense_first(bound, max(query_start, 0), max(query_end, 0), 0, hint):
+            if chunks is None:
+                bound, chunks = region_chunks(in_file, query_record, query_start, query_end)
+            try:
+                with IndexBuilder(bound, device, dense=dense) as builder:
+                    for cols in chunks:
+                        builder.push(*cols)
+                    index = builder.finish()
+                if dense:
+                    inf = index.info()
+                    if not dense_rows_can_answer(inf["rows"], inf["min_start"], inf["max_start"], inf["max_annot"], *hint):
+                        index.close()             # (sparser than the statistics promised, or an annot outside the matrix)
+                        chunks = None
+                        continue
+                return index
+            except MemoUnpackable:
+                chunks = None                     # read the slice again: 4-byte words, then int64 columns
+        if packed_only:
+            raise MemoUnpackable(-6, "rows of %s cannot take the packed way in" % query_record)
     bound, chunks = region_chunks(in_file, query_record, query_start, query_end)
     index = DeviceIndex(bound, device)
     written = 0
@@ -165,6 +193,22 @@ def _region_index_from_parquet(in_file, query_record, query_start, query_end, de
         written += len(cols[0])
     index.truncate(written)
     return index.finalize()
+
+
+def _from_host_rows(s, e, o, device, hint):
+    """host columns -> packed index: dense rows when they can answer the query, else 4-byte words; None = unpackable"""
+    s = np.asarray(s)
+    n = len(s)
+    tries = [False]
+    if hint is not None and n:
+        o_ = np.asarray(o)
+        tries = _dense_first(n, int(s[0]), int(s[-1]), int(o_.max()) if int(o_.min()) >= 0 else 1 << 20, hint)
+    for dense in tries:
+        try:
+            return DeviceIndex.from_host_packed(s, e, o, device=device, dense=dense)
+        except MemoUnpackable:
+            continue
+    return None
 
 
 class QueryResult:
@@ -198,10 +242,8 @@ def memo_init(mem_arr, k, true_start, true_end, num_docs, membership_query):
         s, e, o = (np.ascontiguousarray(arr[:, i]) for i in range(3))
     index = None
     if 1 < k <= 256:
-        try:
-            index = DeviceIndex.from_host_packed(s, e, o, device=_device())
-        except MemoUnpackable:
-            pass
+        hint = None if os.environ.get("MEMO_QUERY_PACKED") else (k, num_docs, bool(membership_query))
+        index = _from_host_rows(s, e, o, _device(), hint)
     if index is None:
         index = DeviceIndex.from_host(s, e, o, device=_device())
     return index, QueryResult(true_start, true_end, k, num_docs, membership_query)
@@ -267,7 +309,8 @@ def _main_sharded(args):
                            dtype=torch.int32 if membership_query else torch.int16, device=dev)
 
     def sweep(a, b, out):
-        ix = region_index(args.in_file, query_record, a, b + k, device=local, k=k)
+        ix = region_index(args.in_file, query_record, a, b + k, device=local, k=k, num_docs=num_docs,
+                          membership=membership_query)
         held.append(ix)
         if membership_query:
             ix.membership_dev(a, b, k, num_docs, out, stream.cuda_stream)
@@ -299,11 +342,13 @@ def main(args):
     query_record, start_end = args.genome_region.split(':')      # exactly one ':' and one '-'
     query_start, query_end = map(int, start_end.split('-'))
     t = [time.perf_counter()]
-    rows = region_index(args.in_file, query_record, query_start, query_end + k, k=k)     # filter_pq, :100
+    rows = region_index(args.in_file, query_record, query_start, query_end + k, k=k,      # filter_pq, :100
+                        num_docs=num_docs, membership=membership_query)
     t.append(time.perf_counter())
     mem_arr, rec = memo_init(rows, k, query_start, query_end, num_docs, membership_query)
     try:
         rec = memo_query(mem_arr, rec, membership_query)
+        inf = mem_arr.info() if os.environ.get("MEMO_TIMING") else None
     finally:
         mem_arr.close()
     t.append(time.perf_counter())
@@ -313,7 +358,9 @@ def main(args):
     if isinstance(miss, tuple) and mem_arr.rows:          # answered from the Parquet file: leave a cache for next time
         from . import cache
         try:                                              # the answer is written: a cache that cannot be left
-            if cache.mode() == "sync":                    # (read-only directory, full disk) is not an error
+            if cache.uncacheable(*miss):                  # (read-only directory, full disk) is not an error
+                pass                                      # an earlier build found this record's rows unpackable
+            elif cache.mode() == "sync":
                 cache.build(*miss, device=_device())
             elif cache.mode() == "on":
                 cache.build_in_background(*miss)
@@ -321,10 +368,12 @@ def main(args):
             if os.environ.get("MEMO_TIMING"):
                 sys.stderr.write("memo_query: no sidecar cache written (%s)\n" % exc)
     if os.environ.get("MEMO_TIMING"):          # stderr only: stdout stays the reference's
+        fmt = ("int64 columns" if inf["has_wide"] else "dense rows (3.2 B)" if inf["dense_rows"] else
+               "%d-byte rows" % (6 if inf["packed_format"] == 6 else 4))
         sys.stderr.write("memo_query timing: region slice+upload %.3f s%s, sweep+download %.3f s, text+write %.3f s "
-                         "(%d rows, %d positions)\n" % (t[1] - t[0], " (from the sidecar cache)" if miss == "hit" else "",
-                                                       t[2] - t[1], t[3] - t[2], mem_arr.rows,
-                                                       max(query_end - query_start, 0)))
+                         "(%d rows as %s, kernel family %d, %d positions)\n"
+                         % (t[1] - t[0], " (from the sidecar cache)" if miss == "hit" else "", t[2] - t[1], t[3] - t[2],
+                            mem_arr.rows, fmt, inf["last_sweep"], max(query_end - query_start, 0)))
 
 
 if __name__ == "__main__":

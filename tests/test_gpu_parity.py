@@ -35,8 +35,22 @@ def _cons(memo, rows, qs, qe, k, n):
 # ---------------------------------------------------------------------------------------
 # golden vectors (the reference's own output), through the one-shot host ABI
 # ---------------------------------------------------------------------------------------
+def _dense_can_answer(rows, k, n, membership):
+    """the library's own rule (memo_dense_rows_can_answer) on host columns"""
+    from memo_amd.index import dense_rows_can_answer
+    s, _, o = rows
+    return len(s) > 0 and int(o.min()) >= 0 and dense_rows_can_answer(len(s), int(s[0]), int(s[-1]), int(o.max()), k, n, membership)
+
+
+_ONE_SHOT_SWEEPS = {}
+
+
 @pytest.mark.parametrize("c", G.cases(raises=False), ids=lambda c: c["name"])
-def test_golden_one_shot(c, memo):
+def test_golden_one_shot(c, memo, ab):
+    """every golden through the one-shot seam (memo_conservation / memo_membership: host columns in, host result
+    out) -- and WHICH kernel answered: wherever the dense rows alone can answer (conservation, k <= 64, <= 255 genomes,
+    >= 1 row per position) the call must have gone the dense way in and run sweep_conservation_halo3_kernel, the
+    benchmarked kernel (last_sweep 5): the shortest chain from the reference's own bytes to that kernel."""
     from memo_amd.index import bits_to_matrix
     rec, qs, qe = G.region(c)
     z = G.load(c)
@@ -54,7 +68,19 @@ def test_golden_one_shot(c, memo):
             got = memo.conservation(*rows, qs, qe, c["k"], c["n"])
             assert np.array_equal(got.astype(np.int64), z["vec"])
             text = memo.emit_conservation(got)
+            family = ab.lib().memo_debug_last_one_shot_sweep()
+            if qe > qs and c["k"] > 1 and len(rows[0]):
+                dense = _dense_can_answer(rows, c["k"], c["n"], False)
+                assert (family == 5) == dense, (family, dense)
+                _ONE_SHOT_SWEEPS[family] = _ONE_SHOT_SWEEPS.get(family, 0) + 1
         assert G.sha(text) == c["sha256"]
+
+
+def test_golden_one_shot_reached_the_benchmarked_kernel():
+    """(runs after the cases above) a fair share of the reference's goldens was answered by halo3"""
+    if not _ONE_SHOT_SWEEPS:
+        pytest.skip("test_golden_one_shot did not run in this session")
+    assert _ONE_SHOT_SWEEPS.get(5, 0) >= 20, _ONE_SHOT_SWEEPS
 
 
 @pytest.mark.parametrize("c", G.cases(raises=False)[::4], ids=lambda c: c["name"])
@@ -72,6 +98,42 @@ def test_golden_one_shot_int64_way_in(c, memo, monkeypatch):
     else:
         got = memo.conservation(*rows, qs, qe, c["k"], c["n"])
         assert np.array_equal(got.astype(np.int64), z["vec"])
+
+
+def test_goldens_on_dense_only_resident_indexes(memo):
+    """every golden with n <= 255 and k <= 64 on a RESIDENT index that holds the dense rows and, as the fallback,
+    the int64 columns (from_host -> pack -> pack_dense(keep_packed=False)); counts how many ran on halo3 (5) /
+    planes3 (6) and how many fell back to the int64 kernels (1 / 7)."""
+    from memo_amd.index import bits_to_matrix
+    ran = {}
+    by_index = {}
+    for c in G.cases(raises=False):
+        if c["n"] <= 255 and 1 < c["k"] <= 64:
+            by_index.setdefault((c["index"], G.region(c)[0]), []).append(c)
+    for (index, rec), cases in by_index.items():
+        s, e, o = G.index_columns(index, rec)
+        if not len(s) or o.max() > 255 or o.min() < 0 or s.min() < 0:
+            continue
+        with memo.DeviceIndex.from_host(s, e, o) as ix:
+            ix.pack(keep_wide=True)
+            ix.pack_dense(keep_packed=False)
+            inf = ix.info()
+            assert inf["dense_rows"] == 1 and inf["has_wide"] == 1
+            for c in cases:
+                _, qs, qe = G.region(c)
+                if qe <= qs:
+                    continue
+                z = G.load(c)
+                if c["membership"]:
+                    got = ix.membership(qs, qe, c["k"], c["n"])
+                    assert np.array_equal(bits_to_matrix(got, c["n"]), G.expected_matrix(c, z)), c["name"]
+                else:
+                    got = ix.conservation(qs, qe, c["k"], c["n"])
+                    assert np.array_equal(got.astype(np.int64), z["vec"]), c["name"]
+                fam = ix.info()["last_sweep"]
+                ran[fam] = ran.get(fam, 0) + 1
+    print("goldens on dense-only resident indexes, by kernel family:", ran)
+    assert ran.get(5, 0) >= 10 and set(ran) <= {1, 5, 6, 7}, ran
 
 
 @pytest.mark.parametrize("c", G.cases(raises=True), ids=lambda c: c["name"])
@@ -389,6 +451,95 @@ def test_builder_equals_int64_upload(n_rows, n_docs, pieces, memo, oracle):
                 ix.conservation(0, 1000, 300, n_docs)               # k > 256 needs the int64 columns
 
 
+@pytest.mark.parametrize("n_rows,n_docs,pieces", [(300_003, 90, 1), (300_001, 255, 9), (9_500_002, 200, 3), (6, 5, 1), (4, 5, 2)])
+def test_dense_builder_equals_device_packing(n_rows, n_docs, pieces, memo, oracle):
+    """memo_builder_create_rows(MEMO_ROWS_DENSE): rows narrowed on the host straight to the dense format (five rows per
+    16 bytes; PCIe carries 3.2 B per row), pushed in ragged pieces that end inside a group -- the groups, bucket table
+    and long rows are bit for bit what memo_index_pack + memo_index_pack_dense build on the device, and the index answers
+    on sweep_conservation_halo3_kernel."""
+    import ctypes as C
+    from memo_amd import _lib
+    rng = np.random.default_rng(n_rows + pieces)
+    length = max(n_rows // 4, 8)
+    s, e, o = _random_index(rng, n_rows, length, n_docs, 70)
+    e[::13] = s[::13] + rng.integers(60, 5000, len(s[::13]))       # overlaps that saturate the 6-bit length
+    e[5::1001] = s[5::1001] - rng.integers(1, 300, len(s[5::1001]))   # a few rows with end < start
+    cuts = [0] + sorted(int(x) for x in rng.integers(0, n_rows, pieces - 1)) + [n_rows]
+
+    def export(ix):
+        inf = ix.info()
+        g = np.empty(4 * ((inf["rows"] + 4) // 5), np.uint32)
+        boff = np.empty(inf["buckets"], np.int64)
+        longs = np.empty(3 * inf["long_rows"], np.int64)
+        _lib.check(_lib.lib().memo_index_export_dense(ix._h, g.ctypes.data, boff.ctypes.data, longs.ctypes.data if len(longs) else None))
+        return g, boff, longs
+    with memo.IndexBuilder(n_rows + 77, dense=True) as b:
+        for a, z in zip(cuts[:-1], cuts[1:]):
+            b.push(s[a:z], e[a:z], o[a:z])
+        with b.finish() as ix:
+            inf = ix.info()
+            assert inf["rows"] == n_rows and inf["dense_rows"] == 1 and inf["has_wide"] == 0 and inf["finalized"] == 1
+            assert inf["device_bytes"] < 3.3 * n_rows + 2_000_000
+            with memo.DeviceIndex.from_host(s, e, o) as ref:
+                ref.pack(keep_wide=False)
+                ref.pack_dense(keep_packed=False)
+                got, want = export(ix), export(ref)
+                pad = (5 - n_rows % 5) % 5                         # rows behind the last one in its group: never read by number
+                if pad == 0:
+                    assert np.array_equal(got[0], want[0])
+                else:
+                    assert np.array_equal(got[0][:-4], want[0][:-4])
+                assert np.array_equal(got[1], want[1])
+
+                def triples(x):                                   # (the device collects them with atomics: any order)
+                    t = x.reshape(3, -1).T
+                    return t[np.lexsort(t.T[::-1])]
+                assert np.array_equal(triples(got[2]), triples(want[2]))
+            if n_rows > 1000:
+                for k in (31, 64, 2):
+                    qs, qe = int(rng.integers(0, length // 2)), int(rng.integers(length // 2, length + 40))
+                    want_v = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                    assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want_v), (k, qs, qe)
+                    assert ix.info()["last_sweep"] == 5
+                qe2 = min(qe, qs + 20_000)
+                wantb = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe2, 31), qs, qe2, 31, n_docs, literal=False)
+                assert np.array_equal(ix.membership(qs, qe2, 31, n_docs), wantb) and ix.info()["last_sweep"] == 6
+                with pytest.raises(memo.MemoError):
+                    ix.conservation(0, 1000, 101, n_docs)            # k > 64 needs the 4-byte rows
+    # an annot above 255 is refused: the caller starts over with the 4-byte rows
+    o2 = o.copy()
+    o2[-1] = 300
+    with memo.IndexBuilder(n_rows, dense=True) as b:
+        with pytest.raises(memo.MemoUnpackable):
+            b.push(s, e, o2)
+        with pytest.raises(memo.MemoError):
+            b.finish()
+    # import of a slice that starts inside a group (what the cache does), straight through the ABI
+    if n_rows > 100_000:
+        with memo.DeviceIndex.from_host(s, e, o) as ref:
+            ref.pack(keep_wide=False)
+            ref.pack_dense(keep_packed=True)
+            g, boff, longs = export(ref)
+            inf = ref.info()
+            shift, nb = inf["bucket_shift"], inf["buckets"]
+            for qs, qe, k in ((length // 3 + 3, length // 2, 31), (1, 777, 64), (length - 500, length + 10, 5)):
+                b_lo = min(max(qs, 0) >> shift, nb - 1)
+                b_hi = min(((qe + k) >> shift) + 1, nb - 1)
+                r0, r1 = int(boff[b_lo]), int(boff[b_hi])
+                base = r0 // 5 * 5
+                table = np.ascontiguousarray(boff[b_lo:b_hi + 1])
+                grp = np.ascontiguousarray(g[4 * (base // 5):4 * ((r1 + 4) // 5)])
+                h = C.c_void_p()
+                _lib.check(_lib.lib().memo_index_import_dense(r1 - base, 0, shift, b_lo, grp.ctypes.data, table.ctypes.data,
+                                                              len(table) + 1, base, max(b_lo << shift, int(s[0])),
+                                                              min(((b_hi + 1) << shift) - 1, int(s[-1])), inf["max_annot"],
+                                                              longs.ctypes.data if len(longs) else None, len(longs) // 3, C.byref(h)))
+                with memo.DeviceIndex(r1 - base, 0, _handle=h) as part:
+                    want_v = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                    assert np.array_equal(part.conservation(qs, qe, k, n_docs), want_v), (qs, qe, k)
+                    assert part.info()["last_sweep"] == 5 and part.info()["bucket_base"] == b_lo
+
+
 def test_builder_switches_to_12_bit_annots_late(memo, oracle):
     """the first annot > 255 arrives after 5 M rows are already on the device in format 4: they are rewritten
     in format 12 in place (widen_annot_kernel) and the current piece is packed again"""
@@ -500,6 +651,9 @@ def test_sidecar_cache_round_trip(memo, oracle, tmp_path, monkeypatch):
         assert os.path.exists(cache.cache_path(path, record))
         text2, err2 = query(record, 1000, 60_000, 31, n_docs, "1")                  # hit
         assert text2 == text0 and "from the sidecar cache, ctypes-only path" in err2
+        # the cache holds the dense rows where every annot fits 8 bits; a conservation query they can answer reads THEM
+        assert ("dense rows (3.2 B)" if n_docs <= 255 else "4-byte rows") in err2, err2
+        assert "dense rows (3.2 B)" in err1 if n_docs <= 255 else "4-byte rows" in err1, err1     # ... and so does the miss
         text2w, err2w = query(record, 1000, 60_000, 300, n_docs, "1")               # k > 256: not the fast path, not the cache
         assert "sidecar cache" not in err2w
         assert text2w == memo.emit_conservation(oracle.conservation(*oracle.filter_rows(s, e, o, 1000, 60_000, 300), 1000,
@@ -531,11 +685,21 @@ def test_sidecar_cache_round_trip(memo, oracle, tmp_path, monkeypatch):
                                                                71_000, 21, n_docs, literal=False), n_docs)
         monkeypatch.setenv("MEMO_CACHE", "read")
         for qs, qe, k in ((0, 150_100, 31), (149_000, 160_000, 101), (77_777, 77_778, 2), (5, 6, 256), (200_000, 200_010, 31),
-                          (31, 64, 31), (32, 95, 3)):
+                          (31, 64, 31), (32, 95, 3), (1003, 90_001, 64), (64, 65_000, 21)):
             with mq.region_index(path, record, qs, qe + k, k=k) as ix:
                 assert ix.cache == "hit"
                 want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
                 assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (record, qs, qe, k)
+            # with the query known, the slice comes in as dense rows wherever they can answer (row slices that start
+            # inside a group of five, bucket tables rebased to the group's first row)
+            with mq.region_index(path, record, qs, qe + k, k=k, num_docs=n_docs, membership=False) as ix:
+                assert ix.cache == "hit"
+                assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (record, qs, qe, k)
+                inf = ix.info()
+                if n_docs <= 255 and k <= 64 and inf["rows"] >= inf["max_start"] - inf["min_start"] + 1 and inf["rows"]:
+                    assert inf["dense_rows"] == 1 and inf["last_sweep"] == 5, (inf, k)
+                else:
+                    assert inf["dense_rows"] == 0
         with mq.region_index(path, record, 10, 5000 + 300, k=300) as ix:            # k > 256: int64 columns, not the cache
             assert ix.cache is None and ix.info()["has_wide"] == 1
     # a changed index file invalidates its caches
@@ -870,10 +1034,11 @@ _C3_FNV = {}
 @pytest.mark.parametrize("membership,pack,dtype,k", [
     (False, None, np.uint16, 31), (False, "keep", np.uint16, 31), (False, "keep", np.uint8, 31), (False, "only", np.uint8, 31),
     (False, "dense", np.uint8, 31), (False, "dense", np.uint16, 31), (True, None, None, 31), (True, "keep", None, 31),
-    (False, "only", np.uint8, 101), (False, "keep", np.uint16, 101), (False, "only", np.uint8, 128), (True, "only", None, 101)],
+    (False, "only", np.uint8, 101), (False, "keep", np.uint16, 101), (False, "only", np.uint8, 128), (True, "only", None, 101),
+    (True, "dense", None, 31)],
     ids=["cons-int64-u16", "cons-packed-u16", "cons-packed-u8", "cons-packedonly-u8", "cons-dense-u8", "cons-dense-u16",
          "memb-int64", "memb-packed", "cons-packedonly-u8-k101-mixed", "cons-packed-u16-k101-mixed", "cons-packedonly-u8-k128-radix4",
-         "memb-packedonly-k101"])
+         "memb-packedonly-k101", "memb-dense-planes3"])
 def test_config3_full_size_properties(membership, pack, dtype, k, memo, oracle):
     """configs 3/4 at full size: 100 genomes x 100 Mbp, 500 M rows, on the int64 columns AND on the
     packed rows (the benchmarked kernels: sweep_conservation_halo_kernel<PackedRows<false,false>,..,uint8>,
@@ -910,6 +1075,8 @@ def test_config3_full_size_properties(membership, pack, dtype, k, memo, oracle):
         assert _C3_FNV.setdefault((membership, k), fnv) == fnv
         if not membership and pack in ("keep", "only"):   # the kernel family the library chose
             assert ix.info()["last_sweep"] == {31: 2, 101: 4, 128: 3}[k]
+        if pack == "dense":                               # a fact, not an inference: halo3 / planes3 answered
+            assert ix.info()["last_sweep"] == (6 if membership else 5)
         rng = np.random.default_rng(3)
         for a in [0, L - 300_000] + [int(x) for x in rng.integers(0, L - 300_000, 4)]:
             b = a + 300_000
@@ -1166,6 +1333,8 @@ def test_config5_shard_packed_rows(memo, oracle):
         for k in (21, 31, 101):
             full = ix.conservation(qs, qe, k, n)
             assert full.dtype == np.uint16 and 1 <= full.min() and full.max() <= n
+            bad, _ = oracle.synth_window_compare(full, qs, qe, k, n, pivot)   # the WHOLE 2^25-position shard
+            assert bad == 0, (k, bad)
             for a in [qs, qe - 200_000] + [int(x) for x in rng.integers(qs, qe - 200_000, 3)]:
                 b = a + 200_000
                 sr0, sr1 = synth.shard_rows(a, b, k, num, den, pivot)

@@ -76,3 +76,24 @@ def test_oracle_under_asan(tmp_path):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_oracle.py"), "-q", "-x",
                         "-k", "ex_ or rnd_n4 or negoverlap or synth or split"], capture_output=True, text=True, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("sanitizer", ["address,undefined", "thread"])
+def test_host_packer_under_sanitizers(tmp_path, sanitizer):
+    """memo_amd/csrc/memo_hostcore.cpp -- worker pool, pinned ring, row packers (4-byte words and dense rows), the
+    builder's push loop: the library's only multi-threaded host code -- with the device seam stubbed by
+    tests/host_stub.cpp (memcpy on copier threads), under ASan + UBSan and under ThreadSanitizer: two builders on two
+    threads, ragged pieces, the late switch to 12-bit annots, refusals, the pipelined transfers."""
+    lib = subprocess.run(["gcc", "-print-file-name=lib%s.so" % ("tsan" if sanitizer == "thread" else "asan")],
+                         capture_output=True, text=True).stdout.strip()
+    if not (os.path.isabs(lib) and os.path.exists(lib)):
+        pytest.skip("sanitizer runtime not installed")
+    exe = str(tmp_path / "hostcore")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=" + sanitizer,
+                           "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host_stub.cpp"),
+                           os.path.join(ROOT, "memo_amd", "csrc", "memo_hostcore.cpp"), "-o", exe])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="halt_on_error=1", MEMO_HOST_THREADS="6")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "hostcore ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]

@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 3: the persistent LDS-DMA sweep (memo_sweep_cons3p.hip) -- parity against the tile-per-workgroup kernel, then sustained A/B
+TAG=${1:-r3p}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 600 python tools/p3_check.py 2>&1 | tail -25
+for rep in 1 2; do for v in "0,0,0,5" "0,0,0,6" "0,0,0,7"; do for k in 31 64; do
+  printf "c3 k=%-3s %-10s: " $k $v >> $OUT/ab.txt
+  timeout 300 python tools/ab.py --workload c3 --k $k --pack dense --u8 --rounds 2000 "$v" 2>>$OUT/err.txt | python -c "
+import json,sys
+for l in sys.stdin:
+    j=json.loads(l); print('%.4f ms median  min %.4f  frac %.3f'%(j['ms_median'], j['ms_min'], j['frac_of_8TBs']))" >> $OUT/ab.txt
+done; done; done
+sort $OUT/ab.txt; grep -v amdgpu.ids $OUT/err.txt | tail -3
