@@ -80,6 +80,10 @@ def parse():
                     help="also run the read-once calibration kernel (for the FETCH_SIZE PMC pass)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gather path even with one rank (validation)")
+    ap.add_argument("--rows-file", default=None,
+                    help="an index from a file instead of the synthetic generator: .npz with start, end, annot (int64, "
+                         "start-sorted), num_docs, length (tools/realistic_index.py writes them); the window is [0, length)")
+    ap.add_argument("--membership", action="store_true", help="with --rows-file: membership query (the file holds a membership index)")
     ap.add_argument("--launch", action="store_true",
                     help="start the ranks as a child torch.distributed.run even when --gpus is 1 (N > 1 without "
                          "WORLD_SIZE in the environment does so by itself)")
@@ -150,9 +154,14 @@ def cpu_baseline(args, num_docs, L, k, membership, gpu_result_slice):
     S = min(args.cpu_sample, L)
     if membership:
         S = min(S, 3_000_000)
-    num, den = synth.rows_per_position(num_docs)
-    r0, r1 = synth.shard_rows(0, S, k, num, den, L)
-    s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, num_docs)
+    if args.rows_file:
+        z = np.load(args.rows_file)
+        r0, r1 = 0, int(np.searchsorted(z["start"], S + k, side="left"))
+        s, e, o = (np.ascontiguousarray(z[c][:r1]) for c in ("start", "end", "annot"))
+    else:
+        num, den = synth.rows_per_position(num_docs)
+        r0, r1 = synth.shard_rows(0, S, k, num, den, L)
+        s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, num_docs)
     fn = oracle.membership if membership else oracle.conservation
     t0 = time.perf_counter()
     want = fn(s, e, o, 0, S, k, num_docs, literal=True)
@@ -222,6 +231,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     num_docs, L, membership = WORKLOADS[args.workload]
+    host_rows = None
+    if args.rows_file:                       # an index built elsewhere (sequences -> matching statistics -> dap_to_bed)
+        if world != 1:
+            raise SystemExit("--rows-file is a single-GPU workload")
+        z = np.load(args.rows_file)
+        host_rows = tuple(np.ascontiguousarray(z[c], dtype=np.int64) for c in ("start", "end", "annot"))
+        num_docs, L, membership = int(z["num_docs"]), int(z["length"]), bool(args.membership)
+        args.workload = "rows-file"
     k = args.k
     pivot = L * world
     qs, qe = rank * L, (rank + 1) * L
@@ -231,6 +248,11 @@ def main():
     # the dense rows answer the unclipped conservation sweep only: k <= 64, num_docs <= 255, >= 1 row per position
     # (membership reads them too when an index holds nothing else, 4 % slower than the 4-byte rows: not a bench format)
     can_dense = (not membership) and k - 1 <= 63 and num_docs <= 255 and not args.wide and num_docs >= 20
+    if host_rows is not None:                # the library's own rule, on the rows the window sees
+        from memo_amd.index import dense_rows_can_answer
+        hs, _, ho = host_rows
+        can_dense = not args.wide and len(hs) > 0 and dense_rows_can_answer(len(hs), int(hs[0]), int(hs[-1]), int(ho.max()), k,
+                                                                             num_docs, membership)
     if args.rows == "auto":     # the fastest format that can answer: dense rows (back to back they are 13 % ahead of the
         args.rows = "wide" if k - 1 > 255 else ("dense" if can_dense else "packed")     # 4-byte rows: DESIGN.md section 7)
     if args.rows == "dense" and not can_dense:
@@ -248,7 +270,11 @@ def main():
     formats = [args.rows] + ([f for f in ("wide", "packed", "dense") if f != args.rows and
                               (f != "dense" or can_dense) and (f == "wide" or k - 1 <= 255)] if others else [])
     for f in formats:
-        ixf, (r0, r1) = synth.device_index(qs, qe, k, num_docs, pivot, device=local)
+        if host_rows is not None:
+            ixf = memo_amd.DeviceIndex.from_host(*host_rows, device=local)
+            r0, r1 = int(np.searchsorted(host_rows[0], qs, side="right")), int(np.searchsorted(host_rows[0], qe + k, side="left"))
+        else:
+            ixf, (r0, r1) = synth.device_index(qs, qe, k, num_docs, pivot, device=local)
         nrows = r1 - r0
         if f != "wide":
             ixf.pack(keep_wide=True)            # allocates the packed rows
@@ -528,7 +554,11 @@ def main():
 
     def kernel_name(which):
         if which == "dense" and not membership:
-            return "sweep_conservation_halo3_kernel<...> (PackedRows3: five rows per 16 bytes)"
+            inf = indexes[which].info()
+            if inf["last_sweep"] == 5:
+                return ("sweep_conservation_halo3t_kernel<...> (dense rows, five per 16 bytes; the tile's row slice from the index's tile table)"
+                        if inf["last_variant"] == 2 else "sweep_conservation_halo3_kernel<...> (PackedRows3: five rows per 16 bytes)")
+            return {1: "sweep_conservation_kernel<", 2: "sweep_conservation_halo_kernel<"}.get(inf["last_sweep"], "?<") + "...> (the dense rows could not answer)"
         rows_t = "WideRows" if which == "wide" else ("PackedRows<true, false>" if packed_fmt == 6 else
                                                      "PackedRows<false, false, true>" if packed_fmt == 12 else "PackedRows<false, false>")
         if membership:      # packed rows: per-genome bit planes (unclipped + staged up to 512 genomes,
@@ -635,8 +665,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int64" if args.rows == "wide" else "u32", "data": "synthetic",
-            "config": {"workload": f"BASELINE config {args.workload[1:]}: synthetic {num_docs}-genome index, "
+            "dtype": "int64" if args.rows == "wide" else "u32",
+            "data": "synthetic" if host_rows is None else "synthetic sequences (random pivot + mutated copies), real matching statistics",
+            "config": {"workload": (f"BASELINE config {args.workload[1:]}: synthetic {num_docs}-genome index, "
+                                    if host_rows is None else
+                                    f"index from sequences ({os.path.basename(args.rows_file)}: tools/realistic_index.py), {num_docs} genomes, ") +
                                    f"{L} positions/GPU window, {rows} rows/GPU, k={k}, "
                                    f"{'membership' if membership else 'conservation'}",
                        "num_docs": num_docs, "window_per_gpu": L, "rows_per_gpu": rows, "k": k,

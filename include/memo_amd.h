@@ -76,7 +76,7 @@ typedef struct memo_index_info {
                                radix-4, 4 unclipped mixed (1, 4, 16, then doubling), 5 dense rows -- the library picks
                                2 / 3 / 4 per query from k and the overlap lengths of the rows it sampled when the
                                packed rows were made; membership: 6 bit planes on the dense rows, 7 any other */
-    int32_t last_variant;   /* 1 when that sweep ran as persistent workgroups (dense rows streamed by LDS-DMA), else 0 */
+    int32_t last_variant;   /* of the dense-row sweep: 0 every wave worked its tile out, 2 tile table; 1 persistent workgroups (A/B library) */
 } memo_index_info_t;
 
 const char *memo_last_error(void);

@@ -66,7 +66,8 @@ struct memo_tuning {
     int memb_algo = 0;   // membership: 2 = doubling, 3 = runs, 4 = planes
     int force_wide = 0;  // 1 = read the int64 columns even when packed rows exist
     int scatter = 0;     // conservation, packed rows: 1 = clipped, 2 = unclipped + halo
-    int persistent = 0;  // dense rows: 0 = the library's choice, 1 = one workgroup per tile (sweep_conservation_halo3_kernel),
+    int persistent = 0;  // dense rows: 0 = the library's choice, 5 = the table-driven kernel (sweep_conservation_halo3t_kernel),
+                         //   1 = every wave works its tile out by itself (sweep_conservation_halo3_kernel),
                          //   2 / 3 / 4 = persistent workgroups (sweep_conservation_halo3p_kernel) wherever the query fits: rows by
                          //   LDS-DMA / into registers at the head of a tile / into registers one tile ahead
     int force_packed = 0;  // 1 = read the 4-byte rows even when the dense rows are resident and could answer (they are
@@ -102,8 +103,19 @@ struct memo_index {
     // 4- / 6-byte rows come into being: memo_index_pack, memo_builder_finish, memo_index_import_packed.
     uint32_t len_hist[256] = {0};
     uint64_t len_hist_rows = 0;  // rows sampled (0: no histogram)
+    // Tile tables of the table-driven dense-row sweep (memo_sweep_cons3t.hip): per (tile width, k) the row slice of every
+    // tile of the chromosome, 32 bytes per tile, built by the first query that needs one and kept (least recently used of
+    // four replaced); dropped with the dense rows.
+    struct TileTable {
+        int w = 0, km1 = 0;
+        void *d = nullptr;
+        int64_t n = 0;
+        uint64_t stamp = 0;
+    };
+    TileTable ttab[4];
+    uint64_t ttab_clock = 0;
     int last_sweep = 0;          // level arrays of the last conservation sweep (memo_index_info_t.last_sweep)
-    int last_variant = 0;        // ... 1 when it ran as persistent workgroups (memo_sweep_cons3p.hip)
+    int last_variant = 0;        // ... 1 when it ran as persistent workgroups (memo_sweep_cons3p.hip), 2 table-driven (memo_sweep_cons3t.hip)
     int has_wide = 1;          // the three int64 columns are still resident
     // rows with end < start (never written by the reference's index builder, but legal input to
     // memo_query.py): copied aside at finalize and applied by long_rows_kernel after each sweep
@@ -119,6 +131,7 @@ struct memo_index {
 };
 
 namespace memo {
+void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables derive from the dense rows and the bucket table
 extern thread_local int g_last_one_shot_sweep;  // which kernel family answered this thread's last one-shot call
 }
 

@@ -287,6 +287,7 @@ int memo_device_count(void) {
 }
 
 static void drop_packed(memo_index *ix) {  // the rows are about to change
+    drop_tile_tables(ix);
     (void)hipFree(ix->pk);
     (void)hipFree(ix->pa);
     (void)hipFree(ix->p3);
@@ -300,6 +301,7 @@ static void drop_packed(memo_index *ix) {  // the rows are about to change
 // the rows are about to change but the index keeps its size: the packed copy is stale, its buffers
 // can serve the next memo_index_pack
 static void stale_packed(memo_index *ix) {
+    drop_tile_tables(ix);
     ix->packed_fmt = 0;
     (void)hipFree(ix->p3);
     ix->p3 = nullptr;
@@ -340,6 +342,7 @@ void memo_index_destroy(memo_index_t *ix) {
     (void)hipFree(ix->s);
     (void)hipFree(ix->e);
     (void)hipFree(ix->o);
+    drop_tile_tables(ix);
     (void)hipFree(ix->boff);
     (void)hipFree(ix->pk);
     (void)hipFree(ix->pa);
@@ -559,6 +562,7 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
         ~Events() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
     } events{ev0, ev1};
     // a packed copy of the same size is reused (packing again after a re-finalize, or to time the pass)
+    drop_tile_tables(ix);
     (void)hipFree(ix->p3);  // derived from the words that are about to be rewritten
     ix->p3 = nullptr;
     const bool had = ix->pk && ix->packed_rows == ix->padded;

@@ -24,6 +24,9 @@ struct SweepArgs {
     int64_t tiles_per_xcd;  // ceil(ntiles / 8)
     int64_t tiles_per_wg;   // persistent sweeps (memo_sweep_cons3p.hip): tiles per workgroup; tiles_per_xcd = runs per XCD group
     int x_lo_first, x_hi_last;  //   ... and the window's edges inside its first / last tile
+    int64_t tile_abs0;      // table-driven dense sweep (memo_sweep_cons3t.hip): tile 0's number in pivot coordinates (tile0 / w),
+    const void *ttab;       //   the tile table (32 bytes per tile) and its length
+    int64_t ntab;
     void *out;
     int *status;
     int bshift;
@@ -532,6 +535,8 @@ inline int floor_log2(uint32_t v) { return 31 - __builtin_clz(v); }
 int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st);
 // memo_sweep_cons3p.hip (linked into libmemo_amd_ab.so only: an experiment that lost, kept for A/B): the persistent
 // dense-row sweep registers itself here; 1 = this query does not fit it (take the tile-per-workgroup kernel)
+// memo_sweep_cons3t.hip: the table-driven dense-row sweep; 1 = this query does not fit it
+int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStream_t st);
 using PersistentLaunch = int (*)(SweepArgs &A, int tw, int elem_bytes, int device, int mode, hipStream_t st);
 extern PersistentLaunch g_persistent_launch;
 int pick_rows(const memo_index *ix, int32_t k, int &fmt);

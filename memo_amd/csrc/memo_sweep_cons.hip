@@ -1029,6 +1029,10 @@ static int pick_levels(const memo_index *ix, int k, bool moderate) {
     return blocks4 <= (km1 >= 128 && moderate ? 2.9 : 2.15) * rows ? 3 : 4;
 }
 
+#ifndef MEMO_TABLE_DEFAULT
+#define MEMO_TABLE_DEFAULT 1  // the dense rows are swept by the table-driven kernel wherever the query fits it (0: A/B builds)
+#endif
+
 template <typename OutT>
 static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
                               OutT *d_out, void *stream) {
@@ -1172,7 +1176,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             const bool top8 = num_docs <= 255;
             const bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && top8;
             ix->last_variant = 0;
-            if (three && g_persistent_launch && tune.persistent >= 2) {
+            if (three && g_persistent_launch && tune.persistent >= 2 && tune.persistent <= 4) {
                 // persistent workgroups (memo_sweep_cons3p.hip, AB library only: 17 - 50 % slower than a workgroup per tile,
                 // profiles/r03_persistent_sweep.txt); 1 = this query does not fit it
                 const int prc = g_persistent_launch(A, tw, (int)sizeof(OutT), ix->device, tune.persistent - 2, st);
@@ -1180,6 +1184,16 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                 if (prc == MEMO_OK) {
                     ix->last_sweep = 5;
                     ix->last_variant = 1;
+                    return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
+                }
+            }
+            if (three && (tune.persistent == 5 || (tune.persistent == 0 && MEMO_TABLE_DEFAULT))) {
+                // the tile's row slice from a table built once per (index, k): memo_sweep_cons3t.hip; 1 = does not fit
+                const int trc = launch_halo3t(ix, A, tw, (int)sizeof(OutT), st);
+                if (trc < 0) return trc;
+                if (trc == MEMO_OK) {
+                    ix->last_sweep = 5;
+                    ix->last_variant = 2;
                     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
                 }
             }

@@ -1,0 +1,235 @@
+// memo_sweep_cons3t.hip -- the conservation sweep on the dense rows, one workgroup per tile, with the tile's row slice
+// read from a TILE TABLE instead of being worked out by every wave (round 3; the counterpart of
+// /root/reference/src/memo_query.py:42-63 + :70 like every sweep here).
+//
+// sweep_conservation_halo3_kernel (memo_sweep_cons.hip) spends ~300 scalar instructions per wave, ~130 of them finding
+// its tile: 64-bit tile arithmetic, two divisions by five, two dependent bucket-table loads, bounds.  The CU has one
+// scalar unit, and the sweep's time follows its scalar instruction count (+100 do-nothing SALU per wave: +6.6 %; +100
+// VALU: +5.3 %; profiles/r03_issue_diagnostic.txt).  A tile's slice -- first group, groups, first and last valid row --
+// depends on the index, the tile width and k only (tiles are aligned in PIVOT coordinates), so it is computed once per
+// (index, k) by tile_table_kernel, 32 bytes per tile (3.4 MB for BASELINE config 3), kept with the index, and every
+// later query's waves fetch their tile with ONE s_load_dwordx8.  The rest of the tile body is the lean one of
+// memo_sweep_dense.h: clear, level reads and fold unrolled for the number of level arrays (template parameter), four
+// row loads in a row, rows masked by number only in the pieces that straddle an end of the slice.
+#include "memo_sweep_dense.h"
+
+using namespace memo;
+using namespace memo::dense;
+
+namespace {
+
+struct TileDesc {  // 32 bytes
+    uint32_t g0_lo, g0_hi;  // first group of the slice (a multiple of 8)
+    uint32_t ng;            // groups; 0xFFFFFFFF: more than 2^32 rows reach this tile (unsupported)
+    uint32_t first, end;    // rows [first, end) of the slice, counted from row 5 * g0
+    uint32_t pad[3];
+};
+
+// tile T covers pivot positions [T * w, (T + 1) * w); its rows: T * w <= start < roundup((T + 1) * w + k - 1, bucket)
+__global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase, int bshift, int w, int km1, int64_t ntab,
+                                  TileDesc *out) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= ntab) return;
+    const int64_t a = t * w, last = nb - 1, lim = a + w + km1;
+    int64_t b0 = (a >> bshift) - bbase, b1 = ((lim + ((int64_t)1 << bshift) - 1) >> bshift) - bbase;
+    b0 = b0 < 0 ? 0 : (b0 > last ? last : b0);
+    b1 = b1 < 0 ? 0 : (b1 > last ? last : b1);
+    const uint64_t r0 = a <= 0 ? 0 : (uint64_t)boff[b0], r1 = (uint64_t)boff[b1];
+    const uint64_t g0 = (r0 / 5) & ~(uint64_t)7, g1 = (r1 + 4) / 5;
+    TileDesc d;
+    d.g0_lo = (uint32_t)g0;
+    d.g0_hi = (uint32_t)(g0 >> 32);
+    d.ng = r1 - 5 * g0 >= 0xFFFF0000ull ? 0xFFFFFFFFu : (uint32_t)(g1 - g0);
+    d.first = (uint32_t)(r0 - 5 * g0);
+    d.end = (uint32_t)(r1 - 5 * g0);
+    d.pad[0] = d.pad[1] = d.pad[2] = 0;
+    out[t] = d;
+}
+
+template <int NLEV, typename OutT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void sweep_conservation_halo3t_kernel(const SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr int T = 256, NW = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t blk = blockIdx.x;
+    const uint32_t tile = (blk & 7u) * (uint32_t)A.tiles_per_xcd + (blk >> 3);  // each XCD group: a contiguous run of tiles
+    if (tile >= (uint32_t)A.ntiles) return;
+    const uint32_t tabs = (uint32_t)A.tile_abs0 + tile;  // the tile's number in pivot coordinates
+    const TileDesc *dp = static_cast<const TileDesc *>(A.ttab) + (tabs < (uint32_t)A.ntab ? tabs : (uint32_t)A.ntab - 1u);
+    const uint4 d0 = *reinterpret_cast<const uint4 *>(dp);
+    const uint32_t d_end = dp->end;
+    Geo g;
+    g.g0 = 0;
+    g.ng = d0.z;
+    g.first = d0.w;
+    g.end = d_end;
+    if (g.ng == 0xFFFFFFFFu) {
+        if (tid == 0) atomicOr(A.status, kStatusHugeSlice);
+        return;
+    }
+    const uint4 *src0 = reinterpret_cast<const uint4 *>(A.p3) + (((uint64_t)d0.y << 32) | d0.x);
+    // a lane's four groups of a batch of 1024 (group tid + 256 j): four loads in a row, none under a branch; a piece
+    // past the tile's groups loads ONE group for the whole wave (one request)
+    uint4 V[4];
+    auto issue = [&](uint32_t batch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t pg = batch * kStageGroups + (uint32_t)(j * T + wave * 64);
+            V[j] = src0[pg < g.ng ? pg + (uint32_t)lane : 0u];
+        }
+    };
+    issue(0);
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
+    const int HL = A.hl, W = A.w;
+    clear_levels<NLEV>(lds_base, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
+    RowConst C;
+    C.km1 = A.km1;
+    C.ls4 = 4u * kLS;
+    C.bias4 = (uint32_t)pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)(32 - NLEV) * C.ls4));
+    C.top_bit = (uint32_t)pin_vgpr((int)0x80000000u);
+    C.a10s = (uint32_t)pin_vgpr((int)(((tabs * (uint32_t)W) & 1023u) << 6));
+    const uint32_t span = g.end - g.first;
+    barrier_lds();  // the level arrays are clear
+
+    const uint32_t nbatch = (g.ng + kStageGroups - 1) / kStageGroups;
+    for (uint32_t batch = 0; batch == 0 || batch < nbatch; ++batch) {
+        if (batch) issue(batch);  // (a tile with more than 5120 rows: the rest)
+        const uint32_t gbase = batch * kStageGroups;
+        const uint32_t gleft = g.ng > gbase ? g.ng - gbase : 0;
+        // a wave whose four pieces (64 groups each, 256 apart) all lie inside the slice: twenty rows, not one test
+        const uint32_t w_row0 = 5u * (gbase + (uint32_t)wave * 64u);
+        if (w_row0 >= g.first && w_row0 + 5u * (3u * T + 64u) <= g.end) {
+            group_rows<false>(V[0], C, 0, 0);
+            group_rows<false>(V[1], C, 0, 0);
+            group_rows<false>(V[2], C, 0, 0);
+            group_rows<false>(V[3], C, 0, 0);
+            continue;
+        }
+        (void)(reg_piece<0>(V[0], tid, wave, gbase, gleft, g, C, span) && reg_piece<1>(V[1], tid, wave, gbase, gleft, g, C, span) &&
+               reg_piece<2>(V[2], tid, wave, gbase, gleft, g, C, span) && reg_piece<3>(V[3], tid, wave, gbase, gleft, g, C, span));
+    }
+    barrier_lds();  // (lgkmcnt(0): the ds_min above are invisible to the compiler)
+
+    // fold in registers + store (halo_fold_store_dpp of memo_sweep_cons.hip, unrolled for NLEV)
+    OutT *out = static_cast<OutT *>(A.out);
+    const int cells = HL + W;
+    constexpr int ctx = NLEV <= 1 ? 0 : (NLEV <= 3 ? 1 : 1 << (NLEV - 3));
+    constexpr int valid = 64 - ctx;
+    const int64_t a_rel = (int64_t)tabs * W - A.qs;  // the tile's first position, as an output index
+    const int64_t ob = a_rel - HL;
+    const int64_t o_lo = a_rel + (tile == 0 ? A.x_lo_first : 0);
+    const int64_t o_hi = a_rel + (tile == (uint32_t)A.ntiles - 1u ? A.x_hi_last : W);
+    for (int base = wave * 4 * valid; base + 4 * ctx < cells; base += NW * 4 * valid) {
+        const int x0 = base + 4 * lane;
+        const int xr = x0 < kLS - 4 ? x0 : kLS - 4;  // (past the array: lanes whose results are dropped below)
+        u32x4 L[6];
+        read_levels<NLEV>(lds_base + 4u * (uint32_t)xr, L);
+        auto lv = [&](int i) { return make_uint4(L[i].x, L[i].y, L[i].z, L[i].w); };
+        uint4 M = lv(0);
+        if constexpr (NLEV >= 6) fold_step_dpp<4>(M, lv(NLEV - 5), lane);
+        if constexpr (NLEV >= 5) fold_step_dpp<3>(M, lv(NLEV - 4), lane);
+        if constexpr (NLEV >= 4) fold_step_dpp<2>(M, lv(NLEV - 3), lane);
+        if constexpr (NLEV >= 3) fold_step_dpp<1>(M, lv(NLEV - 2), lane);
+        if constexpr (NLEV >= 2) fold_step_dpp<0>(M, lv(NLEV - 1), lane);
+        if (lane < ctx || x0 >= cells) continue;
+        const int64_t o = ob + x0;
+        if (o >= o_lo && o + 4 <= o_hi) {
+            if constexpr (sizeof(OutT) == 1) {
+                *reinterpret_cast<uint32_t *>(out + o) = __builtin_amdgcn_perm(M.y, M.x, 0x0c0c0703u) |
+                                                         __builtin_amdgcn_perm(M.w, M.z, 0x07030c0cu);
+            } else {
+                *reinterpret_cast<uint2 *>(out + o) = make_uint2(__builtin_amdgcn_perm(M.y, M.x, 0x0c070c03u),
+                                                                 __builtin_amdgcn_perm(M.w, M.z, 0x0c070c03u));
+            }
+        } else {
+            const uint32_t v[4] = {M.x >> 24, M.y >> 24, M.z >> 24, M.w >> 24};
+            for (int i = 0; i < 4; ++i)
+                if (o + i >= o_lo && o + i < o_hi) out[o + i] = (OutT)v[i];
+        }
+    }
+}
+
+template <typename OutT>
+SweepKernel kernel_for(int nlev) {
+    switch (nlev) {
+        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, OutT>;
+        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, OutT>;
+        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, OutT>;
+        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, OutT>;
+        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, OutT>;
+        case 6: return (SweepKernel)sweep_conservation_halo3t_kernel<6, OutT>;
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+namespace memo {
+
+void drop_tile_tables(memo_index *ix) {
+    for (memo_index::TileTable &t : ix->ttab) {
+        if (t.d) (void)hipFree(t.d);
+        t = memo_index::TileTable();
+    }
+}
+
+// the table of (index, tile width, k): built by the first query that needs it, kept with the index (four of them)
+static int tile_table(memo_index *ix, int w, int km1, hipStream_t st, const void **tab, int64_t *ntab) {
+    memo_index::TileTable *slot = nullptr;
+    for (memo_index::TileTable &t : ix->ttab)
+        if (t.d && t.w == w && t.km1 == km1) slot = &t;
+    if (!slot) {
+        slot = &ix->ttab[0];
+        for (memo_index::TileTable &t : ix->ttab)
+            if (t.stamp < slot->stamp) slot = &t;  // (an empty slot has stamp 0)
+        if (slot->d) {
+            HIP_TRY(hipStreamSynchronize(st));  // (a sweep queued on this stream may still read it)
+            (void)hipFree(slot->d);
+            *slot = memo_index::TileTable();
+        }
+        const int64_t top = ix->max_s < 0 ? 0 : ix->max_s;
+        const int64_t n = (top + km1 + ((int64_t)1 << ix->bshift)) / w + 3;  // past the last row: empty slices
+        if (n >= ((int64_t)1 << 31)) return 1;
+        HIP_TRY(hipMalloc(&slot->d, (size_t)n * sizeof(TileDesc)));
+        hipLaunchKernelGGL(tile_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->boff, (int64_t)ix->nb, ix->bbase,
+                           ix->bshift, w, km1, n, static_cast<TileDesc *>(slot->d));
+        HIP_TRY(hipGetLastError());
+        slot->w = w;
+        slot->km1 = km1;
+        slot->n = n;
+    }
+    slot->stamp = ++ix->ttab_clock;
+    *tab = slot->d;
+    *ntab = slot->n;
+    return MEMO_OK;
+}
+
+// Launch the table-driven dense-row sweep if this query fits it (else return 1: the caller takes
+// sweep_conservation_halo3_kernel).  A: filled for the unclipped sweep (hl, w, ls, nlev, ncols); tw = tile width.
+int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStream_t st) {
+    if (!A.p3 || A.ls > kLS || A.nlev < 1 || A.nlev > 6 || A.km1 > 63 || A.qs < 0) return 1;
+    const int64_t q = A.qs / tw, tile0 = q * tw;
+    if ((tile0 - A.qs) & 3) return 1;  // the register fold needs the tile grid on the output's 4-position raster
+    const int64_t ntiles = ((A.qe - tile0) + tw - 1) / tw;
+    if (ntiles + 8 >= ((int64_t)1 << 31) || q + ntiles >= ((int64_t)1 << 31)) return 1;
+    const void *tab = nullptr;
+    int64_t ntab = 0;
+    const int rc = tile_table(ix, tw, A.km1, st, &tab, &ntab);
+    if (rc) return rc;
+    A.tile0 = tile0;
+    A.ntiles = ntiles;
+    A.tiles_per_xcd = (ntiles + 7) / 8;
+    A.tile_abs0 = q;
+    A.ttab = tab;
+    A.ntab = ntab;
+    A.x_lo_first = (int)(A.qs - tile0);
+    A.x_hi_last = (int)(A.qe - (tile0 + (ntiles - 1) * tw));
+    SweepKernel kern = elem_bytes == 1 ? kernel_for<uint8_t>(A.nlev) : kernel_for<uint16_t>(A.nlev);
+    if (!kern) return 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(256), (size_t)A.nlev * 4096, st, A);
+    HIP_TRY(hipGetLastError());
+    return MEMO_OK;
+}
+
+}  // namespace memo

@@ -1,0 +1,160 @@
+// memo_sweep_dense.h -- device pieces shared by the sweeps that read the dense rows with a lean, unrolled tile body
+// (memo_sweep_cons3t.hip: the product's table-driven kernel; memo_sweep_cons3p.hip: the persistent experiment of the
+// AB library): level clear / read in inline asm, the branch-free row block (plain and masked by row number), a group's
+// five rows, the register fold + store.
+#ifndef MEMO_SWEEP_DENSE_H
+#define MEMO_SWEEP_DENSE_H
+
+#include "memo_sweep.h"
+#include "memo_sweep_fold.h"
+
+namespace memo {
+namespace dense {
+
+constexpr int kLS = 1024;              // cells per level array (the dense rows' 10-bit start field)
+constexpr int kStageGroups = 1024;     // groups (16 B) per stage
+constexpr uint32_t kStageBytes = kStageGroups * 16;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (a native vector: what a 128-bit asm operand has to be)
+
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// what a tile needs, relative to the run's first group (all 32-bit)
+struct Geo {
+    uint32_t g0;     // first group of the slice (a multiple of 8), relative to the run's base group
+    uint32_t ng;     // groups
+    uint32_t first;  // rows [first, end) of the slice, counted from row 5 * g0
+    uint32_t end;
+};
+
+// bucket-table entries of a tile (row numbers, absolute)
+struct Slice {
+    uint64_t r0, r1;
+};
+
+template <int NLEV>
+__device__ __forceinline__ void clear_levels(uint32_t lds_base, uint32_t sent) {
+    // every level starts at the sentinel column N (memo_query.py:53-54): NLEV x 4 KiB, 16 B per lane and store
+    const u32x4 sv = {sent, sent, sent, sent};
+    const uint32_t at = lds_base + 16u * threadIdx.x;
+    static_assert(NLEV >= 1 && NLEV <= 6, "1 .. 6 level arrays (k - 1 <= 63)");
+#define MEMO_CLR(off) "ds_write_b128 %0, %1 offset:" #off "\n\t"
+    if constexpr (NLEV == 1) asm volatile(MEMO_CLR(0) :: "v"(at), "v"(sv) : "memory");
+    if constexpr (NLEV == 2) asm volatile(MEMO_CLR(0) MEMO_CLR(4096) :: "v"(at), "v"(sv) : "memory");
+    if constexpr (NLEV == 3) asm volatile(MEMO_CLR(0) MEMO_CLR(4096) MEMO_CLR(8192) :: "v"(at), "v"(sv) : "memory");
+    if constexpr (NLEV == 4) asm volatile(MEMO_CLR(0) MEMO_CLR(4096) MEMO_CLR(8192) MEMO_CLR(12288) :: "v"(at), "v"(sv) : "memory");
+    if constexpr (NLEV == 5)
+        asm volatile(MEMO_CLR(0) MEMO_CLR(4096) MEMO_CLR(8192) MEMO_CLR(12288) MEMO_CLR(16384) :: "v"(at), "v"(sv) : "memory");
+    if constexpr (NLEV == 6)
+        asm volatile(MEMO_CLR(0) MEMO_CLR(4096) MEMO_CLR(8192) MEMO_CLR(12288) MEMO_CLR(16384) MEMO_CLR(20480) :: "v"(at), "v"(sv) : "memory");
+#undef MEMO_CLR
+}
+
+// one ds_read_b128 per level at the same cell (levels are 4 KiB apart), waited for in the same statement
+template <int NLEV>
+__device__ __forceinline__ void read_levels(uint32_t addr, u32x4 (&L)[6]) {
+#define MEMO_RD(i, off) "ds_read_b128 %" #i ", %" MEMO_ADDR " offset:" #off "\n\t"
+#define MEMO_ADDR "1"
+    if constexpr (NLEV == 1) asm volatile(MEMO_RD(0, 0) "s_waitcnt lgkmcnt(0)" : "=&v"(L[0]) : "v"(addr) : "memory");
+#undef MEMO_ADDR
+#define MEMO_ADDR "2"
+    if constexpr (NLEV == 2)
+        asm volatile(MEMO_RD(0, 0) MEMO_RD(1, 4096) "s_waitcnt lgkmcnt(0)" : "=&v"(L[0]), "=&v"(L[1]) : "v"(addr) : "memory");
+#undef MEMO_ADDR
+#define MEMO_ADDR "3"
+    if constexpr (NLEV == 3)
+        asm volatile(MEMO_RD(0, 0) MEMO_RD(1, 4096) MEMO_RD(2, 8192) "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(L[0]), "=&v"(L[1]), "=&v"(L[2]) : "v"(addr) : "memory");
+#undef MEMO_ADDR
+#define MEMO_ADDR "4"
+    if constexpr (NLEV == 4)
+        asm volatile(MEMO_RD(0, 0) MEMO_RD(1, 4096) MEMO_RD(2, 8192) MEMO_RD(3, 12288) "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(L[0]), "=&v"(L[1]), "=&v"(L[2]), "=&v"(L[3]) : "v"(addr) : "memory");
+#undef MEMO_ADDR
+#define MEMO_ADDR "5"
+    if constexpr (NLEV == 5)
+        asm volatile(MEMO_RD(0, 0) MEMO_RD(1, 4096) MEMO_RD(2, 8192) MEMO_RD(3, 12288) MEMO_RD(4, 16384) "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(L[0]), "=&v"(L[1]), "=&v"(L[2]), "=&v"(L[3]), "=&v"(L[4]) : "v"(addr) : "memory");
+#undef MEMO_ADDR
+#define MEMO_ADDR "6"
+    if constexpr (NLEV == 6)
+        asm volatile(MEMO_RD(0, 0) MEMO_RD(1, 4096) MEMO_RD(2, 8192) MEMO_RD(3, 12288) MEMO_RD(4, 16384) MEMO_RD(5, 20480)
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(L[0]), "=&v"(L[1]), "=&v"(L[2]), "=&v"(L[3]), "=&v"(L[4]), "=&v"(L[5]) : "v"(addr) : "memory");
+#undef MEMO_ADDR
+#undef MEMO_RD
+}
+
+// The row block of sweep_conservation_halo3_kernel: 16-bit subtract (start - a, length untouched below it), length,
+// "this row writes" into EXEC, level and both cells, ds_min x 2, EXEC restored.  MASKED: the row's number (tmp + I,
+// counted from the slice's first row) is tested against the slice's row count first.
+struct RowConst {
+    uint32_t a10s, bias4, top_bit;  // VGPRs
+    int km1;                        // SGPRs
+    uint32_t ls4;
+};
+
+// One group's five rows as ONE statement (PackedRows3: rows 0 .. 3 as loaded, row 4 from the spare bytes).  Five
+// separate statements cost an s_nop each: the compiler cannot see into an asm block and pads for a hazard the next
+// block might have (none here: an SALU write of EXEC needs no wait states before a VALU that only uses it as its mask).
+// operands: %0-%3 temporaries; %4-%7 the group's dwords; %8 / %9 row 4's field and order word; %10 a10s, %11 km1 (SGPR),
+// %12 ls4 (SGPR), %13 bias4, %14 top_bit; masked form: %15 tmp, %16 span (SGPR)
+#define MEMO_ROW3_AT(B, D)                               \
+    "v_sub_u16 %3, " B ", %10\n\t"                       \
+    "v_and_b32 %0, 63, %3\n\t"                           \
+    "v_sub_u32 %0, %11, %0\n\t"                          \
+    "v_cmpx_lt_i32 vcc, 0, %0\n\t"                       \
+    "v_ffbh_u32 %1, %0\n\t"                              \
+    "v_bfe_u32 %3, %3, 6, 10\n\t"                        \
+    "v_mad_u32_u24 %2, %1, %12, %13\n\t"                 \
+    "v_lshl_add_u32 %2, %3, 2, %2\n\t"                   \
+    "v_mad_i32_i24 %3, %0, -4, %2\n\t"                   \
+    "v_ashrrev_i32 %1, %1, %14\n\t"                      \
+    "v_lshl_add_u32 %2, %1, 2, %2\n\t"                   \
+    "ds_min_u32 %3, " D "\n\t"                           \
+    "ds_min_u32 %2, " D "\n\t"                           \
+    "s_mov_b64 exec, -1\n\t"
+#define MEMO_ROW3_MASK(I) "v_add_u32 %0, %15, " #I "\n\tv_cmpx_gt_u32 vcc, %16, %0\n\t"
+
+template <bool MASKED>
+__device__ __forceinline__ void group_rows(const uint4 &V, const RowConst &C, uint32_t tmp, uint32_t span) {
+    const uint32_t b4 = __builtin_amdgcn_perm(V.y, V.x, 0x0c0c0602u), d4 = V.z << 8;
+    uint32_t r0, r1, r2, r3;
+    if constexpr (MASKED) {
+        asm volatile(MEMO_ROW3_MASK(0) MEMO_ROW3_AT("%4", "%4") MEMO_ROW3_MASK(1) MEMO_ROW3_AT("%5", "%5")
+                     MEMO_ROW3_MASK(2) MEMO_ROW3_AT("%6", "%6") MEMO_ROW3_MASK(3) MEMO_ROW3_AT("%7", "%7")
+                     MEMO_ROW3_MASK(4) MEMO_ROW3_AT("%8", "%9")
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                     : "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w), "v"(b4), "v"(d4), "v"(C.a10s), "s"(C.km1), "s"(C.ls4), "v"(C.bias4),
+                       "v"(C.top_bit), "v"(tmp), "s"(span)
+                     : "memory", "vcc");
+    } else {
+        asm volatile(MEMO_ROW3_AT("%4", "%4") MEMO_ROW3_AT("%5", "%5") MEMO_ROW3_AT("%6", "%6") MEMO_ROW3_AT("%7", "%7")
+                     MEMO_ROW3_AT("%8", "%9")
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                     : "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w), "v"(b4), "v"(d4), "v"(C.a10s), "s"(C.km1), "s"(C.ls4), "v"(C.bias4),
+                       "v"(C.top_bit)
+                     : "memory", "vcc");
+    }
+}
+
+// the J-th group of a lane, already in registers (MODE 1 / 2)
+template <int J>
+__device__ __forceinline__ bool reg_piece(const uint4 &V, int tid, int wave, uint32_t gbase, uint32_t gleft, const Geo &g,
+                                          const RowConst &C, uint32_t span) {
+    const uint32_t pg = (uint32_t)(J * 256 + wave * 64);
+    if (pg >= gleft) return false;
+    const uint32_t row0 = 5u * (gbase + pg);
+    if (row0 >= g.first && row0 + 320u <= g.end) {
+        group_rows<false>(V, C, 0, 0);
+    } else {
+        const uint32_t tmp = 5u * (gbase + (uint32_t)(J * 256 + tid)) - g.first;
+        group_rows<true>(V, C, tmp, span);
+    }
+    return true;
+}
+
+
+}  // namespace dense
+}  // namespace memo
+
+#endif  // MEMO_SWEEP_DENSE_H

@@ -2,7 +2,7 @@
 # round 3: the persistent LDS-DMA sweep (memo_sweep_cons3p.hip) -- parity against the tile-per-workgroup kernel, then sustained A/B
 TAG=${1:-r3p}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 600 python tools/p3_check.py 2>&1 | tail -25
-for rep in 1 2; do for v in "0,0,0,5" "0,0,0,6" "0,0,0,7"; do for k in 31 64; do
+for rep in 1 2; do for v in "0,0,0,5" "0,0,0,8"; do for k in 31 21 64; do
   printf "c3 k=%-3s %-10s: " $k $v >> $OUT/ab.txt
   timeout 300 python tools/ab.py --workload c3 --k $k --pack dense --u8 --rounds 2000 "$v" 2>>$OUT/err.txt | python -c "
 import json,sys

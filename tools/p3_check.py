@@ -22,12 +22,12 @@ with ix:
                 ix.debug_set_tuning(0, 0, 0, 5, 0)
                 ref = ix.conservation(qs, qe, k, n, dtype=dt)
                 v_ref = ix.info()["last_variant"]
-                for src in (4, 6, 7):
+                for src in (8, 4, 6, 7):
                     ix.debug_set_tuning(0, 0, 0, src, 0)
                     got = ix.conservation(qs, qe, k, n, dtype=dt)
                     inf = ix.info()
                     same = np.array_equal(ref, got)
-                    if not same or inf["last_variant"] != 1 or v_ref != 0:
+                    if not same or inf["last_variant"] != (2 if src == 8 else 1) or v_ref != 0:
                         bad += 1
                         d = np.flatnonzero(ref != got)
                         print("MISMATCH" if not same else "variant?", src, k, qs, qe, dt.__name__, inf["last_sweep"], inf["last_variant"],
@@ -36,7 +36,7 @@ with ix:
         sr0, sr1 = synth.shard_rows(a, b, k, num, den, L)
         s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
         want = oracle.conservation(s, e, o, a, b, k, n, literal=False)
-        ix.debug_set_tuning(0, 0, 0, 4, 0)
+        ix.debug_set_tuning(0, 0, 0, 8, 0)
         full = ix.conservation(0, L, k, n)
         if not np.array_equal(full[a:b], want):
             bad += 1
