@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--launch", action="store_true",
                     help="start the ranks as a child torch.distributed.run even when --gpus is 1 (N > 1 without "
                          "WORLD_SIZE in the environment does so by itself)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="N = 1: skip the legs that time the other resident row formats (rocprofv3 passes: every launch of the "
+                         "headline kernel in the trace is then the headline workload)")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000,
                     help="positions of the window the 1-core CPU baseline is timed on (0 = skip)")
     return ap.parse_args()
@@ -266,7 +269,7 @@ def main():
     # kernel inside memo_index_pack, buffers allocated by the first call and reused by the second; an event
     # pair on the same stream around memo_index_pack_dense).
     indexes, pack_pass, dense_pass, packed_fmt = {}, None, None, 0
-    others = (world == 1 and not args.force_dist)
+    others = (world == 1 and not args.force_dist and not args.headline_only)
     formats = [args.rows] + ([f for f in ("wide", "packed", "dense") if f != args.rows and
                               (f != "dense" or can_dense) and (f == "wide" or k - 1 <= 255)] if others else [])
     for f in formats:
@@ -304,6 +307,7 @@ def main():
                           "ms": dms, "rows": nrows, "bytes": 7.2 * nrows, "GBs": 7.2 * nrows / (dms * 1e-3) / 1e9}
         indexes[f] = ixf
     rows = r1 - r0
+    rows_read = {f: rows for f in indexes}
     ix = indexes[args.rows]
     fmt_bytes = {"wide": 24, "packed": 6 if packed_fmt == 6 else 4, "dense": 3.2}
     row_bytes = fmt_bytes[args.rows]
@@ -469,6 +473,24 @@ def main():
     nibble = coding != "plain"              # (name kept: "the slices travel coded")
     # rank 0 sweeps the first root_weight of its window (a multiple of 8 positions); everybody else all of it
     L_mine = L if rank != 0 else max(8, int(L * root_weight) // 8 * 8)
+    # One launch per resident format before anything is timed: the first conservation query of a k class on the dense rows
+    # builds their k-class VIEW (the rows whose overlap is below 8 / 16 / 32: all that can write at this k; memo_query.py:49
+    # drops the others per query, the library once per index and class -- memo_index_info_t.last_rows_read) and the tile
+    # table; both stay with the index.  What each format's sweep reads is what its roofline is priced on.
+    view_pass = None
+    for f, ixf in indexes.items():
+        for _ in range(8):                  # (a view is built by the fifth query of its class)
+            launch(outs[0], ixf)
+            torch.cuda.synchronize()
+            inf = ixf.info()
+            if f == "dense" and inf["last_view_ms"] > 0:
+                view_pass = {"what": "k-class view of the dense rows, built by the fifth query of its class (rows whose overlap is below "
+                                     "the class's cap; one pass over the dense rows + their bucket table), once per index and class, kept",
+                             "ms": float(inf["last_view_ms"]), "rows_in": int(inf["dense_row_count"]), "rows_kept": int(inf["last_rows_read"])}
+            if f != "dense" or membership:
+                break
+        if not membership and inf["last_rows_read"]:
+            rows_read[f] = int(inf["last_rows_read"])
     for o in outs:                          # (every result buffer holds a whole-window result behind L_mine)
         launch(o)
     qe_mine = qs + L_mine
@@ -603,14 +625,26 @@ def main():
                 return {"launches": n, "ms": (time.perf_counter() - t_ramp) * 1e3}
 
     other = []
-    for which in formats[1:]:
+    legs = [(w, w, None) for w in formats[1:]]
+    if others and "dense" in indexes and rows_read["dense"] != int(indexes["dense"].info()["dense_row_count"]):
+        # the same kernel on ALL the dense rows (MEMO_DENSE_VIEWS=0: no k-class view), for the record: what round 2 timed
+        legs.append(("dense", "dense, all rows (no k-class view)", int(indexes["dense"].info()["dense_row_count"])))
+    for which, label, all_rows in legs:
         ob = fmt_bytes[which]
-        settle(lambda: launch(outs[0], indexes[which]))
-        ms2 = per_step(lambda: launch(outs[0], indexes[which]), max(args.steps, 20))
-        indexes[which].check(stream.cuda_stream)
-        alg2 = ob * rows + b_out * L
+        if all_rows:
+            os.environ["MEMO_DENSE_VIEWS"] = "0"
+        try:
+            settle(lambda: launch(outs[0], indexes[which]))
+            ms2 = per_step(lambda: launch(outs[0], indexes[which]), max(args.steps, 20))
+            indexes[which].check(stream.cuda_stream)
+            name2 = kernel_name(which)
+        finally:
+            if all_rows:
+                del os.environ["MEMO_DENSE_VIEWS"]
+        alg2 = ob * (all_rows or rows_read[which]) + b_out * L
         med2 = float(np.median(ms2))
-        other.append({"rows": which, "row_bytes": ob, "kernel": kernel_name(which), "kernel_ms": float(np.mean(ms2)),
+        other.append({"rows": label, "row_bytes": ob, "rows_read": all_rows or rows_read[which], "kernel": name2,
+                      "kernel_ms": float(np.mean(ms2)),
                       "kernel_ms_median": med2, "kernel_ms_min": float(np.min(ms2)),
                       "query_positions_per_s": L / (med2 * 1e-3), "algorithmic_bytes": alg2,
                       "achieved_GBs": alg2 / (med2 * 1e-3) / 1e9, "frac": alg2 / (med2 * 1e-3) / 1e9 / HBM_PEAK_GBS})
@@ -638,10 +672,10 @@ def main():
         step(i)
     if not multi:
         ev[1].record(stream)
-    drain()
-    if multi:
+    drain()                                  # (torch.cuda.synchronize(): this rank's K steps are done, rank 0's incl. every slice received)
+    dt = time.perf_counter() - t0            # N > 1: the MAX over ranks below is the barrier-to-barrier time of the job without
+    if multi:                                # the closing barrier's own latency (~0.1 ms of RCCL against K = 20 steps of 0.2 ms)
         dist.barrier()
-    dt = time.perf_counter() - t0
     ix.check(stream.cuda_stream)
     out = outs[(args.steps - 1) % nbuf]
     # per-step spread (and, N > 1, the sweep's own time): K more sweeps with an event pair each, outside the
@@ -656,7 +690,7 @@ def main():
 
     if rank == 0:
         # bytes of the row layout the timed kernel reads + the result it writes
-        b_alg = row_bytes * rows + b_out * L
+        b_alg = row_bytes * rows_read[args.rows] + b_out * L
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         res = {
             "metric": "query-positions/sec (chr window, k=%d)" % k,
@@ -677,14 +711,20 @@ def main():
                        "row_format": "3 x int64 per row as uploaded (24 B)" if args.rows == "wide" else
                                      f"packed {6 if packed_fmt == 6 else 4} B/row (format {packed_fmt}) built once per index by memo_index_pack" if args.rows == "packed"
                                      else "3.2 B/row (five 24-bit rows per 16 bytes: start mod 2^10, length saturated at 63, 8-bit "
-                                          "order) built once per index by memo_index_pack + memo_index_pack_dense",
-                       "row_bytes": row_bytes, "result_bytes_per_position": b_out,
+                                          "order) built once per index by memo_index_pack + memo_index_pack_dense" +
+                                          ("" if rows_read["dense"] == rows else
+                                           f"; the sweep reads the k-class view of them: the {rows_read['dense']} rows whose overlap is below "
+                                           f"{8 if k - 1 <= 8 else 16 if k - 1 <= 16 else 32} -- the others cannot write at k = {k} "
+                                           "(memo_query.py:49 drops them per query) -- built once per index and class by the first query, "
+                                           "timed in dense_view_pass; `roofline` is priced on the rows read; other_row_formats has the same "
+                                           "kernel on all the dense rows"),
+                       "row_bytes": row_bytes, "rows_read": rows_read[args.rows], "result_bytes_per_position": b_out,
                        "row_format_choice": "--rows auto = the format that answers this query fastest: the dense rows where they "
                                             "can (conservation, k <= 64, num_docs <= 255), else the 4- / 6-byte rows (k <= 256), "
                                             "else int64.  roofline is priced on the bytes of the format read (fewer bytes per row "
                                             "lower `frac` at the same speed); the other resident formats are timed in "
                                             "other_row_formats",
-                       "row_format_pass": pack_pass, "dense_format_pass": dense_pass,
+                       "row_format_pass": pack_pass, "dense_format_pass": dense_pass, "dense_view_pass": view_pass,
                        "clock_ramp": {"what": "untimed headline launches before the warm-up steps, in batches of 20 until two "
                                               "batches in a row are within 1 % of the one before them", **ramp},
                        "sharding": f"window split into {world} contiguous sub-windows, slices gathered to rank 0 "
@@ -704,7 +744,8 @@ def main():
         prof = os.path.join(ROOT, "profiles", "traffic.json")    # PMC passes are separate runs
         if os.path.exists(prof):
             tj = json.load(open(prof)).get(f"{args.workload}_{args.rows}")
-            if tj and tj.get("result_bytes_per_position", b_out) == b_out:   # same kernel instantiation
+            if tj and tj.get("result_bytes_per_position", b_out) == b_out and \
+                    abs(tj.get("algorithmic_bytes", b_alg) - b_alg) <= 0.01 * b_alg:   # same kernel instantiation, same rows read
                 res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
                 res["roofline"]["traffic_source"] = (
                     "profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "

@@ -77,6 +77,16 @@ typedef struct memo_index_info {
                                2 / 3 / 4 per query from k and the overlap lengths of the rows it sampled when the
                                packed rows were made; membership: 6 bit planes on the dense rows, 7 any other */
     int32_t last_variant;   /* of the dense-row sweep: 0 every wave worked its tile out, 2 tile table; 1 persistent workgroups (A/B library) */
+    uint64_t dense_row_count; /* rows the dense rows hold (0: none resident): fewer than `rows` when the rows that can never
+                               write at k <= 64 (overlap >= 63, or end < start) were left out of them -- they are when more
+                               than a tenth of the rows are such rows (none of the synthetic index, 40 % of one built from
+                               sequences) -- the dense rows then have their own numbering and bucket table */
+    uint64_t last_rows_read;  /* rows of the row source the last sweep read: the index's rows, the dense rows, or -- conservation
+                               on the dense rows with k <= 33 -- a k-class VIEW of them that leaves out the rows whose overlap is
+                               8 / 16 / 32 or more (none of them can write at k - 1 <= 8 / 16 / 32; memo_query.py:49 drops them
+                               per query, the view once per index and class, when that spares a fifth of the rows) */
+    float last_view_ms;       /* device time of building that view, when the last sweep was the one that built it (else 0) */
+    int32_t reserved;
 } memo_index_info_t;
 
 const char *memo_last_error(void);

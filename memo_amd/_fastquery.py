@@ -42,7 +42,10 @@ def _header_ok(head, file_bytes):       # (= memo_amd.cache.header_ok)
         if fmt == 6:
             need.append((int(head["off_pa"]), 2 * rows))
         if head.get("off_p3") is not None:
-            need.append((int(head["off_p3"]), 16 * ((rows + 4) // 5)))
+            rows3 = int(head["rows3"])
+            if not (0 <= rows3 <= rows):
+                return False
+            need += [(int(head["off_p3"]), 16 * ((rows3 + 4) // 5)), (int(head["off_boff3"]), 8 * nb)]
         return all(off >= HEADER_BYTES and size >= 0 and off + size <= total for off, size in need)
     except (KeyError, TypeError, ValueError):
         return False
@@ -115,13 +118,17 @@ def try_query(in_file, region, k, num_docs, out_file, membership):
     try:
         # the dense rows (3.2 B per row, the benchmarked conservation kernel) when the file has them and they alone can
         # answer this query; else the 4- / 6-byte rows
-        if head.get("off_p3") is not None and lib.memo_dense_rows_can_answer(n, lo, hi, head["max_annot"], k, num_docs,
-                                                                             1 if membership else 0):
-            row_base = r0 // 5 * 5                # the slice starts with the group that holds row r0
-            dense = True
+        d0 = d1 = 0
+        if head.get("off_p3") is not None:        # (the dense rows' own numbering and bucket table)
+            d0 = struct.unpack_from("<q", mm, head["off_boff3"] + 8 * b_lo)[0]
+            d1 = struct.unpack_from("<q", mm, head["off_boff3"] + 8 * b_hi)[0]
+            dense = 0 <= d0 <= d1 <= head["rows3"] and bool(lib.memo_dense_rows_can_answer(
+                d1 - d0, lo, hi, head["max_annot"], k, num_docs, 1 if membership else 0))
+        if dense:
+            row_base = d0 // 5 * 5                # the slice starts with the group that holds row d0
             _lib.check(lib.memo_index_import_dense(
-                r1 - row_base, device, shift, b_lo, base + head["off_p3"] + 16 * (row_base // 5),
-                base + head["off_boff"] + 8 * b_lo, b_hi - b_lo + 2, row_base, lo, hi, head["max_annot"],
+                d1 - row_base, device, shift, b_lo, base + head["off_p3"] + 16 * (row_base // 5),
+                base + head["off_boff3"] + 8 * b_lo, b_hi - b_lo + 2, row_base, lo, hi, head["max_annot"],
                 (base + head["off_long"]) if n_long else None, n_long, C.byref(ix)))
         else:
             _lib.check(lib.memo_index_import_packed(

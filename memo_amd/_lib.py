@@ -42,7 +42,8 @@ class IndexInfo(C.Structure):
                 ("was_sorted", C.c_int32), ("finalized", C.c_int32), ("device_bytes", C.c_uint64),
                 ("packed_format", C.c_int32), ("has_wide", C.c_int32), ("pack_ms", C.c_float),
                 ("dense_rows", C.c_int32), ("long_rows", C.c_uint64), ("max_annot", C.c_uint64),
-                ("bucket_base", C.c_int64), ("last_sweep", C.c_int32), ("last_variant", C.c_int32)]
+                ("bucket_base", C.c_int64), ("last_sweep", C.c_int32), ("last_variant", C.c_int32), ("dense_row_count", C.c_uint64), ("last_rows_read", C.c_uint64),
+                ("last_view_ms", C.c_float), ("reserved", C.c_int32)]
 
 
 # every symbol the product headers declare: name -> (restype, argtypes)

@@ -81,7 +81,10 @@ def header_ok(head, file_bytes):
         if fmt == 6:
             need.append((int(head["off_pa"]), 2 * rows))
         if head.get("off_p3") is not None:
-            need.append((int(head["off_p3"]), 16 * ((rows + 4) // 5)))
+            rows3 = int(head["rows3"])
+            if not (0 <= rows3 <= rows):
+                return False
+            need += [(int(head["off_p3"]), 16 * ((rows3 + 4) // 5)), (int(head["off_boff3"]), 8 * nb)]
         return all(off >= HEADER_BYTES and size >= 0 and off + size <= total for off, size in need)
     except (KeyError, TypeError, ValueError):
         return False
@@ -102,22 +105,25 @@ def write(in_file, record, ix):
     longs = np.empty(3 * n_long, np.int64)
     check(lib().memo_index_export_packed(ix._h, pk.ctypes.data, pa.ctypes.data if fmt == 6 else None, boff.ctypes.data,
                                          longs.ctypes.data if n_long else None))
-    p3 = np.empty(0, np.uint32)
+    p3, boff3, rows3 = np.empty(0, np.uint32), np.empty(0, np.int64), 0
     if fmt == 4 and rows:
         ix.pack_dense(keep_packed=True)
-        p3 = np.empty(4 * ((rows + 4) // 5), np.uint32)
-        boff2 = np.empty(nb, np.int64)
-        check(lib().memo_index_export_dense(ix._h, p3.ctypes.data, boff2.ctypes.data, longs.ctypes.data if n_long else None))
+        rows3 = ix.info()["dense_row_count"]          # (fewer than rows when the rows that never write at k <= 64 were left out)
+        p3 = np.empty(4 * ((rows3 + 4) // 5), np.uint32)
+        boff3 = np.empty(nb, np.int64)                # the dense rows' own bucket table
+        check(lib().memo_index_export_dense(ix._h, p3.ctypes.data, boff3.ctypes.data, longs.ctypes.data if n_long else None))
     off_pk = HEADER_BYTES
     off_pa = _align(off_pk + pk.nbytes)
     off_p3 = _align(off_pa + pa.nbytes)
-    off_boff = _align(off_p3 + p3.nbytes)
+    off_boff3 = _align(off_p3 + p3.nbytes)
+    off_boff = _align(off_boff3 + boff3.nbytes)
     off_long = _align(off_boff + boff.nbytes)
     total = off_long + longs.nbytes
     head = {"version": VERSION, "record": record, "source": _source_key(in_file), "rows": rows, "format": fmt,
             "bucket_shift": inf["bucket_shift"], "buckets": nb, "min_start": inf["min_start"], "max_start": inf["max_start"],
             "max_annot": inf["max_annot"], "long_rows": n_long, "off_pk": off_pk, "off_pa": off_pa,
-            "off_p3": off_p3 if p3.nbytes else None, "off_boff": off_boff, "off_long": off_long, "bytes": total}
+            "off_p3": off_p3 if p3.nbytes else None, "off_boff3": off_boff3, "rows3": rows3, "off_boff": off_boff,
+            "off_long": off_long, "bytes": total}
     blob = MAGIC + json.dumps(head).encode()
     if len(blob) > HEADER_BYTES:
         raise ValueError("cache header too large")
@@ -126,7 +132,7 @@ def write(in_file, record, ix):
     tmp = "%s.tmp.%d" % (path, os.getpid())
     with open(tmp, "wb") as fh:
         fh.write(blob.ljust(HEADER_BYTES, b"\0"))
-        for off, arr in ((off_pk, pk), (off_pa, pa), (off_p3, p3), (off_boff, boff), (off_long, longs)):
+        for off, arr in ((off_pk, pk), (off_pa, pa), (off_p3, p3), (off_boff3, boff3), (off_boff, boff), (off_long, longs)):
             fh.seek(off)
             fh.write(memoryview(arr).cast("B"))
         fh.truncate(total)
@@ -152,10 +158,11 @@ def _open(in_file, record):
         return None
 
 
-def bucket_slice(head, entry, query_start, query_end):
+def bucket_slice(head, entry, query_start, query_end, rows=None):
     """(b_lo, b_hi, r0, r1) of the rows with query_start < start < query_end (+ the rest of the two edge buckets);
-    entry(b) reads table entry b; None when the table is inconsistent"""
-    nb, shift, rows = head["buckets"], head["bucket_shift"], head["rows"]
+    entry(b) reads table entry b (of the rows' own table: `rows` of them); None when the table is inconsistent"""
+    nb, shift = head["buckets"], head["bucket_shift"]
+    rows = head["rows"] if rows is None else rows
     b_lo = min(max(query_start, 0) >> shift, nb - 1)
     b_hi = min(max((max(query_end, 0) >> shift) + 1, b_lo), nb - 1)
     r0, r1 = int(entry(b_lo)), int(entry(b_hi))
@@ -185,14 +192,19 @@ def load_region(in_file, record, query_start, query_end, device=0, k=None, num_d
     h = C.c_void_p()
     n = r1 - r0
     lo, hi = slice_extent(head, b_lo, b_hi, n)
-    if (head.get("off_p3") is not None and k is not None and num_docs is not None and
-            dense_rows_can_answer(n, lo, hi, head["max_annot"], k, num_docs, membership)):
-        base = r0 // 5 * 5                           # the slice starts with the group that holds row r0
-        g = mm[head["off_p3"] + 16 * (base // 5):head["off_p3"] + 16 * ((r1 + 4) // 5)]
-        check(lib().memo_index_import_dense(r1 - base, device, shift, b_lo, g.ctypes.data, table.ctypes.data, len(table) + 1,
-                                            base, lo, hi, head["max_annot"], longs.ctypes.data if n_long else None, n_long,
-                                            C.byref(h)))
-        return DeviceIndex(r1 - base, device, _handle=h)
+    if head.get("off_p3") is not None and k is not None and num_docs is not None:
+        # the dense rows have their own numbering and table (rows that never write at k <= 64 may be left out of them)
+        boff3 = mm[head["off_boff3"]:head["off_boff3"] + 8 * nb].view(np.int64)
+        cut3 = bucket_slice(head, lambda b: boff3[b], query_start, query_end, rows=head["rows3"])
+        if cut3 is not None and dense_rows_can_answer(cut3[3] - cut3[2], lo, hi, head["max_annot"], k, num_docs, membership):
+            _, _, d0, d1 = cut3
+            base = d0 // 5 * 5                       # the slice starts with the group that holds row d0
+            g = mm[head["off_p3"] + 16 * (base // 5):head["off_p3"] + 16 * ((d1 + 4) // 5)]
+            table3 = boff3[b_lo:b_hi + 1]
+            check(lib().memo_index_import_dense(d1 - base, device, shift, b_lo, g.ctypes.data, table3.ctypes.data, len(table3) + 1,
+                                                base, lo, hi, head["max_annot"], longs.ctypes.data if n_long else None, n_long,
+                                                C.byref(h)))
+            return DeviceIndex(d1 - base, device, _handle=h)
     pk = mm[head["off_pk"] + 4 * r0:head["off_pk"] + 4 * r1]
     pa = mm[head["off_pa"] + 2 * r0:head["off_pa"] + 2 * r1] if head["format"] == 6 else None
     check(lib().memo_index_import_packed(n, device, shift, b_lo, pk.ctypes.data if n else None,

@@ -45,6 +45,7 @@ constexpr int kDefaultBucketShift = 5;        // 32 pivot positions per bucket
 constexpr int64_t kCoordLimit = (int64_t)1 << 61;
 constexpr int kStatusBadAnnot = 1;            // sticky device flag: the reference's IndexError case
 constexpr int kStatusHugeSlice = 2;           // sticky device flag: >= 2^32 rows reach one tile
+constexpr int kStatusExecNarrow = 4;          // -DMEMO_EXEC_CHECK builds: a branch-free row block was entered with lanes disabled
 
 }  // namespace memo
 
@@ -70,6 +71,7 @@ struct memo_tuning {
                          //   1 = every wave works its tile out by itself (sweep_conservation_halo3_kernel),
                          //   2 / 3 / 4 = persistent workgroups (sweep_conservation_halo3p_kernel) wherever the query fits: rows by
                          //   LDS-DMA / into registers at the head of a tile / into registers one tile ahead
+    int no_views = 0;    // dense rows: 1 = never read a k-class view (A/B)
     int force_packed = 0;  // 1 = read the 4-byte rows even when the dense rows are resident and could answer (they are
                            //     the faster source for the conservation sweep: profiles/r02_dense_rows_ab.txt)
 };
@@ -96,6 +98,26 @@ struct memo_index {
     uint64_t packed_rows = 0;  // rows the pk (pa) allocation holds (reused by the next memo_index_pack)
     float pack_ms = 0.f;       // device time of the last memo_index_pack (census + packing kernel)
     uint32_t *p3 = nullptr;    // dense rows (memo_index_pack_dense): 16 bytes per 5 rows; annot <= 255 only
+    // The dense rows may be FEWER than the index's rows: a row whose 6-bit length field is saturated (overlap >= 63, or
+    // end < start) can never write at k <= 64 -- all the dense rows answer -- so when more than a tenth of the rows are
+    // such rows they are left out (dense_compact, memo_index.hip: 40 % of the rows of an index built from sequences,
+    // profiles/r03_realistic_index*.json; none of the synthetic one).  The dense stream then has its own row numbers and
+    // its own bucket table; boff3 == nullptr: the dense rows are the index's rows, numbered alike (rows3 == rows).
+    int64_t *boff3 = nullptr;
+    uint64_t rows3 = 0, padded3 = 0;
+    // k-class views of the dense rows (dense_rows_for, memo_index.hip): the rows whose overlap is below 8 / 16 / 32 -- all a
+    // query with k - 1 <= 8 / 16 / 32 can be touched by -- with their own bucket table; built by the first query of the class
+    struct DenseView {
+        int cap = 0, state = 0;  // state: 0 not looked at yet, 1 built, 2 not worth it (it would spare less than a fifth)
+        int queries = 0;         // queries of this class so far (a view is built by the fifth)
+        uint32_t *p3 = nullptr;
+        int64_t *boff = nullptr;
+        uint64_t rows = 0, padded = 0;
+        float build_ms = 0.f;
+    };
+    DenseView views[3];
+    uint64_t last_rows_read = 0;  // rows of the row source the last sweep read (info.last_rows_read)
+    float last_view_ms = 0.f;     // device time of the view build, when the last sweep's view was built by it (else 0)
     uint64_t max_annot = 0;    // largest annot of the packed rows
     // Sampled histogram of the packed rows' overlap field (min(end - start, 255)): with it the length n = k - 1 -
     // overlap of a row's interval is known in distribution for any k, which is what the choice between the level
@@ -107,6 +129,7 @@ struct memo_index {
     // tile of the chromosome, 32 bytes per tile, built by the first query that needs one and kept (least recently used of
     // four replaced); dropped with the dense rows.
     struct TileTable {
+        const void *rows_of = nullptr;  // the dense rows (or view) the table was made for
         int w = 0, km1 = 0;
         void *d = nullptr;
         int64_t n = 0;
@@ -131,6 +154,11 @@ struct memo_index {
 };
 
 namespace memo {
+void drop_dense(memo_index *ix);       // frees the dense rows, their bucket table and the tile tables
+int dense_compact(memo_index *ix);     // memo_index.hip: leave the rows that can never write out of the dense rows (see boff3)
+int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows);  // ... or a k-class view
+void drop_dense_views(memo_index *ix);
+inline uint64_t dense_groups_for(uint64_t padded) { return (padded + 4) / 5 + 64; }  // (+ one wave-load of slack: a wave reads its 64 groups whole)
 void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables derive from the dense rows and the bucket table
 extern thread_local int g_last_one_shot_sweep;  // which kernel family answered this thread's last one-shot call
 }

@@ -87,7 +87,6 @@ int upload_pipelined(int device, void *dev, const void *host, size_t bytes) { re
 // ------------------------------------------------------------------------------------------
 // the builder
 // ------------------------------------------------------------------------------------------
-static uint64_t dense_groups_for(uint64_t padded) { return (padded + 4) / 5 + 64; }  // (+ one wave-load of slack: a wave reads its 64 groups whole)
 
 extern "C" {
 
@@ -231,6 +230,14 @@ int memo_builder_finish(memo_builder_t *b, memo_index_t **out) {
     ix->packed_fmt = b->dense ? 4 : b->fmt;  // (dense rows: what an index looks like after memo_index_pack_dense(ix, 0))
     ix->finalized = 1;
     b->failed = MEMO_EINVAL;  // a builder finishes once
+    if (b->dense) {  // rows that can never write at k <= 64 leave the dense rows when they are many (memo_common.h: boff3)
+        ix->rows3 = ix->rows;
+        ix->padded3 = ix->padded;
+        if (int rc3 = dense_compact(ix)) {
+            memo_index_destroy(ix);
+            return rc3;
+        }
+    }
     if (int rc2 = memo_len_census(ix)) {
         memo_index_destroy(ix);
         return rc2;
@@ -265,8 +272,9 @@ int memo_index_export_dense(memo_index_t *ix, void *groups, int64_t *boff, int64
     if (!ix->finalized || !ix->p3) return fail(MEMO_ENOTREADY, "the index has no dense rows (memo_index_pack_dense)");
     if ((ix->rows && !groups) || !boff || (ix->n_long && !long_rows)) return fail(MEMO_EINVAL, "output pointer is NULL");
     int rc;
-    if ((rc = download_pipelined(ix->device, groups, ix->p3, (size_t)((ix->rows + 4) / 5) * 16, nullptr))) return rc;
-    if ((rc = download_pipelined(ix->device, boff, ix->boff, ix->nb * 8, nullptr))) return rc;
+    const uint64_t drows = ix->boff3 ? ix->rows3 : ix->rows;  // (info.dense_row_count)
+    if ((rc = download_pipelined(ix->device, groups, ix->p3, (size_t)((drows + 4) / 5) * 16, nullptr))) return rc;
+    if ((rc = download_pipelined(ix->device, boff, ix->boff3 ? ix->boff3 : ix->boff, ix->nb * 8, nullptr))) return rc;
     if (ix->n_long) {
         DeviceGuard guard(ix->device);
         HIP_TRY(hipMemcpy(long_rows, ix->ls, ix->n_long * 8, hipMemcpyDeviceToHost));
@@ -316,6 +324,10 @@ static int import_rows(uint64_t rows, int32_t device, int32_t bucket_shift, int6
     ix->max_s = max_start;
     ix->max_annot = max_annot;
     const uint64_t groups = dense_groups_for(ix->padded), used = (rows + 4) / 5;
+    if (dense) {
+        ix->rows3 = rows;
+        ix->padded3 = ix->padded;
+    }
     int rc = MEMO_OK;
     do {
         hipError_t err = dense ? hipMalloc(&ix->p3, groups * 16) : hipMalloc(&ix->pk, ix->padded * 4);

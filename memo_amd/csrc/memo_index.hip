@@ -12,6 +12,18 @@
 using namespace memo;
 
 namespace memo {
+void drop_dense(memo_index *ix) {
+    drop_tile_tables(ix);
+    drop_dense_views(ix);
+    (void)hipFree(ix->p3);
+    (void)hipFree(ix->boff3);
+    ix->p3 = nullptr;
+    ix->boff3 = nullptr;
+    ix->rows3 = ix->padded3 = 0;
+}
+}  // namespace memo
+
+namespace memo {
 thread_local int g_last_one_shot_sweep = 0;  // memo_index_info_t.last_sweep of this thread's last one-shot call (memo_debug.hip)
 }
 
@@ -124,6 +136,108 @@ __global__ void pack3_rows_kernel(const uint32_t *pk, uint64_t padded, uint64_t 
         p3[g] = make_uint4(B(w[0]) | ((b4 & 0xFFu) << 16) | (w[0] & 0xFF000000u), B(w[1]) | ((b4 >> 8) << 16) | (w[1] & 0xFF000000u),
                            B(w[2]) | ((w[4] >> 24) << 16) | (w[2] & 0xFF000000u), B(w[3]) | (w[3] & 0xFF000000u));
     }
+}
+
+// ---- dense_compact: the rows whose length field is saturated (they can never write at k <= 64) leave the dense rows ----
+// field and annot of dense row r (PackedRows3, memo_sweep.h)
+__device__ __forceinline__ void dense_row(const uint4 *p3, uint64_t r, uint32_t &B, uint32_t &A) {
+    const uint4 g = p3[r / 5];
+    switch ((int)(r % 5)) {
+        case 0: B = g.x & 0xFFFFu; A = g.x >> 24; break;
+        case 1: B = g.y & 0xFFFFu; A = g.y >> 24; break;
+        case 2: B = g.z & 0xFFFFu; A = g.z >> 24; break;
+        case 3: B = g.w & 0xFFFFu; A = g.w >> 24; break;
+        default: B = ((g.x >> 16) & 0xFFu) | (((g.y >> 16) & 0xFFu) << 8); A = (g.z >> 16) & 0xFFu; break;
+    }
+}
+
+// keep[r / 32] bit r % 32 = row r stays; count[r / 32] = how many of the 32
+__global__ __launch_bounds__(256) void dense_keep_kernel(const uint4 *p3, uint64_t rows, uint32_t cap, uint32_t *keep, uint32_t *count) {
+    const uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x;
+    uint32_t B = 63, A = 0;
+    if (r < rows) dense_row(p3, r, B, A);
+    const unsigned long long m = __ballot(r < rows && (B & 63u) < cap);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 31) == 0 && (r >> 5) < ((rows + 31) >> 5)) {
+        const uint32_t half = (uint32_t)(m >> (lane & 32));
+        keep[r >> 5] = half;
+        count[r >> 5] = (uint32_t)__popc(half);
+    }
+}
+
+// two-level exclusive scan of count[] (n entries): local[i] = prefix inside i's block of 1024, blocksum[b] = the block's total
+__global__ __launch_bounds__(256) void scan_local_kernel(const uint32_t *count, uint64_t n, uint32_t *local, uint64_t *blocksum) {
+    __shared__ uint32_t part[256];
+    const uint64_t base = blockIdx.x * (uint64_t)1024 + 4 * threadIdx.x;
+    uint32_t v[4], sum = 0;
+    for (int i = 0; i < 4; ++i) {
+        v[i] = base + i < n ? count[base + i] : 0;
+        sum += v[i];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t add = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (int i = 0; i < 4; ++i) {
+        if (base + i < n) local[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 255) blocksum[blockIdx.x] = part[255];
+}
+
+// exclusive scan of blocksum[] in place (one workgroup; nb entries), total -> blocksum[nb]
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(uint64_t *blocksum, uint64_t nb) {
+    __shared__ uint64_t part[1024];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t at = 0; at < nb; at += 1024) {
+        const uint64_t i = at + threadIdx.x;
+        const uint64_t v = i < nb ? blocksum[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const uint64_t add = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nb) blocksum[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blocksum[nb] = carry;
+}
+
+__device__ __forceinline__ uint64_t kept_before(uint64_t r, const uint32_t *keep, const uint32_t *local, const uint64_t *blockpre) {
+    const uint64_t w = r >> 5;
+    return blockpre[w >> 10] + local[w] + (uint32_t)__popc(keep[w] & ((1u << (r & 31)) - 1u));
+}
+
+// the rows that stay, as format-4 words (start mod 2^10 | length << 16 | annot << 24) at their new numbers: what
+// pack3_rows_kernel takes
+__global__ __launch_bounds__(256) void dense_scatter_kernel(const uint4 *p3, uint64_t rows, const uint32_t *keep, const uint32_t *local,
+                                                            const uint64_t *blockpre, uint32_t *words) {
+    const uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x;
+    if (r >= rows || !((keep[r >> 5] >> (r & 31)) & 1u)) return;
+    uint32_t B, A;
+    dense_row(p3, r, B, A);
+    words[kept_before(r, keep, local, blockpre)] = (B >> 6) | ((B & 63u) << 16) | (A << 24);
+}
+
+// boff3[b] = rows that stay among the first boff[b] rows; the last entry is pinned to the total
+__global__ void dense_table_kernel(const int64_t *boff, uint64_t nb, uint64_t rows, uint64_t total, const uint32_t *keep,
+                                   const uint32_t *local, const uint64_t *blockpre, int64_t *boff3) {
+    const uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint64_t r = (uint64_t)boff[b];
+    boff3[b] = (b == nb - 1 || r >= rows) ? (int64_t)total : (int64_t)kept_before(r, keep, local, blockpre);
 }
 
 // boff[b] = lower_bound(start, b << shift); the last bucket is pinned to `rows`
@@ -287,13 +401,11 @@ int memo_device_count(void) {
 }
 
 static void drop_packed(memo_index *ix) {  // the rows are about to change
-    drop_tile_tables(ix);
+    drop_dense(ix);
     (void)hipFree(ix->pk);
     (void)hipFree(ix->pa);
-    (void)hipFree(ix->p3);
     ix->pk = nullptr;
     ix->pa = nullptr;
-    ix->p3 = nullptr;
     ix->packed_fmt = 0;
     ix->packed_rows = 0;
 }
@@ -301,10 +413,8 @@ static void drop_packed(memo_index *ix) {  // the rows are about to change
 // the rows are about to change but the index keeps its size: the packed copy is stale, its buffers
 // can serve the next memo_index_pack
 static void stale_packed(memo_index *ix) {
-    drop_tile_tables(ix);
+    drop_dense(ix);
     ix->packed_fmt = 0;
-    (void)hipFree(ix->p3);
-    ix->p3 = nullptr;
 }
 
 int memo_index_create(uint64_t rows, int32_t device, memo_index_t **out) {
@@ -342,11 +452,10 @@ void memo_index_destroy(memo_index_t *ix) {
     (void)hipFree(ix->s);
     (void)hipFree(ix->e);
     (void)hipFree(ix->o);
-    drop_tile_tables(ix);
+    drop_dense(ix);
     (void)hipFree(ix->boff);
     (void)hipFree(ix->pk);
     (void)hipFree(ix->pa);
-    (void)hipFree(ix->p3);
     (void)hipFree(ix->ls);
     (void)hipFree(ix->le);
     (void)hipFree(ix->lo);
@@ -519,6 +628,140 @@ __global__ __launch_bounds__(256) void len_census_kernel(const uint32_t *__restr
 }
 }  // namespace
 
+namespace memo {
+// The rows of `src` (dense groups, bucket table, row count) whose length field is below `cap`, as dense rows of their own
+// with their own bucket table -- or nothing (out->p3 stays NULL) when fewer than min_tenths tenths of the rows would go.
+// A row with length >= cap cannot write at any k with k - 1 <= cap.  Synchronous on stream `st`.
+static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_boff, uint64_t rows, uint64_t nb, int cap,
+                        int min_tenths, hipStream_t st, uint32_t **out_p3, int64_t **out_boff, uint64_t *out_rows,
+                        uint64_t *out_padded) {
+    *out_p3 = nullptr;
+    *out_boff = nullptr;
+    if (!rows || rows >= ((uint64_t)1 << 38)) return MEMO_OK;
+    DeviceGuard guard(device);
+    const uint64_t n32 = (rows + 31) >> 5, nblk = (n32 + 1023) >> 10;
+    uint32_t *keep = nullptr, *local = nullptr, *words = nullptr;
+    uint64_t *blockpre = nullptr;
+    uint4 *p3n = nullptr;
+    int64_t *boff3 = nullptr;
+    int rc = MEMO_OK;
+    do {
+        hipError_t err = hipMalloc(&keep, n32 * 4 + 4);
+        if (err == hipSuccess) err = hipMalloc(&local, n32 * 4);
+        if (err == hipSuccess) err = hipMalloc(&blockpre, (nblk + 1) * 8);
+        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
+        const uint4 *p3 = reinterpret_cast<const uint4 *>(src_p3);
+        hipLaunchKernelGGL(dense_keep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p3, rows, (uint32_t)cap, keep, local);
+        hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblk), dim3(256), 0, st, local, n32, local, blockpre);
+        hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, blockpre, nblk);
+        uint64_t total = 0;
+        err = hipGetLastError();
+        if (err == hipSuccess) err = hipMemcpyAsync(&total, blockpre + nblk, 8, hipMemcpyDeviceToHost, st);
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
+        if (total + rows / 10 * (uint64_t)min_tenths > rows) break;  // too few would go
+        const uint64_t padded3 = ((total + 15) & ~(uint64_t)15) + kPadRows, groups = dense_groups_for(padded3);
+        err = hipMalloc(&words, padded3 * 4);
+        if (err == hipSuccess) err = hipMemsetAsync(words, 0, padded3 * 4, st);
+        if (err == hipSuccess) err = hipMalloc(&p3n, groups * 16);
+        if (err == hipSuccess) err = hipMalloc(&boff3, nb * 8);
+        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
+        hipLaunchKernelGGL(dense_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p3, rows, keep, local, blockpre, words);
+        hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, words, padded3, groups, p3n);
+        hipLaunchKernelGGL(dense_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, src_boff, nb, rows, total, keep, local,
+                           blockpre, boff3);
+        err = hipGetLastError();
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
+        *out_p3 = reinterpret_cast<uint32_t *>(p3n);
+        *out_boff = boff3;
+        *out_rows = total;
+        *out_padded = padded3;
+        p3n = nullptr;
+        boff3 = nullptr;
+    } while (0);
+    (void)hipFree(keep);
+    (void)hipFree(local);
+    (void)hipFree(blockpre);
+    (void)hipFree(words);
+    (void)hipFree(p3n);
+    (void)hipFree(boff3);
+    return rc;
+}
+
+// ix->p3 holds every row of the index (rows3 == rows, no boff3).  When more than a tenth of them can never write at
+// k <= 64 (6-bit length field saturated), rebuild the dense rows without them, with a bucket table of their own.
+int dense_compact(memo_index *ix) {
+    if (!ix->p3 || ix->boff3 || !ix->rows || getenv("MEMO_DENSE_KEEP_ALL")) return MEMO_OK;
+    uint32_t *p3n = nullptr;
+    int64_t *boff3 = nullptr;
+    uint64_t total = 0, padded3 = 0;
+    const int rc = dense_filter(ix->device, ix->p3, ix->boff, ix->rows, ix->nb, 63, 1, nullptr, &p3n, &boff3, &total, &padded3);
+    if (rc || !p3n) return rc;
+    DeviceGuard guard(ix->device);
+    drop_tile_tables(ix);
+    (void)hipFree(ix->p3);
+    ix->p3 = p3n;
+    ix->boff3 = boff3;
+    ix->rows3 = total;
+    ix->padded3 = padded3;
+    return MEMO_OK;
+}
+
+void drop_dense_views(memo_index *ix) {
+    for (memo_index::DenseView &v : ix->views) {
+        (void)hipFree(v.p3);
+        (void)hipFree(v.boff);
+        v = memo_index::DenseView();
+    }
+}
+
+constexpr int kViewAfterQueries = 4;
+
+// The dense rows a conservation / membership sweep with k - 1 = km1 should read: the k-class VIEW that leaves out the rows
+// whose overlap is cap or more (cap = 8, 16 or 32, the smallest that is >= km1: such a row cannot write at this k --
+// memo_query.py:49 drops it per query; here it is dropped once per index and class) when that spares a fifth of the rows or
+// more, else the dense rows themselves.  A view is built by the fifth query of its class (a few ms for 5 * 10^8 rows: one pass
+// over the dense rows, timed in view.build_ms) and kept with the index; MEMO_DENSE_VIEWS=0 turns them off.
+int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows) {
+    *p3 = ix->p3;
+    *boff = ix->boff3 ? ix->boff3 : ix->boff;
+    *rows = ix->boff3 ? ix->rows3 : ix->rows;
+    const char *env = getenv("MEMO_DENSE_VIEWS");  // (read per query: bench.py times the same index with and without)
+    if ((env && env[0] == '0') || ix->tune.no_views || km1 > 32 || km1 < 1) return MEMO_OK;
+    const int slot = km1 <= 8 ? 0 : (km1 <= 16 ? 1 : 2), cap = 8 << slot;
+    memo_index::DenseView &v = ix->views[slot];
+    // a view costs about as much as fifty sweeps of config 3: it is built by the class's FIFTH query, not its first -- an index
+    // that answers one query (the one-shot forms, `memo query`) never builds one
+    if (v.state == 0 && ++v.queries <= kViewAfterQueries) return MEMO_OK;
+    if (v.state == 0) {
+        DeviceGuard guard(ix->device);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIP_TRY(hipEventCreate(&e0));
+        if (hipEventCreate(&e1) != hipSuccess) {
+            (void)hipEventDestroy(e0);
+            return fail(MEMO_EHIP, "hipEventCreate failed");
+        }
+        (void)hipEventRecord(e0, st);
+        const int rc = dense_filter(ix->device, *p3, *boff, *rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&v.build_ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (rc) return rc;
+        v.cap = cap;
+        v.state = v.p3 ? 1 : 2;
+    }
+    if (v.state == 1) {
+        *p3 = v.p3;
+        *boff = v.boff;
+        *rows = v.rows;
+    }
+    return MEMO_OK;
+}
+}  // namespace memo
+
 int memo_len_census(memo_index *ix) {
     ix->len_hist_rows = 0;
     for (unsigned int &c : ix->len_hist) c = 0;
@@ -562,9 +805,7 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
         ~Events() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
     } events{ev0, ev1};
     // a packed copy of the same size is reused (packing again after a re-finalize, or to time the pass)
-    drop_tile_tables(ix);
-    (void)hipFree(ix->p3);  // derived from the words that are about to be rewritten
-    ix->p3 = nullptr;
+    drop_dense(ix);  // derived from the words that are about to be rewritten
     const bool had = ix->pk && ix->packed_rows == ix->padded;
     const bool had_pa = had && ix->pa;
     if (!had) drop_packed(ix);
@@ -626,12 +867,15 @@ int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed) {
         return fail(MEMO_EINVAL, "dense rows are built from the 4-byte rows: memo_index_pack first, and every annot <= 255");
     DeviceGuard guard(ix->device);
     hipStream_t st = nullptr;
-    const uint64_t groups = (ix->padded + 4) / 5 + 64;  // (+ one wave-load of slack: a wave reads its 64 groups whole)
+    const uint64_t groups = dense_groups_for(ix->padded);
     HIP_TRY(hipMalloc(&ix->p3, groups * 16));
     hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, ix->pk, ix->padded, groups,
                        reinterpret_cast<uint4 *>(ix->p3));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
+    ix->rows3 = ix->rows;
+    ix->padded3 = ix->padded;
+    if (int rc = dense_compact(ix)) return rc;
     if (!keep_packed) {
         (void)hipFree(ix->pk);
         ix->pk = nullptr;
@@ -660,7 +904,12 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     info->max_annot = ix->max_annot;
     info->bucket_base = ix->bbase;
     info->device_bytes = (ix->has_wide ? ix->padded * 3 * sizeof(int64_t) : 0) + ix->nb * sizeof(int64_t) + 128 +
-                         (ix->pk ? ix->padded * 4 : 0) + (ix->pa ? ix->padded * 2 : 0) + (ix->p3 ? ((ix->padded + 4) / 5 + 64) * 16 : 0);
+                         (ix->pk ? ix->padded * 4 : 0) + (ix->pa ? ix->padded * 2 : 0) +
+                         (ix->p3 ? dense_groups_for(ix->boff3 ? ix->padded3 : ix->padded) * 16 : 0) + (ix->boff3 ? ix->nb * 8 : 0);
+    info->dense_row_count = ix->p3 ? (ix->boff3 ? ix->rows3 : ix->rows) : 0;
+    info->last_rows_read = ix->last_rows_read;
+    info->last_view_ms = ix->last_view_ms;
+    for (const memo_index::DenseView &v : ix->views) info->device_bytes += v.p3 ? dense_groups_for(v.padded) * 16 + ix->nb * 8 : 0;
     return MEMO_OK;
 }
 
@@ -698,7 +947,8 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
                 ix = nullptr;
             } else if (rc) {
                 return rc;
-            } else if (dense && !memo_dense_rows_can_answer(ix->rows, ix->min_s, ix->max_s, ix->max_annot, k, num_docs, membership)) {
+            } else if (dense && !memo_dense_rows_can_answer(ix->boff3 ? ix->rows3 : ix->rows, ix->min_s, ix->max_s, ix->max_annot, k,
+                                                            num_docs, membership)) {
                 memo_index_destroy(ix);  // (an annot outside the result matrix: the 4-byte kernels flag the reference's IndexError)
                 ix = nullptr;
             }

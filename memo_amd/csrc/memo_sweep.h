@@ -96,6 +96,19 @@ __device__ __forceinline__ void row_slice(const SweepArgs &A, int64_t a, int64_t
 #endif
 }
 
+// The branch-free row blocks (v_cmpx ... s_mov_b64 exec, -1) are right only when every lane is enabled on entry, which
+// the compiler is never told.  Two guards: a scan of the shipped code (tests/test_host_cpu.py::
+// test_row_blocks_run_with_every_lane_enabled) and, in -DMEMO_EXEC_CHECK builds of the AB library (tools/build_variant.sh
+// execcheck -DMEMO_EXEC_CHECK; the GPU tier and the fuzzer run on it once per round), this test in front of every block.
+#ifdef MEMO_EXEC_CHECK
+#define MEMO_EXEC_ALL_ONES(status)                                                              \
+    do {                                                                                        \
+        if (__builtin_amdgcn_read_exec() != ~0ull) atomicOr((status), memo::kStatusExecNarrow); \
+    } while (0)
+#else
+#define MEMO_EXEC_ALL_ONES(status) do { } while (0)
+#endif
+
 __device__ __forceinline__ int clamp_to_tile(int64_t v, int lo, int hi) {
     const int64_t l = lo, h = hi;
     return (int)(v < l ? l : (v > h ? h : v));

@@ -136,6 +136,9 @@ int memo_query_check(memo_index_t *ix, void *stream) {
         HIP_TRY(hipStreamSynchronize(st));
         if (flags & kStatusHugeSlice)
             return fail(MEMO_EINVAL, "more than 2^32 index rows can reach one tile of the window: unsupported");
+        if (flags & kStatusExecNarrow)
+            return fail(MEMO_EINVAL, "EXEC check: a branch-free row block was entered with lanes disabled (its s_mov_b64 exec, -1 "
+                                     "would have enabled them): a compiler change broke the blocks' invariant");
         if (flags & kStatusBadAnnot)
             return fail(MEMO_EINVAL,
                         "a row that covers the window has an order/genome column outside the "

@@ -280,6 +280,7 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
         }
         if (MEMO_ROW_CMPX && !(MEMO_ABLATE & 3)) {  // n, the test, start - a, the two cells, both ds_min: one block
             uint32_t r0, r1, r2, nn;
+            MEMO_EXEC_ALL_ONES(A.status);
             if constexpr (!Rows::kW12)
                 asm volatile(
                     "v_sub_u32_sdwa %3, %5, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
@@ -431,6 +432,7 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
             // the whole row in one block, no branch: v_cmpx puts "this row writes" into EXEC itself, everything after it
             // runs on those lanes only, s_mov restores EXEC (every lane of the wave is active in the row loop)
             uint32_t r0, r1, r2, r3;
+            MEMO_EXEC_ALL_ONES(A.status);
             asm volatile(
                 "v_sub_u16 %3, %4, %5\n\t"
                 "v_and_b32 %0, 63, %3\n\t"
@@ -616,6 +618,7 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
             // the third and fourth stay behind the compiler's branches: where no row of a wave needs them (k = 128 on config 3)
             // skipping them beats issuing them with no lane -- 0.395 against 0.415 ms (profiles/r02_mixed_levels.txt)
             uint32_t tmp, a1, a2, s4, q, dd;
+            MEMO_EXEC_ALL_ONES(A.status);
 #define MEMO_R4_BLOCK(LEN_SEL, REL_START)                                                                         \
             asm volatile(                                                                                          \
                 "v_mov_b32 %4, 0\n\t"                 /* q = 0 where the row does not write */                     \
@@ -760,6 +763,7 @@ void sweep_conservation_mixed_kernel(const SweepArgs A) {
             // compiler's branch is the rare short interval (0 < n < 16).
             int n;
             uint32_t r0, r1, r2, d;
+            MEMO_EXEC_ALL_ONES(A.status);
             if constexpr (!Rows::kW12)
                 asm volatile(
                     "v_sub_u32_sdwa %3, %6, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
@@ -1174,7 +1178,24 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             // sets off a swing of the clocks that lasts some thirty launches, and the dense kernel, which draws more
             // power per unit of time, sits on the cap at a lower clock (2.2 against 2.36 GHz).
             const bool top8 = num_docs <= 255;
-            const bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && top8;
+            // (the dense rows may leave out the rows that can never write at k <= 64 -- memo_common.h: boff3 -- and then have
+            // their own row numbers and bucket table; they answer only while they still hold a row per position)
+            const uint64_t drows = ix->boff3 ? ix->rows3 : ix->rows;
+            const bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && top8 &&
+                               ((double)drows >= span || !ix->pk);
+            ix->last_view_ms = 0.f;
+            if (three) {  // the dense rows of this k's class (a view that leaves out the rows that cannot write at this k), or all
+                uint32_t *vp3 = nullptr;
+                int64_t *vboff = nullptr;
+                uint64_t vrows = 0;
+                const int before = k - 1 <= 32 ? ix->views[k - 1 <= 8 ? 0 : (k - 1 <= 16 ? 1 : 2)].state : 1;
+                if ((rc = dense_rows_for(ix, k - 1, st, &vp3, &vboff, &vrows))) return rc;
+                A.p3 = vp3;
+                A.boff = vboff;
+                ix->last_rows_read = vrows;
+                const memo_index::DenseView &view = ix->views[k - 1 <= 8 ? 0 : (k - 1 <= 16 ? 1 : 2)];
+                if (k - 1 <= 32 && before == 0 && view.state == 1) ix->last_view_ms = view.build_ms;
+            }
             ix->last_variant = 0;
             if (three && g_persistent_launch && tune.persistent >= 2 && tune.persistent <= 4) {
                 // persistent workgroups (memo_sweep_cons3p.hip, AB library only: 17 - 50 % slower than a workgroup per tile,
@@ -1243,6 +1264,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         if ((rc = launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * A.ls * 4, st))) return rc;
         ix->last_sweep = 1;
     }
+    if (ix->last_sweep != 5) ix->last_rows_read = ix->rows;
     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
 }
 

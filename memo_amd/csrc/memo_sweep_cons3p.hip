@@ -135,6 +135,7 @@ void sweep_conservation_halo3p_kernel(const SweepArgs A) {
     const uint32_t sent = ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu;
     RowConst C;
     C.km1 = A.km1;
+    C.status = A.status;
     C.ls4 = 4u * kLS;
     C.bias4 = (uint32_t)pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)(32 - NLEV) * C.ls4));
     C.top_bit = (uint32_t)pin_vgpr((int)0x80000000u);

@@ -85,6 +85,7 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     clear_levels<NLEV>(lds_base, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
     RowConst C;
     C.km1 = A.km1;
+    C.status = A.status;
     C.ls4 = 4u * kLS;
     C.bias4 = (uint32_t)pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)(32 - NLEV) * C.ls4));
     C.top_bit = (uint32_t)pin_vgpr((int)0x80000000u);
@@ -175,10 +176,11 @@ void drop_tile_tables(memo_index *ix) {
 }
 
 // the table of (index, tile width, k): built by the first query that needs it, kept with the index (four of them)
-static int tile_table(memo_index *ix, int w, int km1, hipStream_t st, const void **tab, int64_t *ntab) {
+static int tile_table(memo_index *ix, const void *rows_of, const int64_t *boff, int w, int km1, hipStream_t st, const void **tab,
+                      int64_t *ntab) {
     memo_index::TileTable *slot = nullptr;
     for (memo_index::TileTable &t : ix->ttab)
-        if (t.d && t.w == w && t.km1 == km1) slot = &t;
+        if (t.d && t.w == w && t.km1 == km1 && t.rows_of == rows_of) slot = &t;
     if (!slot) {
         slot = &ix->ttab[0];
         for (memo_index::TileTable &t : ix->ttab)
@@ -192,9 +194,10 @@ static int tile_table(memo_index *ix, int w, int km1, hipStream_t st, const void
         const int64_t n = (top + km1 + ((int64_t)1 << ix->bshift)) / w + 3;  // past the last row: empty slices
         if (n >= ((int64_t)1 << 31)) return 1;
         HIP_TRY(hipMalloc(&slot->d, (size_t)n * sizeof(TileDesc)));
-        hipLaunchKernelGGL(tile_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ix->boff, (int64_t)ix->nb, ix->bbase,
+        hipLaunchKernelGGL(tile_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, boff, (int64_t)ix->nb, ix->bbase,
                            ix->bshift, w, km1, n, static_cast<TileDesc *>(slot->d));
         HIP_TRY(hipGetLastError());
+        slot->rows_of = rows_of;
         slot->w = w;
         slot->km1 = km1;
         slot->n = n;
@@ -215,7 +218,7 @@ int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStrea
     if (ntiles + 8 >= ((int64_t)1 << 31) || q + ntiles >= ((int64_t)1 << 31)) return 1;
     const void *tab = nullptr;
     int64_t ntab = 0;
-    const int rc = tile_table(ix, tw, A.km1, st, &tab, &ntab);
+    const int rc = tile_table(ix, A.p3, A.boff, tw, A.km1, st, &tab, &ntab);
     if (rc) return rc;
     A.tile0 = tile0;
     A.ntiles = ntiles;

@@ -91,6 +91,7 @@ struct RowConst {
     uint32_t a10s, bias4, top_bit;  // VGPRs
     int km1;                        // SGPRs
     uint32_t ls4;
+    int *status;                    // (the index's sticky flags: -DMEMO_EXEC_CHECK builds report through them)
 };
 
 // One group's five rows as ONE statement (PackedRows3: rows 0 .. 3 as loaded, row 4 from the spare bytes).  Five
@@ -119,6 +120,7 @@ template <bool MASKED>
 __device__ __forceinline__ void group_rows(const uint4 &V, const RowConst &C, uint32_t tmp, uint32_t span) {
     const uint32_t b4 = __builtin_amdgcn_perm(V.y, V.x, 0x0c0c0602u), d4 = V.z << 8;
     uint32_t r0, r1, r2, r3;
+    MEMO_EXEC_ALL_ONES(C.status);
     if constexpr (MASKED) {
         asm volatile(MEMO_ROW3_MASK(0) MEMO_ROW3_AT("%4", "%4") MEMO_ROW3_MASK(1) MEMO_ROW3_AT("%5", "%5")
                      MEMO_ROW3_MASK(2) MEMO_ROW3_AT("%6", "%6") MEMO_ROW3_MASK(3) MEMO_ROW3_AT("%7", "%7")

@@ -474,6 +474,8 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                               num_docs <= 255 && ix->max_annot < (uint64_t)num_docs && (double)ix->rows >= span &&
                               (tune0.memb_algo == 0 || tune0.memb_algo == 4) && tw >= bw && tw >= 32 && tw % bw == 0;
         if (dense_ok) {
+            if (ix->boff3) A.boff = ix->boff3;  // (the dense rows' own bucket table: memo_common.h, boff3)
+            ix->last_rows_read = ix->boff3 ? ix->rows3 : ix->rows;
             const int pw = tw / 32;
             int skew = 0;
             for (int pow2 = 4; pow2 <= 64; pow2 <<= 1)

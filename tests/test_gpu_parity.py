@@ -38,8 +38,14 @@ def _cons(memo, rows, qs, qe, k, n):
 def _dense_can_answer(rows, k, n, membership):
     """the library's own rule (memo_dense_rows_can_answer) on host columns"""
     from memo_amd.index import dense_rows_can_answer
-    s, _, o = rows
-    return len(s) > 0 and int(o.min()) >= 0 and dense_rows_can_answer(len(s), int(s[0]), int(s[-1]), int(o.max()), k, n, membership)
+    s, e, o = rows
+    if not len(s) or int(o.min()) < 0 or not dense_rows_can_answer(len(s), int(s[0]), int(s[-1]), int(o.max()), k, n, membership):
+        return False
+    # the dense rows leave out the rows that can never write at k <= 64 (overlap >= 63, end < start) when those are more
+    # than a tenth of the rows (dense_compact); what is left still has to be a row per position
+    kept = int(((e - s >= 0) & (e - s < 63)).sum())
+    drows = len(s) if kept + len(s) // 10 > len(s) else kept
+    return dense_rows_can_answer(drows, int(s[0]), int(s[-1]), int(o.max()), k, n, membership)
 
 
 _ONE_SHOT_SWEEPS = {}
@@ -468,7 +474,7 @@ def test_dense_builder_equals_device_packing(n_rows, n_docs, pieces, memo, oracl
 
     def export(ix):
         inf = ix.info()
-        g = np.empty(4 * ((inf["rows"] + 4) // 5), np.uint32)
+        g = np.empty(4 * ((inf["dense_row_count"] + 4) // 5), np.uint32)      # (rows that cannot write at k <= 64 may be left out)
         boff = np.empty(inf["buckets"], np.int64)
         longs = np.empty(3 * inf["long_rows"], np.int64)
         _lib.check(_lib.lib().memo_index_export_dense(ix._h, g.ctypes.data, boff.ctypes.data, longs.ctypes.data if len(longs) else None))
@@ -479,12 +485,13 @@ def test_dense_builder_equals_device_packing(n_rows, n_docs, pieces, memo, oracl
         with b.finish() as ix:
             inf = ix.info()
             assert inf["rows"] == n_rows and inf["dense_rows"] == 1 and inf["has_wide"] == 0 and inf["finalized"] == 1
-            assert inf["device_bytes"] < 3.3 * n_rows + 2_000_000
+            assert inf["device_bytes"] < 3.3 * n_rows + 16 * inf["buckets"] + 2_000_000
             with memo.DeviceIndex.from_host(s, e, o) as ref:
                 ref.pack(keep_wide=False)
                 ref.pack_dense(keep_packed=False)
                 got, want = export(ix), export(ref)
-                pad = (5 - n_rows % 5) % 5                         # rows behind the last one in its group: never read by number
+                assert inf["dense_row_count"] == ref.info()["dense_row_count"]
+                pad = (5 - inf["dense_row_count"] % 5) % 5         # rows behind the last one in its group: never read by number
                 if pad == 0:
                     assert np.array_equal(got[0], want[0])
                 else:
@@ -538,6 +545,69 @@ def test_dense_builder_equals_device_packing(n_rows, n_docs, pieces, memo, oracl
                     want_v = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
                     assert np.array_equal(part.conservation(qs, qe, k, n_docs), want_v), (qs, qe, k)
                     assert part.info()["last_sweep"] == 5 and part.info()["bucket_base"] == b_lo
+
+
+@pytest.mark.parametrize("way", ["device", "builder"])
+def test_dense_rows_leave_out_rows_that_cannot_write(way, memo, oracle, ab):
+    """An index built from sequences has 40 % of its rows with an overlap of 63 and more (profiles/r03_realistic_index*):
+    such a row -- like a row with end < start -- can never write at k <= 64, which is all the dense rows answer, so the
+    dense rows leave them out when they are more than a tenth (dense_compact): their own row numbers, their own bucket
+    table, fewer bytes to sweep.  Same results from every kernel that reads them, slices included."""
+    import ctypes as C
+    from memo_amd import _lib
+    rng = np.random.default_rng(41)
+    n_rows, length, n_docs = 2_000_003, 400_000, 90
+    s, e, o = _random_index(rng, n_rows, length, n_docs, 62)
+    far = rng.random(n_rows) < 0.45
+    e[far] = s[far] + rng.integers(63, 4000, int(far.sum()))          # 45 % of the rows: overlaps of 63 .. 4000
+    e[7::5003] = s[7::5003] - rng.integers(1, 200, len(s[7::5003]))    # and a few rows with end < start
+    clump = (s > 100_000) & (s < 100_300)                              # a stretch where nearly every row goes
+    e[clump] = s[clump] + 500
+    if way == "device":
+        ix = memo.DeviceIndex.from_host(s, e, o)
+        ix.pack(keep_wide=False)
+        ix.pack_dense(keep_packed=False)
+    else:
+        cuts = [0, 3, 700_001, 1_234_567, n_rows]
+        with memo.IndexBuilder(n_rows, dense=True) as b:
+            for a, z in zip(cuts[:-1], cuts[1:]):
+                b.push(s[a:z], e[a:z], o[a:z])
+            ix = b.finish()
+    with ix:
+        inf = ix.info()
+        kept = int(((e - s >= 0) & (e - s < 63)).sum())
+        assert inf["rows"] == n_rows and inf["dense_row_count"] == kept and inf["dense_rows"] == 1
+        assert inf["device_bytes"] < 3.3 * kept + 8 * inf["buckets"] * 2 + 3_000_000
+        for k in (31, 64, 5, 21):
+            for qs, qe in ((0, length + 30), (99_000, 102_004), (4, 333_336), (123_457, 300_001)):
+                want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                for src in (0, 5):                                        # the table-driven kernel, the round-2 kernel
+                    ix.debug_set_tuning(0, 0, 0, src, 0)
+                    assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (k, qs, qe, src)
+                    assert ix.info()["last_sweep"] == 5
+            ix.debug_set_tuning(0, 0, 0, 0, 0)
+            wantb = oracle.membership(*oracle.filter_rows(s, e, o, 90_000, 120_000, k), 90_000, 120_000, k, n_docs, literal=False)
+            assert np.array_equal(ix.membership(90_000, 120_000, k, n_docs), wantb) and ix.info()["last_sweep"] == 6
+        # export / import of a slice of the (shorter) dense stream with its own table
+        g = np.empty(4 * ((kept + 4) // 5), np.uint32)
+        boff3 = np.empty(inf["buckets"], np.int64)
+        longs = np.empty(3 * inf["long_rows"], np.int64)
+        _lib.check(_lib.lib().memo_index_export_dense(ix._h, g.ctypes.data, boff3.ctypes.data, longs.ctypes.data))
+        assert boff3[-1] == kept and np.all(np.diff(boff3) >= 0)
+        shift, nb = inf["bucket_shift"], inf["buckets"]
+        for qs, qe, k in ((150_003, 250_000, 31), (99_000, 101_000, 64)):
+            b_lo, b_hi = qs >> shift, min(((qe + k) >> shift) + 1, nb - 1)
+            d0, d1 = int(boff3[b_lo]), int(boff3[b_hi])
+            base = d0 // 5 * 5
+            table = np.ascontiguousarray(boff3[b_lo:b_hi + 1])
+            grp = np.ascontiguousarray(g[4 * (base // 5):4 * ((d1 + 4) // 5)])
+            h = C.c_void_p()
+            _lib.check(_lib.lib().memo_index_import_dense(d1 - base, 0, shift, b_lo, grp.ctypes.data, table.ctypes.data, len(table) + 1,
+                                                          base, b_lo << shift, ((b_hi + 1) << shift) - 1, inf["max_annot"],
+                                                          longs.ctypes.data, len(longs) // 3, C.byref(h)))
+            with memo.DeviceIndex(d1 - base, 0, _handle=h) as part:
+                want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                assert np.array_equal(part.conservation(qs, qe, k, n_docs), want), (qs, qe, k)
 
 
 def test_builder_switches_to_12_bit_annots_late(memo, oracle):
@@ -1342,6 +1412,68 @@ def test_config5_shard_packed_rows(memo, oracle):
                 want = oracle.conservation(s, e, o, a, b, k, n, literal=False)
                 assert np.array_equal(full[a - qs:b - qs], want), (k, a)
                 assert np.array_equal(ix.conservation(a + 3, b - 11, k, n), want[3:-11])
+
+
+def test_dense_row_sweep_variants(memo, oracle, ab):
+    """The dense rows are swept by sweep_conservation_halo3t_kernel (the tile's row slice from the index's tile table;
+    memo_sweep_cons3t.hip) wherever the query fits it; the round-2 kernel (every wave works its tile out) answers the
+    rest, and the AB library also carries the persistent experiments (LDS-DMA / register staging).  Every variant, every
+    k <= 64 that changes the number of level arrays, windows on and off the 4-position raster, both result types:
+    bit-equal to each other and to the oracle; the table is rebuilt when the dense rows change; five values of k make the
+    four-table cache evict."""
+    from memo_amd import synth
+    n, L = 100, 6_000_000
+    ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack="dense")
+    num, den = synth.rows_per_position(n)
+    with ix:
+        for k in (2, 3, 4, 5, 8, 9, 16, 17, 21, 31, 32, 33, 48, 64, 31):
+            for qs, qe in ((0, L), (4, L - 3), (1_000_000, 5_000_001), (2_345_676, 2_345_680 + 1_500_000), (777, 5_555_555)):
+                for dt in (np.uint8, np.uint16):
+                    ix.debug_set_tuning(0, 0, 0, 5, 0)
+                    ref = ix.conservation(qs, qe, k, n, dtype=dt)
+                    assert ix.info()["last_sweep"] == 5 and ix.info()["last_variant"] == 0
+                    for src, variant in ((8, 2), (0, 2), (4, 1), (6, 1), (7, 1)):
+                        ix.debug_set_tuning(0, 0, 0, src, 0)
+                        got = ix.conservation(qs, qe, k, n, dtype=dt)
+                        assert np.array_equal(got, ref), (src, k, qs, qe, dt)
+                        inf = ix.info()
+                        assert inf["last_sweep"] == 5
+                        if variant == 2:      # (the persistent kernels decline short windows; the table kernel only windows
+                            assert inf["last_variant"] == (2 if qs % 4 == 0 else 0), (src, k, qs, qe, inf)    # off the raster)
+                        else:
+                            assert inf["last_variant"] in (0, 1)
+            a, b = 3_000_000, 3_300_000
+            sr0, sr1 = synth.shard_rows(a, b, k, num, den, L)
+            s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
+            ix.debug_set_tuning(0, 0, 0, 0, 0)
+            assert np.array_equal(ix.conservation(a, b, k, n), oracle.conservation(s, e, o, a, b, k, n, literal=False)), k
+    # k-class views: conservation with k - 1 <= 8 / 16 / 32 reads the dense rows whose overlap is below 8 / 16 / 32 when that
+    # spares a fifth of them (here: overlaps uniform in 0 .. 59, so every class does); row_source 9 reads them all
+    ix, (r0, r1) = synth.device_index(0, 2_000_000, 64, n, 2_000_000, pack="dense")
+    with ix:
+        for k, cap in ((5, 8), (9, 8), (10, 16), (17, 16), (18, 32), (31, 32), (33, 32), (34, None), (64, None)):
+            ix.debug_set_tuning(0, 0, 0, 9, 0)
+            ref = ix.conservation(0, 2_000_000, k, n, dtype=np.uint8)
+            inf = ix.info()
+            assert inf["last_rows_read"] == inf["dense_row_count"] == r1 - r0
+            for src in (0, 10):
+                ix.debug_set_tuning(0, 0, 0, src, 0)
+                for _ in range(6 if src == 0 else 1):                # (a view is built by the fifth query of its class)
+                    assert np.array_equal(ix.conservation(0, 2_000_000, k, n, dtype=np.uint8), ref), (k, src)
+                inf = ix.info()
+                if cap is None:
+                    assert inf["last_rows_read"] == r1 - r0
+                else:
+                    assert abs(inf["last_rows_read"] / (r1 - r0) - cap / 60) < 0.01, (k, inf["last_rows_read"])
+    # a window that runs far past the last row, and one that starts past it: tiles beyond the table read its last (empty) entry
+    rng = np.random.default_rng(77)
+    s, e, o = _random_index(rng, 700_000, 200_000, 60, 70)
+    with memo.DeviceIndex.from_host_packed(s, e, o, dense=True) as ix2:
+        for qs, qe in ((0, 1_000_000), (150_000, 3_000_000), (400_000, 900_000), (199_996, 200_100)):
+            for k in (31, 5):
+                want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, 60, literal=False)
+                assert np.array_equal(ix2.conservation(qs, qe, k, 60), want), (qs, qe, k)
+                assert ix2.info()["last_variant"] == 2
 
 
 def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):

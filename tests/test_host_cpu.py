@@ -268,8 +268,8 @@ def _cache_header(cache, body):
     """a header that describes a (zero-filled) body of `body` bytes: 10 rows in format 4, a 2-entry table"""
     return {"version": cache.VERSION, "record": "?", "source": None, "rows": 10, "format": 4, "bucket_shift": 5, "buckets": 2,
             "min_start": 0, "max_start": 31, "max_annot": 3, "long_rows": 0, "off_pk": cache.HEADER_BYTES,
-            "off_pa": cache.HEADER_BYTES + 40, "off_p3": cache.HEADER_BYTES + 48, "off_boff": cache.HEADER_BYTES + 80,
-            "off_long": cache.HEADER_BYTES + 96, "bytes": cache.HEADER_BYTES + body}
+            "off_pa": cache.HEADER_BYTES + 40, "off_p3": cache.HEADER_BYTES + 48, "off_boff3": cache.HEADER_BYTES + 80,
+            "rows3": 10, "off_boff": cache.HEADER_BYTES + 80, "off_long": cache.HEADER_BYTES + 96, "bytes": cache.HEADER_BYTES + body}
 
 
 def test_sidecar_cache_lock_and_negative_marker(memo, tmp_path, monkeypatch):
@@ -324,7 +324,8 @@ def test_sidecar_cache_file_validation(memo, tmp_path, monkeypatch):
     # the cache invisible (it used to reach struct.unpack_from and raw pointer arithmetic)
     for bad in (dict(good, rows=1000), dict(good, off_pk=10), dict(good, off_boff=cache.HEADER_BYTES + 96),
                 dict(good, buckets=1), dict(good, long_rows=3), dict(good, rows=-1), dict(good, format=5),
-                dict(good, off_p3=cache.HEADER_BYTES + 90), dict(good, bucket_shift=40), {k: v for k, v in good.items() if k != "off_long"}):
+                dict(good, off_p3=cache.HEADER_BYTES + 90), dict(good, rows3=11), dict(good, off_boff3=cache.HEADER_BYTES + 90),
+                dict(good, bucket_shift=40), {k: v for k, v in good.items() if k != "off_long"}):
         write(bad)
         assert cache._open(str(index), "chr 1/x") is None, bad
     write(good)

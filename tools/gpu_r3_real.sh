@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, VERDICT item 6: an index from sequences, measured.  50 genomes x 5 Mbp by default.
 TAG=${1:-r3real}; LEN=${2:-5000000}; N=${3:-50}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 1500 python tools/realistic_index.py --length $LEN --genomes $N --out /tmp/real --threads 32 > $OUT/index_stats.json 2> $OUT/index.err; echo "index rc=$?"; cut -c1-600 $OUT/index_stats.json
+timeout 1500 python tools/realistic_index.py --length $LEN --genomes $N --out /tmp/real --threads ${4:-32} > $OUT/index_stats.json 2> $OUT/index.err; echo "index rc=$?"; cut -c1-600 $OUT/index_stats.json
 : > $OUT/bench.jsonl
 for k in 21 31 101; do
   timeout 600 python bench.py --rows-file /tmp/real/cons.npz --k $k --steps 200 --warmup 20 --cpu-sample $LEN >> $OUT/bench.jsonl 2>> $OUT/bench.err; echo "cons k=$k rc=$?"

@@ -26,8 +26,10 @@ def counter_rows(d, counter):
 
 
 def mean(rows, key):
-    v = [float(r["Counter_Value"]) for r in rows if key in r["Kernel_Name"]]
-    return (sum(v) / len(v), len(v)) if v else (None, 0)
+    """the MEDIAN over the kernel's launches (the first launches of a run may be another workload of the same kernel: the
+    dense-row sweep reads all the dense rows until the k-class view is built by the fifth query)"""
+    v = sorted(float(r["Counter_Value"]) for r in rows if key in r["Kernel_Name"])
+    return (v[len(v) // 2], len(v)) if v else (None, 0)
 
 
 def main():
@@ -56,6 +58,8 @@ def main():
     allw = json.load(open(path)) if os.path.exists(path) else {}
     out["round"] = tag
     out["result_bytes_per_position"] = int(os.environ.get("RESULT_BYTES", "1"))   # bench default: uint8 results
+    if os.environ.get("ALG_BYTES"):
+        out["algorithmic_bytes"] = float(os.environ["ALG_BYTES"])                # what bench.py prices this launch at
     allw[wl] = out
     json.dump(allw, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
