@@ -478,18 +478,20 @@ def main():
     # drops the others per query, the library once per index and class -- memo_index_info_t.last_rows_read) and the tile
     # table; both stay with the index.  What each format's sweep reads is what its roofline is priced on.
     view_pass = None
+    full_rows = {}
     for f, ixf in indexes.items():
-        for _ in range(8):                  # (a view is built by the fifth query of its class)
+        for _ in range(8 if f != "wide" else 1):    # (a view is built by the fifth query of its class)
             launch(outs[0], ixf)
             torch.cuda.synchronize()
             inf = ixf.info()
-            if f == "dense" and inf["last_view_ms"] > 0:
-                view_pass = {"what": "k-class view of the dense rows, built by the fifth query of its class (rows whose overlap is below "
-                                     "the class's cap; one pass over the dense rows + their bucket table), once per index and class, kept",
-                             "ms": float(inf["last_view_ms"]), "rows_in": int(inf["dense_row_count"]), "rows_kept": int(inf["last_rows_read"])}
-            if f != "dense" or membership:
-                break
-        if not membership and inf["last_rows_read"]:
+            if f == args.rows and inf["last_view_ms"] > 0:
+                view_pass = {"what": "k-class view of the rows the sweep reads (rows whose overlap is below the class's cap: all that can "
+                                     "write at this k), built by the fifth query of its class -- one pass over the rows + their bucket "
+                                     "table -- once per index and class, kept",
+                             "ms": float(inf["last_view_ms"]), "rows_in": int(inf["dense_row_count"] if f == "dense" else inf["rows"]),
+                             "rows_kept": int(inf["last_rows_read"])}
+        full_rows[f] = int(inf["dense_row_count"]) if f == "dense" else rows
+        if inf["last_rows_read"]:
             rows_read[f] = int(inf["last_rows_read"])
     for o in outs:                          # (every result buffer holds a whole-window result behind L_mine)
         launch(o)
@@ -626,9 +628,9 @@ def main():
 
     other = []
     legs = [(w, w, None) for w in formats[1:]]
-    if others and "dense" in indexes and rows_read["dense"] != int(indexes["dense"].info()["dense_row_count"]):
-        # the same kernel on ALL the dense rows (MEMO_DENSE_VIEWS=0: no k-class view), for the record: what round 2 timed
-        legs.append(("dense", "dense, all rows (no k-class view)", int(indexes["dense"].info()["dense_row_count"])))
+    if others and args.rows != "wide" and rows_read[args.rows] != full_rows[args.rows]:
+        # the same kernel on ALL the rows of the headline format (MEMO_DENSE_VIEWS=0: no k-class view), for the record: what round 2 timed
+        legs.append((args.rows, args.rows + ", all rows (no k-class view)", full_rows[args.rows]))
     for which, label, all_rows in legs:
         ob = fmt_bytes[which]
         if all_rows:
@@ -712,13 +714,19 @@ def main():
                                      f"packed {6 if packed_fmt == 6 else 4} B/row (format {packed_fmt}) built once per index by memo_index_pack" if args.rows == "packed"
                                      else "3.2 B/row (five 24-bit rows per 16 bytes: start mod 2^10, length saturated at 63, 8-bit "
                                           "order) built once per index by memo_index_pack + memo_index_pack_dense" +
-                                          ("" if rows_read["dense"] == rows else
+                                          ("" if rows_read.get("dense", rows) == rows else
                                            f"; the sweep reads the k-class view of them: the {rows_read['dense']} rows whose overlap is below "
                                            f"{8 if k - 1 <= 8 else 16 if k - 1 <= 16 else 32} -- the others cannot write at k = {k} "
                                            "(memo_query.py:49 drops them per query) -- built once per index and class by the first query, "
                                            "timed in dense_view_pass; `roofline` is priced on the rows read; other_row_formats has the same "
                                            "kernel on all the dense rows"),
-                       "row_bytes": row_bytes, "rows_read": rows_read[args.rows], "result_bytes_per_position": b_out,
+                       "row_bytes": row_bytes, "rows_read": rows_read[args.rows],
+                       "rows_read_note": None if args.rows == "wide" or rows_read[args.rows] == full_rows.get(args.rows) else
+                                         f"the sweep reads the k-class view of the {args.rows} rows: the {rows_read[args.rows]} of "
+                                         f"{full_rows.get(args.rows)} rows that can write at k = {k} (memo_query.py:49 drops the others per "
+                                         "query; the library once per index and class, by the class's fifth query: dense_view_pass); "
+                                         "`roofline` is priced on the rows read, other_row_formats has the same kernel on all the rows",
+                       "result_bytes_per_position": b_out,
                        "row_format_choice": "--rows auto = the format that answers this query fastest: the dense rows where they "
                                             "can (conservation, k <= 64, num_docs <= 255), else the 4- / 6-byte rows (k <= 256), "
                                             "else int64.  roofline is priced on the bytes of the format read (fewer bytes per row "

@@ -116,6 +116,7 @@ struct memo_index {
         float build_ms = 0.f;
     };
     DenseView views[3];
+    DenseView pviews[5];          // the same for the 4-byte words (caps 8 .. 128; `p3` holds words there): packed_rows_for
     uint64_t last_rows_read = 0;  // rows of the row source the last sweep read (info.last_rows_read)
     float last_view_ms = 0.f;     // device time of the view build, when the last sweep's view was built by it (else 0)
     uint64_t max_annot = 0;    // largest annot of the packed rows
@@ -158,6 +159,8 @@ void drop_dense(memo_index *ix);       // frees the dense rows, their bucket tab
 int dense_compact(memo_index *ix);     // memo_index.hip: leave the rows that can never write out of the dense rows (see boff3)
 int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows);  // ... or a k-class view
 void drop_dense_views(memo_index *ix);
+int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows);  // k-class view of the words
+void drop_packed_views(memo_index *ix);
 inline uint64_t dense_groups_for(uint64_t padded) { return (padded + 4) / 5 + 64; }  // (+ one wave-load of slack: a wave reads its 64 groups whole)
 void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables derive from the dense rows and the bucket table
 extern thread_local int g_last_one_shot_sweep;  // which kernel family answered this thread's last one-shot call

@@ -240,6 +240,27 @@ __global__ void dense_table_kernel(const int64_t *boff, uint64_t nb, uint64_t ro
     boff3[b] = (b == nb - 1 || r >= rows) ? (int64_t)total : (int64_t)kept_before(r, keep, local, blockpre);
 }
 
+// the same for the 4-byte words (formats 4 and 12): keep the rows whose overlap byte is below cap
+__global__ __launch_bounds__(256) void packed_keep_kernel(const uint32_t *pk, uint64_t rows, int len_shift, uint32_t cap, uint32_t *keep,
+                                                          uint32_t *count) {
+    const uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x;
+    const uint32_t len = r < rows ? (pk[r] >> len_shift) & 0xFFu : 255u;
+    const unsigned long long m = __ballot(r < rows && len < cap);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 31) == 0 && (r >> 5) < ((rows + 31) >> 5)) {
+        const uint32_t half = (uint32_t)(m >> (lane & 32));
+        keep[r >> 5] = half;
+        count[r >> 5] = (uint32_t)__popc(half);
+    }
+}
+
+__global__ __launch_bounds__(256) void packed_scatter_kernel(const uint32_t *pk, uint64_t rows, const uint32_t *keep, const uint32_t *local,
+                                                             const uint64_t *blockpre, uint32_t *out) {
+    const uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x;
+    if (r >= rows || !((keep[r >> 5] >> (r & 31)) & 1u)) return;
+    out[kept_before(r, keep, local, blockpre)] = pk[r];
+}
+
 // boff[b] = lower_bound(start, b << shift); the last bucket is pinned to `rows`
 __global__ void bucket_table_kernel(const int64_t *s, uint64_t rows, int64_t *boff, uint64_t nb,
                                     int shift) {
@@ -402,6 +423,7 @@ int memo_device_count(void) {
 
 static void drop_packed(memo_index *ix) {  // the rows are about to change
     drop_dense(ix);
+    drop_packed_views(ix);
     (void)hipFree(ix->pk);
     (void)hipFree(ix->pa);
     ix->pk = nullptr;
@@ -414,6 +436,7 @@ static void drop_packed(memo_index *ix) {  // the rows are about to change
 // can serve the next memo_index_pack
 static void stale_packed(memo_index *ix) {
     drop_dense(ix);
+    drop_packed_views(ix);
     ix->packed_fmt = 0;
 }
 
@@ -453,6 +476,7 @@ void memo_index_destroy(memo_index_t *ix) {
     (void)hipFree(ix->e);
     (void)hipFree(ix->o);
     drop_dense(ix);
+    drop_packed_views(ix);
     (void)hipFree(ix->boff);
     (void)hipFree(ix->pk);
     (void)hipFree(ix->pa);
@@ -632,9 +656,10 @@ namespace memo {
 // The rows of `src` (dense groups, bucket table, row count) whose length field is below `cap`, as dense rows of their own
 // with their own bucket table -- or nothing (out->p3 stays NULL) when fewer than min_tenths tenths of the rows would go.
 // A row with length >= cap cannot write at any k with k - 1 <= cap.  Synchronous on stream `st`.
+// len_shift >= 0: src_p3 / out_p3 are 4-byte WORDS (formats 4 / 12: the overlap byte sits at bit len_shift) instead of dense groups.
 static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_boff, uint64_t rows, uint64_t nb, int cap,
                         int min_tenths, hipStream_t st, uint32_t **out_p3, int64_t **out_boff, uint64_t *out_rows,
-                        uint64_t *out_padded) {
+                        uint64_t *out_padded, int len_shift = -1) {
     *out_p3 = nullptr;
     *out_boff = nullptr;
     if (!rows || rows >= ((uint64_t)1 << 38)) return MEMO_OK;
@@ -651,7 +676,11 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
         if (err == hipSuccess) err = hipMalloc(&blockpre, (nblk + 1) * 8);
         if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
         const uint4 *p3 = reinterpret_cast<const uint4 *>(src_p3);
-        hipLaunchKernelGGL(dense_keep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p3, rows, (uint32_t)cap, keep, local);
+        if (len_shift >= 0)
+            hipLaunchKernelGGL(packed_keep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, src_p3, rows, len_shift, (uint32_t)cap,
+                               keep, local);
+        else
+            hipLaunchKernelGGL(dense_keep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p3, rows, (uint32_t)cap, keep, local);
         hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblk), dim3(256), 0, st, local, n32, local, blockpre);
         hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, blockpre, nblk);
         uint64_t total = 0;
@@ -663,17 +692,27 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
         const uint64_t padded3 = ((total + 15) & ~(uint64_t)15) + kPadRows, groups = dense_groups_for(padded3);
         err = hipMalloc(&words, padded3 * 4);
         if (err == hipSuccess) err = hipMemsetAsync(words, 0, padded3 * 4, st);
-        if (err == hipSuccess) err = hipMalloc(&p3n, groups * 16);
+        if (err == hipSuccess && len_shift < 0) err = hipMalloc(&p3n, groups * 16);
         if (err == hipSuccess) err = hipMalloc(&boff3, nb * 8);
         if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
-        hipLaunchKernelGGL(dense_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p3, rows, keep, local, blockpre, words);
-        hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, words, padded3, groups, p3n);
+        if (len_shift >= 0) {
+            hipLaunchKernelGGL(packed_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, src_p3, rows, keep, local, blockpre,
+                               words);
+        } else {
+            hipLaunchKernelGGL(dense_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p3, rows, keep, local, blockpre, words);
+            hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, words, padded3, groups, p3n);
+        }
         hipLaunchKernelGGL(dense_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, src_boff, nb, rows, total, keep, local,
                            blockpre, boff3);
         err = hipGetLastError();
         if (err == hipSuccess) err = hipStreamSynchronize(st);
         if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
-        *out_p3 = reinterpret_cast<uint32_t *>(p3n);
+        if (len_shift >= 0) {
+            *out_p3 = words;  // (the compacted words are the result)
+            words = nullptr;
+        } else {
+            *out_p3 = reinterpret_cast<uint32_t *>(p3n);
+        }
         *out_boff = boff3;
         *out_rows = total;
         *out_padded = padded3;
@@ -708,6 +747,8 @@ int dense_compact(memo_index *ix) {
     return MEMO_OK;
 }
 
+constexpr int kViewAfterQueries = 4;
+
 void drop_dense_views(memo_index *ix) {
     for (memo_index::DenseView &v : ix->views) {
         (void)hipFree(v.p3);
@@ -716,7 +757,66 @@ void drop_dense_views(memo_index *ix) {
     }
 }
 
-constexpr int kViewAfterQueries = 4;
+void drop_packed_views(memo_index *ix) {
+    for (memo_index::DenseView &v : ix->pviews) {
+        (void)hipFree(v.p3);
+        (void)hipFree(v.boff);
+        v = memo_index::DenseView();
+    }
+}
+
+static int view_slot(int km1, int nslots, int *cap) {  // the smallest class cap (8, 16, 32, 64, 128) that is >= km1
+    for (int s = 0; s < nslots; ++s)
+        if (km1 <= (8 << s)) {
+            *cap = 8 << s;
+            return s;
+        }
+    return -1;
+}
+
+// The same k-class views for the 4-byte words (formats 4 and 12; what membership queries, k > 64 and indexes of more than 255
+// genomes read): the rows whose overlap is below 8 / 16 / 32 / 64 / 128, with their own bucket table, built by the class's
+// fifth query when that spares a fifth of the rows.  BASELINE config 5 at k = 31 sweeps half of its 8.4 * 10^8 rows that way.
+int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows) {
+    *pk = ix->pk;
+    *boff = ix->boff;
+    *rows = ix->rows;
+    ix->last_view_ms = 0.f;
+    const char *env = getenv("MEMO_DENSE_VIEWS");
+    if ((env && env[0] == '0') || ix->tune.no_views || km1 < 1 || !ix->pk || (ix->packed_fmt != 4 && ix->packed_fmt != 12)) return MEMO_OK;
+    int cap = 0;
+    const int slot = view_slot(km1, 5, &cap);
+    if (slot < 0) return MEMO_OK;
+    memo_index::DenseView &v = ix->pviews[slot];
+    if (v.state == 0 && ++v.queries <= kViewAfterQueries) return MEMO_OK;
+    if (v.state == 0) {
+        DeviceGuard guard(ix->device);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIP_TRY(hipEventCreate(&e0));
+        if (hipEventCreate(&e1) != hipSuccess) {
+            (void)hipEventDestroy(e0);
+            return fail(MEMO_EHIP, "hipEventCreate failed");
+        }
+        (void)hipEventRecord(e0, st);
+        const int rc = dense_filter(ix->device, ix->pk, ix->boff, ix->rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded,
+                                    ix->packed_fmt == 12 ? 0 : 16);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&v.build_ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (rc) return rc;
+        v.cap = cap;
+        v.state = v.p3 ? 1 : 2;
+        if (v.state == 1) ix->last_view_ms = v.build_ms;
+    }
+    if (v.state == 1) {
+        *pk = v.p3;
+        *boff = v.boff;
+        *rows = v.rows;
+    }
+    return MEMO_OK;
+}
 
 // The dense rows a conservation / membership sweep with k - 1 = km1 should read: the k-class VIEW that leaves out the rows
 // whose overlap is cap or more (cap = 8, 16 or 32, the smallest that is >= km1: such a row cannot write at this k --
@@ -806,6 +906,7 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
     } events{ev0, ev1};
     // a packed copy of the same size is reused (packing again after a re-finalize, or to time the pass)
     drop_dense(ix);  // derived from the words that are about to be rewritten
+    drop_packed_views(ix);
     const bool had = ix->pk && ix->packed_rows == ix->padded;
     const bool had_pa = had && ix->pa;
     if (!had) drop_packed(ix);
@@ -857,6 +958,7 @@ int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed) {
     if (ix->p3) {
         if (!keep_packed && ix->pk) {
             DeviceGuard guard(ix->device);
+            drop_packed_views(ix);
             (void)hipFree(ix->pk);
             ix->pk = nullptr;
             ix->packed_rows = 0;
@@ -877,6 +979,7 @@ int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed) {
     ix->padded3 = ix->padded;
     if (int rc = dense_compact(ix)) return rc;
     if (!keep_packed) {
+        drop_packed_views(ix);
         (void)hipFree(ix->pk);
         ix->pk = nullptr;
         ix->packed_rows = 0;
@@ -910,6 +1013,7 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     info->last_rows_read = ix->last_rows_read;
     info->last_view_ms = ix->last_view_ms;
     for (const memo_index::DenseView &v : ix->views) info->device_bytes += v.p3 ? dense_groups_for(v.padded) * 16 + ix->nb * 8 : 0;
+    for (const memo_index::DenseView &v : ix->pviews) info->device_bytes += v.p3 ? v.padded * 4 + ix->nb * 8 : 0;
     return MEMO_OK;
 }
 

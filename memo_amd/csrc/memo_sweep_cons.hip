@@ -1060,6 +1060,20 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     A.nwords = 0;
     int fmt;
     if ((rc = pick_rows(ix, k, fmt))) return rc;
+    hipStream_t st_early = static_cast<hipStream_t>(stream);
+    // the 4-byte words a sweep reads: the k-class view of them where one exists or is due (packed_rows_for, memo_index.hip)
+    auto use_words = [&]() -> int {
+        if (fmt != 4 && fmt != 12) return MEMO_OK;
+        uint32_t *vpk = nullptr;
+        int64_t *vboff = nullptr;
+        uint64_t vrows = 0;
+        const int vrc = packed_rows_for(ix, k - 1, st_early, &vpk, &vboff, &vrows);
+        if (vrc) return vrc;
+        A.pk = vpk;
+        A.boff = vboff;
+        ix->last_rows_read = vrows;
+        return MEMO_OK;
+    };
     // Tile shape, from interleaved A/B on one device (profiles/r01_ab_*.txt).
     //  int64 rows (HBM-bound): four waves share a 4096-position tile -- fewest k-1 row halos per
     //    position; 1-3 % over one wave per 1024 positions at k <= 32, 10 % at k = 101.
@@ -1120,6 +1134,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                : fmt == 12 ? (num_docs <= 4095 ? r4_kernel<PackedRows<false, false, true>, OutT, 20>(waves)
                                                                : r4_kernel<PackedRows<false, false, true>, OutT, 0>(waves))
                                            : r4_kernel<PackedRows<true, false>, OutT, 0>(waves);
+            if ((rc = use_words())) return rc;
             if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)m * A.ls * 4, st))) return rc;
             ix->last_sweep = 3;
             return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
@@ -1146,6 +1161,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                : fmt == 12 ? (num_docs <= 4095 ? mixed_kernel<PackedRows<false, false, true>, OutT, 20>(waves)
                                                                : mixed_kernel<PackedRows<false, false, true>, OutT, 0>(waves))
                                            : mixed_kernel<PackedRows<true, false>, OutT, 0>(waves);
+            if ((rc = use_words())) return rc;
             if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)m * A.ls * 4, st))) return rc;
             ix->last_sweep = 4;
             return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
@@ -1227,6 +1243,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                : fmt == 12 ? (num_docs <= 4095 ? halo_kernel<PackedRows<false, false, true>, OutT, 20>(waves)
                                                                : halo_kernel<PackedRows<false, false, true>, OutT, 0>(waves))
                                           : halo_kernel<PackedRows<true, false>, OutT, 0>(waves);
+            if (!three && (rc = use_words())) return rc;
             if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)A.nlev * A.ls * 4, st))) return rc;
             ix->last_sweep = three ? 5 : 2;
             }
@@ -1261,10 +1278,11 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                                  : cons_kernel<PackedRows<true, false>, OutT>(w, waves))
                                       : cons_kernel<WideRows, OutT>(w, waves);
         if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+        ix->last_rows_read = ix->rows;
+        if ((rc = use_words())) return rc;
         if ((rc = launch_tiles(kern, A, w, 64 * waves, (size_t)A.nlev * A.ls * 4, st))) return rc;
         ix->last_sweep = 1;
     }
-    if (ix->last_sweep != 5) ix->last_rows_read = ix->rows;
     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
 }
 

@@ -455,6 +455,20 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     A.nwords = nw;
     int fmt;
     if ((rc = pick_rows(ix, k, fmt))) return rc;
+    // the 4-byte words a sweep reads: the k-class view of them where one exists or is due (packed_rows_for, memo_index.hip)
+    auto use_words = [&]() -> int {
+        ix->last_rows_read = ix->rows;
+        if (fmt != 4 && fmt != 12) return MEMO_OK;
+        uint32_t *vpk = nullptr;
+        int64_t *vboff = nullptr;
+        uint64_t vrows = 0;
+        const int vrc = packed_rows_for(ix, k - 1, st, &vpk, &vboff, &vrows);
+        if (vrc) return vrc;
+        A.pk = vpk;
+        A.boff = vboff;
+        ix->last_rows_read = vrows;
+        return MEMO_OK;
+    };
     ix->last_sweep = 7;  // a membership kernel on the 4- / 6-byte rows or the int64 columns (6: on the dense rows)
     const memo_tuning &tune0 = ix->tune;
     // The dense rows where an index holds no 4- / 6-byte rows and they can answer: the planes kernel on them (k - 1 <= 63,
@@ -474,8 +488,15 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                               num_docs <= 255 && ix->max_annot < (uint64_t)num_docs && (double)ix->rows >= span &&
                               (tune0.memb_algo == 0 || tune0.memb_algo == 4) && tw >= bw && tw >= 32 && tw % bw == 0;
         if (dense_ok) {
-            if (ix->boff3) A.boff = ix->boff3;  // (the dense rows' own bucket table: memo_common.h, boff3)
-            ix->last_rows_read = ix->boff3 ? ix->rows3 : ix->rows;
+            {   // the dense rows of this k's class (a view that leaves out the rows that cannot write at this k), or all of them
+                uint32_t *vp3 = nullptr;
+                int64_t *vboff = nullptr;
+                uint64_t vrows = 0;
+                if ((rc = dense_rows_for(ix, k - 1, st, &vp3, &vboff, &vrows))) return rc;
+                A.p3 = vp3;
+                A.boff = vboff;
+                ix->last_rows_read = vrows;
+            }
             const int pw = tw / 32;
             int skew = 0;
             for (int pow2 = 4; pow2 <= 64; pow2 <<= 1)
@@ -543,6 +564,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                                       : (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false, true>, 6, 256>)
                                         : (T == 64 ? (SweepKernel)sweep_membership_planes_kernel<PackedRows<true, false>, 6, 64>
                                                    : (SweepKernel)sweep_membership_planes_kernel<PackedRows<true, false>, 6, 256>);
+            if ((rc = use_words())) return rc;
             if ((rc = launch_tiles(kern, A, tw, T, planes > staged ? planes : staged, st))) return rc;
             return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
         }
@@ -577,6 +599,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         for (int base = 0; base < nw; base += slice) {
             A.word_base = base;
             A.nwords = nw - base < slice ? nw - base : slice;
+            if ((rc = use_words())) return rc;
             if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st))) return rc;
         }
         return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
@@ -599,6 +622,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                              : memb_kernel<PackedRows<true, false>>(w, waves))
                                   : memb_kernel<WideRows>(w, waves);
     if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+    if ((rc = use_words())) return rc;
     if ((rc = launch_tiles(kern, A, w, 64 * waves, per_pos * w, st))) return rc;
     return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
 }

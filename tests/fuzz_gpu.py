@@ -53,31 +53,40 @@ while time.time() < t_end:
     packable = not (m and s.min() < 0)
     # a third of the packable indexes come in the packed, pinned way (memo_builder_*: host packer + bucket table
     # built on the host), in ragged pieces; the rest as int64 columns
-    via_builder = packable and m > 0 and int(o.max()) <= 4095 and int(o.min()) >= 0 and rng.random() < 0.33
+    via_builder = packable and m > 0 and int(o.max()) <= 4095 and int(o.min()) >= 0 and rng.random() < 0.4
+    # ... a third of those as DENSE rows straight from the host packer (five rows per 16 bytes; such an index answers k <= 64
+    # only, may leave out the rows that can never write, and builds k-class views and tile tables behind its queries)
+    dense_only = via_builder and int(o.max()) <= 255 and n_docs <= 255 and rng.random() < 0.4
     if via_builder:
         cuts = [0] + sorted(int(x) for x in rng.integers(0, m, int(rng.integers(0, 4)))) + [m]
-        with memo_amd.IndexBuilder(m + int(rng.integers(0, 100)), bucket_shift=bshift) as b:
+        with memo_amd.IndexBuilder(m + int(rng.integers(0, 100)), bucket_shift=bshift, dense=dense_only) as b:
             for a_, z_ in zip(cuts[:-1], cuts[1:]):
                 b.push(s[a_:z_], e[a_:z_], o[a_:z_])
             made = b.finish()
     else:
         made = memo_amd.DeviceIndex.from_host(s, e, o, bucket_shift=bshift)
     with made as ix:
-        if via_builder:
+        if via_builder and not dense_only:
             if ix.info()["packed_format"] == 4 and rng.random() < 0.5:
                 ix.pack_dense(keep_packed=True)
         elif packable and rng.random() < 0.7:
             ix.pack(keep_wide=True)
             if ix.info()["packed_format"] == 4 and rng.random() < 0.6:
                 ix.pack_dense(keep_packed=True)
-        for _ in range(6):
+        k_pet = int(rng.choice([5, 9, 17, 31, 33]))               # (asked often enough for its class's view to be built)
+        for _ in range(12):
             queries += 1
-            k = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 21, 31, 32, 33, 64, 65, 101, 128, 129, 255, 256] +
-                               ([] if via_builder else [257, 1000])))        # (a packed-only index answers k <= 256)
+            k = k_pet if rng.random() < 0.45 else int(rng.choice(
+                [1, 2, 3, 5, 8, 9, 16, 17, 21, 31, 32, 33, 64] + ([] if dense_only else [65, 101, 128, 129, 255, 256]) +
+                ([] if via_builder else [257, 1000])))                       # (a packed-only index answers k <= 256, dense rows k <= 64)
             qs = int(rng.integers(0, length))
+            if rng.random() < 0.5:
+                qs &= ~3                                                      # (the table-driven kernel wants the 4-position raster)
             qe = int(rng.integers(qs, length + 200))
             tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096, 1472, 1728])), int(rng.choice([0, 1, 4, 8])),
-                    int(rng.choice([0, 2, 3, 4])), int(rng.integers(0, 4)), int(rng.integers(0, 5)))
+                    int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])), int(rng.integers(0, 5)))
+            if dense_only and tune[3] in (1, 3):
+                tune = tune[:3] + (0,) + tune[4:]                             # (no int64 columns / 4-byte rows to force)
             ix.debug_set_tuning(*tune)
             memb = rng.random() < 0.4
             if memb and (qe - qs) * n_docs > 30_000_000:
@@ -93,6 +102,10 @@ while time.time() < t_end:
                 got, gerr = fn_g(qs, qe, k, n_docs), None
             except IndexError:
                 got, gerr = None, IndexError
+            except memo_amd.MemoError as exc:
+                if dense_only and "needs the" in str(exc):     # (sparse index, tile shape, ...: the dense rows alone cannot answer;
+                    continue                                    #  the product's callers ask memo_dense_rows_can_answer first)
+                raise
             ok = werr == gerr and (werr is not None or np.array_equal(got, want))
             if not ok:
                 print("MISMATCH", dict(seed=a.seed, case=cases, via_builder=via_builder, n_docs=n_docs, length=length, m=m, mode=mode, k=k, qs=qs, qe=qe,

@@ -1476,6 +1476,41 @@ def test_dense_row_sweep_variants(memo, oracle, ab):
                 assert ix2.info()["last_variant"] == 2
 
 
+@pytest.mark.parametrize("n", [100, 500])
+def test_packed_k_class_views(n, memo, oracle, ab):
+    """The 4-byte words have k-class views too (packed_rows_for: the rows whose overlap is below 8 / 16 / 32 / 64 / 128, built by
+    the class's fifth query when that spares a fifth of the rows): what membership queries, k > 64 and indexes of more than 255
+    genomes read (format 4 at 100 genomes, format 12 at 500).  Same results as on all the rows (row_source 9), conservation and
+    membership, every kernel family; info.last_rows_read says what was read."""
+    from memo_amd import synth
+    L = 1_500_000
+    ix, (r0, r1) = synth.device_index(0, L, 256, n, L, pack="only")
+    num, den = synth.rows_per_position(n)
+    with ix:
+        assert ix.info()["packed_format"] == (4 if n <= 255 else 12)
+        for k, cap in ((7, 8), (9, 8), (17, 16), (31, 32), (33, 32), (34, 64), (64, 64), (65, 64), (101, 128), (129, 128), (130, None)):
+            for memb in (False, True):
+                qs, qe = (40_000, 40_000 + 60_000) if memb else (4, L - 3)
+                ix.debug_set_tuning(0, 0, 0, 9, 0)
+                ref = ix.membership(qs, qe, k, n) if memb else ix.conservation(qs, qe, k, n)
+                assert ix.info()["last_rows_read"] == r1 - r0
+                ix.debug_set_tuning(0, 0, 0, 0, 0)
+                for _ in range(6):                                  # (a view is built by the fifth query of its class)
+                    got = ix.membership(qs, qe, k, n) if memb else ix.conservation(qs, qe, k, n)
+                    assert np.array_equal(got, ref), (k, memb)
+                read = ix.info()["last_rows_read"]
+                if cap is None or cap >= 64:                        # overlaps are uniform in 0 .. 59: caps of 64 and more spare nothing
+                    assert read == r1 - r0, (k, cap, read)
+                else:
+                    assert abs(read / (r1 - r0) - cap / 60) < 0.01, (k, cap, read)
+        a, b = 700_000, 900_000
+        sr0, sr1 = synth.shard_rows(a, b, 31, num, den, L)
+        s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
+        assert np.array_equal(ix.conservation(a, b, 31, n), oracle.conservation(s, e, o, a, b, 31, n, literal=False))
+        assert np.array_equal(ix.membership(a, a + 50_000, 31, n), oracle.membership(s, e, o, a, a + 50_000, 31, n, literal=False))
+        assert ix.info()["device_bytes"] > 4 * (r1 - r0) * (1 + 8 / 60)      # the views are counted
+
+
 def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
     """k >= 65, unclipped conservation sweep: the library picks doubling / radix-4 / mixed level arrays from k and the
     overlap lengths it sampled when the packed rows were made (info.last_sweep says which ran); every choice is
