@@ -827,6 +827,7 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
     *p3 = ix->p3;
     *boff = ix->boff3 ? ix->boff3 : ix->boff;
     *rows = ix->boff3 ? ix->rows3 : ix->rows;
+    ix->last_view_ms = 0.f;
     const char *env = getenv("MEMO_DENSE_VIEWS");  // (read per query: bench.py times the same index with and without)
     if ((env && env[0] == '0') || ix->tune.no_views || km1 > 32 || km1 < 1) return MEMO_OK;
     const int slot = km1 <= 8 ? 0 : (km1 <= 16 ? 1 : 2), cap = 8 << slot;
@@ -852,6 +853,7 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
         if (rc) return rc;
         v.cap = cap;
         v.state = v.p3 ? 1 : 2;
+        if (v.state == 1) ix->last_view_ms = v.build_ms;
     }
     if (v.state == 1) {
         *p3 = v.p3;

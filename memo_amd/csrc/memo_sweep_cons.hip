@@ -1199,18 +1199,14 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             const uint64_t drows = ix->boff3 ? ix->rows3 : ix->rows;
             const bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && top8 &&
                                ((double)drows >= span || !ix->pk);
-            ix->last_view_ms = 0.f;
             if (three) {  // the dense rows of this k's class (a view that leaves out the rows that cannot write at this k), or all
                 uint32_t *vp3 = nullptr;
                 int64_t *vboff = nullptr;
                 uint64_t vrows = 0;
-                const int before = k - 1 <= 32 ? ix->views[k - 1 <= 8 ? 0 : (k - 1 <= 16 ? 1 : 2)].state : 1;
                 if ((rc = dense_rows_for(ix, k - 1, st, &vp3, &vboff, &vrows))) return rc;
                 A.p3 = vp3;
                 A.boff = vboff;
                 ix->last_rows_read = vrows;
-                const memo_index::DenseView &view = ix->views[k - 1 <= 8 ? 0 : (k - 1 <= 16 ? 1 : 2)];
-                if (k - 1 <= 32 && before == 0 && view.state == 1) ix->last_view_ms = view.build_ms;
             }
             ix->last_variant = 0;
             if (three && g_persistent_launch && tune.persistent >= 2 && tune.persistent <= 4) {

@@ -46,11 +46,12 @@ __global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase
     out[t] = d;
 }
 
-template <int NLEV, typename OutT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+// T = 256: four waves per tile (eight tiles = 32 waves per CU), the only form instantiated (T = 128 lost: see the launcher)
+template <int NLEV, typename OutT, int T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 : 4, 8)))
 void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    constexpr int T = 256, NW = 4;
+    constexpr int NW = T / 64, NL = kStageGroups / T;  // waves; 16-byte groups per lane and batch
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t blk = blockIdx.x;
     const uint32_t tile = (blk & 7u) * (uint32_t)A.tiles_per_xcd + (blk >> 3);  // each XCD group: a contiguous run of tiles
@@ -71,10 +72,10 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     const uint4 *src0 = reinterpret_cast<const uint4 *>(A.p3) + (((uint64_t)d0.y << 32) | d0.x);
     // a lane's four groups of a batch of 1024 (group tid + 256 j): four loads in a row, none under a branch; a piece
     // past the tile's groups loads ONE group for the whole wave (one request)
-    uint4 V[4];
+    uint4 V[NL];
     auto issue = [&](uint32_t batch) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NL; ++j) {
             const uint32_t pg = batch * kStageGroups + (uint32_t)(j * T + wave * 64);
             V[j] = src0[pg < g.ng ? pg + (uint32_t)lane : 0u];
         }
@@ -82,7 +83,7 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     issue(0);
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
     const int HL = A.hl, W = A.w;
-    clear_levels<NLEV>(lds_base, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
+    clear_levels<NLEV, T>(lds_base, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
     RowConst C;
     C.km1 = A.km1;
     C.status = A.status;
@@ -100,15 +101,12 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
         const uint32_t gleft = g.ng > gbase ? g.ng - gbase : 0;
         // a wave whose four pieces (64 groups each, 256 apart) all lie inside the slice: twenty rows, not one test
         const uint32_t w_row0 = 5u * (gbase + (uint32_t)wave * 64u);
-        if (w_row0 >= g.first && w_row0 + 5u * (3u * T + 64u) <= g.end) {
-            group_rows<false>(V[0], C, 0, 0);
-            group_rows<false>(V[1], C, 0, 0);
-            group_rows<false>(V[2], C, 0, 0);
-            group_rows<false>(V[3], C, 0, 0);
+        if (w_row0 >= g.first && w_row0 + 5u * ((uint32_t)(NL - 1) * T + 64u) <= g.end) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) group_rows<false>(V[j], C, 0, 0);
             continue;
         }
-        (void)(reg_piece<0>(V[0], tid, wave, gbase, gleft, g, C, span) && reg_piece<1>(V[1], tid, wave, gbase, gleft, g, C, span) &&
-               reg_piece<2>(V[2], tid, wave, gbase, gleft, g, C, span) && reg_piece<3>(V[3], tid, wave, gbase, gleft, g, C, span));
+        reg_pieces<T, NL>(V, tid, wave, gbase, gleft, g, C, span);
     }
     barrier_lds();  // (lgkmcnt(0): the ds_min above are invisible to the compiler)
 
@@ -151,15 +149,15 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     }
 }
 
-template <typename OutT>
+template <typename OutT, int T>
 SweepKernel kernel_for(int nlev) {
     switch (nlev) {
-        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, OutT>;
-        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, OutT>;
-        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, OutT>;
-        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, OutT>;
-        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, OutT>;
-        case 6: return (SweepKernel)sweep_conservation_halo3t_kernel<6, OutT>;
+        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, OutT, T>;
+        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, OutT, T>;
+        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, OutT, T>;
+        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, OutT, T>;
+        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, OutT, T>;
+        case 6: return (SweepKernel)sweep_conservation_halo3t_kernel<6, OutT, T>;
     }
     return nullptr;
 }
@@ -228,7 +226,11 @@ int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStrea
     A.ntab = ntab;
     A.x_lo_first = (int)(A.qs - tile0);
     A.x_hi_last = (int)(A.qe - (tile0 + (ntiles - 1) * tw));
-    SweepKernel kern = elem_bytes == 1 ? kernel_for<uint8_t>(A.nlev) : kernel_for<uint16_t>(A.nlev);
+    // (Two waves per tile, each with twice the rows -- T = 128 -- were tried for row sources with few rows per position, where
+    // what a wave does around its rows outweighs the rows: 7-9 % SLOWER on the k-class views of config 3 (0.217 against
+    // 0.203 ms at k = 31, 0.168 against 0.154 at k = 17) and 1-4 % slower on all the rows; profiles/r03_views.txt.  Sixteen
+    // waves per CU hide the scatter's LDS latency worse than thirty-two, whatever they save in instructions.)
+    SweepKernel kern = elem_bytes == 1 ? kernel_for<uint8_t, 256>(A.nlev) : kernel_for<uint16_t, 256>(A.nlev);
     if (!kern) return 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(256), (size_t)A.nlev * 4096, st, A);
     HIP_TRY(hipGetLastError());

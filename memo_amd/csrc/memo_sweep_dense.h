@@ -31,12 +31,24 @@ struct Slice {
     uint64_t r0, r1;
 };
 
-template <int NLEV>
+template <int N, int STEP, int I = 0>
+__device__ __forceinline__ void clear_n(uint32_t at, const u32x4 &sv) {  // N stores of 16 B per lane, STEP bytes apart
+    if constexpr (I < N) {
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(at), "v"(sv), "n"(I * STEP) : "memory");
+        clear_n<N, STEP, I + 1>(at, sv);
+    }
+}
+
+template <int NLEV, int T = 256>
 __device__ __forceinline__ void clear_levels(uint32_t lds_base, uint32_t sent) {
     // every level starts at the sentinel column N (memo_query.py:53-54): NLEV x 4 KiB, 16 B per lane and store
     const u32x4 sv = {sent, sent, sent, sent};
     const uint32_t at = lds_base + 16u * threadIdx.x;
     static_assert(NLEV >= 1 && NLEV <= 6, "1 .. 6 level arrays (k - 1 <= 63)");
+    if constexpr (T != 256) {  // (T threads cover 16 T bytes per store)
+        clear_n<NLEV * 256 / T, 16 * T>(at, sv);
+        return;
+    }
 #define MEMO_CLR(off) "ds_write_b128 %0, %1 offset:" #off "\n\t"
     if constexpr (NLEV == 1) asm volatile(MEMO_CLR(0) :: "v"(at), "v"(sv) : "memory");
     if constexpr (NLEV == 2) asm volatile(MEMO_CLR(0) MEMO_CLR(4096) :: "v"(at), "v"(sv) : "memory");
@@ -140,19 +152,28 @@ __device__ __forceinline__ void group_rows(const uint4 &V, const RowConst &C, ui
 }
 
 // the J-th group of a lane, already in registers (MODE 1 / 2)
-template <int J>
+template <int J, int T = 256>
 __device__ __forceinline__ bool reg_piece(const uint4 &V, int tid, int wave, uint32_t gbase, uint32_t gleft, const Geo &g,
                                           const RowConst &C, uint32_t span) {
-    const uint32_t pg = (uint32_t)(J * 256 + wave * 64);
+    const uint32_t pg = (uint32_t)(J * T + wave * 64);
     if (pg >= gleft) return false;
     const uint32_t row0 = 5u * (gbase + pg);
     if (row0 >= g.first && row0 + 320u <= g.end) {
         group_rows<false>(V, C, 0, 0);
     } else {
-        const uint32_t tmp = 5u * (gbase + (uint32_t)(J * 256 + tid)) - g.first;
+        const uint32_t tmp = 5u * (gbase + (uint32_t)(J * T + tid)) - g.first;
         group_rows<true>(V, C, tmp, span);
     }
     return true;
+}
+
+// the NL groups of a lane, one after the other, until the tile's groups end
+template <int T, int NL, int J = 0>
+__device__ __forceinline__ void reg_pieces(const uint4 (&V)[NL], int tid, int wave, uint32_t gbase, uint32_t gleft, const Geo &g,
+                                           const RowConst &C, uint32_t span) {
+    if constexpr (J < NL) {
+        if (reg_piece<J, T>(V[J], tid, wave, gbase, gleft, g, C, span)) reg_pieces<T, NL, J + 1>(V, tid, wave, gbase, gleft, g, C, span);
+    }
 }
 
 
