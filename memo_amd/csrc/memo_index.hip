@@ -152,16 +152,19 @@ __device__ __forceinline__ void dense_row(const uint4 *p3, uint64_t r, uint32_t 
 }
 
 // keep[r / 32] bit r % 32 = row r stays; count[r / 32] = how many of the 32
+// (grid-stride over whole waves: a launch cannot have 2^32 work-items, and an index can have more rows than that)
 __global__ __launch_bounds__(256) void dense_keep_kernel(const uint4 *p3, uint64_t rows, uint32_t cap, uint32_t *keep, uint32_t *count) {
-    const uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x;
-    uint32_t B = 63, A = 0;
-    if (r < rows) dense_row(p3, r, B, A);
-    const unsigned long long m = __ballot(r < rows && (B & 63u) < cap);
-    const int lane = threadIdx.x & 63;
-    if ((lane & 31) == 0 && (r >> 5) < ((rows + 31) >> 5)) {
-        const uint32_t half = (uint32_t)(m >> (lane & 32));
-        keep[r >> 5] = half;
-        count[r >> 5] = (uint32_t)__popc(half);
+    const uint64_t top = (rows + 255) & ~(uint64_t)255;
+    for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < top; r += (uint64_t)gridDim.x * 256) {
+        uint32_t B = 63, A = 0;
+        if (r < rows) dense_row(p3, r, B, A);
+        const unsigned long long m = __ballot(r < rows && (B & 63u) < cap);
+        const int lane = threadIdx.x & 63;
+        if ((lane & 31) == 0 && (r >> 5) < ((rows + 31) >> 5)) {
+            const uint32_t half = (uint32_t)(m >> (lane & 32));
+            keep[r >> 5] = half;
+            count[r >> 5] = (uint32_t)__popc(half);
+        }
     }
 }
 
@@ -224,11 +227,12 @@ __device__ __forceinline__ uint64_t kept_before(uint64_t r, const uint32_t *keep
 // pack3_rows_kernel takes
 __global__ __launch_bounds__(256) void dense_scatter_kernel(const uint4 *p3, uint64_t rows, const uint32_t *keep, const uint32_t *local,
                                                             const uint64_t *blockpre, uint32_t *words) {
-    const uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x;
-    if (r >= rows || !((keep[r >> 5] >> (r & 31)) & 1u)) return;
-    uint32_t B, A;
-    dense_row(p3, r, B, A);
-    words[kept_before(r, keep, local, blockpre)] = (B >> 6) | ((B & 63u) << 16) | (A << 24);
+    for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * 256) {
+        if (!((keep[r >> 5] >> (r & 31)) & 1u)) continue;
+        uint32_t B, A;
+        dense_row(p3, r, B, A);
+        words[kept_before(r, keep, local, blockpre)] = (B >> 6) | ((B & 63u) << 16) | (A << 24);
+    }
 }
 
 // boff3[b] = rows that stay among the first boff[b] rows; the last entry is pinned to the total
@@ -243,22 +247,23 @@ __global__ void dense_table_kernel(const int64_t *boff, uint64_t nb, uint64_t ro
 // the same for the 4-byte words (formats 4 and 12): keep the rows whose overlap byte is below cap
 __global__ __launch_bounds__(256) void packed_keep_kernel(const uint32_t *pk, uint64_t rows, int len_shift, uint32_t cap, uint32_t *keep,
                                                           uint32_t *count) {
-    const uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x;
-    const uint32_t len = r < rows ? (pk[r] >> len_shift) & 0xFFu : 255u;
-    const unsigned long long m = __ballot(r < rows && len < cap);
-    const int lane = threadIdx.x & 63;
-    if ((lane & 31) == 0 && (r >> 5) < ((rows + 31) >> 5)) {
-        const uint32_t half = (uint32_t)(m >> (lane & 32));
-        keep[r >> 5] = half;
-        count[r >> 5] = (uint32_t)__popc(half);
+    const uint64_t top = (rows + 255) & ~(uint64_t)255;
+    for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < top; r += (uint64_t)gridDim.x * 256) {
+        const uint32_t len = r < rows ? (pk[r] >> len_shift) & 0xFFu : 255u;
+        const unsigned long long m = __ballot(r < rows && len < cap);
+        const int lane = threadIdx.x & 63;
+        if ((lane & 31) == 0 && (r >> 5) < ((rows + 31) >> 5)) {
+            const uint32_t half = (uint32_t)(m >> (lane & 32));
+            keep[r >> 5] = half;
+            count[r >> 5] = (uint32_t)__popc(half);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void packed_scatter_kernel(const uint32_t *pk, uint64_t rows, const uint32_t *keep, const uint32_t *local,
                                                              const uint64_t *blockpre, uint32_t *out) {
-    const uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x;
-    if (r >= rows || !((keep[r >> 5] >> (r & 31)) & 1u)) return;
-    out[kept_before(r, keep, local, blockpre)] = pk[r];
+    for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * 256)
+        if ((keep[r >> 5] >> (r & 31)) & 1u) out[kept_before(r, keep, local, blockpre)] = pk[r];
 }
 
 // boff[b] = lower_bound(start, b << shift); the last bucket is pinned to `rows`
@@ -665,6 +670,7 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
     if (!rows || rows >= ((uint64_t)1 << 38)) return MEMO_OK;
     DeviceGuard guard(device);
     const uint64_t n32 = (rows + 31) >> 5, nblk = (n32 + 1023) >> 10;
+    const unsigned row_grid = (unsigned)((rows + 255) / 256 < ((uint64_t)1 << 20) ? (rows + 255) / 256 : (uint64_t)1 << 20);
     uint32_t *keep = nullptr, *local = nullptr, *words = nullptr;
     uint64_t *blockpre = nullptr;
     uint4 *p3n = nullptr;
@@ -677,10 +683,10 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
         if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
         const uint4 *p3 = reinterpret_cast<const uint4 *>(src_p3);
         if (len_shift >= 0)
-            hipLaunchKernelGGL(packed_keep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, src_p3, rows, len_shift, (uint32_t)cap,
+            hipLaunchKernelGGL(packed_keep_kernel, dim3(row_grid), dim3(256), 0, st, src_p3, rows, len_shift, (uint32_t)cap,
                                keep, local);
         else
-            hipLaunchKernelGGL(dense_keep_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p3, rows, (uint32_t)cap, keep, local);
+            hipLaunchKernelGGL(dense_keep_kernel, dim3(row_grid), dim3(256), 0, st, p3, rows, (uint32_t)cap, keep, local);
         hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblk), dim3(256), 0, st, local, n32, local, blockpre);
         hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, blockpre, nblk);
         uint64_t total = 0;
@@ -696,10 +702,10 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
         if (err == hipSuccess) err = hipMalloc(&boff3, nb * 8);
         if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
         if (len_shift >= 0) {
-            hipLaunchKernelGGL(packed_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, src_p3, rows, keep, local, blockpre,
+            hipLaunchKernelGGL(packed_scatter_kernel, dim3(row_grid), dim3(256), 0, st, src_p3, rows, keep, local, blockpre,
                                words);
         } else {
-            hipLaunchKernelGGL(dense_scatter_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p3, rows, keep, local, blockpre, words);
+            hipLaunchKernelGGL(dense_scatter_kernel, dim3(row_grid), dim3(256), 0, st, p3, rows, keep, local, blockpre, words);
             hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, words, padded3, groups, p3n);
         }
         hipLaunchKernelGGL(dense_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, src_boff, nb, rows, total, keep, local,
