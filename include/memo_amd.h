@@ -29,6 +29,14 @@
  *   membership    uint32 out[L * W], W = ceil(num_docs / 32): genome g of
  *                 position p is bit (g & 31) of word p*W + (g >> 5); 1 = k-mer
  *                 present (= rec[p, g], :51 / :68); bits >= num_docs are 0
+ *
+ * Threads and streams.  A memo_index_t is used by ONE host thread at a time: a query updates the handle (which kernel
+ * family answered, the k-class views and tile tables it builds on the way, the sticky status word) without a lock.
+ * Different indexes -- and builders, one-shot calls, transfers -- are independent and may run on different threads;
+ * the process-wide pieces (pinned staging rings, the worker pool, memo_last_error) are locked or thread-local.  The
+ * *_dev forms enqueue on the caller's stream and return; one thread may put queries of one index on several streams:
+ * whatever a query builds for later ones (views, tile tables) is complete on the device before the call returns, and
+ * nothing a queued sweep reads is freed before the device has drained.
  */
 #ifndef MEMO_AMD_H
 #define MEMO_AMD_H

@@ -184,7 +184,7 @@ static int tile_table(memo_index *ix, const void *rows_of, const int64_t *boff, 
         for (memo_index::TileTable &t : ix->ttab)
             if (t.stamp < slot->stamp) slot = &t;  // (an empty slot has stamp 0)
         if (slot->d) {
-            HIP_TRY(hipStreamSynchronize(st));  // (a sweep queued on this stream may still read it)
+            HIP_TRY(hipDeviceSynchronize());  // (a sweep queued on any of the caller's streams may still read it)
             (void)hipFree(slot->d);
             *slot = memo_index::TileTable();
         }
@@ -195,6 +195,9 @@ static int tile_table(memo_index *ix, const void *rows_of, const int64_t *boff, 
         hipLaunchKernelGGL(tile_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, boff, (int64_t)ix->nb, ix->bbase,
                            ix->bshift, w, km1, n, static_cast<TileDesc *>(slot->d));
         HIP_TRY(hipGetLastError());
+        // complete before this call returns: the next query may come on another stream, and nothing would order its sweep
+        // behind this kernel (once per index, tile width and k: some tens of microseconds)
+        HIP_TRY(hipStreamSynchronize(st));
         slot->rows_of = rows_of;
         slot->w = w;
         slot->km1 = km1;

@@ -1511,6 +1511,36 @@ def test_packed_k_class_views(n, memo, oracle, ab):
         assert ix.info()["device_bytes"] > 4 * (r1 - r0) * (1 + 8 / 60)      # the views are counted
 
 
+def test_queries_of_one_index_on_several_streams(memo, oracle):
+    """include/memo_amd.h, "Threads and streams": one thread may enqueue queries of one index on several streams.  What a
+    query builds for later ones -- a tile table per (rows, tile width, k), a k-class view by the class's fifth query -- is
+    built on the stream of the query that needed it and read by the next query on ANOTHER stream, so it has to be complete
+    when the call returns; an evicted tile table (more than four (k, view) pairs) must outlive the sweeps queued on it.
+    Thirty-six queries, six k, three streams, nothing synchronised until the end: every result equals the oracle's."""
+    import torch
+    from memo_amd import synth
+    n, L = 100, 600_000
+    ix, (r0, r1) = synth.device_index(0, L, 256, n, L, pack="dense")
+    num, den = synth.rows_per_position(n)
+    s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, n)
+    streams = [torch.cuda.Stream(device=0) for _ in range(3)]
+    ks = (21, 31, 17, 48, 64, 9)
+    qs, qe = 8, L - 5
+    want = {k: oracle.conservation(s, e, o, qs, qe, k, n, literal=False).astype(np.uint8) for k in ks}
+    outs = []
+    with ix:
+        for i in range(36):
+            k, st = ks[i % 6], streams[(i // 2) % 3]
+            out = torch.empty(qe - qs, dtype=torch.uint8, device="cuda:0")
+            ix.conservation_u8_dev(qs, qe, k, n, out, stream=st.cuda_stream)
+            outs.append((k, out))
+        torch.cuda.synchronize()
+        ix.check()
+        assert ix.info()["last_sweep"] == 5
+        for i, (k, out) in enumerate(outs):
+            assert np.array_equal(out.cpu().numpy(), want[k]), (i, k)
+
+
 def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
     """k >= 65, unclipped conservation sweep: the library picks doubling / radix-4 / mixed level arrays from k and the
     overlap lengths it sampled when the packed rows were made (info.last_sweep says which ran); every choice is
