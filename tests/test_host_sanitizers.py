@@ -94,6 +94,7 @@ def test_host_packer_under_sanitizers(tmp_path, sanitizer):
                            os.path.join(ROOT, "tests", "host_stub.cpp"),
                            os.path.join(ROOT, "memo_amd", "csrc", "memo_hostcore.cpp"), "-o", exe])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="halt_on_error=1", MEMO_HOST_THREADS="6")
-    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0 and "hostcore ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
-    assert "WARNING: ThreadSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    for simd in ("1", "0"):          # the packers' row pass: the AVX2 instance where the CPU has it, and the plain one
+        r = subprocess.run([exe], capture_output=True, text=True, env=dict(env, MEMO_HOST_SIMD=simd), timeout=600)
+        assert r.returncode == 0 and "hostcore ok" in r.stdout, (simd, (r.stdout + r.stderr)[-3000:])
+        assert "WARNING: ThreadSanitizer" not in r.stderr and "runtime error" not in r.stderr, (simd, r.stderr[-3000:])

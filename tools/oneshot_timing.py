@@ -12,14 +12,18 @@ import memo_amd  # noqa: E402
 from memo_amd import synth  # noqa: E402
 
 os.environ["MEMO_TIMING"] = "1"          # the library prints the phases of every call on stderr
-for n, L in ((10, 10_000_000), (100, 20_000_000), (100, 100_000_000)):
+BIG_ONLY = "--big-only" in sys.argv      # BASELINE config 3 through the dense way in only (thread-count sweeps)
+for n, L in ((100, 100_000_000),) if BIG_ONLY else ((10, 10_000_000), (100, 20_000_000), (100, 100_000_000)):
     num, den = synth.rows_per_position(n)
     r0, r1 = synth.shard_rows(0, L, 31, num, den, L)
     s, e, o = synth.host_rows(r0, r1 - r0, num, den, n)
-    for rep in range(3):
+    for rep in range(5 if BIG_ONLY else 3):
         t = time.perf_counter()
         out = memo_amd.conservation(s, e, o, 0, L, 31, n)
         dt = time.perf_counter() - t
+    if BIG_ONLY:
+        print(f"N={n} L={L}: dense way in {dt * 1e3:.1f} ms -> {L / dt:.3g} positions/s", flush=True)
+        sys.exit(0)
     os.environ["MEMO_ONESHOT_PACKED"] = "1"   # the 4-byte words (round 2's way in) instead of the dense rows
     for rep in range(2):
         t = time.perf_counter()
