@@ -79,6 +79,7 @@ def region_chunks(in_file, query_record, query_start, query_end):
     names = [md.schema.column(i).name for i in range(md.num_columns)]
     i0, i1 = names.index("f0"), names.index("f1")
     groups, bound = [], 0
+    one_record, inside = {}, {}
     for g in range(md.num_row_groups):
         rg = md.row_group(g)
         s0, s1 = rg.column(i0).statistics, rg.column(i1).statistics
@@ -88,6 +89,12 @@ def region_chunks(in_file, query_record, query_start, query_end):
             continue
         groups.append(g)
         bound += rg.num_rows
+        # what the statistics already prove about every row of the group: f0 is the record (then the name column --
+        # two thirds of the decode -- is not read), f1 lies inside the window (then nothing is filtered)
+        one_record[g] = bool(s0 is not None and s0.has_min_max and s0.min == query_record == s0.max and
+                             s0.has_null_count and s0.null_count == 0)
+        inside[g] = bool(s1 is not None and s1.has_min_max and s1.min > query_start and s1.max < query_end and
+                         s1.has_null_count and s1.null_count == 0)
 
     import threading
     tls = threading.local()
@@ -95,10 +102,13 @@ def region_chunks(in_file, query_record, query_start, query_end):
     def load(g):
         if not hasattr(tls, "pf"):              # one reader per decode thread: a ParquetFile's
             tls.pf = pq.ParquetFile(in_file)    # read cache is not safe to share
-        t = tls.pf.read_row_group(g, columns=["f0", "f1", "f2", "f3"])
+        t = tls.pf.read_row_group(g, columns=["f1", "f2", "f3"] if one_record[g] else ["f0", "f1", "f2", "f3"])
+        if one_record[g] and inside[g]:
+            return _columns(t)
         f1 = t.column("f1")
-        keep = pc.and_(pc.equal(t.column("f0"), query_record),
-                       pc.and_(pc.greater(f1, query_start), pc.less(f1, query_end)))
+        keep = pc.and_(pc.greater(f1, query_start), pc.less(f1, query_end))
+        if not one_record[g]:
+            keep = pc.and_(pc.equal(t.column("f0"), query_record), keep)
         return _columns(t.filter(keep))
 
     def chunks():

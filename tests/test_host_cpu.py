@@ -149,7 +149,7 @@ def test_region_chunks_equal_filter_pq(memo, tmp_path):
     from memo_amd import memo_query as mq
     rng = np.random.default_rng(8)
     tabs = []
-    for name, n in (("chrA", 7000), ("chrB", 12000), ("chrC", 300)):
+    for name, n in (("chrA", 7300), ("chrB", 12000), ("chrC", 300)):   # (row groups of 1000: two of them hold two records)
         s = np.sort(rng.integers(1, 50_000, n))
         tabs.append(pa.table({"f0": pa.array([name] * n, pa.utf8()), "f1": s, "f2": s + rng.integers(0, 60, n),
                               "f3": rng.integers(1, 9, n)}))
@@ -166,6 +166,16 @@ def test_region_chunks_equal_filter_pq(memo, tmp_path):
         assert len(want) <= bound
         if rec == "chrB" and qs == 10_000:
             assert bound < 12_000                      # pruning really skipped row groups
+    # rows with a null name or a null start: the reference's filter drops them, and so does the slice (a group whose
+    # statistics count a null is filtered row by row, never taken whole)
+    s = np.arange(1, 4001)
+    f0 = pa.array(["chrA"] * 1500 + [None] + ["chrA"] * 2499, pa.utf8())
+    f1 = pa.array([None if i == 3200 else int(v) for i, v in enumerate(s)], pa.int64())
+    path2 = str(tmp_path / "nulls.parquet")
+    pq.write_table(pa.table({"f0": f0, "f1": f1, "f2": s + 3, "f3": s % 7}), path2, row_group_size=1000)
+    want = mq.filter_pq(path2, "chrA", 0, 10_000)
+    got = list(mq.region_chunks(path2, "chrA", 0, 10_000)[1])
+    assert len(want) == 3998 and np.array_equal(np.concatenate([c[0] for c in got]), want.start)
     for c in G.cases(raises=False)[::23]:
         rec, qs, qe = G.region(c)
         want = mq.filter_pq(os.path.join(G.GOLD, c["index"]), rec, qs, qe + c["k"])
