@@ -218,6 +218,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus disagree")
+    # TEST transport (tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu): RCCL refuses two ranks on one device and this
+    # pool gives one GPU per box, so the N > 1 control flow -- link probe, coding choice, root weight, per-step send / receive,
+    # decode on rank 0, parity of the gathered result -- can run here only with every rank on GPU 0 (MEMO_BENCH_ONE_DEVICE=1)
+    # and gloo carrying the bytes through host memory (MEMO_BENCH_BACKEND=gloo).  The line says so ("test_transport"); its
+    # numbers are not bench numbers.
+    backend = os.environ.get("MEMO_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit("MEMO_BENCH_BACKEND: nccl (RCCL; the bench) or gloo (test transport through host memory)")
+    if os.environ.get("MEMO_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    staged = backend == "gloo"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     multi = world > 1 or args.force_dist
@@ -229,9 +240,36 @@ def main():
                 with socket.socket() as sk:
                     sk.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+            dist.init_process_group(backend, rank=0, world_size=1, **({} if staged else {"device_id": dev}))
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group(backend, **({} if staged else {"device_id": dev}))
+
+    def all_reduce_max(x):                  # (device tensor; through host memory on the test transport)
+        if not staged:
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
+            return
+        h = x.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        x.copy_(h)
+
+    def broadcast0(x):
+        if not staged:
+            dist.broadcast(x, src=0)
+            return
+        h = x.cpu()
+        dist.broadcast(h, src=0)
+        x.copy_(h)
+
+    def gather0(x, bufs):
+        if not staged:
+            dist.gather(x, bufs, dst=0)
+            return
+        h = x.cpu()
+        hb = [torch.empty_like(h) for _ in range(world)] if rank == 0 else None
+        dist.gather(h, hb, dst=0)
+        if rank == 0:
+            for d_, s_ in zip(bufs, hb):
+                d_.copy_(s_)
 
     num_docs, L, membership = WORKLOADS[args.workload]
     host_rows = None
@@ -366,16 +404,16 @@ def main():
         probe = outs[0].view(torch.uint8).reshape(-1)
         probe = probe[:min(probe.numel(), 1 << 28)]
         bufs = [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None
-        dist.gather(probe, bufs, dst=0)
+        gather0(probe, bufs)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         t_g0 = time.perf_counter()
         for _ in range(3):
-            dist.gather(probe, bufs, dst=0)
+            gather0(probe, bufs)
         torch.cuda.synchronize()
         t_g = torch.tensor([(time.perf_counter() - t_g0) / 3], dtype=torch.float64, device=dev)
-        dist.all_reduce(t_g, op=dist.ReduceOp.MAX)
+        all_reduce_max(t_g)
         link_probe = {"bytes_per_rank": probe.numel(), "gather_ms": float(t_g[0]) * 1e3, "reps": 3}
         if world > 1:
             link_measured = probe.numel() / float(t_g[0])
@@ -406,7 +444,7 @@ def main():
         _lib.check(lib.memo_transport_dense_stats(probe.data_ptr(), local, stream.cuda_stream, C.byref(found),
                                                   C.byref(have), C.byref(taken), C.byref(room)))
         need = torch.tensor([taken.value, found.value], dtype=torch.int64, device=dev)
-        dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        all_reduce_max(need)
         b_cap = (int(need[0].item()) + 4096 + 3) & ~3                      # exact + slack
         dense_cap = int(need[1].item()) + 1024
         if not args.nibble_gather:
@@ -420,7 +458,7 @@ def main():
         _lib.check(lib.memo_transport_pack_dev(outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream))
         _lib.check(lib.memo_transport_exceptions(probe.data_ptr(), local, stream.cuda_stream, C.byref(found), C.byref(have)))
         need = torch.tensor([found.value], dtype=torch.int64, device=dev)
-        dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        all_reduce_max(need)
         nibble_cap = int(need.item()) + int(need.item()) // 16 + 1024          # what the ranks found + slack
         if nibble_cap * 8 <= L // 8:                                       # else the list outweighs the saving
             t = timed(lambda: _lib.check(lib.memo_transport_unpack_dev(
@@ -434,7 +472,7 @@ def main():
         _lib.check(lib.memo_transport_runs_pack_dev(outs[0].data_ptr(), L, trial_r, probe.data_ptr(), local, stream.cuda_stream))
         _lib.check(lib.memo_transport_runs_stats(probe.data_ptr(), local, stream.cuda_stream, C.byref(taken), C.byref(room)))
         need = torch.tensor([taken.value], dtype=torch.int64, device=dev)
-        dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        all_reduce_max(need)
         runs_cap = (int(need.item()) + int(need.item()) // 16 + 4096 + 3) & ~3       # what the ranks needed + slack
         if not args.nibble_gather:
             t = timed(lambda: _lib.check(lib.memo_transport_runs_unpack_dev(
@@ -453,7 +491,7 @@ def main():
             best = args.coding
         names = sorted(usable)
         pick = torch.tensor([names.index(best), int(round(w_best * 1000))], device=dev)
-        dist.broadcast(pick, src=0)                                        # rank 0's timings decide for everybody
+        broadcast0(pick)                                        # rank 0's timings decide for everybody
         coding = names[int(pick[0].item())]
         root_weight = int(pick[1].item()) / 1000.0
         if coding == "dense":
@@ -533,6 +571,7 @@ def main():
     decoded = [[torch.empty(L, dtype=torch.uint8, device=dev) for _ in range(world)] if (nibble and rank == 0) else None
                for _ in range(nbuf)]
     pending = [None] * nbuf
+    host_side = [None] * nbuf               # (test transport only)
     # rank 0's own slice never travels: its sweep writes straight into the gathered result (no pack, no
     # unpack; the wire it contributes to the gather is ignored).  --code-own-slice codes it like a
     # peer's, so that one GPU can exercise the whole path.
@@ -547,9 +586,13 @@ def main():
         if rank == 0:
             if nibble and args.code_own_slice:
                 roots[b][0].copy_(wires[b])     # (validation mode: rank 0's slice coded like a peer's)
-            ops = [dist.P2POp(dist.irecv, roots[b][g], g) for g in range(1, world)]
+            if staged:
+                host_side[b] = [None] + [torch.empty(wires[b].numel(), dtype=torch.uint8) for _ in range(1, world)]
+            ops = [dist.P2POp(dist.irecv, host_side[b][g] if staged else roots[b][g], g) for g in range(1, world)]
         else:
-            ops = [dist.P2POp(dist.isend, wires[b], 0)]
+            if staged:
+                host_side[b] = wires[b].cpu()   # (test transport: the wire leaves through host memory)
+            ops = [dist.P2POp(dist.isend, host_side[b] if staged else wires[b], 0)]
         return dist.batch_isend_irecv(ops) if ops else []
 
     def finish(b):                          # gather b done -> (root) slices back in result form
@@ -558,6 +601,9 @@ def main():
         for work in pending[b]:
             work.wait()
         pending[b] = None
+        if staged and rank == 0:
+            for g in range(1, world):
+                roots[b][g].copy_(host_side[b][g])
         if nibble and rank == 0:
             for g in range(1 if skip_own else 0, world):
                 unpack(roots[b][g], decoded[b][g])
@@ -687,7 +733,7 @@ def main():
     if multi:
         launch(outs[args.steps % nbuf])     # (leave every buffer holding a complete result)
         t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_max(t)
         dt, kern_ms = float(t[0]), float(t[1])
 
     if rank == 0:
@@ -816,6 +862,9 @@ def main():
             res["link_GBs_assumed_when_unmeasured"] = shard.XGMI_LINK_BYTES_PER_S / 1e9
             res["link_probe"] = link_probe
             res["ranks_seen"] = ranks_seen
+            if staged:
+                res["test_transport"] = ("gloo through host memory" + (", every rank on GPU 0" if os.environ.get("MEMO_BENCH_ONE_DEVICE") == "1" else "") +
+                                         ": a run of the N > 1 control flow, NOT a bench line (value, link and step times mean nothing)")
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     for x in indexes.values():
         x.close()

@@ -1541,6 +1541,36 @@ def test_queries_of_one_index_on_several_streams(memo, oracle):
             assert np.array_equal(out.cpu().numpy(), want[k]), (i, k)
 
 
+@pytest.mark.parametrize("n_ranks,workload,extra", [(2, "c3", []), (3, "c2", []), (2, "c2", ["--plain-gather"]),
+                                                     (2, "c4", []), (2, "c3", ["--root-weight", "0.3"])])
+def test_bench_two_ranks_on_one_gpu(n_ranks, workload, extra):
+    """`python bench.py --gpus N` as the driver spells it, with N > 1 RANKS for the first time on this pool's one-GPU boxes:
+    RCCL refuses two ranks on a device, so the ranks share GPU 0 (MEMO_BENCH_ONE_DEVICE=1) and gloo carries the bytes through
+    host memory (MEMO_BENCH_BACKEND=gloo; bench.py marks the line "test_transport").  Everything else is the N > 1 path as
+    an 8-GPU node runs it: self-launch through torch.distributed.run, link probe, coding choice from the ranks' statistics,
+    root weight, double-buffered send / receive per step, decode on rank 0, the gathered slice of the last rank against the
+    oracle, every slice complete, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MEMO_BENCH_ONE_DEVICE="1", MEMO_BENCH_BACKEND="gloo", MEMO_BENCH_ASSUME_DEVICES=str(n_ranks))
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n_ranks), "--steps", "4", "--warmup", "2",
+                        "--workload", workload] + extra, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == n_ranks and j["steps"] == 4 and j["scaling"] == "weak" and "test_transport" in j
+    assert j["ranks_seen"]["world_size"] == n_ranks and len(j["ranks_seen"]["ranks"]) == n_ranks
+    assert j["gather_parity_sample"]["equal_to_oracle"] is True and j["gather_parity_sample"]["rank"] == n_ranks - 1
+    assert j["gather_parity_sample"].get("every_slice_complete", True) is True
+    assert j["link_GBs_measured"] and j["link_probe"]["bytes_per_rank"] > 0
+    assert j["value"] > 0 and j["config"]["gather_payload"]
+
+
 def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
     """k >= 65, unclipped conservation sweep: the library picks doubling / radix-4 / mixed level arrays from k and the
     overlap lengths it sampled when the packed rows were made (info.last_sweep says which ran); every choice is
