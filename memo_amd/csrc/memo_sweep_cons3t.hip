@@ -46,6 +46,13 @@ __global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase
     out[t] = d;
 }
 
+// Diagnostic builds only (tools/build_variant.sh NAME -DMEMO_T_ABLATE=bits; results are wrong, they size a phase:
+// profiles/r03_phase_ablation.txt): 1 = rows loaded and dropped, 2 = no clear of the level arrays, 4 = no fold (the finest
+// level is stored as it is), 8 = no store, 16 = no row loads
+#ifndef MEMO_T_ABLATE
+#define MEMO_T_ABLATE 0
+#endif
+
 // T = 256: four waves per tile (eight tiles = 32 waves per CU), the only form instantiated (T = 128 lost: see the launcher)
 template <int NLEV, typename OutT, int T>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 : 4, 8)))
@@ -77,13 +84,17 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             const uint32_t pg = batch * kStageGroups + (uint32_t)(j * T + wave * 64);
+            if (MEMO_T_ABLATE & 16) {
+                V[j] = make_uint4(0x0000003Fu, 0x0000003Fu, 0x0000003Fu, 0x0000003Fu);  // (rows that cannot write)
+                continue;
+            }
             V[j] = src0[pg < g.ng ? pg + (uint32_t)lane : 0u];
         }
     };
     issue(0);
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
     const int HL = A.hl, W = A.w;
-    clear_levels<NLEV, T>(lds_base, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
+    if (!(MEMO_T_ABLATE & 2)) clear_levels<NLEV, T>(lds_base, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
     RowConst C;
     C.km1 = A.km1;
     C.status = A.status;
@@ -97,6 +108,11 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     const uint32_t nbatch = (g.ng + kStageGroups - 1) / kStageGroups;
     for (uint32_t batch = 0; batch == 0 || batch < nbatch; ++batch) {
         if (batch) issue(batch);  // (a tile with more than 5120 rows: the rest)
+        if (MEMO_T_ABLATE & 1) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) asm volatile("" ::"v"(V[j].x), "v"(V[j].y), "v"(V[j].z), "v"(V[j].w));
+            continue;
+        }
         const uint32_t gbase = batch * kStageGroups;
         const uint32_t gleft = g.ng > gbase ? g.ng - gbase : 0;
         // a wave whose four pieces (64 groups each, 256 apart) all lie inside the slice: twenty rows, not one test
@@ -126,11 +142,19 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
         read_levels<NLEV>(lds_base + 4u * (uint32_t)xr, L);
         auto lv = [&](int i) { return make_uint4(L[i].x, L[i].y, L[i].z, L[i].w); };
         uint4 M = lv(0);
+        if constexpr (MEMO_T_ABLATE & 4) {
+            M = lv(NLEV - 1);
+        } else {
         if constexpr (NLEV >= 6) fold_step_dpp<4>(M, lv(NLEV - 5), lane);
         if constexpr (NLEV >= 5) fold_step_dpp<3>(M, lv(NLEV - 4), lane);
         if constexpr (NLEV >= 4) fold_step_dpp<2>(M, lv(NLEV - 3), lane);
         if constexpr (NLEV >= 3) fold_step_dpp<1>(M, lv(NLEV - 2), lane);
         if constexpr (NLEV >= 2) fold_step_dpp<0>(M, lv(NLEV - 1), lane);
+        }
+        if (MEMO_T_ABLATE & 8) {
+            asm volatile("" ::"v"(M.x), "v"(M.y), "v"(M.z), "v"(M.w));
+            continue;
+        }
         if (lane < ctx || x0 >= cells) continue;
         const int64_t o = ob + x0;
         if (o >= o_lo && o + 4 <= o_hi) {
