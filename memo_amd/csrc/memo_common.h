@@ -105,8 +105,8 @@ struct memo_index {
     // its own bucket table; boff3 == nullptr: the dense rows are the index's rows, numbered alike (rows3 == rows).
     int64_t *boff3 = nullptr;
     uint64_t rows3 = 0, padded3 = 0;
-    // k-class views of the dense rows (dense_rows_for, memo_index.hip): the rows whose overlap is below 8 / 16 / 32 -- all a
-    // query with k - 1 <= 8 / 16 / 32 can be touched by -- with their own bucket table; built by the first query of the class
+    // k-class views of the dense rows (dense_rows_for, memo_index.hip): the rows whose overlap is below 4 / 8 / ... / 32 -- all a
+    // query with k - 1 <= 4 / 8 / ... / 32 can be touched by -- with their own bucket table; built by the first query of the class
     struct DenseView {
         int cap = 0, state = 0;  // state: 0 not looked at yet, 1 built, 2 not worth it (it would spare less than a fifth)
         int queries = 0;         // queries of this class so far (a view is built by the fifth)
@@ -115,7 +115,7 @@ struct memo_index {
         uint64_t rows = 0, padded = 0;
         float build_ms = 0.f;
     };
-    DenseView views[3];
+    DenseView views[8];           // classes of four: overlaps below 4, 8, 12 ... 32
     DenseView pviews[5];          // the same for the 4-byte words (caps 8 .. 128; `p3` holds words there): packed_rows_for
     uint64_t last_rows_read = 0;  // rows of the row source the last sweep read (info.last_rows_read)
     float last_view_ms = 0.f;     // device time of the view build, when the last sweep's view was built by it (else 0)
@@ -158,6 +158,8 @@ namespace memo {
 void drop_dense(memo_index *ix);       // frees the dense rows, their bucket table and the tile tables
 int dense_compact(memo_index *ix);     // memo_index.hip: leave the rows that can never write out of the dense rows (see boff3)
 int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows);  // ... or a k-class view
+constexpr int kNoRoom = 1;  // (internal) the device has no memory for a view / tile table: run without it
+hipError_t side_alloc(void **p, size_t bytes);
 void drop_dense_views(memo_index *ix);
 int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows);  // k-class view of the words
 void drop_packed_views(memo_index *ix);

@@ -662,6 +662,17 @@ namespace memo {
 // with their own bucket table -- or nothing (out->p3 stays NULL) when fewer than min_tenths tenths of the rows would go.
 // A row with length >= cap cannot write at any k with k - 1 <= cap.  Synchronous on stream `st`.
 // len_shift >= 0: src_p3 / out_p3 are 4-byte WORDS (formats 4 / 12: the overlap byte sits at bit len_shift) instead of dense groups.
+// Device memory for what a query builds on the side (views, tile tables).  These are optimisations: when the device has no
+// room for them the query runs on the rows it has (callers see kNoRoom, not an error).  MEMO_VIEW_ALLOC_FAIL=1 makes every
+// such allocation fail (the test of that path).
+hipError_t side_alloc(void **p, size_t bytes) {
+    const char *env = getenv("MEMO_VIEW_ALLOC_FAIL");
+    if (env && env[0] == '1') return hipErrorOutOfMemory;
+    const hipError_t err = hipMalloc(p, bytes);
+    if (err == hipErrorOutOfMemory) (void)hipGetLastError();  // (not sticky: later calls are clean)
+    return err;
+}
+
 static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_boff, uint64_t rows, uint64_t nb, int cap,
                         int min_tenths, hipStream_t st, uint32_t **out_p3, int64_t **out_boff, uint64_t *out_rows,
                         uint64_t *out_padded, int len_shift = -1) {
@@ -677,9 +688,10 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
     int64_t *boff3 = nullptr;
     int rc = MEMO_OK;
     do {
-        hipError_t err = hipMalloc(&keep, n32 * 4 + 4);
-        if (err == hipSuccess) err = hipMalloc(&local, n32 * 4);
-        if (err == hipSuccess) err = hipMalloc(&blockpre, (nblk + 1) * 8);
+        hipError_t err = side_alloc((void **)&keep, n32 * 4 + 4);
+        if (err == hipSuccess) err = side_alloc((void **)&local, n32 * 4);
+        if (err == hipSuccess) err = side_alloc((void **)&blockpre, (nblk + 1) * 8);
+        if (err == hipErrorOutOfMemory) { rc = kNoRoom; break; }
         if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
         const uint4 *p3 = reinterpret_cast<const uint4 *>(src_p3);
         if (len_shift >= 0)
@@ -696,10 +708,11 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
         if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
         if (total + rows / 10 * (uint64_t)min_tenths > rows) break;  // too few would go
         const uint64_t padded3 = ((total + 15) & ~(uint64_t)15) + kPadRows, groups = dense_groups_for(padded3);
-        err = hipMalloc(&words, padded3 * 4);
+        err = side_alloc((void **)&words, padded3 * 4);
         if (err == hipSuccess) err = hipMemsetAsync(words, 0, padded3 * 4, st);
-        if (err == hipSuccess && len_shift < 0) err = hipMalloc(&p3n, groups * 16);
-        if (err == hipSuccess) err = hipMalloc(&boff3, nb * 8);
+        if (err == hipSuccess && len_shift < 0) err = side_alloc((void **)&p3n, groups * 16);
+        if (err == hipSuccess) err = side_alloc((void **)&boff3, nb * 8);
+        if (err == hipErrorOutOfMemory) { rc = kNoRoom; break; }
         if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
         if (len_shift >= 0) {
             hipLaunchKernelGGL(packed_scatter_kernel, dim3(row_grid), dim3(256), 0, st, src_p3, rows, keep, local, blockpre,
@@ -741,7 +754,8 @@ int dense_compact(memo_index *ix) {
     uint32_t *p3n = nullptr;
     int64_t *boff3 = nullptr;
     uint64_t total = 0, padded3 = 0;
-    const int rc = dense_filter(ix->device, ix->p3, ix->boff, ix->rows, ix->nb, 63, 1, nullptr, &p3n, &boff3, &total, &padded3);
+    int rc = dense_filter(ix->device, ix->p3, ix->boff, ix->rows, ix->nb, 63, 1, nullptr, &p3n, &boff3, &total, &padded3);
+    if (rc == kNoRoom) rc = MEMO_OK;  // (no room for a second copy: every row stays)
     if (rc || !p3n) return rc;
     DeviceGuard guard(ix->device);
     drop_tile_tables(ix);
@@ -811,7 +825,7 @@ int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int6
         (void)hipEventElapsedTime(&v.build_ms, e0, e1);
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-        if (rc) return rc;
+        if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)
         v.cap = cap;
         v.state = v.p3 ? 1 : 2;
         if (v.state == 1) ix->last_view_ms = v.build_ms;
@@ -825,7 +839,7 @@ int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int6
 }
 
 // The dense rows a conservation / membership sweep with k - 1 = km1 should read: the k-class VIEW that leaves out the rows
-// whose overlap is cap or more (cap = 8, 16 or 32, the smallest that is >= km1: such a row cannot write at this k --
+// whose overlap is cap or more (cap = 4, 8, 12 ... 32, the smallest that is >= km1: such a row cannot write at this k --
 // memo_query.py:49 drops it per query; here it is dropped once per index and class) when that spares a fifth of the rows or
 // more, else the dense rows themselves.  A view is built by the fifth query of its class (a few ms for 5 * 10^8 rows: one pass
 // over the dense rows, timed in view.build_ms) and kept with the index; MEMO_DENSE_VIEWS=0 turns them off.
@@ -836,7 +850,7 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
     ix->last_view_ms = 0.f;
     const char *env = getenv("MEMO_DENSE_VIEWS");  // (read per query: bench.py times the same index with and without)
     if ((env && env[0] == '0') || ix->tune.no_views || km1 > 32 || km1 < 1) return MEMO_OK;
-    const int slot = km1 <= 8 ? 0 : (km1 <= 16 ? 1 : 2), cap = 8 << slot;
+    const int slot = (km1 + 3) / 4 - 1, cap = 4 * (slot + 1);  // classes of four: k - 1 <= 4, 8, 12, ... 32
     memo_index::DenseView &v = ix->views[slot];
     // a view costs about as much as fifty sweeps of config 3: it is built by the class's FIFTH query, not its first -- an index
     // that answers one query (the one-shot forms, `memo query`) never builds one
@@ -856,7 +870,7 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
         (void)hipEventElapsedTime(&v.build_ms, e0, e1);
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
-        if (rc) return rc;
+        if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)
         v.cap = cap;
         v.state = v.p3 ? 1 : 2;
         if (v.state == 1) ix->last_view_ms = v.build_ms;

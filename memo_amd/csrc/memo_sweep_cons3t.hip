@@ -215,7 +215,9 @@ static int tile_table(memo_index *ix, const void *rows_of, const int64_t *boff, 
         const int64_t top = ix->max_s < 0 ? 0 : ix->max_s;
         const int64_t n = (top + km1 + ((int64_t)1 << ix->bshift)) / w + 3;  // past the last row: empty slices
         if (n >= ((int64_t)1 << 31)) return 1;
-        HIP_TRY(hipMalloc(&slot->d, (size_t)n * sizeof(TileDesc)));
+        const hipError_t aerr = side_alloc(&slot->d, (size_t)n * sizeof(TileDesc));
+        if (aerr == hipErrorOutOfMemory) return kNoRoom;  // (the caller takes the kernel that needs no table)
+        HIP_TRY(aerr);
         hipLaunchKernelGGL(tile_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, boff, (int64_t)ix->nb, ix->bbase,
                            ix->bshift, w, km1, n, static_cast<TileDesc *>(slot->d));
         HIP_TRY(hipGetLastError());

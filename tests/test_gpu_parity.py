@@ -1447,11 +1447,12 @@ def test_dense_row_sweep_variants(memo, oracle, ab):
             s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
             ix.debug_set_tuning(0, 0, 0, 0, 0)
             assert np.array_equal(ix.conservation(a, b, k, n), oracle.conservation(s, e, o, a, b, k, n, literal=False)), k
-    # k-class views: conservation with k - 1 <= 8 / 16 / 32 reads the dense rows whose overlap is below 8 / 16 / 32 when that
+    # k-class views: conservation with k - 1 <= 4 / 8 / 12 ... / 32 reads the dense rows whose overlap is below that cap when that
     # spares a fifth of them (here: overlaps uniform in 0 .. 59, so every class does); row_source 9 reads them all
     ix, (r0, r1) = synth.device_index(0, 2_000_000, 64, n, 2_000_000, pack="dense")
     with ix:
-        for k, cap in ((5, 8), (9, 8), (10, 16), (17, 16), (18, 32), (31, 32), (33, 32), (34, None), (64, None)):
+        for k, cap in ((2, 4), (5, 4), (6, 8), (9, 8), (10, 12), (17, 16), (18, 20), (21, 20), (22, 24), (29, 28), (31, 32), (33, 32),
+                       (34, None), (64, None)):
             ix.debug_set_tuning(0, 0, 0, 9, 0)
             ref = ix.conservation(0, 2_000_000, k, n, dtype=np.uint8)
             inf = ix.info()
@@ -1569,6 +1570,36 @@ def test_bench_two_ranks_on_one_gpu(n_ranks, workload, extra):
     assert j["gather_parity_sample"].get("every_slice_complete", True) is True
     assert j["link_GBs_measured"] and j["link_probe"]["bytes_per_rank"] > 0
     assert j["value"] > 0 and j["config"]["gather_payload"]
+
+
+def test_no_room_on_the_device_for_views_and_tile_tables(memo, oracle, monkeypatch):
+    """Views and tile tables are optimisations: when the device has no memory left for them (MEMO_VIEW_ALLOC_FAIL=1 makes
+    those allocations fail the way a full device does) queries answer from the rows they have -- same results, no error,
+    info.last_variant / last_rows_read say that no table and no view were used.  Row dropping at pack time keeps every row."""
+    from memo_amd import synth
+    n, L = 100, 800_000
+    num, den = synth.rows_per_position(n)
+    monkeypatch.setenv("MEMO_VIEW_ALLOC_FAIL", "1")
+    for pack in ("dense", "only"):
+        ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack=pack)
+        s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, n)
+        with ix:
+            for k in (21, 31, 64):
+                want = oracle.conservation(s, e, o, 4, L - 3, k, n, literal=False)
+                for _ in range(7):
+                    assert np.array_equal(ix.conservation(4, L - 3, k, n), want), (pack, k)
+                inf = ix.info()
+                assert inf["last_rows_read"] == r1 - r0 and inf["last_variant"] == 0, (pack, k, inf)
+            wantm = oracle.membership(s, e, o, 1000, 60_000, 31, n, literal=False)
+            for _ in range(7):
+                assert np.array_equal(ix.membership(1000, 60_000, 31, n), wantm)
+    monkeypatch.delenv("MEMO_VIEW_ALLOC_FAIL")
+    ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack="dense")
+    with ix:
+        for _ in range(7):
+            ix.conservation(4, L - 3, 21, n)
+        inf = ix.info()
+        assert inf["last_variant"] == 2 and abs(inf["last_rows_read"] / (r1 - r0) - 20 / 60) < 0.01      # (table + view of overlaps < 20)
 
 
 def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
