@@ -116,7 +116,7 @@ struct memo_index {
         float build_ms = 0.f;
     };
     DenseView views[8];           // classes of four: overlaps below 4, 8, 12 ... 32
-    DenseView pviews[5];          // the same for the 4-byte words (caps 8 .. 128; `p3` holds words there): packed_rows_for
+    DenseView pviews[16];         // the same for the 4-byte words (caps 4 .. 32 by 4, .. 64 by 8, .. 128 by 16; `p3` holds words there): packed_rows_for
     uint64_t last_rows_read = 0;  // rows of the row source the last sweep read (info.last_rows_read)
     float last_view_ms = 0.f;     // device time of the view build, when the last sweep's view was built by it (else 0)
     uint64_t max_annot = 0;    // largest annot of the packed rows

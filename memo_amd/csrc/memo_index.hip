@@ -785,17 +785,25 @@ void drop_packed_views(memo_index *ix) {
     }
 }
 
-static int view_slot(int km1, int nslots, int *cap) {  // the smallest class cap (8, 16, 32, 64, 128) that is >= km1
-    for (int s = 0; s < nslots; ++s)
-        if (km1 <= (8 << s)) {
-            *cap = 8 << s;
-            return s;
-        }
+// the class of k - 1 = km1 for the 4-byte words: caps in steps of 4 up to 32, of 8 up to 64, of 16 up to 128 (sixteen classes)
+static int view_slot(int km1, int *cap) {
+    if (km1 <= 32) {
+        *cap = 4 * ((km1 + 3) / 4);
+        return *cap / 4 - 1;
+    }
+    if (km1 <= 64) {
+        *cap = 8 * ((km1 + 7) / 8);
+        return 8 + (*cap - 40) / 8;
+    }
+    if (km1 <= 128) {
+        *cap = 16 * ((km1 + 15) / 16);
+        return 12 + (*cap - 80) / 16;
+    }
     return -1;
 }
 
 // The same k-class views for the 4-byte words (formats 4 and 12; what membership queries, k > 64 and indexes of more than 255
-// genomes read): the rows whose overlap is below 8 / 16 / 32 / 64 / 128, with their own bucket table, built by the class's
+// genomes read): the rows whose overlap is below the class's cap (4, 8 ... 32, 40 ... 64, 80 ... 128), with their own bucket table, built by the class's
 // fifth query when that spares a fifth of the rows.  BASELINE config 5 at k = 31 sweeps half of its 8.4 * 10^8 rows that way.
 int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows) {
     *pk = ix->pk;
@@ -805,7 +813,7 @@ int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int6
     const char *env = getenv("MEMO_DENSE_VIEWS");
     if ((env && env[0] == '0') || ix->tune.no_views || km1 < 1 || !ix->pk || (ix->packed_fmt != 4 && ix->packed_fmt != 12)) return MEMO_OK;
     int cap = 0;
-    const int slot = view_slot(km1, 5, &cap);
+    const int slot = view_slot(km1, &cap);
     if (slot < 0) return MEMO_OK;
     memo_index::DenseView &v = ix->pviews[slot];
     if (v.state == 0 && ++v.queries <= kViewAfterQueries) return MEMO_OK;
