@@ -512,7 +512,7 @@ def main():
     # rank 0 sweeps the first root_weight of its window (a multiple of 8 positions); everybody else all of it
     L_mine = L if rank != 0 else max(8, int(L * root_weight) // 8 * 8)
     # One launch per resident format before anything is timed: the first conservation query of a k class on the dense rows
-    # builds their k-class VIEW (the rows whose overlap is below the class's cap -- 4, 8, 12 ... 32 --: all that can write at this k; memo_query.py:49
+    # builds their k-class VIEW (the rows whose overlap is below the class's cap -- 2, 4, 6 ... 32 --: all that can write at this k; memo_query.py:49
     # drops the others per query, the library once per index and class -- memo_index_info_t.last_rows_read) and the tile
     # table; both stay with the index.  What each format's sweep reads is what its roofline is priced on.
     view_pass = None
@@ -762,7 +762,7 @@ def main():
                                           "order) built once per index by memo_index_pack + memo_index_pack_dense" +
                                           ("" if rows_read.get("dense", rows) == rows else
                                            f"; the sweep reads the k-class view of them: the {rows_read['dense']} rows whose overlap is below "
-                                           f"{4 * ((k - 1 + 3) // 4)} -- the others cannot write at k = {k} "
+                                           f"{2 * (k // 2)} -- the others cannot write at k = {k} "
                                            "(memo_query.py:49 drops them per query) -- built once per index and class by the first query, "
                                            "timed in dense_view_pass; `roofline` is priced on the rows read; other_row_formats has the same "
                                            "kernel on all the dense rows"),

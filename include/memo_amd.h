@@ -91,7 +91,7 @@ typedef struct memo_index_info {
                                sequences) -- the dense rows then have their own numbering and bucket table */
     uint64_t last_rows_read;  /* rows of the row source the last sweep read: the index's rows, the dense rows, or -- conservation
                                on the dense rows with k <= 33 -- a k-class VIEW of them that leaves out the rows whose overlap is
-                               the class's cap -- 4, 8, 12 ... 32 -- or more (none of them can write at a k - 1 up to that cap;
+                               the class's cap -- 2, 4, 6 ... 32 -- or more (none of them can write at a k - 1 up to that cap;
                                memo_query.py:49 drops them per query, the view once per index and class, when that spares a fifth
                                of the rows and the device has room for it) */
     float last_view_ms;       /* device time of building that view, when the last sweep was the one that built it (else 0) */

@@ -105,8 +105,8 @@ struct memo_index {
     // its own bucket table; boff3 == nullptr: the dense rows are the index's rows, numbered alike (rows3 == rows).
     int64_t *boff3 = nullptr;
     uint64_t rows3 = 0, padded3 = 0;
-    // k-class views of the dense rows (dense_rows_for, memo_index.hip): the rows whose overlap is below 4 / 8 / ... / 32 -- all a
-    // query with k - 1 <= 4 / 8 / ... / 32 can be touched by -- with their own bucket table; built by the first query of the class
+    // k-class views of the dense rows (dense_rows_for, memo_index.hip): the rows whose overlap is below 2 / 4 / ... / 32 -- all a
+    // query with k - 1 <= 2 / 4 / ... / 32 can be touched by -- with their own bucket table; built by the first query of the class
     struct DenseView {
         int cap = 0, state = 0;  // state: 0 not looked at yet, 1 built, 2 not worth it (it would spare less than a fifth)
         int queries = 0;         // queries of this class so far (a view is built by the fifth)
@@ -115,8 +115,8 @@ struct memo_index {
         uint64_t rows = 0, padded = 0;
         float build_ms = 0.f;
     };
-    DenseView views[8];           // classes of four: overlaps below 4, 8, 12 ... 32
-    DenseView pviews[16];         // the same for the 4-byte words (caps 4 .. 32 by 4, .. 64 by 8, .. 128 by 16; `p3` holds words there): packed_rows_for
+    DenseView views[16];          // classes of two: overlaps below 2, 4, 6 ... 32
+    DenseView pviews[24];         // the same for the 4-byte words (caps 2 .. 32 by 2, .. 64 by 8, .. 128 by 16; `p3` holds words there): packed_rows_for
     uint64_t last_rows_read = 0;  // rows of the row source the last sweep read (info.last_rows_read)
     float last_view_ms = 0.f;     // device time of the view build, when the last sweep's view was built by it (else 0)
     uint64_t max_annot = 0;    // largest annot of the packed rows

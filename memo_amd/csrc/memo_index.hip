@@ -785,25 +785,26 @@ void drop_packed_views(memo_index *ix) {
     }
 }
 
-// the class of k - 1 = km1 for the 4-byte words: caps in steps of 4 up to 32, of 8 up to 64, of 16 up to 128 (sixteen classes)
+// the class of k - 1 = km1 for the 4-byte words: caps in steps of 2 up to 32 (an odd k -- 21, 31 -- gets exactly the rows that
+// can write), of 8 up to 64, of 16 up to 128 (twenty-four classes)
 static int view_slot(int km1, int *cap) {
     if (km1 <= 32) {
-        *cap = 4 * ((km1 + 3) / 4);
-        return *cap / 4 - 1;
+        *cap = 2 * ((km1 + 1) / 2);
+        return *cap / 2 - 1;
     }
     if (km1 <= 64) {
         *cap = 8 * ((km1 + 7) / 8);
-        return 8 + (*cap - 40) / 8;
+        return 16 + (*cap - 40) / 8;
     }
     if (km1 <= 128) {
         *cap = 16 * ((km1 + 15) / 16);
-        return 12 + (*cap - 80) / 16;
+        return 20 + (*cap - 80) / 16;
     }
     return -1;
 }
 
 // The same k-class views for the 4-byte words (formats 4 and 12; what membership queries, k > 64 and indexes of more than 255
-// genomes read): the rows whose overlap is below the class's cap (4, 8 ... 32, 40 ... 64, 80 ... 128), with their own bucket table, built by the class's
+// genomes read): the rows whose overlap is below the class's cap (2, 4 ... 32, 40 ... 64, 80 ... 128), with their own bucket table, built by the class's
 // fifth query when that spares a fifth of the rows.  BASELINE config 5 at k = 31 sweeps half of its 8.4 * 10^8 rows that way.
 int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows) {
     *pk = ix->pk;
@@ -847,7 +848,7 @@ int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int6
 }
 
 // The dense rows a conservation / membership sweep with k - 1 = km1 should read: the k-class VIEW that leaves out the rows
-// whose overlap is cap or more (cap = 4, 8, 12 ... 32, the smallest that is >= km1: such a row cannot write at this k --
+// whose overlap is cap or more (cap = 2, 4, 6 ... 32, the smallest that is >= km1: such a row cannot write at this k --
 // memo_query.py:49 drops it per query; here it is dropped once per index and class) when that spares a fifth of the rows or
 // more, else the dense rows themselves.  A view is built by the fifth query of its class (a few ms for 5 * 10^8 rows: one pass
 // over the dense rows, timed in view.build_ms) and kept with the index; MEMO_DENSE_VIEWS=0 turns them off.
@@ -858,7 +859,7 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
     ix->last_view_ms = 0.f;
     const char *env = getenv("MEMO_DENSE_VIEWS");  // (read per query: bench.py times the same index with and without)
     if ((env && env[0] == '0') || ix->tune.no_views || km1 > 32 || km1 < 1) return MEMO_OK;
-    const int slot = (km1 + 3) / 4 - 1, cap = 4 * (slot + 1);  // classes of four: k - 1 <= 4, 8, 12, ... 32
+    const int slot = (km1 + 1) / 2 - 1, cap = 2 * (slot + 1);  // classes of two: k - 1 <= 2, 4, 6 ... 32 (an odd k: exactly its rows)
     memo_index::DenseView &v = ix->views[slot];
     // a view costs about as much as fifty sweeps of config 3: it is built by the class's FIFTH query, not its first -- an index
     // that answers one query (the one-shot forms, `memo query`) never builds one

@@ -1447,12 +1447,12 @@ def test_dense_row_sweep_variants(memo, oracle, ab):
             s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
             ix.debug_set_tuning(0, 0, 0, 0, 0)
             assert np.array_equal(ix.conservation(a, b, k, n), oracle.conservation(s, e, o, a, b, k, n, literal=False)), k
-    # k-class views: conservation with k - 1 <= 4 / 8 / 12 ... / 32 reads the dense rows whose overlap is below that cap when that
+    # k-class views: conservation with k - 1 <= 2 / 4 / 6 ... / 32 reads the dense rows whose overlap is below that cap when that
     # spares a fifth of them (here: overlaps uniform in 0 .. 59, so every class does); row_source 9 reads them all
     ix, (r0, r1) = synth.device_index(0, 2_000_000, 64, n, 2_000_000, pack="dense")
     with ix:
-        for k, cap in ((2, 4), (5, 4), (6, 8), (9, 8), (10, 12), (17, 16), (18, 20), (21, 20), (22, 24), (29, 28), (31, 32), (33, 32),
-                       (34, None), (64, None)):
+        for k, cap in ((2, 2), (5, 4), (6, 6), (9, 8), (10, 10), (17, 16), (18, 18), (21, 20), (22, 22), (30, 30), (31, 30), (32, 32),
+                       (33, 32), (34, None), (64, None)):
             ix.debug_set_tuning(0, 0, 0, 9, 0)
             ref = ix.conservation(0, 2_000_000, k, n, dtype=np.uint8)
             inf = ix.info()
@@ -1479,7 +1479,7 @@ def test_dense_row_sweep_variants(memo, oracle, ab):
 
 @pytest.mark.parametrize("n", [100, 500])
 def test_packed_k_class_views(n, memo, oracle, ab):
-    """The 4-byte words have k-class views too (packed_rows_for: the rows whose overlap is below the class's cap -- 4 ... 32 by 4, ... 64 by 8, ... 128 by 16 --, built by
+    """The 4-byte words have k-class views too (packed_rows_for: the rows whose overlap is below the class's cap -- 2 ... 32 by 2, ... 64 by 8, ... 128 by 16 --, built by
     the class's fifth query when that spares a fifth of the rows): what membership queries, k > 64 and indexes of more than 255
     genomes read (format 4 at 100 genomes, format 12 at 500).  Same results as on all the rows (row_source 9), conservation and
     membership, every kernel family; info.last_rows_read says what was read."""
@@ -1489,7 +1489,7 @@ def test_packed_k_class_views(n, memo, oracle, ab):
     num, den = synth.rows_per_position(n)
     with ix:
         assert ix.info()["packed_format"] == (4 if n <= 255 else 12)
-        for k, cap in ((4, 4), (7, 8), (9, 8), (17, 16), (21, 20), (31, 32), (33, 32), (34, 40), (50, 56), (64, 64), (65, 64), (101, 112),
+        for k, cap in ((4, 4), (7, 6), (9, 8), (17, 16), (21, 20), (31, 30), (33, 32), (34, 40), (50, 56), (64, 64), (65, 64), (101, 112),
                        (129, 128), (130, None)):
             for memb in (False, True):
                 qs, qe = (40_000, 40_000 + 60_000) if memb else (4, L - 3)
