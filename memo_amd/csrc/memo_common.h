@@ -114,7 +114,9 @@ struct memo_index {
         int64_t *boff = nullptr;
         uint64_t rows = 0, padded = 0;
         float build_ms = 0.f;
+        uint64_t stamp = 0;      // last use (view_clock): past the views' budget the least recently used one goes
     };
+    uint64_t view_clock = 0;
     DenseView views[16];          // classes of two: overlaps below 2, 4, 6 ... 32
     DenseView pviews[24];         // the same for the 4-byte words (caps 2 .. 32 by 2, .. 64 by 8, .. 128 by 16; `p3` holds words there): packed_rows_for
     uint64_t last_rows_read = 0;  // rows of the row source the last sweep read (info.last_rows_read)

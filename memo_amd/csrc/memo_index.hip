@@ -785,6 +785,34 @@ void drop_packed_views(memo_index *ix) {
     }
 }
 
+// All the views of one row source together may take TWICE the bytes of the rows they are views of (sixteen classes of the dense
+// rows would come to 4.5 times on BASELINE's generator); past that the least recently used view goes -- with the tile tables made
+// for it (a later allocation may land on its address) -- and its class starts counting queries again.
+static void keep_views_in_budget(memo_index *ix, memo_index::DenseView *views, int n, const memo_index::DenseView *fresh,
+                                 uint64_t base_bytes, bool dense) {
+    auto bytes_of = [&](const memo_index::DenseView &v) -> uint64_t {
+        return v.p3 ? (dense ? dense_groups_for(v.padded) * 16 : v.padded * 4) + ix->nb * 8 : 0;
+    };
+    for (;;) {
+        uint64_t total = 0;
+        memo_index::DenseView *lru = nullptr;
+        for (int i = 0; i < n; ++i) {
+            total += bytes_of(views[i]);
+            if (views[i].p3 && &views[i] != fresh && (!lru || views[i].stamp < lru->stamp)) lru = &views[i];
+        }
+        if (total <= 2 * base_bytes || !lru) return;
+        (void)hipDeviceSynchronize();  // (a sweep queued on any stream may still read it)
+        for (memo_index::TileTable &tt : ix->ttab)
+            if (tt.d && tt.rows_of == lru->p3) {
+                (void)hipFree(tt.d);
+                tt = memo_index::TileTable();
+            }
+        (void)hipFree(lru->p3);
+        (void)hipFree(lru->boff);
+        *lru = memo_index::DenseView();
+    }
+}
+
 // the class of k - 1 = km1 for the 4-byte words: caps in steps of 2 up to 32 (an odd k -- 21, 31 -- gets exactly the rows that
 // can write), of 8 up to 64, of 16 up to 128 (twenty-four classes)
 static int view_slot(int km1, int *cap) {
@@ -837,9 +865,13 @@ int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int6
         if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)
         v.cap = cap;
         v.state = v.p3 ? 1 : 2;
-        if (v.state == 1) ix->last_view_ms = v.build_ms;
+        if (v.state == 1) {
+            ix->last_view_ms = v.build_ms;
+            keep_views_in_budget(ix, ix->pviews, (int)(sizeof(ix->pviews) / sizeof(ix->pviews[0])), &v, ix->rows * 4, false);
+        }
     }
     if (v.state == 1) {
+        v.stamp = ++ix->view_clock;
         *pk = v.p3;
         *boff = v.boff;
         *rows = v.rows;
@@ -882,9 +914,14 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
         if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)
         v.cap = cap;
         v.state = v.p3 ? 1 : 2;
-        if (v.state == 1) ix->last_view_ms = v.build_ms;
+        if (v.state == 1) {
+            ix->last_view_ms = v.build_ms;
+            keep_views_in_budget(ix, ix->views, (int)(sizeof(ix->views) / sizeof(ix->views[0])), &v,
+                                 dense_groups_for(ix->boff3 ? ix->padded3 : ix->padded) * 16, true);
+        }
     }
     if (v.state == 1) {
+        v.stamp = ++ix->view_clock;
         *p3 = v.p3;
         *boff = v.boff;
         *rows = v.rows;

@@ -1604,6 +1604,32 @@ def test_no_room_on_the_device_for_views_and_tile_tables(memo, oracle, monkeypat
         assert inf["last_variant"] == 2 and abs(inf["last_rows_read"] / (r1 - r0) - 20 / 60) < 0.01      # (table + view of overlaps < 20)
 
 
+def test_views_stay_within_their_budget(memo, oracle, ab):
+    """All the k-class views of one row source together may take twice the bytes of the rows they are views of; past that the least
+    recently used view goes (with the tile tables made for it) and its class starts counting again.  Every class of the dense rows
+    and of the 4-byte words in turn, twice around: results equal the sweep of all the rows throughout, the index never grows past
+    rows + 2 x rows (+ bucket tables), and a class that was evicted builds its view again."""
+    from memo_amd import synth
+    n, L = 100, 1_200_000
+    for pack, row_bytes in (("dense", 3.2), ("only", 4.0)):
+        ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack=pack)
+        with ix:
+            base = ix.info()["device_bytes"]
+            rows_bytes = row_bytes * (r1 - r0)
+            seen_view = 0
+            for turn in range(2):
+                for k in range(3, 34, 2):
+                    ix.debug_set_tuning(0, 0, 0, 9, 0)
+                    ref = ix.conservation(8, L - 4, k, n, dtype=np.uint8)
+                    ix.debug_set_tuning(0, 0, 0, 0, 0)
+                    for _ in range(6):
+                        assert np.array_equal(ix.conservation(8, L - 4, k, n, dtype=np.uint8), ref), (pack, turn, k)
+                    inf = ix.info()
+                    seen_view += inf["last_rows_read"] < r1 - r0
+                    assert inf["device_bytes"] <= base + 2.0 * rows_bytes + 64 * (L // 32 + 64) * 8 + (1 << 20), (pack, turn, k, inf["device_bytes"], base)
+            assert seen_view >= 24, (pack, seen_view)          # (k - 1 <= 48 of 60 spares a fifth: every class here builds its view, both turns)
+
+
 def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
     """k >= 65, unclipped conservation sweep: the library picks doubling / radix-4 / mixed level arrays from k and the
     overlap lengths it sampled when the packed rows were made (info.last_sweep says which ran); every choice is
