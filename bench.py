@@ -763,7 +763,7 @@ def main():
                                           ("" if rows_read.get("dense", rows) == rows else
                                            f"; the sweep reads the k-class view of them: the {rows_read['dense']} rows whose overlap is below "
                                            f"{2 * (k // 2)} -- the others cannot write at k = {k} "
-                                           "(memo_query.py:49 drops them per query) -- built once per index and class by the first query, "
+                                           "(memo_query.py:49 drops them per query) -- built once per index and class by the fifth query of the class, "
                                            "timed in dense_view_pass; `roofline` is priced on the rows read; other_row_formats has the same "
                                            "kernel on all the dense rows"),
                        "row_bytes": row_bytes, "rows_read": rows_read[args.rows],
