@@ -517,17 +517,22 @@ def main():
     # table; both stay with the index.  What each format's sweep reads is what its roofline is priced on.
     view_pass = None
     full_rows = {}
+    prepared = {}
     for f, ixf in indexes.items():
-        for _ in range(8 if f != "wide" else 1):    # (a view is built by the fifth query of its class)
-            launch(outs[0], ixf)
-            torch.cuda.synchronize()
+        if f != "wide":
+            # memo_index_prepare: the k-class view and the tile table NOW (a host that sweeps one k over many windows calls it
+            # once; without it the class's fifth query builds the view on the way) -- timed on the device by the library
+            prepared[f] = ixf.prepare(k, num_docs, membership)
             inf = ixf.info()
             if f == args.rows and inf["last_view_ms"] > 0:
                 view_pass = {"what": "k-class view of the rows the sweep reads (rows whose overlap is below the class's cap: all that can "
-                                     "write at this k), built by the fifth query of its class -- one pass over the rows + their bucket "
-                                     "table -- once per index and class, kept",
+                                     "write at this k), built by memo_index_prepare (else: by the fifth query of its class) -- one pass over "
+                                     "the rows + their bucket table -- once per index and class, kept",
                              "ms": float(inf["last_view_ms"]), "rows_in": int(inf["dense_row_count"] if f == "dense" else inf["rows"]),
-                             "rows_kept": int(inf["last_rows_read"])}
+                             "rows_kept": int(inf["last_rows_read"]), "device_bytes_taken_by_prepare": int(prepared[f])}
+        launch(outs[0], ixf)
+        torch.cuda.synchronize()
+        inf = ixf.info()
         full_rows[f] = int(inf["dense_row_count"]) if f == "dense" else rows
         if inf["last_rows_read"]:
             rows_read[f] = int(inf["last_rows_read"])
@@ -675,12 +680,12 @@ def main():
     other = []
     legs = [(w, w, None) for w in formats[1:]]
     if others and args.rows != "wide" and rows_read[args.rows] != full_rows[args.rows]:
-        # the same kernel on ALL the rows of the headline format (MEMO_DENSE_VIEWS=0: no k-class view), for the record: what round 2 timed
+        # the same kernel on ALL the rows of the headline format (MEMO_OPT_VIEWS off: no k-class view), for the record: what round 2 timed
         legs.append((args.rows, args.rows + ", all rows (no k-class view)", full_rows[args.rows]))
     for which, label, all_rows in legs:
         ob = fmt_bytes[which]
         if all_rows:
-            os.environ["MEMO_DENSE_VIEWS"] = "0"
+            indexes[which].set_option(1, 0)         # MEMO_OPT_VIEWS = 0: the views go, every sweep reads all the rows
         try:
             settle(lambda: launch(outs[0], indexes[which]))
             ms2 = per_step(lambda: launch(outs[0], indexes[which]), max(args.steps, 20))
@@ -688,7 +693,8 @@ def main():
             name2 = kernel_name(which)
         finally:
             if all_rows:
-                del os.environ["MEMO_DENSE_VIEWS"]
+                indexes[which].set_option(1, 1)
+                indexes[which].prepare(k, num_docs, membership)     # (the headline's view again)
         alg2 = ob * (all_rows or rows_read[which]) + b_out * L
         med2 = float(np.median(ms2))
         other.append({"rows": label, "row_bytes": ob, "rows_read": all_rows or rows_read[which], "kernel": name2,
@@ -763,14 +769,14 @@ def main():
                                           ("" if rows_read.get("dense", rows) == rows else
                                            f"; the sweep reads the k-class view of them: the {rows_read['dense']} rows whose overlap is below "
                                            f"{2 * (k // 2)} -- the others cannot write at k = {k} "
-                                           "(memo_query.py:49 drops them per query) -- built once per index and class by the fifth query of the class, "
-                                           "timed in dense_view_pass; `roofline` is priced on the rows read; other_row_formats has the same "
+                                           "(memo_query.py:49 drops them per query) -- built once per index and class by memo_index_prepare (else "
+                                           "by the class's fifth query), timed in dense_view_pass; `roofline` is priced on the rows read; other_row_formats has the same "
                                            "kernel on all the dense rows"),
                        "row_bytes": row_bytes, "rows_read": rows_read[args.rows],
                        "rows_read_note": None if args.rows == "wide" or rows_read[args.rows] == full_rows.get(args.rows) else
                                          f"the sweep reads the k-class view of the {args.rows} rows: the {rows_read[args.rows]} of "
                                          f"{full_rows.get(args.rows)} rows that can write at k = {k} (memo_query.py:49 drops the others per "
-                                         "query; the library once per index and class, by the class's fifth query: dense_view_pass); "
+                                         "query; the library once per index and class -- memo_index_prepare, else the class's fifth query: dense_view_pass); "
                                          "`roofline` is priced on the rows read, other_row_formats has the same kernel on all the rows",
                        "result_bytes_per_position": b_out,
                        "row_format_choice": "--rows auto = the format that answers this query fastest: the dense rows where they "

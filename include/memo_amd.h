@@ -36,7 +36,9 @@
  * the process-wide pieces (pinned staging rings, the worker pool, memo_last_error) are locked or thread-local.  The
  * *_dev forms enqueue on the caller's stream and return; one thread may put queries of one index on several streams:
  * whatever a query builds for later ones (views, tile tables) is complete on the device before the call returns, and
- * nothing a queued sweep reads is freed before the device has drained.
+ * nothing a queued sweep reads is freed before the device has drained: what a query takes out of service (a view past the
+ * budget) waits on the index's retire list for the next memo_query_check -- queries themselves do not wait for the device
+ * (except the one that BUILDS a view: it waits for its own stream; memo_index_prepare moves that out of the query path).
  */
 #ifndef MEMO_AMD_H
 #define MEMO_AMD_H
@@ -61,7 +63,15 @@ extern "C" {
 
 typedef struct memo_index memo_index_t; /* one chromosome's rows, resident in HBM */
 
+/* Versioned: the CALLER sets struct_bytes = sizeof(memo_index_info_t) as it compiled it (a binder built against an older
+ * header has a shorter struct); memo_index_get_info writes no more than that many bytes -- whole leading fields of the layout
+ * below, which only ever grows at its end -- and puts the number of bytes it wrote back into struct_bytes, its own layout
+ * version into `version`.  struct_bytes below 16 (never set) is MEMO_EINVAL.  (Rounds 1-3 had no such field, and every round
+ * grew the struct: a round-2 binder would have had its stack overwritten by round 3's library.) */
+#define MEMO_INDEX_INFO_VERSION 4
 typedef struct memo_index_info {
+    uint32_t struct_bytes;  /* in: sizeof of the caller's struct; out: bytes written */
+    uint32_t version;       /* out: MEMO_INDEX_INFO_VERSION of the library */
     uint64_t rows;          /* m */
     int64_t min_start;      /* valid after finalize */
     int64_t max_start;
@@ -70,11 +80,11 @@ typedef struct memo_index_info {
     uint64_t buckets;
     int32_t was_sorted;     /* 1 if the rows arrived start-sorted */
     int32_t finalized;
-    uint64_t device_bytes;  /* HBM held by this index (columns + padding + bucket table) */
+    uint64_t device_bytes;  /* HBM held by this index: rows in every resident format, bucket tables, and side_bytes */
     int32_t packed_format;  /* 0 = none; 4, 12 = 4 B/row (8- / 12-bit annot); 6 = 6 B/row (memo_index_pack) */
     int32_t has_wide;       /* 1 while the three int64 columns are resident */
-    float pack_ms;          /* device time of the last memo_index_pack: annot census + packing kernel,
-                               HIP events on its stream (the narrowing pass, timed apart) */
+    float pack_ms;          /* device time of the last memo_index_pack: annot census + packing kernel + the ordering of the rows
+                               inside their buckets, HIP events on its stream (the narrowing pass, timed apart) */
     int32_t dense_rows;     /* 1 while the dense rows of memo_index_pack_dense are resident */
     uint64_t long_rows;     /* rows with end < start, kept aside (see above) */
     uint64_t max_annot;     /* largest annot of the packed rows (valid when packed_format != 0) */
@@ -89,13 +99,21 @@ typedef struct memo_index_info {
                                write at k <= 64 (overlap >= 63, or end < start) were left out of them -- they are when more
                                than a tenth of the rows are such rows (none of the synthetic index, 40 % of one built from
                                sequences) -- the dense rows then have their own numbering and bucket table */
-    uint64_t last_rows_read;  /* rows of the row source the last sweep read: the index's rows, the dense rows, or -- conservation
-                               on the dense rows with k <= 33 -- a k-class VIEW of them that leaves out the rows whose overlap is
-                               the class's cap -- 2, 4, 6 ... 32 -- or more (none of them can write at a k - 1 up to that cap;
-                               memo_query.py:49 drops them per query, the view once per index and class, when that spares a fifth
-                               of the rows and the device has room for it) */
+    uint64_t last_rows_read;  /* rows of the row source the last sweep read: the index's rows, the dense rows, or a k-class VIEW
+                               of the dense rows (conservation, k - 1 <= 32: classes of two, caps 2, 4 ... 32) or of the 4-byte
+                               words (any query on formats 4 / 12 with k - 1 <= 128: caps 2 ... 32 by 2, ... 64 by 8, ... 128 by
+                               16) that leaves out the rows whose overlap is the class's cap or more -- none of them can write at
+                               a k - 1 up to that cap; memo_query.py:49 drops them per query, the view once per index and class,
+                               when that spares a fifth of the rows and the device has room for it (see memo_index_prepare) */
     float last_view_ms;       /* device time of building that view, when the last sweep was the one that built it (else 0) */
-    int32_t reserved;
+    int32_t row_order;        /* order of the 4-byte rows inside a start bucket: 0 by start (as packed), 1 / 2 dealt round-robin
+                               over the bucket's starts in chunks of four (2: the rows of a start by overlap mod 32) -- the order
+                               never changes a result, it spreads a wave's LDS atomics (memo_amd/csrc/memo_interleave.hip) */
+    uint64_t side_bytes;      /* of device_bytes: what queries built on the side -- k-class views, tile tables, and buffers taken
+                               out of service that wait for the device to drain (freed by the next memo_query_check) */
+    int32_t views_resident;   /* k-class views held now */
+    int32_t tile_tables_resident;
+    uint64_t view_builds;     /* k-class views built over the index's lifetime: a service can watch it for thrashing */
 } memo_index_info_t;
 
 const char *memo_last_error(void);
@@ -144,7 +162,27 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide);
  * rows: such an index holds 3.2 B per row and answers only what the dense rows (or, if still resident, the int64
  * columns) can. */
 int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed);
-int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);
+int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);  /* set info->struct_bytes first (see the struct) */
+/* Options of one index (queries never change a result with them).
+ *   MEMO_OPT_VIEWS            1 (default): queries may build k-class views of the rows (memo_index_info_t.last_rows_read);
+ *                             0: never -- resident views are dropped (the call waits for the device), every sweep reads all
+ *                             the rows of its format
+ *   MEMO_OPT_VIEW_BUDGET_PCT  the views of ONE row source (the dense rows; the 4-byte words) together stay within this many
+ *                             percent of that row source's own bytes; past it the least recently used view is dropped (its
+ *                             class is then rebuilt only after four times as many queries as the last time).  Default 200:
+ *                             a long-lived index that holds both row sources can grow to three times their bytes.  0 .. 1600. */
+#define MEMO_OPT_VIEWS 1
+#define MEMO_OPT_VIEW_BUDGET_PCT 2
+int memo_index_set_option(memo_index_t *ix, int32_t option, int64_t value);
+/* Build NOW what queries of one kind would otherwise build on the way: the k-class view of the rows such a query reads (else
+ * built inside the class's fifth query, on the caller's stream, with a wait for it) and the tile table of the table-driven
+ * sweep (else built by the first query that needs it).  The stand-in for what memo_init does per query (memo_query.py:45-49:
+ * recentre, shadow-cast, drop the rows that cannot write) done once for every later query of this k class.  window_hint: the
+ * length of the windows to come (0 = the whole chromosome; it decides tile shapes only).  Blocking; returns the device bytes
+ * the call took in *bytes_taken (may be NULL; 0 when everything was there, or when a view would not pay or does not fit).
+ * A host that will sweep one k over many windows calls this once; one that asks a single question need not. */
+int memo_index_prepare(memo_index_t *ix, int32_t k, int32_t num_docs, int32_t membership, int64_t window_hint, void *stream,
+                       uint64_t *bytes_taken);
 /* A packed index to host memory and back: what the CLI's sidecar cache (memo_amd/cache.py) stores next to
  * the Parquet file, so that a repeat query uploads packed rows from the page cache instead of decoding ZSTD
  * pages.  _export copies the packed rows (rows x uint32; rows x uint16 more when packed_format == 6), the

@@ -33,6 +33,22 @@ extern "C" {
  *   the result matrix, else 1. */
 int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32_t membership_algo,
                           int32_t row_source, int32_t scatter);
+/* Order of the 4-byte rows inside a start bucket (memo_amd/csrc/memo_interleave.hip): 0 = the library's choice, 1 = start order
+ * (as the packers write them), 2 = chunks of four rows dealt round-robin over the bucket's starts, 3 = the same with the rows
+ * of a start ordered by overlap mod 32.  Applied at once to resident 4-byte rows (their k-class views are dropped) and by every
+ * later memo_index_pack of this index.  Results never depend on it. */
+int memo_debug_row_order(memo_index_t *ix, int32_t order);
+/* 1 = this index's sweeps read all the rows of their format even where a k-class view is resident (views already built stay:
+ * bench.py times the same index with and without); 0 = back to the library's choice.  (The product switch is
+ * memo_index_set_option(MEMO_OPT_VIEWS), which also drops the views.) */
+int memo_debug_no_views(memo_index_t *ix, int32_t on);
+/* this THREAD's later calls: every device allocation for a view or a tile table fails (the test of the no-memory path) */
+int memo_debug_fail_side_allocations(int32_t on);
+/* this thread's later memo_index_pack_dense / dense builders keep the rows that can never write at k <= 64 in the dense rows */
+int memo_debug_dense_keep_all(int32_t on);
+/* this thread's later one-shot calls (memo_conservation / memo_membership): 0 = the library's way in, 1 = int64 columns
+ * uploaded as they are, 2 = 4-byte words even where the dense rows could answer */
+int memo_debug_one_shot_way(int32_t way);
 /* memo_index_info_t.last_sweep of the index this thread's last memo_conservation / memo_membership call built and
  * swept (the one-shot forms destroy their index before they return): which kernel family -- hence which row format --
  * answered it */

@@ -1,5 +1,5 @@
 /*
- * memo_amd_transport.h -- lossless transport codings of uint8 conservation slices for the multi-GPU gather
+ * memo_amd_transport.h -- lossless transport codings of conservation slices (uint8; the runs coding also uint16) for the multi-GPU gather
  * (new: the reference is single-process).
  * Part of the C ABI of libmemo_amd.so (see memo_amd.h for conventions: plain C types, 0 or a negative
  * code, memo_last_error()).
@@ -50,6 +50,13 @@ int memo_transport_runs_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t b_cap
 int memo_transport_runs_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint8_t *d_vec, int32_t device,
                                    void *stream);
 int memo_transport_runs_stats(const void *d_wire, int32_t device, void *stream, uint32_t *b_taken, uint32_t *b_capacity);
+/* The runs coding of uint16 results (more than 255 genomes: BASELINE config 5): the same streams with TWO bytes per marked
+ * position in the B region (at most 2 n + 4 * ceil(n / 32768) bytes of it); memo_transport_runs_bytes and _stats serve both.
+ * A config-5 slice (500 genomes, 2^25 positions, k = 31) is 67 MB as plain uint16 and ~9 MB coded. */
+int memo_transport_runs16_pack_dev(const uint16_t *d_vec, int64_t n, uint32_t b_capacity, void *d_wire, int32_t device,
+                                   void *stream);
+int memo_transport_runs16_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint16_t *d_vec, int32_t device,
+                                     void *stream);
 
 #ifdef __cplusplus
 }

@@ -37,13 +37,16 @@ class MemoUnpackable(MemoError):
 
 
 class IndexInfo(C.Structure):
-    _fields_ = [("rows", C.c_uint64), ("min_start", C.c_int64), ("max_start", C.c_int64),
+    """memo_index_info_t (include/memo_amd.h): versioned -- set struct_bytes before memo_index_get_info"""
+    _fields_ = [("struct_bytes", C.c_uint32), ("version", C.c_uint32),
+                ("rows", C.c_uint64), ("min_start", C.c_int64), ("max_start", C.c_int64),
                 ("device", C.c_int32), ("bucket_shift", C.c_int32), ("buckets", C.c_uint64),
                 ("was_sorted", C.c_int32), ("finalized", C.c_int32), ("device_bytes", C.c_uint64),
                 ("packed_format", C.c_int32), ("has_wide", C.c_int32), ("pack_ms", C.c_float),
                 ("dense_rows", C.c_int32), ("long_rows", C.c_uint64), ("max_annot", C.c_uint64),
                 ("bucket_base", C.c_int64), ("last_sweep", C.c_int32), ("last_variant", C.c_int32), ("dense_row_count", C.c_uint64), ("last_rows_read", C.c_uint64),
-                ("last_view_ms", C.c_float), ("reserved", C.c_int32)]
+                ("last_view_ms", C.c_float), ("row_order", C.c_int32), ("side_bytes", C.c_uint64),
+                ("views_resident", C.c_int32), ("tile_tables_resident", C.c_int32), ("view_builds", C.c_uint64)]
 
 
 # every symbol the product headers declare: name -> (restype, argtypes)
@@ -61,6 +64,8 @@ SYMBOLS = {
     "memo_index_pack": (C.c_int, [_P, _I32]),
     "memo_index_pack_dense": (C.c_int, [_P, _I32]),
     "memo_index_get_info": (C.c_int, [_P, C.POINTER(IndexInfo)]),
+    "memo_index_set_option": (C.c_int, [_P, _I32, _I64]),
+    "memo_index_prepare": (C.c_int, [_P, _I32, _I32, _I32, _I64, _P, C.POINTER(_U64)]),
     "memo_index_export_packed": (C.c_int, [_P, _P, _P, _P, _P]),
     "memo_index_import_packed": (C.c_int, [_U64, _I32, _I32, _I64, _P, _P, _P, _U64, _I64, _I64, _I64, _U64, _P, _U64,
                                            C.POINTER(_P)]),
@@ -103,6 +108,8 @@ SYMBOLS = {
     "memo_transport_runs_pack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
     "memo_transport_runs_unpack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
     "memo_transport_runs_stats": (C.c_int, [_P, _I32, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "memo_transport_runs16_pack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
+    "memo_transport_runs16_unpack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
     "memo_transport_bytes": (_SZ, [_I64, C.c_uint32]),
     "memo_transport_pack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
     "memo_transport_unpack_dev": (C.c_int, [_P, _I64, _P, _I32, _P]),
@@ -119,6 +126,11 @@ SYMBOLS = {
 DEBUG_SYMBOLS = {
     "memo_debug_set_tuning": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32]),
     "memo_debug_stream_rows": (C.c_int, [_P, _P]),
+    "memo_debug_row_order": (C.c_int, [_P, _I32]),
+    "memo_debug_no_views": (C.c_int, [_P, _I32]),
+    "memo_debug_fail_side_allocations": (C.c_int, [_I32]),
+    "memo_debug_dense_keep_all": (C.c_int, [_I32]),
+    "memo_debug_one_shot_way": (C.c_int, [_I32]),
     "memo_debug_last_one_shot_sweep": (C.c_int, []),
     "memo_debug_set_stamp_buffer": (C.c_int, [_P]),
 }

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "memo_amd.h"
 #include "memo_amd_dap.h"
@@ -74,6 +75,9 @@ struct memo_tuning {
     int no_views = 0;    // dense rows: 1 = never read a k-class view (A/B)
     int force_packed = 0;  // 1 = read the 4-byte rows even when the dense rows are resident and could answer (they are
                            //     the faster source for the conservation sweep: profiles/r02_dense_rows_ab.txt)
+    int row_order = 0;     // order of the 4-byte rows inside a bucket (memo_interleave.hip): 0 = the library's (kRowOrderDefault),
+                           //     1 = start order as packed, 2 = chunks of four dealt over the starts, 3 = the same with the rows of a
+                           //     start ordered by overlap mod 32
 };
 
 // one chromosome's rows, resident in HBM (the opaque memo_index_t of the ABI)
@@ -96,6 +100,13 @@ struct memo_index {
     int packed_fmt = 0;        // 0 = none, 4 = word with 8-bit annot, 12 = word with 12-bit annot and 12-bit start,
                                //   6 = word + 16-bit annot column
     uint64_t packed_rows = 0;  // rows the pk (pa) allocation holds (reused by the next memo_index_pack)
+    int row_order = 0;         // how the 4-byte rows are ordered inside a bucket: 0 = by start (as packed), 1 / 2 = interleave_words modes
+    // Rows that came in through memo_builder_* or memo_index_import_packed are in start order (or in whatever order their
+    // file holds): an index that answers one query -- the one-shot forms, `memo query` -- should not pay a pass over its rows
+    // for an order that spares a fraction of one sweep, so they are ordered by the FIFTH query that reads them (like the
+    // k-class views), by memo_index_prepare, or by memo_index_pack on the finished index (order_words_now, memo_index.hip).
+    int order_pending = 0;
+    int word_queries = 0;
     float pack_ms = 0.f;       // device time of the last memo_index_pack (census + packing kernel)
     uint32_t *p3 = nullptr;    // dense rows (memo_index_pack_dense): 16 bytes per 5 rows; annot <= 255 only
     // The dense rows may be FEWER than the index's rows: a row whose 6-bit length field is saturated (overlap >= 63, or
@@ -109,14 +120,19 @@ struct memo_index {
     // query with k - 1 <= 2 / 4 / ... / 32 can be touched by -- with their own bucket table; built by the first query of the class
     struct DenseView {
         int cap = 0, state = 0;  // state: 0 not looked at yet, 1 built, 2 not worth it (it would spare less than a fifth)
-        int queries = 0;         // queries of this class so far (a view is built by the fifth)
+        int queries = 0;         // queries of this class since it was last looked at (a view is built by query build_after + 1)
+        int build_after = 4;     // ... the fifth at first; four times as many after every eviction or failed allocation (back-off:
+                                 //   a service that cycles through more classes than the budget holds must not rebuild all the time)
         uint32_t *p3 = nullptr;
         int64_t *boff = nullptr;
         uint64_t rows = 0, padded = 0;
         float build_ms = 0.f;
         uint64_t stamp = 0;      // last use (view_clock): past the views' budget the least recently used one goes
     };
+    int views_on = 1;             // memo_index_set_option(MEMO_OPT_VIEWS)
+    int view_budget_pct = 200;    // memo_index_set_option(MEMO_OPT_VIEW_BUDGET_PCT)
     uint64_t view_clock = 0;
+    uint64_t view_builds = 0;     // views built over the index's lifetime (memo_index_info_t.view_builds)
     DenseView views[16];          // classes of two: overlaps below 2, 4, 6 ... 32
     DenseView pviews[24];         // the same for the 4-byte words (caps 2 .. 32 by 2, .. 64 by 8, .. 128 by 16; `p3` holds words there): packed_rows_for
     uint64_t last_rows_read = 0;  // rows of the row source the last sweep read (info.last_rows_read)
@@ -138,8 +154,18 @@ struct memo_index {
         int64_t n = 0;
         uint64_t stamp = 0;
     };
-    TileTable ttab[4];
+    std::vector<TileTable> ttabs;  // one per (row source, tile width, k) in use, at most kMaxTileTables (least recently used out first)
     uint64_t ttab_clock = 0;
+    // Device buffers a query took out of service (an evicted view, a tile table past the limit) while sweeps queued on any of
+    // the caller's streams may still read them: they wait here -- no synchronisation on the query path -- and are freed by
+    // the next call that has the device drained anyway (memo_query_check, memo_index_prepare, memo_index_pack*,
+    // memo_index_destroy), or, past kRetiredLimit of the index's own bytes, by a query that then does wait for the device.
+    struct Retired {
+        void *p = nullptr;
+        uint64_t bytes = 0;
+    };
+    std::vector<Retired> retired;
+    uint64_t retired_bytes = 0;
     int last_sweep = 0;          // level arrays of the last conservation sweep (memo_index_info_t.last_sweep)
     int last_variant = 0;        // ... 1 when it ran as persistent workgroups (memo_sweep_cons3p.hip), 2 table-driven (memo_sweep_cons3t.hip)
     int has_wide = 1;          // the three int64 columns are still resident
@@ -161,12 +187,26 @@ void drop_dense(memo_index *ix);       // frees the dense rows, their bucket tab
 int dense_compact(memo_index *ix);     // memo_index.hip: leave the rows that can never write out of the dense rows (see boff3)
 int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows);  // ... or a k-class view
 constexpr int kNoRoom = 1;  // (internal) the device has no memory for a view / tile table: run without it
+constexpr size_t kMaxTileTables = 64;
+void retire(memo_index *ix, void *p, uint64_t bytes);  // memo_index.hip: out of service now, freed once the device has drained
+void flush_retired(memo_index *ix);                    // ... which the caller guarantees (it synchronised the device)
+int builder_why(const memo_builder_t *b);  // memo_hostpack.hip: which rows a builder refused with MEMO_EUNPACKABLE (BlockResult::bad bits)
+extern thread_local bool g_dense_keep_all;  // (AB library, memo_debug_dense_keep_all: dense_compact keeps every row)
+extern thread_local int g_one_shot_way;     // (AB library, memo_debug_one_shot_way: 1 = int64 columns, 2 = 4-byte words)
+extern thread_local bool g_prepare_only;  // memo_index_prepare: the query path builds what it would build and launches nothing
+extern thread_local bool g_side_alloc_fails;  // (AB library, memo_debug_fail_side_allocations: every side_alloc fails -- the test of kNoRoom)
 hipError_t side_alloc(void **p, size_t bytes);
 void drop_dense_views(memo_index *ix);
 int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows);  // k-class view of the words
 void drop_packed_views(memo_index *ix);
 inline uint64_t dense_groups_for(uint64_t padded) { return (padded + 4) / 5 + 64; }  // (+ one wave-load of slack: a wave reads its 64 groups whole)
 void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables derive from the dense rows and the bucket table
+// memo_interleave.hip: reorder the 4-byte rows inside every bucket (mode 0: start order, 1: chunks of four dealt round-robin
+// over the bucket's starts, 2: the same with the rows of a start ordered by overlap mod 32), in place, queued on st
+int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshift, int fmt, int mode, hipStream_t st);
+constexpr int kRowOrderDefault = 2;  // interleave_words mode the product applies wherever 4-byte rows come into being
+int order_words_now(memo_index *ix);  // memo_index.hip: waits for the device, orders ix->pk in place, waits again
+inline int row_order_mode(const memo_index *ix) { return ix->tune.row_order ? ix->tune.row_order - 1 : kRowOrderDefault; }
 extern thread_local int g_last_one_shot_sweep;  // which kernel family answered this thread's last one-shot call
 }
 

@@ -56,6 +56,35 @@ int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32
     return MEMO_OK;
 }
 
+int memo_debug_row_order(memo_index_t *ix, int32_t order) {
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (order < 0 || order > 3) return fail(MEMO_EINVAL, "row order must be 0 (the library's), 1 (start order), 2 (chunks dealt over the starts) or 3 (+ by overlap mod 32)");
+    ix->tune.row_order = order;
+    return order_words_now(ix);  // (resident 4-byte rows: now; every later memo_index_pack: as asked)
+}
+
+int memo_debug_no_views(memo_index_t *ix, int32_t on) {
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    ix->tune.no_views = on ? 1 : 0;  // (views already built stay resident: bench.py times the same index with and without)
+    return MEMO_OK;
+}
+
+int memo_debug_fail_side_allocations(int32_t on) {
+    g_side_alloc_fails = on != 0;
+    return MEMO_OK;
+}
+
+int memo_debug_dense_keep_all(int32_t on) {
+    g_dense_keep_all = on != 0;
+    return MEMO_OK;
+}
+
+int memo_debug_one_shot_way(int32_t way) {
+    if (way < 0 || way > 2) return fail(MEMO_EINVAL, "one-shot way: 0 the library's, 1 int64 columns, 2 4-byte words");
+    g_one_shot_way = way;
+    return MEMO_OK;
+}
+
 int memo_debug_stream_rows(memo_index_t *ix, void *stream) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
     if (!ix->has_wide) return fail(MEMO_EINVAL, "the int64 columns were dropped");

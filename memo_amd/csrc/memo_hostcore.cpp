@@ -433,9 +433,11 @@ template <int FMT>
 static ScanPieceFn scan_piece_for() {
 #if defined(__x86_64__)
     static const bool avx2 = [] {
+#ifdef MEMO_HOST_TEST_KNOBS  // (tests/test_host_sanitizers.py builds this file with it: both instances run under the sanitizers)
         if (const char *v = getenv("MEMO_HOST_SIMD")) {
             if (atoi(v) == 0) return false;
         }
+#endif
         return __builtin_cpu_supports("avx2") != 0;
     }();
     if (avx2) return scan_piece_avx2<FMT>;
@@ -579,7 +581,7 @@ int push_words(memo_builder *b, const PackArgs &A, uint64_t rows) {
                 bad |= r.bad;
                 wide |= r.wide_annot;
             }
-            if (bad) return builder_fail(b, MEMO_EUNPACKABLE, bad_message(bad));
+            if (bad) { b->why = bad; return builder_fail(b, MEMO_EUNPACKABLE, bad_message(bad)); }
             if (wide && fmt == 4) {  // switch the index to 12-bit annots: rewrite what is on the device, redo this chunk
                 if ((rc = hp::stream_sync(ring->stream))) return builder_fail(b, rc, "copy stream failed");
                 if (b->rows + c0 && (rc = hp::widen_annots(b->d_pk, b->rows + c0, ring->stream)))
@@ -613,7 +615,7 @@ int carry_rows(memo_builder *b, const PackArgs &A, uint64_t i0, uint64_t i1) {
     }
     scan.finish(res[0]);
     if (scan.wide) res[0].bad |= 16;
-    if (res[0].bad) return builder_fail(b, MEMO_EUNPACKABLE, bad_message(res[0].bad));
+    if (res[0].bad) { b->why = res[0].bad; return builder_fail(b, MEMO_EUNPACKABLE, bad_message(res[0].bad)); }
     return merge_results(b, res);
 }
 
@@ -656,7 +658,7 @@ int push_dense(memo_builder *b, const PackArgs &A, uint64_t rows) {
         });
         int bad = 0;
         for (const BlockResult &r : res) bad |= r.bad;
-        if (bad) return builder_fail(b, MEMO_EUNPACKABLE, bad_message(bad));
+        if (bad) { b->why = bad; return builder_fail(b, MEMO_EUNPACKABLE, bad_message(bad)); }
         if ((rc = merge_results(b, res))) return rc;
         const uint64_t send = pos + gn;
         if (b->groups_sent + send > b->d_groups) return builder_fail(b, MEMO_EINVAL, "more rows than the builder was made for");
@@ -679,7 +681,10 @@ int builder_push_core(memo_builder *b, const int64_t *start, const int64_t *end,
     // the bucket table has to reach the last row's bucket before the workers fill it
     const int64_t s_last = start[rows - 1];
     if (s_last < 0 || s_last >= kHostCoordLimit || (b->any && start[0] < b->last_start))
+    {
+        b->why = 1;
         return builder_fail(b, MEMO_EUNPACKABLE, "rows are unsorted or have a start outside [0, 2^61): not packable");
+    }
     const int64_t need = (s_last >> b->bshift) + 3;
     if ((int64_t)b->boff.size() < need) {
         if ((uint64_t)need > ((uint64_t)1 << 34)) return builder_fail(b, MEMO_EUNPACKABLE, "bucket table too large");

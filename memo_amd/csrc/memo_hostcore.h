@@ -112,6 +112,7 @@ struct memo_builder {
     uint64_t groups_sent = 0;   // dense: whole groups already on their way to the device
     memo::PinnedRing *ring = nullptr;
     int failed = 0;
+    int why = 0;                // MEMO_EUNPACKABLE: BlockResult::bad bits of the rows that could not be packed
 };
 
 namespace memo {

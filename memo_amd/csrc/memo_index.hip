@@ -490,6 +490,7 @@ void memo_index_destroy(memo_index_t *ix) {
     (void)hipFree(ix->lo);
     (void)hipFree(ix->d_status);
     (void)hipFree(ix->d_scratch);
+    flush_retired(ix);  // (hipFree waits for the device)
     delete ix;
 }
 
@@ -663,11 +664,10 @@ namespace memo {
 // A row with length >= cap cannot write at any k with k - 1 <= cap.  Synchronous on stream `st`.
 // len_shift >= 0: src_p3 / out_p3 are 4-byte WORDS (formats 4 / 12: the overlap byte sits at bit len_shift) instead of dense groups.
 // Device memory for what a query builds on the side (views, tile tables).  These are optimisations: when the device has no
-// room for them the query runs on the rows it has (callers see kNoRoom, not an error).  MEMO_VIEW_ALLOC_FAIL=1 makes every
-// such allocation fail (the test of that path).
+// room for them the query runs on the rows it has (callers see kNoRoom, not an error).  memo_debug_fail_side_allocations (AB
+// library) makes every such allocation fail: the test of that path.
 hipError_t side_alloc(void **p, size_t bytes) {
-    const char *env = getenv("MEMO_VIEW_ALLOC_FAIL");
-    if (env && env[0] == '1') return hipErrorOutOfMemory;
+    if (g_side_alloc_fails) return hipErrorOutOfMemory;  // (memo_debug_fail_side_allocations of the AB library)
     const hipError_t err = hipMalloc(p, bytes);
     if (err == hipErrorOutOfMemory) (void)hipGetLastError();  // (not sticky: later calls are clean)
     return err;
@@ -750,7 +750,7 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
 // ix->p3 holds every row of the index (rows3 == rows, no boff3).  When more than a tenth of them can never write at
 // k <= 64 (6-bit length field saturated), rebuild the dense rows without them, with a bucket table of their own.
 int dense_compact(memo_index *ix) {
-    if (!ix->p3 || ix->boff3 || !ix->rows || getenv("MEMO_DENSE_KEEP_ALL")) return MEMO_OK;
+    if (!ix->p3 || ix->boff3 || !ix->rows || g_dense_keep_all) return MEMO_OK;
     uint32_t *p3n = nullptr;
     int64_t *boff3 = nullptr;
     uint64_t total = 0, padded3 = 0;
@@ -767,7 +767,39 @@ int dense_compact(memo_index *ix) {
     return MEMO_OK;
 }
 
-constexpr int kViewAfterQueries = 4;
+thread_local bool g_dense_keep_all = false;   // (AB library: memo_debug_dense_keep_all)
+thread_local int g_one_shot_way = 0;          // (AB library: memo_debug_one_shot_way: 1 = int64 columns, 2 = 4-byte words)
+
+void retire(memo_index *ix, void *p, uint64_t bytes) {
+    if (!p) return;
+    memo_index::Retired r;
+    r.p = p;
+    r.bytes = bytes;
+    ix->retired.push_back(r);
+    ix->retired_bytes += bytes;
+}
+
+void flush_retired(memo_index *ix) {
+    for (memo_index::Retired &r : ix->retired) (void)hipFree(r.p);
+    ix->retired.clear();
+    ix->retired_bytes = 0;
+}
+
+static void retire_view(memo_index *ix, memo_index::DenseView &v, bool dense) {
+    for (size_t i = 0; i < ix->ttabs.size();) {  // the tile tables made for it go with it (a later allocation may land on its address)
+        if (ix->ttabs[i].rows_of == v.p3) {
+            retire(ix, ix->ttabs[i].d, (uint64_t)ix->ttabs[i].n * 32);
+            ix->ttabs.erase(ix->ttabs.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
+    retire(ix, v.p3, dense ? dense_groups_for(v.padded) * 16 : v.padded * 4);
+    retire(ix, v.boff, ix->nb * 8);
+    const int again = v.build_after < (1 << 16) ? v.build_after * 4 : v.build_after;  // back-off: see DenseView
+    v = memo_index::DenseView();
+    v.build_after = again;
+}
 
 void drop_dense_views(memo_index *ix) {
     for (memo_index::DenseView &v : ix->views) {
@@ -785,14 +817,19 @@ void drop_packed_views(memo_index *ix) {
     }
 }
 
-// All the views of one row source together may take TWICE the bytes of the rows they are views of (sixteen classes of the dense
-// rows would come to 4.5 times on BASELINE's generator); past that the least recently used view goes -- with the tile tables made
-// for it (a later allocation may land on its address) -- and its class starts counting queries again.
+// All the views of one row source together may take view_budget_pct percent (200 by default: memo_index_set_option) of the bytes
+// of the rows they are views of (sixteen classes of the dense rows would come to 4.5 times on BASELINE's generator); past that
+// the least recently used view is RETIRED -- with the tile tables made for it -- and its class starts counting queries again,
+// towards a threshold four times the last one (a service that cycles through more classes than the budget holds settles on
+// the classes that fit and reads all the rows for the others, instead of rebuilding a view every few queries: ADVICE r03).
+// Nothing is waited for here: a sweep queued on any of the caller's streams may still read the view, so its buffers go to
+// the index's retire list (memo_common.h) -- unless that list has itself grown past the budget: then the device is drained.
 static void keep_views_in_budget(memo_index *ix, memo_index::DenseView *views, int n, const memo_index::DenseView *fresh,
                                  uint64_t base_bytes, bool dense) {
     auto bytes_of = [&](const memo_index::DenseView &v) -> uint64_t {
         return v.p3 ? (dense ? dense_groups_for(v.padded) * 16 : v.padded * 4) + ix->nb * 8 : 0;
     };
+    const uint64_t budget = base_bytes / 100 * (uint64_t)ix->view_budget_pct;
     for (;;) {
         uint64_t total = 0;
         memo_index::DenseView *lru = nullptr;
@@ -800,17 +837,28 @@ static void keep_views_in_budget(memo_index *ix, memo_index::DenseView *views, i
             total += bytes_of(views[i]);
             if (views[i].p3 && &views[i] != fresh && (!lru || views[i].stamp < lru->stamp)) lru = &views[i];
         }
-        if (total <= 2 * base_bytes || !lru) return;
-        (void)hipDeviceSynchronize();  // (a sweep queued on any stream may still read it)
-        for (memo_index::TileTable &tt : ix->ttab)
-            if (tt.d && tt.rows_of == lru->p3) {
-                (void)hipFree(tt.d);
-                tt = memo_index::TileTable();
-            }
-        (void)hipFree(lru->p3);
-        (void)hipFree(lru->boff);
-        *lru = memo_index::DenseView();
+        if (total <= budget || !lru) break;
+        retire_view(ix, *lru, dense);
     }
+    if (ix->retired_bytes > budget + base_bytes) {  // (rare: many evictions and no memo_query_check in between)
+        (void)hipDeviceSynchronize();
+        flush_retired(ix);
+    }
+}
+
+// The 4-byte rows of an index that came in through the builder or an import, brought into the query order (memo_interleave.hip).
+// In place: no sweep may be reading them, so the device is drained first (once per index: see memo_index::order_pending).
+int order_words_now(memo_index *ix) {
+    ix->order_pending = 0;
+    const int mode = row_order_mode(ix);
+    if (!ix->pk || !ix->rows || (ix->packed_fmt != 4 && ix->packed_fmt != 12) || mode == ix->row_order) return MEMO_OK;
+    DeviceGuard guard(ix->device);
+    HIP_TRY(hipDeviceSynchronize());
+    drop_packed_views(ix);  // (views are subsets in the old order; none exists before the fifth query, but a debug call may come late)
+    if (int rc = interleave_words(ix->pk, ix->boff, ix->nb, ix->bshift, ix->packed_fmt, mode, nullptr)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    ix->row_order = mode;
+    return MEMO_OK;
 }
 
 // the class of k - 1 = km1 for the 4-byte words: caps in steps of 2 up to 32 (an odd k -- 21, 31 -- gets exactly the rows that
@@ -835,17 +883,18 @@ static int view_slot(int km1, int *cap) {
 // genomes read): the rows whose overlap is below the class's cap (2, 4 ... 32, 40 ... 64, 80 ... 128), with their own bucket table, built by the class's
 // fifth query when that spares a fifth of the rows.  BASELINE config 5 at k = 31 sweeps half of its 8.4 * 10^8 rows that way.
 int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows) {
+    if (ix->order_pending && (g_prepare_only || ++ix->word_queries > 4))
+        if (int rc = order_words_now(ix)) return rc;
     *pk = ix->pk;
     *boff = ix->boff;
     *rows = ix->rows;
     ix->last_view_ms = 0.f;
-    const char *env = getenv("MEMO_DENSE_VIEWS");
-    if ((env && env[0] == '0') || ix->tune.no_views || km1 < 1 || !ix->pk || (ix->packed_fmt != 4 && ix->packed_fmt != 12)) return MEMO_OK;
+    if (!ix->views_on || ix->tune.no_views || km1 < 1 || !ix->pk || (ix->packed_fmt != 4 && ix->packed_fmt != 12)) return MEMO_OK;
     int cap = 0;
     const int slot = view_slot(km1, &cap);
     if (slot < 0) return MEMO_OK;
     memo_index::DenseView &v = ix->pviews[slot];
-    if (v.state == 0 && ++v.queries <= kViewAfterQueries) return MEMO_OK;
+    if (v.state == 0 && !g_prepare_only && ++v.queries <= v.build_after) return MEMO_OK;
     if (v.state == 0) {
         DeviceGuard guard(ix->device);
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -855,8 +904,10 @@ int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int6
             return fail(MEMO_EHIP, "hipEventCreate failed");
         }
         (void)hipEventRecord(e0, st);
-        const int rc = dense_filter(ix->device, ix->pk, ix->boff, ix->rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded,
-                                    ix->packed_fmt == 12 ? 0 : 16);
+        int rc = dense_filter(ix->device, ix->pk, ix->boff, ix->rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded,
+                              ix->packed_fmt == 12 ? 0 : 16);
+        // (what the filter leaves of an interleaved bucket is no longer dealt evenly: the view's buckets are ordered again)
+        if (!rc && v.p3 && ix->row_order) rc = interleave_words(v.p3, v.boff, ix->nb, ix->bshift, ix->packed_fmt, ix->row_order, st);
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&v.build_ms, e0, e1);
@@ -864,8 +915,13 @@ int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int6
         (void)hipEventDestroy(e1);
         if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)
         v.cap = cap;
-        v.state = v.p3 ? 1 : 2;
+        v.state = v.p3 ? 1 : (rc == kNoRoom ? 0 : 2);
+        if (rc == kNoRoom) {  // (the pressure may pass: look again, but not every fifth query)
+            v.queries = 0;
+            if (v.build_after < (1 << 16)) v.build_after *= 4;
+        }
         if (v.state == 1) {
+            ++ix->view_builds;
             ix->last_view_ms = v.build_ms;
             keep_views_in_budget(ix, ix->pviews, (int)(sizeof(ix->pviews) / sizeof(ix->pviews[0])), &v, ix->rows * 4, false);
         }
@@ -889,13 +945,12 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
     *boff = ix->boff3 ? ix->boff3 : ix->boff;
     *rows = ix->boff3 ? ix->rows3 : ix->rows;
     ix->last_view_ms = 0.f;
-    const char *env = getenv("MEMO_DENSE_VIEWS");  // (read per query: bench.py times the same index with and without)
-    if ((env && env[0] == '0') || ix->tune.no_views || km1 > 32 || km1 < 1) return MEMO_OK;
+    if (!ix->views_on || ix->tune.no_views || km1 > 32 || km1 < 1) return MEMO_OK;
     const int slot = (km1 + 1) / 2 - 1, cap = 2 * (slot + 1);  // classes of two: k - 1 <= 2, 4, 6 ... 32 (an odd k: exactly its rows)
     memo_index::DenseView &v = ix->views[slot];
     // a view costs about as much as fifty sweeps of config 3: it is built by the class's FIFTH query, not its first -- an index
     // that answers one query (the one-shot forms, `memo query`) never builds one
-    if (v.state == 0 && ++v.queries <= kViewAfterQueries) return MEMO_OK;
+    if (v.state == 0 && !g_prepare_only && ++v.queries <= v.build_after) return MEMO_OK;
     if (v.state == 0) {
         DeviceGuard guard(ix->device);
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -913,8 +968,13 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
         (void)hipEventDestroy(e1);
         if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)
         v.cap = cap;
-        v.state = v.p3 ? 1 : 2;
+        v.state = v.p3 ? 1 : (rc == kNoRoom ? 0 : 2);
+        if (rc == kNoRoom) {
+            v.queries = 0;
+            if (v.build_after < (1 << 16)) v.build_after *= 4;
+        }
         if (v.state == 1) {
+            ++ix->view_builds;
             ix->last_view_ms = v.build_ms;
             keep_views_in_budget(ix, ix->views, (int)(sizeof(ix->views) / sizeof(ix->views[0])), &v,
                                  dense_groups_for(ix->boff3 ? ix->padded3 : ix->padded) * 16, true);
@@ -956,7 +1016,10 @@ extern "C" {
 int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
     if (!ix->finalized) return fail(MEMO_ENOTREADY, "index not finalized");
-    if (!ix->has_wide) return ix->packed_fmt ? MEMO_OK : fail(MEMO_EINVAL, "nothing to pack");
+    if (!ix->has_wide) {  // packed already (a builder's or an imported index): bring its rows into the query order now
+        if (!ix->packed_fmt) return fail(MEMO_EINVAL, "nothing to pack");
+        return ix->order_pending ? order_words_now(ix) : MEMO_OK;
+    }
     if (ix->rows && ix->min_s < 0) return fail(MEMO_EINVAL, "rows with a negative start cannot be packed");
     DeviceGuard guard(ix->device);
     hipStream_t st = nullptr;
@@ -1003,6 +1066,11 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
     hipLaunchKernelGGL(pack_rows_kernel, dim3(4096), dim3(256), 0, st, ix->s, ix->e, ix->o, ix->rows,
                        ix->padded, ix->pk, fmt == 6 ? ix->pa : nullptr, fmt);
     HIP_TRY(hipGetLastError());
+    ix->row_order = 0;
+    if (const int mode = row_order_mode(ix); mode && (fmt == 4 || fmt == 12) && ix->rows) {  // the order inside a bucket (memo_interleave.hip)
+        if (int rc = interleave_words(ix->pk, ix->boff, ix->nb, ix->bshift, fmt, mode, st)) return rc;
+        ix->row_order = mode;
+    }
     HIP_TRY(hipEventRecord(ev1, st));
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0.f;
@@ -1055,8 +1123,9 @@ int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed) {
     return MEMO_OK;
 }
 
-int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
-    if (!ix || !info) return fail(MEMO_EINVAL, "NULL argument");
+static void fill_info(const memo_index *ix, memo_index_info_t *info) {
+    memset(info, 0, sizeof *info);
+    info->version = MEMO_INDEX_INFO_VERSION;
     info->rows = ix->rows;
     info->min_start = ix->min_s;
     info->max_start = ix->max_s;
@@ -1080,8 +1149,93 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
     info->dense_row_count = ix->p3 ? (ix->boff3 ? ix->rows3 : ix->rows) : 0;
     info->last_rows_read = ix->last_rows_read;
     info->last_view_ms = ix->last_view_ms;
-    for (const memo_index::DenseView &v : ix->views) info->device_bytes += v.p3 ? dense_groups_for(v.padded) * 16 + ix->nb * 8 : 0;
-    for (const memo_index::DenseView &v : ix->pviews) info->device_bytes += v.p3 ? v.padded * 4 + ix->nb * 8 : 0;
+    info->row_order = ix->row_order;
+    uint64_t side = ix->retired_bytes;
+    for (const memo_index::DenseView &v : ix->views) {
+        side += v.p3 ? dense_groups_for(v.padded) * 16 + ix->nb * 8 : 0;
+        info->views_resident += v.p3 ? 1 : 0;
+    }
+    for (const memo_index::DenseView &v : ix->pviews) {
+        side += v.p3 ? v.padded * 4 + ix->nb * 8 : 0;
+        info->views_resident += v.p3 ? 1 : 0;
+    }
+    for (const memo_index::TileTable &t : ix->ttabs) side += (uint64_t)t.n * 32;
+    info->tile_tables_resident = (int32_t)ix->ttabs.size();
+    info->side_bytes = side;
+    info->device_bytes += side;
+    info->view_builds = ix->view_builds;
+}
+
+int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
+    if (!ix || !info) return fail(MEMO_EINVAL, "NULL argument");
+    const uint32_t have = info->struct_bytes;
+    if (have < 16)
+        return fail(MEMO_EINVAL, "memo_index_info_t.struct_bytes = %u: set it to sizeof(memo_index_info_t) before the call", have);
+    memo_index_info_t full;
+    fill_info(ix, &full);
+    // whole leading fields only: a caller's (older, shorter) struct ends at a field boundary of this layout
+    const uint32_t n = have < sizeof full ? have : (uint32_t)sizeof full;
+    full.struct_bytes = n;
+    memcpy(info, &full, n);
+    return MEMO_OK;
+}
+
+int memo_index_set_option(memo_index_t *ix, int32_t option, int64_t value) {
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (option == MEMO_OPT_VIEWS) {
+        if (value != 0 && value != 1) return fail(MEMO_EINVAL, "MEMO_OPT_VIEWS takes 0 or 1");
+        ix->views_on = (int)value;
+        if (!value) {
+            DeviceGuard guard(ix->device);
+            HIP_TRY(hipDeviceSynchronize());
+            for (memo_index::DenseView &v : ix->views)
+                if (v.p3) {  // (their tile tables go with them)
+                    for (size_t i = 0; i < ix->ttabs.size();)
+                        if (ix->ttabs[i].rows_of == v.p3) {
+                            (void)hipFree(ix->ttabs[i].d);
+                            ix->ttabs.erase(ix->ttabs.begin() + (long)i);
+                        } else {
+                            ++i;
+                        }
+                }
+            drop_dense_views(ix);
+            drop_packed_views(ix);
+            flush_retired(ix);
+        }
+        return MEMO_OK;
+    }
+    if (option == MEMO_OPT_VIEW_BUDGET_PCT) {
+        if (value < 0 || value > 1600) return fail(MEMO_EINVAL, "MEMO_OPT_VIEW_BUDGET_PCT takes 0 .. 1600");
+        ix->view_budget_pct = (int)value;
+        return MEMO_OK;
+    }
+    return fail(MEMO_EINVAL, "unknown index option %d", option);
+}
+
+int memo_index_prepare(memo_index_t *ix, int32_t k, int32_t num_docs, int32_t membership, int64_t window_hint, void *stream,
+                       uint64_t *bytes_taken) {
+    if (bytes_taken) *bytes_taken = 0;
+    if (!ix) return fail(MEMO_EINVAL, "index is NULL");
+    if (!ix->finalized) return fail(MEMO_ENOTREADY, "index not finalized");
+    if (window_hint < 0) return fail(MEMO_EINVAL, "window_hint must be >= 0");
+    if (k <= 1 || !ix->rows) return MEMO_OK;  // (no row can write: nothing to build)
+    DeviceGuard guard(ix->device);
+    memo_index_info_t before, after;
+    fill_info(ix, &before);
+    // the window the queries to come are like: it starts on every kernel's tile grid, and nothing is ever written to d_out
+    const int64_t top = ix->max_s < 0 ? 0 : ix->max_s;
+    const int64_t len = window_hint > 0 ? window_hint : (top + 1 > 4096 ? top + 1 : 4096);
+    void *const never_written = reinterpret_cast<void *>(uintptr_t(4096));
+    g_prepare_only = true;
+    const int rc = membership ? memo_query_membership_dev(ix, 0, len, k, num_docs, static_cast<uint32_t *>(never_written), stream)
+                   : num_docs <= 255 ? memo_query_conservation_u8_dev(ix, 0, len, k, num_docs, static_cast<uint8_t *>(never_written), stream)
+                                     : memo_query_conservation_dev(ix, 0, len, k, num_docs, static_cast<uint16_t *>(never_written), stream);
+    g_prepare_only = false;
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());  // (views and tables are complete; and what the builds took out of service can go)
+    flush_retired(ix);
+    fill_info(ix, &after);
+    if (bytes_taken) *bytes_taken = after.device_bytes > before.device_bytes ? after.device_bytes - before.device_bytes : 0;
     return MEMO_OK;
 }
 
@@ -1102,25 +1256,28 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     const auto t0 = now();
-    if (rows && k > 1 && k - 1 <= 255 && !getenv("MEMO_ONESHOT_WIDE")) {
+    if (rows && k > 1 && k - 1 <= 255 && g_one_shot_way != 1) {
         // the dense rows first (3.2 B per row over PCIe and in HBM, sweep_conservation_halo3_kernel) when they can
         // answer THIS query -- judged from the first and last start before the rows are touched, and again from the
         // largest annot once they have been packed; else (or when a row does not fit them) the 4-byte words
-        const bool try_dense = !getenv("MEMO_ONESHOT_PACKED") &&
+        const bool try_dense = g_one_shot_way != 2 &&
                                memo_dense_rows_can_answer(rows, start[0], start[rows - 1], 0, k, num_docs, membership);
         for (int dense = try_dense ? 1 : 0; dense >= 0 && !ix; --dense) {
             memo_builder_t *b = nullptr;
             if ((rc = memo_builder_create_rows(rows, device, 0, dense ? MEMO_ROWS_DENSE : MEMO_ROWS_PACKED, &b))) return rc;
             rc = memo_builder_push(b, start, end, annot, rows);
             if (!rc) rc = memo_builder_finish(b, &ix);
+            const int why = builder_why(b);
             memo_builder_destroy(b);
             if (rc == MEMO_EUNPACKABLE) {
                 rc = MEMO_OK;
                 ix = nullptr;
+                if (dense && (why & ~16)) break;  // (unsorted, negative start, wild annot: the 4-byte words would refuse them too)
             } else if (rc) {
                 return rc;
-            } else if (dense && !memo_dense_rows_can_answer(ix->boff3 ? ix->rows3 : ix->rows, ix->min_s, ix->max_s, ix->max_annot, k,
-                                                            num_docs, membership)) {
+            } else if (dense && !memo_dense_rows_can_answer(ix->rows, ix->min_s, ix->max_s, ix->max_annot, k, num_docs, membership)) {
+                // (the rule query_conservation applies: ALL the index's rows against its span -- rows that can never write
+                // may have left the dense rows, memo_common.h: boff3 -- and the largest annot against the result matrix)
                 memo_index_destroy(ix);  // (an annot outside the result matrix: the 4-byte kernels flag the reference's IndexError)
                 ix = nullptr;
             }

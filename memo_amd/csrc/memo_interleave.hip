@@ -1,0 +1,270 @@
+// memo_interleave.hip -- the order of the 4-byte rows INSIDE a start bucket (round 4).
+//
+// The sweeps never rely on the order of the rows inside a bucket: a tile's row slice begins and ends at bucket
+// boundaries (memo_sweep.h: row_slice), rows outside it are masked by row number, and min / and are commutative
+// (/root/reference/src/memo_query.py:60-62 visits the rows in file order and sets one bool per covered cell: any order
+// gives the same matrix).  What the order does decide is what a wave's 64 LDS atomics of one row instruction collide
+// on.  Measured on gfx950 (tools/lds_atomic_bench.hip, profiles/r04_lds_atomics.txt): a ds_min_u32 / ds_or_b32
+// wave-instruction costs 4.3 cycles of its CU's LDS pipe when its lanes hit different banks; lanes on one bank with
+// DIFFERENT addresses cost one cycle each per half-wave (two of them ride in the instruction's own two cycles: a
+// 2-way bank conflict is free); lanes on the SAME address cost two cycles each (k lanes: 2k - 1 cycles per half-wave;
+// all 64 on one cell: 128).  In start order the rows of one pivot position sit in neighbouring lanes, and the second
+// block of a conservation row -- the cell `start - 2^j` of level j -- is the same cell for every row of that position
+// on that level: BASELINE config 5 (25 rows per position) pays 26 cycles per wave-instruction there, six times the
+// conflict-free price, and its k = 101 sweep was bound by exactly that (0.77 ms; the rows stream in 0.57).
+//
+// The order built here, per bucket: the rows of every start are cut into chunks of four (one lane's 16-byte load) and
+// the chunks are dealt round-robin over the bucket's starts -- pass 0 holds the first chunk of every start, in start
+// order, pass 1 the second, ... -- so that the 32 lanes of a half-wave hold 32 different, consecutive starts: their
+// second blocks fall on 32 different cells in 32 different banks.  Inside a start the rows are ordered by their overlap
+// mod 32 (then overlap, then annot: the order is a function of the bucket's rows alone, whatever order they arrive
+// in), so that the q-th chunk of every start holds that start's q-th quartet of overlaps: the first block of a row lies
+// at cell `start - (k - 1) + overlap`, and lanes whose starts step by one and whose overlaps agree mod 32 up to a few
+// positions spread over the banks better than the pseudo-random overlaps of start order do.
+// Config-5 shard, k = 101, sustained (profiles/r04_row_order.txt): 0.771 -> 0.60-0.62 ms; k = 31: 0.334 -> 0.310.
+//
+// In place: a bucket is staged in LDS before a word of it is written back, and buckets are disjoint.  Buckets of more
+// than kMaxBucketRows rows stay as they are (correct, only slower).  Formats 4 and 12 (one word per row).
+//
+// Sort key of a row inside its bucket (25 + bshift - 5 bits): start in bucket | x | annot, x = the overlap byte -- in
+// mode 2 rotated so that overlap mod 32 leads (x = (ov & 31) << 3 | ov >> 5).  The key and the bucket's common start
+// bits give the word back, so only keys are staged.
+#include "memo_common.h"
+
+namespace memo {
+
+namespace {
+
+constexpr int kMaxBucketRows = 8192;  // rows of a bucket a workgroup can stage (32 KiB of keys)
+constexpr int kWaveRows = 256;        // ... and one wave alone (default bucket width: four buckets per workgroup at a time)
+constexpr int kWaveQ = 16;            // wave path: chunk table for starts of up to 4 * kWaveQ rows (else: the counting loop)
+
+struct KeyCodec {
+    int fmt12, mode, bshift;
+    __device__ __forceinline__ uint32_t key(uint32_t w) const {
+        const uint32_t start = fmt12 ? (w >> 8) & 0xFFFu : w & 0xFFFFu;
+        const uint32_t ov = fmt12 ? w & 0xFFu : (w >> 16) & 0xFFu;
+        const uint32_t annot = fmt12 ? w >> 20 : w >> 24;
+        const uint32_t x = mode == 2 ? ((ov & 31u) << 3) | (ov >> 5) : ov;
+        return ((start & ((1u << bshift) - 1u)) << 20) | (x << 12) | annot;
+    }
+    // high = the start field's bits above the bucket (the same for every row of a bucket)
+    __device__ __forceinline__ uint32_t word(uint32_t k, uint32_t high) const {
+        const uint32_t start = high | (k >> 20), x = (k >> 12) & 0xFFu, annot = k & 0xFFFu;
+        const uint32_t ov = mode == 2 ? ((x & 7u) << 5) | (x >> 3) : x;
+        return fmt12 ? ov | (start << 8) | (annot << 20) : start | (ov << 16) | (annot << 24);
+    }
+    __device__ __forceinline__ uint32_t high_of(uint32_t w) const {
+        const uint32_t start = fmt12 ? (w >> 8) & 0xFFFu : w & 0xFFFFu;
+        return start & ~((1u << bshift) - 1u);
+    }
+};
+
+// LDS written by some lanes of ONE wave, read by others of the same wave: LDS operations of a wave execute in order;
+// this keeps the compiler from moving or caching them across the step (s_waitcnt lgkmcnt(0), no s_barrier)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- one wave, one bucket of at most 256 rows, 32 starts (the default bucket width) -------------------------------
+__device__ __forceinline__ void wave_bucket(uint32_t *__restrict__ words, int64_t r0, int R, const KeyCodec &C, uint32_t *key /*[256]*/,
+                                            uint32_t *first /*[32]*/, uint32_t *cnt /*[32]*/, uint32_t *table /*[kWaveQ * 32]*/) {
+    const int lane = threadIdx.x & 63;
+    int P = 64;
+    while (P < R) P <<= 1;
+    uint32_t high = 0;
+    for (int e = lane; e < P; e += 64) {
+        uint32_t k = 0xFFFFFFFFu;
+        if (e < R) {
+            const uint32_t w = words[r0 + e];
+            k = C.key(w);
+            high = C.high_of(w);
+        }
+        key[e] = k;
+    }
+    high = (uint32_t)__builtin_amdgcn_readfirstlane((int)high);  // (lane 0 always holds a row: R >= 2)
+    if (lane < 32) cnt[lane] = 0;
+    wave_sync();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int c = lane; c < (P >> 1); c += 64) {
+                const int lo = 2 * c - (c & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = key[lo], z = key[hi];
+                if ((a > z) == up) {
+                    key[lo] = z;
+                    key[hi] = a;
+                }
+            }
+            wave_sync();
+        }
+    }
+    for (int e = lane; e < R; e += 64) {
+        const uint32_t s = key[e] >> 20;
+        if (e == 0 || (key[e - 1] >> 20) != s) first[s] = (uint32_t)e;
+        if (e == R - 1 || (key[e + 1] >> 20) != s) cnt[s] = (uint32_t)e + 1u;  // (its end, for now)
+    }
+    wave_sync();
+    uint32_t c_mine = 0;
+    if (lane < 32 && cnt[lane]) {
+        c_mine = cnt[lane] - first[lane];
+        cnt[lane] = c_mine;
+    }
+    wave_sync();
+    uint32_t maxc = c_mine;
+    for (int off = 16; off > 0; off >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, off, 64));
+    maxc = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxc);
+    const bool tabled = C.mode != 0 && maxc <= 4u * kWaveQ;
+    if (tabled) {
+        // where every chunk (pass q, start s) begins: an exclusive scan of the chunk sizes in (q, s) order, two passes at a time
+        const uint32_t c_s = (uint32_t)__shfl((int)c_mine, lane & 31, 64);
+        uint32_t running = 0;
+        for (uint32_t q2 = 0; 8u * q2 < maxc; ++q2) {
+            const uint32_t q4 = 4u * (2u * q2 + (uint32_t)(lane >> 5));
+            const uint32_t v = c_s > q4 ? (c_s - q4 < 4u ? c_s - q4 : 4u) : 0u;
+            uint32_t inc = v;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+                if (lane >= off) inc += t;
+            }
+            table[64u * q2 + (uint32_t)lane] = running + inc - v;
+            running += (uint32_t)__shfl((int)inc, 63, 64);
+        }
+        wave_sync();
+    }
+    for (int e = lane; e < R; e += 64) {
+        const uint32_t k = key[e];
+        uint32_t pos = (uint32_t)e;  // mode 0: the sorted order itself
+        if (C.mode) {
+            const uint32_t s = k >> 20, rank = (uint32_t)e - first[s];
+            if (tabled) {
+                pos = table[32u * (rank >> 2) + s] + (rank & 3u);
+            } else {
+                const uint32_t q4 = rank & ~3u;
+                pos = rank & 3u;
+                for (uint32_t t = 0; t < 32u; ++t) {
+                    const uint32_t c = cnt[t];
+                    pos += c < q4 ? c : q4;
+                    if (t < s) {
+                        const uint32_t left = c > q4 ? c - q4 : 0u;
+                        pos += left < 4u ? left : 4u;
+                    }
+                }
+            }
+        }
+        words[r0 + pos] = C.word(k, high);
+    }
+    wave_sync();  // (key / first / cnt / table are reused by this wave's next bucket)
+}
+
+// ---- a whole workgroup, one bucket of up to kMaxBucketRows rows, any bucket width ---------------------------------
+__device__ __forceinline__ void block_bucket(uint32_t *__restrict__ words, int64_t r0, int R, const KeyCodec &C, uint32_t *key,
+                                             uint32_t *first /*[256]*/, uint32_t *cnt /*[256]*/, uint32_t *shared_high) {
+    const int tid = threadIdx.x;
+    const int S = 1 << C.bshift;
+    int P = 2;
+    while (P < R) P <<= 1;
+    for (int i = tid; i < P; i += 256) {
+        uint32_t k = 0xFFFFFFFFu;
+        if (i < R) {
+            const uint32_t w = words[r0 + i];
+            k = C.key(w);
+            if (i == 0) *shared_high = C.high_of(w);
+        }
+        key[i] = k;
+    }
+    for (int i = tid; i < S; i += 256) cnt[i] = 0;
+    __syncthreads();
+    const uint32_t high = *shared_high;
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int c = tid; c < (P >> 1); c += 256) {
+                const int lo = 2 * c - (c & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = key[lo], z = key[hi];
+                if ((a > z) == up) {
+                    key[lo] = z;
+                    key[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < R; i += 256) {
+        const uint32_t s = key[i] >> 20;
+        if (i == 0 || (key[i - 1] >> 20) != s) first[s] = (uint32_t)i;
+        if (i == R - 1 || (key[i + 1] >> 20) != s) cnt[s] = (uint32_t)i + 1u;
+    }
+    __syncthreads();
+    for (int i = tid; i < S; i += 256)
+        if (cnt[i]) cnt[i] -= first[i];
+    __syncthreads();
+    for (int i = tid; i < R; i += 256) {
+        const uint32_t k = key[i];
+        uint32_t pos = (uint32_t)i;
+        if (C.mode) {
+            const uint32_t s = k >> 20;
+            const uint32_t rank = (uint32_t)i - first[s], q4 = rank & ~3u;
+            pos = rank & 3u;
+            for (int t = 0; t < S; ++t) {
+                const uint32_t c = cnt[t];
+                pos += c < q4 ? c : q4;  // rows of start t in earlier passes
+                if ((uint32_t)t < s) {
+                    const uint32_t left = c > q4 ? c - q4 : 0u;
+                    pos += left < 4u ? left : 4u;  // this pass, starts before s
+                }
+            }
+        }
+        words[r0 + pos] = C.word(k, high);
+    }
+    __syncthreads();  // (the staging arrays are reused by the next bucket)
+}
+
+// mode 0: back to start order (start, overlap, annot); 1: chunks of four dealt over the starts, rows of a start by
+// (overlap, annot); 2: the same with the rows of a start by (overlap mod 32, overlap, annot)
+__global__ __launch_bounds__(256) void interleave_buckets_kernel(uint32_t *__restrict__ words, const int64_t *__restrict__ boff,
+                                                                 int64_t nbuckets, int bshift, int fmt12, int mode) {
+    __shared__ uint32_t key[kMaxBucketRows];
+    __shared__ uint32_t first[4][256], cnt[4][256];  // (block path: first[0] / cnt[0]; wave path: 32 entries of each wave's)
+    __shared__ uint32_t table[4][kWaveQ * 32];
+    __shared__ uint32_t shared_high;
+    KeyCodec C;
+    C.fmt12 = fmt12;
+    C.mode = mode;
+    C.bshift = bshift;
+    const int wave = threadIdx.x >> 6;
+    // four buckets per workgroup and turn: one per wave when all four are small, else one after the other by everybody
+    for (int64_t b0 = 4 * (int64_t)blockIdx.x; b0 < nbuckets; b0 += 4 * (int64_t)gridDim.x) {
+        int64_t r[5];
+        for (int j = 0; j < 5; ++j) r[j] = boff[b0 + j < nbuckets ? b0 + j : nbuckets];
+        int64_t longest = 0;
+        for (int j = 0; j < 4; ++j) longest = r[j + 1] - r[j] > longest ? r[j + 1] - r[j] : longest;
+        if (bshift == 5 && longest <= kWaveRows) {
+            const int64_t R = r[wave + 1] - r[wave];
+            if (R >= 2) wave_bucket(words, r[wave], (int)R, C, key + 256 * wave, first[wave], cnt[wave], table[wave]);
+        } else {
+            for (int j = 0; j < 4; ++j) {
+                const int64_t R = r[j + 1] - r[j];
+                if (R >= 2 && R <= kMaxBucketRows) block_bucket(words, r[j], (int)R, C, key, first[0], cnt[0], &shared_high);
+            }
+        }
+        __syncthreads();  // (a turn that took the wave path may be followed by one that takes the block path)
+    }
+}
+
+}  // namespace
+
+// words: rows of formats 4 / 12, boff: their bucket table (nb entries, the last pinned to the row count).  Queued on st.
+int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshift, int fmt, int mode, hipStream_t st) {
+    if (!words || !boff || nb < 2 || (fmt != 4 && fmt != 12) || bshift < 1 || bshift > 8) return MEMO_OK;
+    const int64_t nbuckets = (int64_t)nb - 1;
+    const int64_t turns = (nbuckets + 3) / 4;
+    const unsigned grid = (unsigned)(turns < 256 * 32 ? turns : 256 * 32);
+    hipLaunchKernelGGL(interleave_buckets_kernel, dim3(grid), dim3(256), 0, st, words, boff, nbuckets, bshift, fmt == 12 ? 1 : 0,
+                       mode);
+    HIP_TRY(hipGetLastError());
+    return MEMO_OK;
+}
+
+}  // namespace memo

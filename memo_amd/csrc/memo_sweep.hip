@@ -58,6 +58,7 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
     }
     if (A.tiles_per_xcd * 8 * threads >= ((int64_t)1 << 32))
         return fail(MEMO_EINVAL, "window too long for one launch at tile width %d", w);
+    if (g_prepare_only) return MEMO_OK;  // memo_index_prepare: everything a query builds on the way exists now; nothing is launched
     hipLaunchKernelGGL(kernel, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(threads), lds, st, A);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
@@ -66,6 +67,8 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
 // which row source a query reads: packed when the index has it and k - 1 <= 255, else the int64 columns.
 // fmt: 0 = int64 columns, 4 / 6 = packed words (+ 16-bit order column), 3 = only the dense rows are left
 // (memo_index_pack_dense dropped the words): k - 1 <= 63, and only kernels that read PackedRows3
+thread_local bool g_prepare_only = false;
+thread_local bool g_side_alloc_fails = false;
 PersistentLaunch g_persistent_launch = nullptr;  // set by memo_sweep_cons3p.o where it is linked in (the AB library)
 
 int pick_rows(const memo_index *ix, int32_t k, int &fmt) {
@@ -131,6 +134,10 @@ int memo_query_check(memo_index_t *ix, void *stream) {
     int flags = 0;
     HIP_TRY(hipMemcpyAsync(&flags, ix->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (!ix->retired.empty()) {  // buffers earlier queries took out of service: the caller is waiting anyway, so wait for
+        HIP_TRY(hipDeviceSynchronize());  // whatever its other streams still run on this index, and free them
+        flush_retired(ix);
+    }
     if (flags) {
         HIP_TRY(hipMemsetAsync(ix->d_status, 0, sizeof(int), st));
         HIP_TRY(hipStreamSynchronize(st));

@@ -994,7 +994,7 @@ static SweepKernel halo3_kernel(int waves) {
 template <typename OutT>
 static int long_rows_conservation(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int ncols,
                                   OutT *d_out, hipStream_t st) {
-    if (!ix->n_long) return MEMO_OK;
+    if (!ix->n_long || g_prepare_only) return MEMO_OK;
     const int64_t fqs = ix->whole_set ? ix->whole_qs : qs, fqe = ix->whole_set ? ix->whole_qe : qe;
     hipLaunchKernelGGL((long_rows_conservation_kernel<OutT>), dim3((unsigned)ix->n_long), dim3(256), 0, st,
                        ix->ls, ix->le, ix->lo, qs, qe, k - 1, ncols, d_out, ix->d_status, fqs, fqe);
@@ -1048,6 +1048,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     DeviceGuard guard(ix->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (k <= 1 || ix->rows == 0) {
+        if (g_prepare_only) return MEMO_OK;
         hipLaunchKernelGGL((fill_conservation_kernel<OutT>), dim3(2048), dim3(256), 0, st, d_out,
                            qe - qs, (OutT)num_docs);
         HIP_TRY(hipGetLastError());
@@ -1063,6 +1064,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     hipStream_t st_early = static_cast<hipStream_t>(stream);
     // the 4-byte words a sweep reads: the k-class view of them where one exists or is due (packed_rows_for, memo_index.hip)
     auto use_words = [&]() -> int {
+        ix->last_rows_read = ix->rows;  // (6-byte rows and the int64 columns have no views)
         if (fmt != 4 && fmt != 12) return MEMO_OK;
         uint32_t *vpk = nullptr;
         int64_t *vboff = nullptr;
@@ -1209,7 +1211,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                 ix->last_rows_read = vrows;
             }
             ix->last_variant = 0;
-            if (three && g_persistent_launch && tune.persistent >= 2 && tune.persistent <= 4) {
+            if (three && g_persistent_launch && tune.persistent >= 2 && tune.persistent <= 4 && !g_prepare_only) {
                 // persistent workgroups (memo_sweep_cons3p.hip, AB library only: 17 - 50 % slower than a workgroup per tile,
                 // profiles/r03_persistent_sweep.txt); 1 = this query does not fit it
                 const int prc = g_persistent_launch(A, tw, (int)sizeof(OutT), ix->device, tune.persistent - 2, st);

@@ -190,44 +190,54 @@ SweepKernel kernel_for(int nlev) {
 
 namespace memo {
 
-void drop_tile_tables(memo_index *ix) {
-    for (memo_index::TileTable &t : ix->ttab) {
+void drop_tile_tables(memo_index *ix) {  // (callers have the device drained: pack / destroy paths)
+    for (memo_index::TileTable &t : ix->ttabs)
         if (t.d) (void)hipFree(t.d);
-        t = memo_index::TileTable();
-    }
+    ix->ttabs.clear();
 }
 
-// the table of (index, tile width, k): built by the first query that needs it, kept with the index (four of them)
+// the table of (row source, tile width, k): built by the first query that needs it (or by memo_index_prepare), kept with the
+// index -- one per combination in use, so that a service that cycles through k classes finds every one of them again
+// (round 3 kept four and rebuilt, behind a hipDeviceSynchronize, on the fifth: ADVICE r03); past kMaxTileTables the least
+// recently used one is retired (memo_common.h: no wait on the query path)
 static int tile_table(memo_index *ix, const void *rows_of, const int64_t *boff, int w, int km1, hipStream_t st, const void **tab,
                       int64_t *ntab) {
     memo_index::TileTable *slot = nullptr;
-    for (memo_index::TileTable &t : ix->ttab)
+    for (memo_index::TileTable &t : ix->ttabs)
         if (t.d && t.w == w && t.km1 == km1 && t.rows_of == rows_of) slot = &t;
     if (!slot) {
-        slot = &ix->ttab[0];
-        for (memo_index::TileTable &t : ix->ttab)
-            if (t.stamp < slot->stamp) slot = &t;  // (an empty slot has stamp 0)
-        if (slot->d) {
-            HIP_TRY(hipDeviceSynchronize());  // (a sweep queued on any of the caller's streams may still read it)
-            (void)hipFree(slot->d);
-            *slot = memo_index::TileTable();
-        }
         const int64_t top = ix->max_s < 0 ? 0 : ix->max_s;
         const int64_t n = (top + km1 + ((int64_t)1 << ix->bshift)) / w + 3;  // past the last row: empty slices
         if (n >= ((int64_t)1 << 31)) return 1;
-        const hipError_t aerr = side_alloc(&slot->d, (size_t)n * sizeof(TileDesc));
+        if (ix->ttabs.size() >= kMaxTileTables) {
+            size_t lru = 0;
+            for (size_t i = 1; i < ix->ttabs.size(); ++i)
+                if (ix->ttabs[i].stamp < ix->ttabs[lru].stamp) lru = i;
+            retire(ix, ix->ttabs[lru].d, (uint64_t)ix->ttabs[lru].n * sizeof(TileDesc));
+            ix->ttabs.erase(ix->ttabs.begin() + (long)lru);
+        }
+        void *d = nullptr;
+        const hipError_t aerr = side_alloc(&d, (size_t)n * sizeof(TileDesc));
         if (aerr == hipErrorOutOfMemory) return kNoRoom;  // (the caller takes the kernel that needs no table)
         HIP_TRY(aerr);
         hipLaunchKernelGGL(tile_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, boff, (int64_t)ix->nb, ix->bbase,
-                           ix->bshift, w, km1, n, static_cast<TileDesc *>(slot->d));
-        HIP_TRY(hipGetLastError());
+                           ix->bshift, w, km1, n, static_cast<TileDesc *>(d));
+        hipError_t err = hipGetLastError();
         // complete before this call returns: the next query may come on another stream, and nothing would order its sweep
         // behind this kernel (once per index, tile width and k: some tens of microseconds)
-        HIP_TRY(hipStreamSynchronize(st));
-        slot->rows_of = rows_of;
-        slot->w = w;
-        slot->km1 = km1;
-        slot->n = n;
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+        if (err != hipSuccess) {
+            (void)hipFree(d);
+            return fail(MEMO_EHIP, "tile table: %s", hipGetErrorString(err));
+        }
+        memo_index::TileTable t;
+        t.rows_of = rows_of;
+        t.w = w;
+        t.km1 = km1;
+        t.d = d;
+        t.n = n;
+        ix->ttabs.push_back(t);
+        slot = &ix->ttabs.back();
     }
     slot->stamp = ++ix->ttab_clock;
     *tab = slot->d;
@@ -261,6 +271,7 @@ int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStrea
     // waves per CU hide the scatter's LDS latency worse than thirty-two, whatever they save in instructions.)
     SweepKernel kern = elem_bytes == 1 ? kernel_for<uint8_t, 256>(A.nlev) : kernel_for<uint16_t, 256>(A.nlev);
     if (!kern) return 1;
+    if (g_prepare_only) return MEMO_OK;  // memo_index_prepare: the table is built, nothing is launched
     hipLaunchKernelGGL(kern, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(256), (size_t)A.nlev * 4096, st, A);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;

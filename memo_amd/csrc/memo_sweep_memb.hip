@@ -424,7 +424,7 @@ SweepKernel memb_runs_kernel(int w, int waves) {
 
 static int long_rows_membership(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int ncols, int nw,
                                 uint32_t *d_out, hipStream_t st) {
-    if (!ix->n_long) return MEMO_OK;
+    if (!ix->n_long || g_prepare_only) return MEMO_OK;
     hipLaunchKernelGGL(long_rows_membership_kernel, dim3((unsigned)ix->n_long), dim3(256), 0, st, ix->ls,
                        ix->le, ix->lo, qs, qe, k - 1, ncols, nw, d_out, ix->d_status,
                        ix->whole_set ? ix->whole_qs : qs, ix->whole_set ? ix->whole_qe : qe);
@@ -443,6 +443,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nw = (num_docs + 31) / 32;
     if (k <= 1 || ix->rows == 0) {
+        if (g_prepare_only) return MEMO_OK;
         hipLaunchKernelGGL(fill_membership_kernel, dim3(2048), dim3(256), 0, st, d_out,
                            (qe - qs) * nw, nw, num_docs);
         HIP_TRY(hipGetLastError());
@@ -596,10 +597,10 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                                                  : memb_runs_kernel<PackedRows<true, false>>(w, waves))
                                       : memb_runs_kernel<WideRows>(w, waves);
         if (!kern) return fail(MEMO_EINVAL, "unsupported tile width %d", w);
+        if ((rc = use_words())) return rc;  // (once per query: every slice of genome words reads the same rows)
         for (int base = 0; base < nw; base += slice) {
             A.word_base = base;
             A.nwords = nw - base < slice ? nw - base : slice;
-            if ((rc = use_words())) return rc;
             if ((rc = launch_tiles(kern, A, w, 64 * waves, lds, st))) return rc;
         }
         return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);

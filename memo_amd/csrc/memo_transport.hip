@@ -244,8 +244,14 @@ __global__ void dense_exceptions_kernel(const unsigned long long *exc, const uns
 // ------------------------------------------------------------------------------------------
 constexpr int kRunsStaged = 8192;  // bytes of a block's values staged in LDS (config 3: ~3300 per block); more: straight to / from HBM
 
-__global__ __launch_bounds__(256) void runs_pack_kernel(const uint8_t *in, int64_t n, uint16_t *A, uint8_t *B,
+// V = uint8_t (results of at most 255 genomes) or uint16_t (BASELINE config 5: 500 genomes -- round 4: a config-5 slice
+// travelled as 67 MB of plain bytes, 0.9 ms of link against sweeps of 0.2-0.6 ms).  Same streams; B holds sizeof(V)
+// bytes per marked position, a thread loads its sixteen positions as one or two 16-byte pieces.
+template <typename V>
+__global__ __launch_bounds__(256) void runs_pack_kernel(const V *in, int64_t n, uint16_t *A, uint8_t *B,
                                                         uint2 *table, unsigned int *head, unsigned int b_cap) {
+    constexpr int VB = (int)sizeof(V), NW = 4 * VB;  // bytes per value; dwords per thread and round
+    constexpr uint32_t VMASK = VB == 1 ? 0xFFu : 0xFFFFu;
     __shared__ __attribute__((aligned(16))) uint8_t vals[kRunsStaged];
     __shared__ int wave_sum[kRounds][4];
     __shared__ uint32_t wave_last[kRounds][4];  // the last value of every (round, wave): the next wave's "value before"
@@ -254,26 +260,38 @@ __global__ __launch_bounds__(256) void runs_pack_kernel(const uint8_t *in, int64
     const int64_t block = blockIdx.x;
     if (block == 0 && tid == 0) head[1] = b_cap;
 
-    uint32_t w[kRounds][4];
+    uint32_t w[kRounds][NW];
     uint32_t before[kRounds];  // the value at the position before this thread's sixteen
     int prefix[kRounds];
     uint32_t marks[kRounds];
+    auto value = [&](int c, int i) -> uint32_t {  // (static c and i everywhere below: registers are never indexed dynamically)
+        return VB == 1 ? (w[c][i >> 2] >> (8 * (i & 3))) & 0xFFu : (w[c][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+    };
 #pragma unroll
     for (int c = 0; c < kRounds; ++c) {
         const int64_t p0 = (block * kRounds + c) * kChunk + (int64_t)tid * kPerThread;
-        w[c][0] = w[c][1] = w[c][2] = w[c][3] = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) w[c][j] = 0;
         if (p0 + kPerThread <= n) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(in + p0);
-            w[c][0] = q.x, w[c][1] = q.y, w[c][2] = q.z, w[c][3] = q.w;
+#pragma unroll
+            for (int h = 0; h < VB; ++h) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(in + p0) + 16 * h);
+                w[c][4 * h + 0] = q.x, w[c][4 * h + 1] = q.y, w[c][4 * h + 2] = q.z, w[c][4 * h + 3] = q.w;
+            }
         } else {
-            for (int i = 0; i < kPerThread && p0 + i < n; ++i) w[c][i >> 2] |= (uint32_t)in[p0 + i] << (8 * (i & 3));
+#pragma unroll
+            for (int i = 0; i < kPerThread; ++i)
+                if (p0 + i < n) {
+                    if (VB == 1) w[c][i >> 2] |= (uint32_t)in[p0 + i] << (8 * (i & 3));
+                    else w[c][i >> 1] |= (uint32_t)in[p0 + i] << (16 * (i & 1));
+                }
         }
     }
     // the value before a thread's sixteen positions: its left neighbour's last one; lane 0 takes it from the wave
     // before (through LDS), the block's first thread needs none (a block starts with a marked position)
 #pragma unroll
     for (int c = 0; c < kRounds; ++c) {
-        const uint32_t last = w[c][3] >> 24;
+        const uint32_t last = value(c, kPerThread - 1);
         before[c] = (uint32_t)__shfl_up((int)last, 1, 64);
         if (lane == 63) wave_last[c][wv] = last;
     }
@@ -285,7 +303,7 @@ __global__ __launch_bounds__(256) void runs_pack_kernel(const uint8_t *in, int64
         uint32_t m = 0, prev = before[c];
 #pragma unroll
         for (int i = 0; i < kPerThread; ++i) {
-            const uint32_t v = (w[c][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            const uint32_t v = value(c, i);
             m |= (v != prev ? 1u : 0u) << i;
             prev = v;
         }
@@ -303,38 +321,38 @@ __global__ __launch_bounds__(256) void runs_pack_kernel(const uint8_t *in, int64
     int total = 0;
 #pragma unroll
     for (int c = 0; c < kRounds; ++c) total += wave_sum[c][0] + wave_sum[c][1] + wave_sum[c][2] + wave_sum[c][3];
-    const unsigned int bytes = (unsigned int)((total + 3) & ~3);
-    const bool staged = total <= kRunsStaged;  // (block-uniform)
+    const unsigned int bytes = (unsigned int)((total * VB + 3) & ~3);
+    const bool staged = total * VB <= kRunsStaged;  // (block-uniform)
     if (tid == 0) {
         b_off = bytes ? atomicAdd(head, bytes) : 0u;
         table[block] = make_uint2(b_off, (unsigned int)total);
     }
     __syncthreads();
     const bool fits = (uint64_t)b_off + bytes <= b_cap;  // else: head[0] > head[1] tells the caller
-    auto scatter_values = [&](auto *dst) {  // (LDS or HBM: two instantiations, no generic pointer)
-        int run = 0;  // bytes of the rounds before this one
+    auto scatter_values = [&](V *dst) {  // (LDS or HBM)
+        int run = 0;  // values of the rounds before this one
 #pragma unroll
         for (int c = 0; c < kRounds; ++c) {
             const int s0 = wave_sum[c][0], s1 = wave_sum[c][1], s2 = wave_sum[c][2], s3 = wave_sum[c][3];
             int r = run + (wv > 0 ? s0 : 0) + (wv > 1 ? s1 : 0) + (wv > 2 ? s2 : 0) + prefix[c];
             run += s0 + s1 + s2 + s3;
             const uint32_t m = marks[c];
-            if (m) {  // (static byte numbers: a loop over the set bits would index the registers dynamically --
-#pragma unroll        //  a chain of selects per byte, 8x the instructions of the whole kernel)
+            if (m) {  // (static value numbers: a loop over the set bits would index the registers dynamically --
+#pragma unroll        //  a chain of selects per value, 8x the instructions of the whole kernel)
                 for (int j = 0; j < 4; ++j) {
-                    if ((m >> (4 * j)) & 0xFu) {  // (one position in ten is marked: most dwords have none)
+                    if ((m >> (4 * j)) & 0xFu) {  // (one position in ten is marked: most quartets have none)
 #pragma unroll
                         for (int i = 4 * j; i < 4 * j + 4; ++i)
-                            if ((m >> i) & 1u) dst[r++] = (uint8_t)(w[c][j] >> (8 * (i & 3)));
+                            if ((m >> i) & 1u) dst[r++] = (V)(value(c, i) & VMASK);
                     }
                 }
             }
         }
     };
     if (staged)
-        scatter_values(vals);
+        scatter_values(reinterpret_cast<V *>(vals));
     else if (fits)
-        scatter_values(B + b_off);
+        scatter_values(reinterpret_cast<V *>(B + b_off));
     if (staged) {
         __syncthreads();
         if (bytes && fits) {
@@ -345,22 +363,24 @@ __global__ __launch_bounds__(256) void runs_pack_kernel(const uint8_t *in, int64
     }
 }
 
+template <typename V>
 __global__ __launch_bounds__(256) void runs_unpack_kernel(const uint16_t *A, const uint8_t *B, const uint2 *table,
-                                                          unsigned int b_cap, int64_t n, uint8_t *out) {
+                                                          unsigned int b_cap, int64_t n, V *out) {
+    constexpr int VB = (int)sizeof(V), NW = 4 * VB;
     __shared__ __attribute__((aligned(16))) uint8_t vals[kRunsStaged];
     __shared__ int wave_sum[kRounds][4];
     const int tid = threadIdx.x, wv = tid >> 6;
     const int64_t block = blockIdx.x;
     const uint2 ent = table[block];
-    const unsigned int bytes = (ent.y + 3u) & ~3u;
+    const unsigned int bytes = (ent.y * (unsigned int)VB + 3u) & ~3u;
     if ((uint64_t)ent.x + bytes > b_cap) return;  // this block did not fit on the sender's side (stats say so)
-    const bool staged = ent.y <= (unsigned int)kRunsStaged;
+    const bool staged = ent.y * (unsigned int)VB <= (unsigned int)kRunsStaged;
     if (staged) {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(B + ent.x);
         uint32_t *dst = reinterpret_cast<uint32_t *>(vals);
         for (unsigned int i = tid; i < bytes / 4; i += 256) dst[i] = src[i];
     }
-    const uint8_t *val = staged ? vals : B + ent.x;
+    const V *val = staged ? reinterpret_cast<const V *>(vals) : reinterpret_cast<const V *>(B + ent.x);
     uint32_t marks[kRounds];
     int prefix[kRounds];
 #pragma unroll
@@ -381,17 +401,25 @@ __global__ __launch_bounds__(256) void runs_unpack_kernel(const uint16_t *A, con
         const int64_t p0 = (block * kRounds + c) * kChunk + (int64_t)tid * kPerThread;
         if (p0 >= n) continue;
         uint32_t cur = r > 0 ? val[r - 1] : 0u;  // (r == 0 only for the block's first thread, whose first bit is set)
-        uint32_t q[4] = {0, 0, 0, 0};
+        uint32_t q[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) q[j] = 0;
         const uint32_t m = marks[c];
 #pragma unroll
         for (int i = 0; i < kPerThread; ++i) {
             if ((m >> i) & 1u) cur = val[r++];
-            q[i >> 2] |= cur << (8 * (i & 3));
+            if (VB == 1) q[i >> 2] |= cur << (8 * (i & 3));
+            else q[i >> 1] |= cur << (16 * (i & 1));
         }
         if (p0 + kPerThread <= n) {
-            *reinterpret_cast<uint4 *>(out + p0) = make_uint4(q[0], q[1], q[2], q[3]);
+#pragma unroll
+            for (int h = 0; h < VB; ++h)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(out + p0) + 16 * h) =
+                    make_uint4(q[4 * h], q[4 * h + 1], q[4 * h + 2], q[4 * h + 3]);
         } else {
-            for (int i = 0; i < kPerThread && p0 + i < n; ++i) out[p0 + i] = (uint8_t)(q[i >> 2] >> (8 * (i & 3)));
+#pragma unroll
+            for (int i = 0; i < kPerThread; ++i)
+                if (p0 + i < n) out[p0 + i] = VB == 1 ? (V)(q[i >> 2] >> (8 * (i & 3))) : (V)(q[i >> 1] >> (16 * (i & 1)));
         }
     }
 }
@@ -411,11 +439,11 @@ RunsLayout runs_layout(int64_t n, uint32_t b_cap) {
     return l;
 }
 
-int runs_check_args(const void *d_vec, const void *d_wire, int64_t n, uint32_t b_cap) {
+int runs_check_args(const void *d_vec, const void *d_wire, int64_t n, uint32_t b_cap, int value_bytes = 1) {
     if (n < 0 || (n > 0 && (!d_vec || !d_wire))) return fail(MEMO_EINVAL, "bad transport arguments");
-    // 32-bit offsets into the B region: the worst case -- every position marked, n bytes + 4 per block of rounding
-    if (n + 4 * ((n + kBlock - 1) / kBlock) >= ((int64_t)1 << 32) - 64)
-        return fail(MEMO_EINVAL, "slice too long for the runs coding (at most ~2^32 positions per slice)");
+    // 32-bit offsets into the B region: the worst case -- every position marked, n values + 4 bytes per block of rounding
+    if (n * value_bytes + 4 * ((n + kBlock - 1) / kBlock) >= ((int64_t)1 << 32) - 64)
+        return fail(MEMO_EINVAL, "slice too long for the runs coding (at most ~2^32 bytes of values per slice)");
     if (b_cap % 4) return fail(MEMO_EINVAL, "the B region's capacity must be a multiple of 4");
     if (((uintptr_t)d_vec & 15) || ((uintptr_t)d_wire & 15))
         return fail(MEMO_EINVAL, "transport buffers must be 16-byte aligned");
@@ -528,9 +556,12 @@ size_t memo_transport_runs_bytes(int64_t n, uint32_t b_capacity) {
     return n < 0 ? 0 : runs_layout(n, b_capacity).bytes;
 }
 
-int memo_transport_runs_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t b_capacity, void *d_wire, int32_t device,
-                                 void *stream) {
-    int rc = runs_check_args(d_vec, d_wire, n, b_capacity);
+}  // extern "C"
+
+namespace {
+template <typename V>
+int runs_pack(const V *d_vec, int64_t n, uint32_t b_capacity, void *d_wire, int32_t device, void *stream) {
+    int rc = runs_check_args(d_vec, d_wire, n, b_capacity, (int)sizeof(V));
     if (rc) return rc;
     DeviceGuard guard(device);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -540,7 +571,7 @@ int memo_transport_runs_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t b_cap
     HIP_TRY(hipMemsetAsync(w, 0, 16, st));
     if (l.blocks) {
         if (l.blocks >= ((int64_t)1 << 31)) return fail(MEMO_EINVAL, "slice too long for one launch");
-        hipLaunchKernelGGL(runs_pack_kernel, dim3((unsigned)l.blocks), dim3(256), 0, st, d_vec, n,
+        hipLaunchKernelGGL(runs_pack_kernel<V>, dim3((unsigned)l.blocks), dim3(256), 0, st, d_vec, n,
                            reinterpret_cast<uint16_t *>(w + l.a_off), reinterpret_cast<uint8_t *>(w + l.b_off),
                            reinterpret_cast<uint2 *>(w + l.t_off), reinterpret_cast<unsigned int *>(w), b_capacity);
         HIP_TRY(hipGetLastError());
@@ -550,21 +581,45 @@ int memo_transport_runs_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t b_cap
     return MEMO_OK;
 }
 
-int memo_transport_runs_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint8_t *d_vec, int32_t device,
-                                   void *stream) {
-    int rc = runs_check_args(d_vec, d_wire, n, b_capacity);
+template <typename V>
+int runs_unpack(const void *d_wire, int64_t n, uint32_t b_capacity, V *d_vec, int32_t device, void *stream) {
+    int rc = runs_check_args(d_vec, d_wire, n, b_capacity, (int)sizeof(V));
     if (rc) return rc;
     DeviceGuard guard(device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const char *w = static_cast<const char *>(d_wire);
     const RunsLayout l = runs_layout(n, b_capacity);
     if (l.blocks) {
-        hipLaunchKernelGGL(runs_unpack_kernel, dim3((unsigned)l.blocks), dim3(256), 0, st,
+        hipLaunchKernelGGL(runs_unpack_kernel<V>, dim3((unsigned)l.blocks), dim3(256), 0, st,
                            reinterpret_cast<const uint16_t *>(w + l.a_off), reinterpret_cast<const uint8_t *>(w + l.b_off),
                            reinterpret_cast<const uint2 *>(w + l.t_off), b_capacity, n, d_vec);
         HIP_TRY(hipGetLastError());
     }
     return MEMO_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int memo_transport_runs_pack_dev(const uint8_t *d_vec, int64_t n, uint32_t b_capacity, void *d_wire, int32_t device,
+                                 void *stream) {
+    return runs_pack<uint8_t>(d_vec, n, b_capacity, d_wire, device, stream);
+}
+
+int memo_transport_runs_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint8_t *d_vec, int32_t device,
+                                   void *stream) {
+    return runs_unpack<uint8_t>(d_wire, n, b_capacity, d_vec, device, stream);
+}
+
+// the same coding for uint16 results (more than 255 genomes): two bytes per marked position in the B region
+int memo_transport_runs16_pack_dev(const uint16_t *d_vec, int64_t n, uint32_t b_capacity, void *d_wire, int32_t device,
+                                   void *stream) {
+    return runs_pack<uint16_t>(d_vec, n, b_capacity, d_wire, device, stream);
+}
+
+int memo_transport_runs16_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint16_t *d_vec, int32_t device,
+                                     void *stream) {
+    return runs_unpack<uint16_t>(d_wire, n, b_capacity, d_vec, device, stream);
 }
 
 // what the sender needed (host values; synchronises `stream`): B bytes taken against the B region's capacity.

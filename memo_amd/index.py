@@ -110,8 +110,22 @@ class DeviceIndex:
 
     def info(self):
         inf = _lib.IndexInfo()
+        inf.struct_bytes = C.sizeof(inf)           # the versioned struct: the library writes no more than this
         check(lib().memo_index_get_info(self._h, C.byref(inf)))
         return {k: getattr(inf, k) for k, _ in inf._fields_}
+
+    def prepare(self, k, num_docs, membership=False, window_hint=0, stream=None):
+        """memo_index_prepare: build now what queries of this kind would build on the way (the k-class view of the rows,
+        the tile table, the query order of rows that came in through the builder); returns the device bytes it took"""
+        taken = C.c_uint64(0)
+        check(lib().memo_index_prepare(self._h, int(k), int(num_docs), 1 if membership else 0, int(window_hint), _ptr(stream),
+                                       C.byref(taken)))
+        return taken.value
+
+    def set_option(self, option, value):
+        """memo_index_set_option: 1 = MEMO_OPT_VIEWS (0 / 1), 2 = MEMO_OPT_VIEW_BUDGET_PCT"""
+        check(lib().memo_index_set_option(self._h, int(option), int(value)))
+        return self
 
     # ---- asynchronous launches on device buffers (torch tensors or raw addresses) ----
     def conservation_dev(self, qs, qe, k, num_docs, out, stream=None):
@@ -126,6 +140,13 @@ class DeviceIndex:
     # ---- include/memo_amd_debug.h: only with _lib.use_ab() (libmemo_amd_ab.so) ----
     def debug_stream_rows(self, stream=None):
         check(lib().memo_debug_stream_rows(self._h, _ptr(stream)))
+
+    def debug_no_views(self, on=True):
+        check(lib().memo_debug_no_views(self._h, 1 if on else 0))
+        return self
+
+    def debug_row_order(self, order):
+        check(lib().memo_debug_row_order(self._h, int(order)))
 
     def debug_set_tuning(self, tile_w=0, waves=0, membership_algo=0, row_source=0, scatter=0):
         check(lib().memo_debug_set_tuning(self._h, tile_w, waves, membership_algo, row_source, scatter))

@@ -39,13 +39,9 @@ def _dense_can_answer(rows, k, n, membership):
     """the library's own rule (memo_dense_rows_can_answer) on host columns"""
     from memo_amd.index import dense_rows_can_answer
     s, e, o = rows
-    if not len(s) or int(o.min()) < 0 or not dense_rows_can_answer(len(s), int(s[0]), int(s[-1]), int(o.max()), k, n, membership):
-        return False
-    # the dense rows leave out the rows that can never write at k <= 64 (overlap >= 63, end < start) when those are more
-    # than a tenth of the rows (dense_compact); what is left still has to be a row per position
-    kept = int(((e - s >= 0) & (e - s < 63)).sum())
-    drows = len(s) if kept + len(s) // 10 > len(s) else kept
-    return dense_rows_can_answer(drows, int(s[0]), int(s[-1]), int(o.max()), k, n, membership)
+    # (ALL the index's rows against its span, as query_conservation judges it: rows that can never write at k <= 64 may have
+    # left the dense rows -- dense_compact -- without changing what the index can answer; ADVICE r03)
+    return bool(len(s)) and int(o.min()) >= 0 and dense_rows_can_answer(len(s), int(s[0]), int(s[-1]), int(o.max()), k, n, membership)
 
 
 _ONE_SHOT_SWEEPS = {}
@@ -90,20 +86,24 @@ def test_golden_one_shot_reached_the_benchmarked_kernel():
 
 
 @pytest.mark.parametrize("c", G.cases(raises=False)[::4], ids=lambda c: c["name"])
-def test_golden_one_shot_int64_way_in(c, memo, monkeypatch):
-    """the same goldens with the packed way in switched off (MEMO_ONESHOT_WIDE): int64 columns uploaded,
-    finalized on the device, WideRows kernels -- what k > 256 and unpackable rows get"""
+def test_golden_one_shot_int64_way_in(c, memo, ab):
+    """the same goldens with the packed way in switched off (memo_debug_one_shot_way(1) of the AB library): int64 columns
+    uploaded, finalized on the device, WideRows kernels -- what k > 256 and unpackable rows get"""
     from memo_amd.index import bits_to_matrix
-    monkeypatch.setenv("MEMO_ONESHOT_WIDE", "1")
-    rec, qs, qe = G.region(c)
-    z = G.load(c)
-    rows = G.index_columns(c["index"], rec)
-    if c["membership"]:
-        got = memo.membership(*rows, qs, qe, c["k"], c["n"])
-        assert np.array_equal(bits_to_matrix(got, c["n"]), G.expected_matrix(c, z))
-    else:
-        got = memo.conservation(*rows, qs, qe, c["k"], c["n"])
-        assert np.array_equal(got.astype(np.int64), z["vec"])
+    ab.check(ab.lib().memo_debug_one_shot_way(1))
+    try:
+        rec, qs, qe = G.region(c)
+        z = G.load(c)
+        rows = G.index_columns(c["index"], rec)
+        if c["membership"]:
+            got = memo.membership(*rows, qs, qe, c["k"], c["n"])
+            assert np.array_equal(bits_to_matrix(got, c["n"]), G.expected_matrix(c, z))
+        else:
+            got = memo.conservation(*rows, qs, qe, c["k"], c["n"])
+            assert np.array_equal(got.astype(np.int64), z["vec"])
+        assert ab.lib().memo_debug_last_one_shot_sweep() in (0, 1, 7)      # (0: nothing to sweep; 1 / 7: the int64-row kernels)
+    finally:
+        ab.check(ab.lib().memo_debug_one_shot_way(0))
 
 
 def test_goldens_on_dense_only_resident_indexes(memo):
@@ -447,7 +447,11 @@ def test_builder_equals_int64_upload(n_rows, n_docs, pieces, memo, oracle):
             with memo.DeviceIndex.from_host(s, e, o) as ref:
                 ref.pack(keep_wide=True)
                 assert ref.info()["buckets"] == inf["buckets"]
-                # the host packer's words, 16-bit annots and bucket table are the device's, bit for bit
+                # the host packer's words, 16-bit annots and bucket table are the device's, bit for bit -- once the builder's
+                # rows are in the query order too (memo_index_pack on a packed index; else: by the fifth query that reads them)
+                assert inf["row_order"] == 0
+                ix.pack(keep_wide=False)
+                assert ix.info()["row_order"] == ref.info()["row_order"] == (0 if _fmt(n_docs) == 6 else 2)
                 a, b = _export(ix), _export(ref)
                 assert all(np.array_equal(x, y) for x, y in zip(a, b))
                 for k in (31, 101):
@@ -458,7 +462,7 @@ def test_builder_equals_int64_upload(n_rows, n_docs, pieces, memo, oracle):
 
 
 @pytest.mark.parametrize("n_rows,n_docs,pieces", [(300_003, 90, 1), (300_001, 255, 9), (9_500_002, 200, 3), (6, 5, 1), (4, 5, 2)])
-def test_dense_builder_equals_device_packing(n_rows, n_docs, pieces, memo, oracle):
+def test_dense_builder_equals_device_packing(n_rows, n_docs, pieces, memo, oracle, ab):
     """memo_builder_create_rows(MEMO_ROWS_DENSE): rows narrowed on the host straight to the dense format (five rows per
     16 bytes; PCIe carries 3.2 B per row), pushed in ragged pieces that end inside a group -- the groups, bucket table
     and long rows are bit for bit what memo_index_pack + memo_index_pack_dense build on the device, and the index answers
@@ -487,7 +491,8 @@ def test_dense_builder_equals_device_packing(n_rows, n_docs, pieces, memo, oracl
             assert inf["rows"] == n_rows and inf["dense_rows"] == 1 and inf["has_wide"] == 0 and inf["finalized"] == 1
             assert inf["device_bytes"] < 3.3 * n_rows + 16 * inf["buckets"] + 2_000_000
             with memo.DeviceIndex.from_host(s, e, o) as ref:
-                ref.pack(keep_wide=False)
+                ref.debug_row_order(1)        # (the device's groups in START order, as the host builder emits them: the 4-byte
+                ref.pack(keep_wide=False)     #  words they are made from are otherwise dealt over their buckets' starts)
                 ref.pack_dense(keep_packed=False)
                 got, want = export(ix), export(ref)
                 assert inf["dense_row_count"] == ref.info()["dense_row_count"]
@@ -669,6 +674,7 @@ def test_builder_rows_with_end_before_start_and_empty(memo, oracle):
         with memo.DeviceIndex.from_host(s, e, o) as ref:
             ref.pack()
             assert ix.info()["long_rows"] == ref.info()["long_rows"] == int(neg.sum())
+            ix.pack(keep_wide=False)                                # (the builder's rows into the query order: memo_interleave.hip)
             assert all(np.array_equal(x, y) for x, y in zip(_export(ix), _export(ref)))
         _check_windows(ix, s, e, o, 40, rng, oracle, 60_000, ks=(3, 31, 200), windows=3)
         for L in (1, 2, 3, 5, 7):                                   # result tails shorter than a 32-bit word
@@ -1127,19 +1133,25 @@ def test_config3_full_size_properties(membership, pack, dtype, k, memo, oracle):
         assert inf["packed_format"] == (4 if pack else 0) and inf["has_wide"] == (0 if pack in ("only", "dense") else 1)
         assert inf["dense_rows"] == int(pack == "dense")
         full = np.empty((L, W), np.uint32) if membership else np.empty(L, dtype)
-        d = C.c_void_p()
-        _lib.check(_lib.lib().memo_dev_malloc(0, full.nbytes, C.byref(d)))
-        try:
-            if membership:
-                ix.membership_dev(0, L, k, n, d.value)
-            elif dtype == np.uint8:
-                ix.conservation_u8_dev(0, L, k, n, d.value)
-            else:
-                ix.conservation_dev(0, L, k, n, d.value)
-            ix.check()
-            _lib.check(_lib.lib().memo_dev_download(0, full.ctypes.data, d, full.nbytes, None))
-        finally:
-            _lib.lib().memo_dev_free(0, d)
+
+        def whole_window(into, times=1):
+            d = C.c_void_p()
+            _lib.check(_lib.lib().memo_dev_malloc(0, into.nbytes, C.byref(d)))
+            try:
+                for _ in range(times):
+                    if membership:
+                        ix.membership_dev(0, L, k, n, d.value)
+                    elif dtype == np.uint8:
+                        ix.conservation_u8_dev(0, L, k, n, d.value)
+                    else:
+                        ix.conservation_dev(0, L, k, n, d.value)
+                ix.check()
+                _lib.check(_lib.lib().memo_dev_download(0, into.ctypes.data, d, into.nbytes, None))
+            finally:
+                _lib.lib().memo_dev_free(0, d)
+
+        whole_window(full)
+        assert ix.info()["last_rows_read"] == r1 - r0          # (the first query of a class reads all the rows)
         bad, fnv = oracle.synth_window_compare(full, 0, L, k, n, L, membership=membership)
         assert bad == 0, f"{bad} chunks of the whole-window result differ from the oracle"
         assert _C3_FNV.setdefault((membership, k), fnv) == fnv
@@ -1154,6 +1166,20 @@ def test_config3_full_size_properties(membership, pack, dtype, k, memo, oracle):
             assert np.array_equal(sub, full[a + 17:b - 5]), a
         if not membership:
             assert full.min() >= 1 and full.max() == n
+        if pack and k == 31:
+            # THE SCOREBOARD INSTANTIATION: what bench.py times is the sweep on the k-class VIEW of the
+            # rows -- built by the class's fifth query -- read through the tile table.  The whole window again, until the
+            # library reads the view, and THAT result against the oracle over all 10^8 positions (not a sub-window, not an
+            # inference from the all-rows result).
+            again = np.empty_like(full)
+            whole_window(again, times=6)
+            inf = ix.info()
+            assert inf["last_rows_read"] < r1 - r0 and abs(inf["last_rows_read"] / (r1 - r0) - 0.5) < 0.01, inf
+            assert inf["views_resident"] >= 1
+            if pack == "dense" and not membership:
+                assert inf["last_sweep"] == 5 and inf["last_variant"] == 2 and inf["tile_tables_resident"] >= 1, inf
+            bad2, fnv2 = oracle.synth_window_compare(again, 0, L, k, n, L, membership=membership)
+            assert bad2 == 0 and fnv2 == fnv, f"{bad2} chunks of the view's whole-window result differ from the oracle"
 
 
 # ---------------------------------------------------------------------------------------
@@ -1403,8 +1429,17 @@ def test_config5_shard_packed_rows(memo, oracle):
         for k in (21, 31, 101):
             full = ix.conservation(qs, qe, k, n)
             assert full.dtype == np.uint16 and 1 <= full.min() and full.max() <= n
-            bad, _ = oracle.synth_window_compare(full, qs, qe, k, n, pivot)   # the WHOLE 2^25-position shard
+            assert ix.info()["last_rows_read"] == r1 - r0 or k != 21
+            bad, fnv = oracle.synth_window_compare(full, qs, qe, k, n, pivot)   # the WHOLE 2^25-position shard
             assert bad == 0, (k, bad)
+            if k in (21, 31):     # the benchmarked regime: the k-class view of the words (built by the fifth query), whole shard
+                for _ in range(5):
+                    again = ix.conservation(qs, qe, k, n)
+                inf = ix.info()
+                assert inf["last_rows_read"] < r1 - r0 and abs(inf["last_rows_read"] / (r1 - r0) - (k - 1) / 60) < 0.01, (k, inf)
+                bad2, fnv2 = oracle.synth_window_compare(again, qs, qe, k, n, pivot)
+                assert bad2 == 0 and fnv2 == fnv, (k, bad2)
+            assert ix.info()["row_order"] == 2      # (memo_index_pack dealt the rows over their buckets' starts)
             for a in [qs, qe - 200_000] + [int(x) for x in rng.integers(qs, qe - 200_000, 3)]:
                 b = a + 200_000
                 sr0, sr1 = synth.shard_rows(a, b, k, num, den, pivot)
@@ -1574,15 +1609,16 @@ def test_bench_two_ranks_on_one_gpu(n_ranks, workload, extra):
     assert j["value"] > 0 and j["config"]["gather_payload"]
 
 
-def test_no_room_on_the_device_for_views_and_tile_tables(memo, oracle, monkeypatch):
-    """Views and tile tables are optimisations: when the device has no memory left for them (MEMO_VIEW_ALLOC_FAIL=1 makes
-    those allocations fail the way a full device does) queries answer from the rows they have -- same results, no error,
+def test_no_room_on_the_device_for_views_and_tile_tables(memo, oracle, ab):
+    """Views and tile tables are optimisations: when the device has no memory left for them (memo_debug_fail_side_allocations
+    of the AB library makes those allocations fail the way a full device does) queries answer from the rows they have -- same results, no error,
     info.last_variant / last_rows_read say that no table and no view were used.  Row dropping at pack time keeps every row."""
     from memo_amd import synth
     n, L = 100, 800_000
     num, den = synth.rows_per_position(n)
-    monkeypatch.setenv("MEMO_VIEW_ALLOC_FAIL", "1")
-    for pack in ("dense", "only"):
+    ab.check(ab.lib().memo_debug_fail_side_allocations(1))
+    try:
+      for pack in ("dense", "only"):
         ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack=pack)
         s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, n)
         with ix:
@@ -1592,10 +1628,13 @@ def test_no_room_on_the_device_for_views_and_tile_tables(memo, oracle, monkeypat
                     assert np.array_equal(ix.conservation(4, L - 3, k, n), want), (pack, k)
                 inf = ix.info()
                 assert inf["last_rows_read"] == r1 - r0 and inf["last_variant"] == 0, (pack, k, inf)
+                assert inf["views_resident"] == 0 and inf["tile_tables_resident"] == 0 and inf["side_bytes"] == 0
             wantm = oracle.membership(s, e, o, 1000, 60_000, 31, n, literal=False)
             for _ in range(7):
                 assert np.array_equal(ix.membership(1000, 60_000, 31, n), wantm)
-    monkeypatch.delenv("MEMO_VIEW_ALLOC_FAIL")
+            assert ix.prepare(31, n) == 0                     # (an explicit prepare finds no room either: no error, nothing taken)
+    finally:
+        ab.check(ab.lib().memo_debug_fail_side_allocations(0))
     ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack="dense")
     with ix:
         for _ in range(7):
@@ -1605,10 +1644,12 @@ def test_no_room_on_the_device_for_views_and_tile_tables(memo, oracle, monkeypat
 
 
 def test_views_stay_within_their_budget(memo, oracle, ab):
-    """All the k-class views of one row source together may take twice the bytes of the rows they are views of; past that the least
-    recently used view goes (with the tile tables made for it) and its class starts counting again.  Every class of the dense rows
-    and of the 4-byte words in turn, twice around: results equal the sweep of all the rows throughout, the index never grows past
-    rows + 2 x rows (+ bucket tables), and a class that was evicted builds its view again."""
+    """All the k-class views of one row source together stay within MEMO_OPT_VIEW_BUDGET_PCT (200 %) of the bytes of the rows
+    they are views of; past that the least recently used view is retired (with the tile tables made for it; freed by the next
+    memo_query_check, no wait on the query path) and its class backs off: it is looked at again only after four times as many
+    queries.  Every class of the dense rows and of the 4-byte words in turn, twice around: results equal the sweep of all the
+    rows throughout, the index never grows past rows + 2 x rows (+ tables), the second turn rebuilds next to nothing, and a
+    class that was evicted does come back when it is asked often enough."""
     from memo_amd import synth
     n, L = 100, 1_200_000
     for pack, row_bytes in (("dense", 3.2), ("only", 4.0)):
@@ -1616,7 +1657,7 @@ def test_views_stay_within_their_budget(memo, oracle, ab):
         with ix:
             base = ix.info()["device_bytes"]
             rows_bytes = row_bytes * (r1 - r0)
-            seen_view = 0
+            builds = []
             for turn in range(2):
                 for k in range(3, 34, 2):
                     ix.debug_set_tuning(0, 0, 0, 9, 0)
@@ -1625,9 +1666,186 @@ def test_views_stay_within_their_budget(memo, oracle, ab):
                     for _ in range(6):
                         assert np.array_equal(ix.conservation(8, L - 4, k, n, dtype=np.uint8), ref), (pack, turn, k)
                     inf = ix.info()
-                    seen_view += inf["last_rows_read"] < r1 - r0
                     assert inf["device_bytes"] <= base + 2.0 * rows_bytes + 64 * (L // 32 + 64) * 8 + (1 << 20), (pack, turn, k, inf["device_bytes"], base)
-            assert seen_view >= 24, (pack, seen_view)          # (k - 1 <= 48 of 60 spares a fifth: every class here builds its view, both turns)
+                builds.append(ix.info()["view_builds"])
+            assert builds[0] >= 12, (pack, builds)            # (k - 1 <= 48 of 60 spares a fifth: every class here builds its view)
+            assert builds[1] - builds[0] <= 2, (pack, builds)  # back-off: six queries do not bring an evicted class back
+            # ... sixteen more of them do (the class evicted first: k = 3)
+            ix.debug_set_tuning(0, 0, 0, 9, 0)
+            ref = ix.conservation(8, L - 4, 3, n, dtype=np.uint8)
+            ix.debug_set_tuning(0, 0, 0, 0, 0)
+            for _ in range(24):
+                assert np.array_equal(ix.conservation(8, L - 4, 3, n, dtype=np.uint8), ref)
+            inf = ix.info()
+            assert inf["view_builds"] == builds[1] + 1 and inf["last_rows_read"] < r1 - r0, (pack, builds, inf)
+
+
+def test_index_info_is_versioned(memo):
+    """memo_index_info_t carries its size: the caller sets struct_bytes, the library writes no more than that (whole leading
+    fields) and says how much it wrote -- a binder built against an older, shorter struct keeps its stack"""
+    import ctypes as C
+    from memo_amd import synth, _lib
+    ix, _ = synth.device_index(0, 50_000, 31, 10, 50_000, pack="only")
+    with ix:
+        full = ix.info()
+        assert full["struct_bytes"] == C.sizeof(_lib.IndexInfo) and full["version"] == 4 and full["rows"] > 0
+        for cut in (16, 24, 88, 136, C.sizeof(_lib.IndexInfo) - 8, C.sizeof(_lib.IndexInfo), C.sizeof(_lib.IndexInfo) + 64):
+            buf = (C.c_ubyte * (C.sizeof(_lib.IndexInfo) + 128))(*([0xA5] * (C.sizeof(_lib.IndexInfo) + 128)))
+            C.cast(buf, C.POINTER(C.c_uint32))[0] = cut
+            _lib.check(_lib.lib().memo_index_get_info(ix._h, C.cast(buf, C.POINTER(_lib.IndexInfo))))
+            wrote = C.cast(buf, C.POINTER(C.c_uint32))[0]
+            assert wrote == min(cut, C.sizeof(_lib.IndexInfo))
+            assert all(b == 0xA5 for b in bytes(buf)[wrote:]), cut          # the guard bytes behind the caller's struct
+            got = _lib.IndexInfo.from_buffer_copy(bytes(buf)[:wrote] + bytes(C.sizeof(_lib.IndexInfo) - wrote))
+            assert got.version == 4 and got.rows == full["rows"]
+            if cut >= 136:
+                assert got.last_rows_read == full["last_rows_read"] and got.max_annot == full["max_annot"]
+        for bad in (0, 8, 15):
+            inf = _lib.IndexInfo()
+            inf.struct_bytes = bad
+            assert _lib.lib().memo_index_get_info(ix._h, C.byref(inf)) == _lib.MEMO_EINVAL
+            assert b"struct_bytes" in _lib.lib().memo_last_error()
+
+
+def test_prepare_builds_views_and_tables_now(memo, oracle):
+    """memo_index_prepare: the k-class view, the tile table and (builder-made indexes) the query order of the rows, built
+    before the first query instead of inside the fifth; idempotent; nothing is launched into the caller's buffer"""
+    from memo_amd import synth
+    n, L = 100, 2_000_000
+    num, den = synth.rows_per_position(n)
+    for pack in ("dense", "only"):
+        ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack=pack)
+        s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, n)
+        with ix:
+            before = ix.info()
+            taken = ix.prepare(31, n)
+            inf = ix.info()
+            assert taken > 0 and inf["device_bytes"] == before["device_bytes"] + taken and inf["side_bytes"] == taken
+            assert inf["views_resident"] == 1 and inf["view_builds"] == 1 and inf["last_view_ms"] > 0
+            assert inf["tile_tables_resident"] == (1 if pack == "dense" else 0)
+            assert ix.prepare(31, n) == 0 and ix.info()["view_builds"] == 1       # everything is there
+            got = ix.conservation(0, L, 31, n, dtype=np.uint8)                  # the FIRST query reads the view
+            inf = ix.info()
+            assert abs(inf["last_rows_read"] / (r1 - r0) - 0.5) < 0.01 and inf["view_builds"] == 1
+            if pack == "dense":
+                assert inf["last_sweep"] == 5 and inf["last_variant"] == 2
+            assert np.array_equal(got, oracle.conservation(s, e, o, 0, L, 31, n, literal=False))
+            if pack == "only":                                                  # membership of the same class: the same view
+                assert ix.prepare(31, n, membership=True) == 0
+                m = ix.membership(1000, 400_000, 31, n)
+                assert ix.info()["last_rows_read"] == inf["last_rows_read"]
+                assert np.array_equal(m, oracle.membership(s, e, o, 1000, 400_000, 31, n, literal=False))
+            if pack == "only":
+                assert ix.prepare(101, n) == 0                                  # every row can write at k = 101: no view pays
+            ix.set_option(1, 0)                                                 # MEMO_OPT_VIEWS off: the views go
+            inf = ix.info()
+            assert inf["views_resident"] == 0 and inf["device_bytes"] <= before["device_bytes"] + (1 << 20)
+            assert np.array_equal(ix.conservation(0, L, 31, n, dtype=np.uint8), got) and ix.info()["last_rows_read"] == r1 - r0
+            ix.set_option(1, 1)
+    # an index that came in through the builder: start order until the fifth query -- or prepare
+    s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, n)
+    with memo.DeviceIndex.from_host_packed(s, e, o) as ix:
+        assert ix.info()["row_order"] == 0
+        ix.prepare(101, n)
+        assert ix.info()["row_order"] == 2
+        assert np.array_equal(ix.conservation(0, L, 101, n), oracle.conservation(s, e, o, 0, L, 101, n, literal=False))
+    with memo.DeviceIndex.from_host_packed(s, e, o) as ix:
+        want = oracle.conservation(s, e, o, 0, L, 101, n, literal=False)
+        for i in range(6):
+            assert np.array_equal(ix.conservation(0, L, 101, n), want)
+            assert ix.info()["row_order"] == (0 if i < 4 else 2), i
+
+
+def test_cycling_through_k_classes_does_not_thrash(memo, oracle):
+    """a long-lived index queried across more k classes than round 3's four tile-table slots (and more than the
+    view budget holds).  After the warm-up nothing is rebuilt: every class finds its view and its tile table again, round
+    after round; with a budget that cannot hold them all the library settles instead of rebuilding a view every few queries."""
+    from memo_amd import synth
+    n, L = 100, 1_500_000
+    num, den = synth.rows_per_position(n)
+    ks = (5, 9, 13, 17, 21, 25, 29, 33)                     # eight classes of the dense rows
+    ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack="dense")
+    s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, n)
+    want = {k: oracle.conservation(s, e, o, 0, L, k, n, literal=False) for k in ks}
+    with ix:
+        ix.set_option(2, 800)                               # MEMO_OPT_VIEW_BUDGET_PCT: room for all eight
+        for k in ks:
+            ix.prepare(k, n)
+        warm = ix.info()
+        assert warm["views_resident"] == 8 and warm["tile_tables_resident"] == 8 and warm["view_builds"] == 8
+        for _ in range(5):
+            for k in ks:
+                assert np.array_equal(ix.conservation(0, L, k, n, dtype=np.uint8), want[k]), k
+                inf = ix.info()
+                assert inf["last_variant"] == 2 and inf["last_rows_read"] < r1 - r0
+        inf = ix.info()
+        assert (inf["view_builds"], inf["views_resident"], inf["tile_tables_resident"]) == (8, 8, 8), inf
+        assert inf["device_bytes"] == warm["device_bytes"]
+    ix, _ = synth.device_index(0, L, 64, n, L, pack="dense")
+    with ix:                                                # the default budget (200 %) holds about five of these classes
+        for rnd in range(12):
+            for k in ks:
+                for _ in range(2):
+                    assert np.array_equal(ix.conservation(0, L, k, n, dtype=np.uint8), want[k]), k
+        inf = ix.info()
+        assert inf["view_builds"] <= 16, inf                # (round 3's rule rebuilt an evicted class every fifth query: ~40 here)
+        assert inf["side_bytes"] <= 2.1 * 3.2 * (r1 - r0) + 16 * (L // 32 + 64) * 8 + (8 << 20)
+
+
+def test_row_order_inside_buckets_never_changes_a_result(memo, oracle, ab):
+    """memo_interleave.hip: the 4-byte rows of a bucket dealt round-robin over the bucket's starts (chunks of four; the rows
+    of a start by overlap mod 32).  Start order, both dealt orders and back again: every sweep family, conservation and
+    membership, views included, on a ragged index with clumps (a bucket of more than 8192 rows stays as it is), both
+    formats; equal to the oracle and to each other; the order is a function of the bucket's rows alone (idempotent)."""
+    rng = np.random.default_rng(41)
+    for n_docs, length, m in ((90, 60_000, 700_000), (600, 30_000, 900_000)):
+        s = rng.integers(1, length, m)
+        s[:9000] = 12_345                                    # a clump: > 8192 rows in one bucket
+        s[9000:12000] = rng.integers(20_000, 20_032, 3000)   # a full bucket of 3000 rows
+        s = np.sort(s).astype(np.int64)
+        ov = rng.integers(0, 70, m)
+        ov[::13] = rng.integers(200, 400, len(ov[::13]))
+        e = s + ov
+        o = rng.integers(1, n_docs, m).astype(np.int64)
+        with memo.DeviceIndex.from_host(s, e, o) as ix:
+            ix.debug_row_order(1)
+            ix.pack(keep_wide=False)
+            assert ix.info()["row_order"] == 0
+            words0 = _export(ix)[0].copy()
+            inf0 = ix.info()
+            results = {}
+            for order in (1, 2, 3, 2, 1):
+                ix.debug_row_order(order)
+                assert ix.info()["row_order"] == order - 1
+                words = _export(ix)[0]
+                assert np.array_equal(np.sort(words), np.sort(words0))          # a permutation of the same words ...
+                boff = _export(ix)[2]
+                for b in (0, len(boff) // 3, len(boff) // 2):                   # ... bucket by bucket
+                    assert np.array_equal(np.sort(words[boff[b]:boff[b + 1]]), np.sort(words0[boff[b]:boff[b + 1]]))
+                came_back = order == 1 and ("seen", 2) in results
+                results[("seen", order)] = True
+                if came_back:                                                   # back in start order (the rows of a start by overlap, annot)
+                    f12 = inf0["packed_format"] == 12
+                    st = ((words >> 8) & 0xFFF) if f12 else (words & 0xFFFF)
+                    ovl = (words & 0xFF) if f12 else ((words >> 16) & 0xFF)
+                    ann = (words >> 20) if f12 else (words >> 24)
+                    key = ((st.astype(np.int64) & 31) << 20) | (ovl.astype(np.int64) << 12) | ann.astype(np.int64)
+                    for b in (0, 5, len(boff) // 3, len(boff) // 2, 625):
+                        assert boff[b + 1] - boff[b] > 8192 or np.all(np.diff(key[boff[b]:boff[b + 1]]) >= 0), b
+                again = words.copy()
+                ix.debug_row_order(order)                                       # idempotent
+                assert np.array_equal(_export(ix)[0], again)
+                for k in (3, 21, 31, 64, 101, 200, 256):
+                    for rep in range(6 if k in (21, 101) else 1):               # (the fifth query of a class builds its view)
+                        qs, qe = 16, length + 40
+                        got = ix.conservation(qs, qe, k, n_docs)
+                    want = results.setdefault((k, "c"), oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs,
+                                                                            literal=False))
+                    assert np.array_equal(got, want), (n_docs, order, k)
+                    gm = ix.membership(9_000, 24_000, k, n_docs)
+                    wm = results.setdefault((k, "m"), oracle.membership(*oracle.filter_rows(s, e, o, 9_000, 24_000, k), 9_000, 24_000, k,
+                                                                        n_docs, literal=False))
+                    assert np.array_equal(gm, wm), (n_docs, order, k)
 
 
 def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):

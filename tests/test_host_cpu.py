@@ -53,6 +53,31 @@ def test_library_exports_every_declared_symbol(memo):
     assert _exported(_lib.AB_SO_PATH) == declared | debug
 
 
+def test_index_info_layout_matches_the_header(memo, tmp_path):
+    """memo_index_info_t as a C compiler lays it out (gcc on include/memo_amd.h) == the ctypes mirror the Python host binds:
+    size, every field's offset; the struct starts with its own size and a version, and the call refuses a struct whose size
+    was never set (no index needed for that)"""
+    import ctypes as C
+    import subprocess
+    from memo_amd import _lib
+    names = [n for n, _ in _lib.IndexInfo._fields_]
+    assert names[:2] == ["struct_bytes", "version"]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "memo_amd.h"\nint main(void) {\n'
+                   '  printf("%zu %d\\n", sizeof(memo_index_info_t), MEMO_INDEX_INFO_VERSION);\n' +
+                   "".join(f'  printf("{n} %zu\\n", offsetof(memo_index_info_t, {n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    lines = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    size, version = (int(x) for x in lines[0].split())
+    assert size == C.sizeof(_lib.IndexInfo) and version == 4
+    for ln in lines[1:]:
+        if ln:
+            n, off = ln.split()
+            assert getattr(_lib.IndexInfo, n).offset == int(off), n
+    assert _lib.lib().memo_index_get_info(None, None) == _lib.MEMO_EINVAL
+
+
 def test_no_gpu_fails_loudly(memo):
     from memo_amd import _lib
     if _lib.lib().memo_device_count() > 0:

@@ -89,7 +89,7 @@ def test_host_packer_under_sanitizers(tmp_path, sanitizer):
     if not (os.path.isabs(lib) and os.path.exists(lib)):
         pytest.skip("sanitizer runtime not installed")
     exe = str(tmp_path / "hostcore")
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=" + sanitizer,
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-DMEMO_HOST_TEST_KNOBS", "-fsanitize=" + sanitizer,
                            "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "host_stub.cpp"),
                            os.path.join(ROOT, "memo_amd", "csrc", "memo_hostcore.cpp"), "-o", exe])

@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--pack", default=None, choices=[None, "keep", "only", "dense", "both"],
                     help="keep: int64 + 4-byte rows; only: 4-byte rows; dense: dense rows only; both: 4- and dense rows "
                          "(the library reads the dense ones where they can answer; row_source 3 in a variant selects the 4-byte rows)")
+    ap.add_argument("--row-order", type=int, default=0,
+                    help="order of the 4-byte rows inside a bucket (memo_debug_row_order): 0 library's, 1 start order, 2 chunks dealt "
+                         "over the starts, 3 + by overlap mod 32")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     num_docs, L, membership = WORKLOADS[a.workload]
@@ -38,6 +41,8 @@ def main():
     _lib.use_ab(True)
     ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L, density=Fraction(a.density),
                                       pack="only" if a.pack == "both" else a.pack)
+    if a.row_order:
+        ix.debug_row_order(a.row_order)
     if a.pack == "both":
         ix.pack_dense(keep_packed=True)
     W = (num_docs + 31) // 32

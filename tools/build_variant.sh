@@ -14,5 +14,5 @@ CXX="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -I../../include"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $CXX $FLAGS -c memo_sweep_cons3t.hip -o /tmp/cons3t_$NAME.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../libmemo_amd_${NAME}_ab.so \
-  /tmp/sweep_$NAME.o /tmp/cons_$NAME.o /tmp/cons3p_$NAME.o /tmp/cons3t_$NAME.o /tmp/memb_$NAME.o memo_index.o memo_hostpack.o memo_hostcore.o memo_multi.o memo_transport.o memo_sort.o memo_dap.o memo_emit.o /tmp/debug_$NAME.o
+  /tmp/sweep_$NAME.o /tmp/cons_$NAME.o /tmp/cons3p_$NAME.o /tmp/cons3t_$NAME.o /tmp/memb_$NAME.o memo_interleave.o memo_index.o memo_hostpack.o memo_hostcore.o memo_multi.o memo_transport.o memo_sort.o memo_dap.o memo_emit.o /tmp/debug_$NAME.o
 echo built libmemo_amd_${NAME}_ab.so

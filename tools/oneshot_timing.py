@@ -9,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import memo_amd  # noqa: E402
-from memo_amd import synth  # noqa: E402
+from memo_amd import _lib, synth  # noqa: E402
 
 os.environ["MEMO_TIMING"] = "1"          # the library prints the phases of every call on stderr
 BIG_ONLY = "--big-only" in sys.argv      # BASELINE config 3 through the dense way in only (thread-count sweeps)
@@ -24,19 +24,21 @@ for n, L in ((100, 100_000_000),) if BIG_ONLY else ((10, 10_000_000), (100, 20_0
     if BIG_ONLY:
         print(f"N={n} L={L}: dense way in {dt * 1e3:.1f} ms -> {L / dt:.3g} positions/s", flush=True)
         sys.exit(0)
-    os.environ["MEMO_ONESHOT_PACKED"] = "1"   # the 4-byte words (round 2's way in) instead of the dense rows
+    _lib.use_ab(True)                         # (the way-in switches live in the AB library: memo_debug_one_shot_way)
+    _lib.check(_lib.lib().memo_debug_one_shot_way(2))   # the 4-byte words (round 2's way in) instead of the dense rows
     for rep in range(2):
         t = time.perf_counter()
         out_p = memo_amd.conservation(s, e, o, 0, L, 31, n)
         dt_p = time.perf_counter() - t
-    del os.environ["MEMO_ONESHOT_PACKED"]
+    _lib.check(_lib.lib().memo_debug_one_shot_way(0))
     assert np.array_equal(out, out_p)
     print(f"N={n} L={L}: 4-byte way in {dt_p * 1e3:.1f} ms", flush=True)
-    os.environ["MEMO_ONESHOT_WIDE"] = "1"     # the int64 way in, for comparison (round 1's only way)
+    _lib.check(_lib.lib().memo_debug_one_shot_way(1))   # the int64 way in, for comparison (round 1's only way)
     t = time.perf_counter()
     out_w = memo_amd.conservation(s, e, o, 0, L, 31, n)
     dt_w = time.perf_counter() - t
-    del os.environ["MEMO_ONESHOT_WIDE"]
+    _lib.check(_lib.lib().memo_debug_one_shot_way(0))
+    _lib.use_ab(False)
     assert np.array_equal(out, out_w)
     gb = (s.nbytes * 3 + out.nbytes) / 1e9
     print(f"N={n} L={L}: {r1 - r0} rows ({gb:.2f} GB of int64 columns + result): one-shot {dt * 1e3:.1f} ms -> "
