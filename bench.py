@@ -375,6 +375,31 @@ def main():
         else:
             ix.conservation_dev(qs, qe_mine, k, num_docs, out, stream.cuda_stream)
 
+    # One launch per resident format before anything is timed: the first conservation query of a k class on the dense rows
+    # builds their k-class VIEW (the rows whose overlap is below the class's cap -- 2, 4, 6 ... 32 --: all that can write at this k; memo_query.py:49
+    # drops the others per query, the library once per index and class -- memo_index_info_t.last_rows_read) and the tile
+    # table; both stay with the index.  What each format's sweep reads is what its roofline is priced on.
+    view_pass = None
+    full_rows = {}
+    prepared = {}
+    for f, ixf in indexes.items():
+        if f != "wide":
+            # memo_index_prepare: the k-class view and the tile table NOW (a host that sweeps one k over many windows calls it
+            # once; without it the class's fifth query builds the view on the way) -- timed on the device by the library
+            prepared[f] = ixf.prepare(k, num_docs, membership)
+            inf = ixf.info()
+            if f == args.rows and inf["last_view_ms"] > 0:
+                view_pass = {"what": "k-class view of the rows the sweep reads (rows whose overlap is below the class's cap: all that can "
+                                     "write at this k), built by memo_index_prepare (else: by the fifth query of its class) -- one pass over "
+                                     "the rows + their bucket table -- once per index and class, kept",
+                             "ms": float(inf["last_view_ms"]), "rows_in": int(inf["dense_row_count"] if f == "dense" else inf["rows"]),
+                             "rows_kept": int(inf["last_rows_read"]), "device_bytes_taken_by_prepare": int(prepared[f])}
+        launch(outs[0], ixf)
+        torch.cuda.synchronize()
+        inf = ixf.info()
+        full_rows[f] = int(inf["dense_row_count"]) if f == "dense" else rows
+        if inf["last_rows_read"]:
+            rows_read[f] = int(inf["last_rows_read"])
     # What travels to rank 0.  A slice's own xGMI link is what bounds N > 1, so uint8
     # conservation slices go in a lossless transport coding: "runs" (one bit per position + a byte per change of
     # value, memo_transport_runs_*), "dense" (2 bits per position + a nibble per value outside 1..3,
@@ -420,7 +445,11 @@ def main():
         del bufs, probe
     link = link_measured or shard.XGMI_LINK_BYTES_PER_S
     root_weight = 1.0 if args.root_weight == "auto" else min(max(float(args.root_weight), 0.01), 1.0)
-    if multi and narrow and not args.plain_gather:
+    vbytes = 1 if narrow else 2                  # bytes per conservation value
+    codable = multi and not membership and not args.plain_gather
+    runs_pack_fn = lib.memo_transport_runs_pack_dev if narrow else lib.memo_transport_runs16_pack_dev
+    runs_unpack_fn = lib.memo_transport_runs_unpack_dev if narrow else lib.memo_transport_runs16_unpack_dev
+    if codable:
         found, have, taken, room = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
 
         def timed(fn, reps=3):
@@ -434,50 +463,52 @@ def main():
             return e0.elapsed_time(e1) / reps * 1e-3
 
         t_sweep = timed(lambda: launch(outs[0]))
-        scratch = torch.empty(L, dtype=torch.uint8, device=dev)
-        usable = {"plain": (L, 0.0, 0.0)}                                  # coding -> (wire bytes, decode s, encode s)
-        # dense
-        trial_b = ((L // 2 + 4 * (L // 32768 + 1)) + 3) & ~3              # every position an escape
-        probe = torch.empty(lib.memo_transport_dense_bytes(L, trial_b, cap), dtype=torch.uint8, device=dev)
-        _lib.check(lib.memo_transport_dense_pack_dev(outs[0].data_ptr(), L, trial_b, cap, probe.data_ptr(), local,
-                                                     stream.cuda_stream))
-        _lib.check(lib.memo_transport_dense_stats(probe.data_ptr(), local, stream.cuda_stream, C.byref(found),
-                                                  C.byref(have), C.byref(taken), C.byref(room)))
-        need = torch.tensor([taken.value, found.value], dtype=torch.int64, device=dev)
-        all_reduce_max(need)
-        b_cap = (int(need[0].item()) + 4096 + 3) & ~3                      # exact + slack
-        dense_cap = int(need[1].item()) + 1024
-        if not args.nibble_gather:
-            t = timed(lambda: _lib.check(lib.memo_transport_dense_unpack_dev(
-                probe.data_ptr(), L, trial_b, cap, scratch.data_ptr(), local, stream.cuda_stream)))
-            tp = timed(lambda: _lib.check(lib.memo_transport_dense_pack_dev(
-                outs[0].data_ptr(), L, trial_b, cap, probe.data_ptr(), local, stream.cuda_stream)))
-            usable["dense"] = (lib.memo_transport_dense_bytes(L, b_cap, dense_cap), t, tp)
-        # nibble
-        probe = torch.empty(lib.memo_transport_bytes(L, cap), dtype=torch.uint8, device=dev)
-        _lib.check(lib.memo_transport_pack_dev(outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream))
-        _lib.check(lib.memo_transport_exceptions(probe.data_ptr(), local, stream.cuda_stream, C.byref(found), C.byref(have)))
-        need = torch.tensor([found.value], dtype=torch.int64, device=dev)
-        all_reduce_max(need)
-        nibble_cap = int(need.item()) + int(need.item()) // 16 + 1024          # what the ranks found + slack
-        if nibble_cap * 8 <= L // 8:                                       # else the list outweighs the saving
-            t = timed(lambda: _lib.check(lib.memo_transport_unpack_dev(
-                probe.data_ptr(), L, scratch.data_ptr(), local, stream.cuda_stream)))
-            tp = timed(lambda: _lib.check(lib.memo_transport_pack_dev(
-                outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream)))
-            usable["nibble"] = (lib.memo_transport_bytes(L, nibble_cap), t, tp)
-        # runs: one bit per position + one byte per change of value
-        trial_r = (L + 4 * (L // 32768 + 1) + 3) & ~3                      # every position a change
+        scratch = torch.empty(L * vbytes, dtype=torch.uint8, device=dev)
+        usable = {"plain": (L * vbytes, 0.0, 0.0)}                         # coding -> (wire bytes, decode s, encode s)
+        if narrow:                               # (the dense and nibble codings carry uint8 values only)
+            # dense
+            trial_b = ((L // 2 + 4 * (L // 32768 + 1)) + 3) & ~3              # every position an escape
+            probe = torch.empty(lib.memo_transport_dense_bytes(L, trial_b, cap), dtype=torch.uint8, device=dev)
+            _lib.check(lib.memo_transport_dense_pack_dev(outs[0].data_ptr(), L, trial_b, cap, probe.data_ptr(), local,
+                                                         stream.cuda_stream))
+            _lib.check(lib.memo_transport_dense_stats(probe.data_ptr(), local, stream.cuda_stream, C.byref(found),
+                                                      C.byref(have), C.byref(taken), C.byref(room)))
+            need = torch.tensor([taken.value, found.value], dtype=torch.int64, device=dev)
+            all_reduce_max(need)
+            b_cap = (int(need[0].item()) + 4096 + 3) & ~3                      # exact + slack
+            dense_cap = int(need[1].item()) + 1024
+            if not args.nibble_gather:
+                t = timed(lambda: _lib.check(lib.memo_transport_dense_unpack_dev(
+                    probe.data_ptr(), L, trial_b, cap, scratch.data_ptr(), local, stream.cuda_stream)))
+                tp = timed(lambda: _lib.check(lib.memo_transport_dense_pack_dev(
+                    outs[0].data_ptr(), L, trial_b, cap, probe.data_ptr(), local, stream.cuda_stream)))
+                usable["dense"] = (lib.memo_transport_dense_bytes(L, b_cap, dense_cap), t, tp)
+            # nibble
+            probe = torch.empty(lib.memo_transport_bytes(L, cap), dtype=torch.uint8, device=dev)
+            _lib.check(lib.memo_transport_pack_dev(outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream))
+            _lib.check(lib.memo_transport_exceptions(probe.data_ptr(), local, stream.cuda_stream, C.byref(found), C.byref(have)))
+            need = torch.tensor([found.value], dtype=torch.int64, device=dev)
+            all_reduce_max(need)
+            nibble_cap = int(need.item()) + int(need.item()) // 16 + 1024          # what the ranks found + slack
+            if nibble_cap * 8 <= L // 8:                                       # else the list outweighs the saving
+                t = timed(lambda: _lib.check(lib.memo_transport_unpack_dev(
+                    probe.data_ptr(), L, scratch.data_ptr(), local, stream.cuda_stream)))
+                tp = timed(lambda: _lib.check(lib.memo_transport_pack_dev(
+                    outs[0].data_ptr(), L, cap, probe.data_ptr(), local, stream.cuda_stream)))
+                usable["nibble"] = (lib.memo_transport_bytes(L, nibble_cap), t, tp)
+        # runs: one bit per position + one value (one or two bytes: memo_transport_runs16_*) per change of value -- the
+        # coding that carries BASELINE config 5's uint16 slices too (67 MB plain against ~9 MB at k = 31)
+        trial_r = (L * vbytes + 4 * (L // 32768 + 1) + 3) & ~3            # every position a change
         probe = torch.empty(lib.memo_transport_runs_bytes(L, trial_r), dtype=torch.uint8, device=dev)
-        _lib.check(lib.memo_transport_runs_pack_dev(outs[0].data_ptr(), L, trial_r, probe.data_ptr(), local, stream.cuda_stream))
+        _lib.check(runs_pack_fn(outs[0].data_ptr(), L, trial_r, probe.data_ptr(), local, stream.cuda_stream))
         _lib.check(lib.memo_transport_runs_stats(probe.data_ptr(), local, stream.cuda_stream, C.byref(taken), C.byref(room)))
         need = torch.tensor([taken.value], dtype=torch.int64, device=dev)
         all_reduce_max(need)
         runs_cap = (int(need.item()) + int(need.item()) // 16 + 4096 + 3) & ~3       # what the ranks needed + slack
         if not args.nibble_gather:
-            t = timed(lambda: _lib.check(lib.memo_transport_runs_unpack_dev(
+            t = timed(lambda: _lib.check(runs_unpack_fn(
                 probe.data_ptr(), L, trial_r, scratch.data_ptr(), local, stream.cuda_stream)))
-            tp = timed(lambda: _lib.check(lib.memo_transport_runs_pack_dev(
+            tp = timed(lambda: _lib.check(runs_pack_fn(
                 outs[0].data_ptr(), L, trial_r, probe.data_ptr(), local, stream.cuda_stream)))
             usable["runs"] = (lib.memo_transport_runs_bytes(L, runs_cap), t, tp)
         del probe, scratch
@@ -511,31 +542,6 @@ def main():
     nibble = coding != "plain"              # (name kept: "the slices travel coded")
     # rank 0 sweeps the first root_weight of its window (a multiple of 8 positions); everybody else all of it
     L_mine = L if rank != 0 else max(8, int(L * root_weight) // 8 * 8)
-    # One launch per resident format before anything is timed: the first conservation query of a k class on the dense rows
-    # builds their k-class VIEW (the rows whose overlap is below the class's cap -- 2, 4, 6 ... 32 --: all that can write at this k; memo_query.py:49
-    # drops the others per query, the library once per index and class -- memo_index_info_t.last_rows_read) and the tile
-    # table; both stay with the index.  What each format's sweep reads is what its roofline is priced on.
-    view_pass = None
-    full_rows = {}
-    prepared = {}
-    for f, ixf in indexes.items():
-        if f != "wide":
-            # memo_index_prepare: the k-class view and the tile table NOW (a host that sweeps one k over many windows calls it
-            # once; without it the class's fifth query builds the view on the way) -- timed on the device by the library
-            prepared[f] = ixf.prepare(k, num_docs, membership)
-            inf = ixf.info()
-            if f == args.rows and inf["last_view_ms"] > 0:
-                view_pass = {"what": "k-class view of the rows the sweep reads (rows whose overlap is below the class's cap: all that can "
-                                     "write at this k), built by memo_index_prepare (else: by the fifth query of its class) -- one pass over "
-                                     "the rows + their bucket table -- once per index and class, kept",
-                             "ms": float(inf["last_view_ms"]), "rows_in": int(inf["dense_row_count"] if f == "dense" else inf["rows"]),
-                             "rows_kept": int(inf["last_rows_read"]), "device_bytes_taken_by_prepare": int(prepared[f])}
-        launch(outs[0], ixf)
-        torch.cuda.synchronize()
-        inf = ixf.info()
-        full_rows[f] = int(inf["dense_row_count"]) if f == "dense" else rows
-        if inf["last_rows_read"]:
-            rows_read[f] = int(inf["last_rows_read"])
     for o in outs:                          # (every result buffer holds a whole-window result behind L_mine)
         launch(o)
     qe_mine = qs + L_mine
@@ -543,7 +549,7 @@ def main():
 
     def pack(src, wire):
         if coding == "runs":
-            _lib.check(lib.memo_transport_runs_pack_dev(src.data_ptr(), L, b_cap, wire.data_ptr(), local, stream.cuda_stream))
+            _lib.check(runs_pack_fn(src.data_ptr(), L, b_cap, wire.data_ptr(), local, stream.cuda_stream))
         elif coding == "dense":
             _lib.check(lib.memo_transport_dense_pack_dev(src.data_ptr(), L, b_cap, cap, wire.data_ptr(), local,
                                                          stream.cuda_stream))
@@ -552,7 +558,7 @@ def main():
 
     def unpack(wire, dst):
         if coding == "runs":
-            _lib.check(lib.memo_transport_runs_unpack_dev(wire.data_ptr(), L, b_cap, dst.data_ptr(), local, stream.cuda_stream))
+            _lib.check(runs_unpack_fn(wire.data_ptr(), L, b_cap, dst.data_ptr(), local, stream.cuda_stream))
         elif coding == "dense":
             _lib.check(lib.memo_transport_dense_unpack_dev(wire.data_ptr(), L, b_cap, cap, dst.data_ptr(), local,
                                                            stream.cuda_stream))
@@ -573,7 +579,7 @@ def main():
         for b in range(nbuf):               # plain bytes: rank 0 sweeps straight into its place of the gathered result
             roots[b][0] = wires[b]
     # rank 0: the gathered slices in result form (decoded when they travelled as nibbles)
-    decoded = [[torch.empty(L, dtype=torch.uint8, device=dev) for _ in range(world)] if (nibble and rank == 0) else None
+    decoded = [[torch.empty(L, dtype=dtype, device=dev) for _ in range(world)] if (nibble and rank == 0) else None
                for _ in range(nbuf)]
     pending = [None] * nbuf
     host_side = [None] * nbuf               # (test transport only)
@@ -853,7 +859,7 @@ def main():
                     whole &= bool(head[0] <= head[1]) and bool(head[2] <= head[3] if coding == "dense" else head[2] == 0)
                 res["gather_parity_sample"]["every_slice_complete"] = whole
             res["config"]["gather_payload"] = (
-                f"runs coding: 1 bit per position + {b_cap} B for one byte per change of value "
+                f"runs coding: 1 bit per position + {b_cap} B for {vbytes} byte(s) per change of value "
                 f"({wires[0].numel()} B per slice, {8 * wires[0].numel() / L:.2f} bits per position)"
                 if coding == "runs" else
                 f"dense coding: 2 bits per position + {b_cap} B of escape nibbles + {cap} exception slots "

@@ -1580,7 +1580,9 @@ def test_queries_of_one_index_on_several_streams(memo, oracle):
 
 
 @pytest.mark.parametrize("n_ranks,workload,extra", [(2, "c3", []), (3, "c2", []), (2, "c2", ["--plain-gather"]),
-                                                     (2, "c4", []), (2, "c3", ["--root-weight", "0.3"])])
+                                                     (2, "c4", []), (2, "c3", ["--root-weight", "0.3"]),
+                                                     (2, "c5", []), (2, "c5", ["--k", "21"]), (2, "c5", ["--plain-gather"]),
+                                                     (2, "c5", ["--k", "101", "--coding", "runs"])])
 def test_bench_two_ranks_on_one_gpu(n_ranks, workload, extra):
     """`python bench.py --gpus N` as the driver spells it, with N > 1 RANKS for the first time on this pool's one-GPU boxes:
     RCCL refuses two ranks on a device, so the ranks share GPU 0 (MEMO_BENCH_ONE_DEVICE=1) and gloo carries the bytes through
@@ -1607,6 +1609,15 @@ def test_bench_two_ranks_on_one_gpu(n_ranks, workload, extra):
     assert j["gather_parity_sample"].get("every_slice_complete", True) is True
     assert j["link_GBs_measured"] and j["link_probe"]["bytes_per_rank"] > 0
     assert j["value"] > 0 and j["config"]["gather_payload"]
+    if workload == "c5":      # BASELINE's multi-GPU config: uint16 slices -- coded by the runs coding unless plain was asked for
+        assert j["config"]["result_bytes_per_position"] == 2
+        if "--plain-gather" in extra:
+            assert j["config"]["gather_payload"].startswith("plain result bytes (67108864 B")
+        else:
+            cands = j["config"]["gather_coding_choice"]["candidates"]
+            assert set(cands) == {"plain", "runs"} and cands["runs"]["wire_bytes"] < 0.3 * cands["plain"]["wire_bytes"]
+            if "--coding" in extra:
+                assert j["config"]["gather_coding_choice"]["picked"] == "runs" and "2 byte(s) per change" in j["config"]["gather_payload"]
 
 
 def test_no_room_on_the_device_for_views_and_tile_tables(memo, oracle, ab):
@@ -1980,6 +1991,71 @@ def test_transport_runs_coding_round_trip(memo, oracle):
     assert size < 0.26 * length, size                                             # < 2.1 bits per position on the wire
     with pytest.raises(memo.MemoError):
         _lib.check(L.memo_transport_runs_pack_dev(1, 100, 6, 16, 0, None))       # capacity not a multiple of 4
+
+
+def test_transport_runs16_coding_round_trip(memo, oracle):
+    """the runs coding of uint16 results (more than 255 genomes: BASELINE config 5): change bitmap + TWO bytes per change;
+    the same shapes as the uint8 test, values above 255, a capacity that does not suffice, and a 500-genome conservation
+    result (~2.3 bits per position at k = 31 against 16 plain)"""
+    import ctypes as C
+    import torch
+    from memo_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(27)
+
+    def round_trip(v, b_cap):
+        n = len(v)
+        src = torch.from_numpy(v.view(np.int16)).cuda() if n else torch.zeros(16, dtype=torch.int16, device="cuda")
+        wire = torch.zeros(L.memo_transport_runs_bytes(n, b_cap), dtype=torch.uint8, device="cuda")
+        dst = torch.full((max(n, 16),), 77, dtype=torch.int16, device="cuda")
+        _lib.check(L.memo_transport_runs16_pack_dev(src.data_ptr(), n, b_cap, wire.data_ptr(), 0, None))
+        taken, room = C.c_uint32(), C.c_uint32()
+        _lib.check(L.memo_transport_runs_stats(wire.data_ptr(), 0, None, C.byref(taken), C.byref(room)))
+        _lib.check(L.memo_transport_runs16_unpack_dev(wire.data_ptr(), n, b_cap, dst.data_ptr(), 0, None))
+        torch.cuda.synchronize()
+        return dst[:n].cpu().numpy().view(np.uint16), taken.value, room.value, wire.numel()
+
+    def wanted(v):
+        n = len(v)
+        ch = np.ones(n, bool)
+        ch[1:] = v[1:] != v[:-1]
+        ch[::32768] = True
+        per_block = [int(ch[i:i + 32768].sum()) for i in range(0, n, 32768)]
+        return sum((2 * c + 3) & ~3 for c in per_block), len(per_block)
+
+    for n in (0, 1, 15, 16, 17, 4095, 4096, 4097, 12345, 32767, 32768, 32769, 65536, 1_000_003, 3_000_000):
+        for mix in ("runs", "uniform", "constant", "alternating"):
+            if mix == "runs":
+                v = np.repeat(np.minimum(rng.geometric(0.01, n // 3 + 1), 65535), rng.integers(1, 30, n // 3 + 1))[:n].astype(np.uint16)
+                v = np.resize(v, n) if len(v) < n else v
+            elif mix == "uniform":
+                v = rng.integers(0, 65536, n).astype(np.uint16)
+            elif mix == "constant":
+                v = np.full(n, 500, np.uint16)
+            else:
+                v = ((np.arange(n) & 1) * 65535).astype(np.uint16)
+            b_want, blocks = wanted(v)
+            got, taken, room, size = round_trip(v, b_want)
+            assert (taken, room) == (b_want, b_want), (n, mix, taken, room, b_want)
+            assert np.array_equal(got, v), (n, mix)
+            assert size == ((((16 + 8 * blocks + 4096 * blocks + 15) & ~15) + b_want + 15) & ~15), (n, mix)
+            if mix == "runs" and n >= 1_000_000:
+                got, taken, room, _ = round_trip(v, (b_want // 2) & ~3)          # too small: said so, never silent
+                assert taken == b_want and room == (b_want // 2) & ~3 and taken > room
+                got, taken, room, _ = round_trip(v, b_want + 4096)               # slack is fine
+                assert taken == b_want and np.array_equal(got, v)
+    from memo_amd import synth
+    n_docs, length, k = 500, 1_000_000, 31
+    ix, (r0, r1) = synth.device_index(0, length, k, n_docs, length, pack="only")
+    with ix:
+        v = ix.conservation(0, length, k, n_docs)
+    assert v.dtype == np.uint16 and v.max() > 255
+    b_want, blocks = wanted(v)
+    got, taken, room, size = round_trip(v, b_want)
+    assert np.array_equal(got, v) and taken == b_want
+    assert size < 0.45 * length, size                                             # < 3.6 bits per position on the wire (16 plain)
+    with pytest.raises(memo.MemoError):
+        _lib.check(L.memo_transport_runs16_pack_dev(1, 100, 6, 16, 0, None))     # capacity not a multiple of 4
 
 
 def test_transport_dense_coding_round_trip(memo):

@@ -22,9 +22,13 @@ ap.add_argument("--link-GBs", type=float, default=75.0, help="one direction of o
 ap.add_argument("--nibble", default="53101352,0.031,0.108", help="wire bytes, decode ms per slice, encode ms")
 ap.add_argument("--dense", default="41250080,0.058,0.153")
 ap.add_argument("--runs", default="23046320,0.036,0.064")
+ap.add_argument("--value-bytes", type=int, default=1, help="bytes per result value as plain bytes (2: more than 255 genomes, config 5)")
+ap.add_argument("--only", default="", help="comma-separated codings to consider besides plain (config 5: runs)")
 a = ap.parse_args()
-codings = {"plain": (a.L, 0.0, 0.0)}
+codings = {"plain": (a.L * a.value_bytes, 0.0, 0.0)}
 for name in ("nibble", "dense", "runs"):
+    if a.only and name not in a.only.split(","):
+        continue
     b, d, e = getattr(a, name).split(",")
     codings[name] = (int(b), float(d) * 1e-3, float(e) * 1e-3)
 sweep, link = a.sweep_ms * 1e-3, a.link_GBs * 1e9
