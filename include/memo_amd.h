@@ -114,6 +114,9 @@ typedef struct memo_index_info {
     int32_t views_resident;   /* k-class views held now */
     int32_t tile_tables_resident;
     uint64_t view_builds;     /* k-class views built over the index's lifetime: a service can watch it for thrashing */
+    int32_t last_level_arrays; /* last_sweep == 4: level arrays the sweep allocated per tile -- only those some row of the index can
+                               write to at this k (which overlaps occur in the index is known exactly since its rows were packed) */
+    int32_t reserved;
 } memo_index_info_t;
 
 const char *memo_last_error(void);

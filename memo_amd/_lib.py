@@ -46,7 +46,8 @@ class IndexInfo(C.Structure):
                 ("dense_rows", C.c_int32), ("long_rows", C.c_uint64), ("max_annot", C.c_uint64),
                 ("bucket_base", C.c_int64), ("last_sweep", C.c_int32), ("last_variant", C.c_int32), ("dense_row_count", C.c_uint64), ("last_rows_read", C.c_uint64),
                 ("last_view_ms", C.c_float), ("row_order", C.c_int32), ("side_bytes", C.c_uint64),
-                ("views_resident", C.c_int32), ("tile_tables_resident", C.c_int32), ("view_builds", C.c_uint64)]
+                ("views_resident", C.c_int32), ("tile_tables_resident", C.c_int32), ("view_builds", C.c_uint64),
+                ("last_level_arrays", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol the product headers declare: name -> (restype, argtypes)

@@ -144,6 +144,10 @@ struct memo_index {
     // 4- / 6-byte rows come into being: memo_index_pack, memo_builder_finish, memo_index_import_packed.
     uint32_t len_hist[256] = {0};
     uint64_t len_hist_rows = 0;  // rows sampled (0: no histogram)
+    // ... and which overlap values occur among ALL the rows (bit v of len_seen: some row has min(end - start, 255) == v), exact:
+    // with it the lengths n = k - 1 - overlap that can occur at a k are known, hence which level arrays a sweep can skip
+    uint32_t len_seen[8] = {0};
+    int len_seen_exact = 0;
     // Tile tables of the table-driven dense-row sweep (memo_sweep_cons3t.hip): per (tile width, k) the row slice of every
     // tile of the chromosome, 32 bytes per tile, built by the first query that needs one and kept (least recently used of
     // four replaced); dropped with the dense rows.
@@ -167,6 +171,7 @@ struct memo_index {
     std::vector<Retired> retired;
     uint64_t retired_bytes = 0;
     int last_sweep = 0;          // level arrays of the last conservation sweep (memo_index_info_t.last_sweep)
+    int last_arrays = 0;         // mixed level arrays (last_sweep 4): how many of them the sweep's level plan allocated
     int last_variant = 0;        // ... 1 when it ran as persistent workgroups (memo_sweep_cons3p.hip), 2 table-driven (memo_sweep_cons3t.hip)
     int has_wide = 1;          // the three int64 columns are still resident
     // rows with end < start (never written by the reference's index builder, but legal input to

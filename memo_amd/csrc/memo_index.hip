@@ -990,8 +990,30 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
 }
 }  // namespace memo
 
+namespace {
+// which overlap values (min(end - start, 255)) occur among ALL the rows: one pass, a flag per value in LDS (plain stores: lanes
+// that hit the same flag merge), the workgroup's flags or-ed into eight words in HBM
+__global__ __launch_bounds__(256) void len_seen_kernel(const uint32_t *__restrict__ pk, uint64_t rows, int shift,
+                                                       unsigned int *__restrict__ seen) {
+    __shared__ uint32_t flag[256];
+    flag[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t r = 4 * (blockIdx.x * (uint64_t)256 + threadIdx.x); r < rows; r += 4 * (uint64_t)gridDim.x * 256) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(pk + r);  // (pk is padded: the 16 bytes are there)
+        flag[(v.x >> shift) & 255u] = 1u;
+        if (r + 1 < rows) flag[(v.y >> shift) & 255u] = 1u;
+        if (r + 2 < rows) flag[(v.z >> shift) & 255u] = 1u;
+        if (r + 3 < rows) flag[(v.w >> shift) & 255u] = 1u;
+    }
+    __syncthreads();
+    if (flag[threadIdx.x]) atomicOr(&seen[threadIdx.x >> 5], 1u << (threadIdx.x & 31));
+}
+}  // namespace
+
 int memo_len_census(memo_index *ix) {
     ix->len_hist_rows = 0;
+    ix->len_seen_exact = 0;
+    for (unsigned int &c : ix->len_seen) c = 0;
     for (unsigned int &c : ix->len_hist) c = 0;
     if (!ix->pk || !ix->rows || (ix->packed_fmt != 4 && ix->packed_fmt != 6 && ix->packed_fmt != 12)) return MEMO_OK;
     DeviceGuard guard(ix->device);
@@ -1005,9 +1027,20 @@ int memo_len_census(memo_index *ix) {
         err = hipGetLastError();
     }
     if (err == hipSuccess) err = hipMemcpy(ix->len_hist, d_hist, sizeof(ix->len_hist), hipMemcpyDeviceToHost);
+    // ... and, exactly, WHICH overlaps occur (every row, not a sample): the sweeps for k - 1 >= 64 allocate, clear and fold
+    // only the level arrays some row of the index can write to (memo_sweep_cons.hip: level_plan)
+    if (err == hipSuccess) err = hipMemsetAsync(d_hist, 0, 32, nullptr);
+    if (err == hipSuccess) {
+        const uint64_t wg = (ix->rows + 1023) / 1024;
+        hipLaunchKernelGGL(len_seen_kernel, dim3((unsigned)(wg < 8192 ? wg : 8192)), dim3(256), 0, nullptr, ix->pk, ix->rows,
+                           ix->packed_fmt == 12 ? 0 : 16, d_hist);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpy(ix->len_seen, d_hist, 32, hipMemcpyDeviceToHost);
     (void)hipFree(d_hist);
     if (err != hipSuccess) return fail(MEMO_EHIP, "overlap census: %s", hipGetErrorString(err));
     for (unsigned int c : ix->len_hist) ix->len_hist_rows += c;
+    ix->len_seen_exact = 1;
     return MEMO_OK;
 }
 
@@ -1164,6 +1197,7 @@ static void fill_info(const memo_index *ix, memo_index_info_t *info) {
     info->side_bytes = side;
     info->device_bytes += side;
     info->view_builds = ix->view_builds;
+    info->last_level_arrays = ix->last_arrays;
 }
 
 int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {

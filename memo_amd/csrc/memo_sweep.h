@@ -39,6 +39,8 @@ struct SweepArgs {
                  //   (membership planes kernel: words per genome's plane row, words of skew per 32-genome group)
     int w;       //   ... and the tile width of both (a multiple of the bucket width, not a template parameter there)
     uint32_t magic;  // membership planes: ceil(2^32 / (32 * nwords)), for q / (32 * nwords) by v_mul_hi
+    uint32_t lvmask; // conservation, mixed level arrays (memo_sweep_cons.hip: level_plan): which arrays exist / are populated
+    int ftop;        //   ... and clz of the largest populated block size (the range's slot 0)
     int word_base;  // membership runs: first genome word of this launch (num_docs too large for one
     int out_words;  //   LDS tile is swept in slices of genome words); out_words = words per position
     unsigned long long *stamps;  // diagnostic builds (-DMEMO_STAMPS): per-phase cycle sums

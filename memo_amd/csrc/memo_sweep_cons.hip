@@ -721,6 +721,164 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Level plan of the mixed arrays (round 4): only the arrays some row of the index can write to are allocated, cleared and
+// folded.  Which lengths n = k - 1 - overlap occur at a k follows from WHICH overlaps occur in the index -- known exactly
+// since the rows were packed (memo_index::len_seen) -- and on BASELINE's generator (overlaps 0 .. 59) a k = 256 query
+// has every interval in 196 .. 255: blocks of 128 only.  Six arrays (1, 4, 16, 32, 64, 128) become two (128, and the
+// blocks of 16 the fold goes through), the tile grows from 1120 to 4576 positions in the same 40 KiB, and what a tile
+// spends on clearing, folding and its k - 1 halo shrinks with them.  An index whose overlaps reach every level (rows
+// built from sequences) gets the arrays it always got.
+//   slots 0 .. D-1   the doubling RANGE: blocks of 2^(31 - ftop - d), from the largest populated size down to the
+//                    smallest populated size >= 16 (a slot inside the range may be unpopulated: never cleared, never read)
+//   then             the blocks of 16 when the range ends above them (the fold's target: written before it is read)
+//   then             blocks of 4, blocks of 1 -- where some row can have fewer than 16 positions
+// A.lvmask: bits 0..7 = populated slots of the range, kPlanSep16 / kPlanHas4 / kPlanHas1; A.nlev = D; A.ftop.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kPlanSep16 = 1u << 16, kPlanHas4 = 1u << 17, kPlanHas1 = 1u << 18;
+
+struct LevelPlan {
+    int D, sep, has4, has1;
+    __host__ __device__ int s16() const { return sep ? D : D - 1; }
+    __host__ __device__ int s4() const { return D + sep; }
+    __host__ __device__ int s1() const { return D + sep + has4; }
+    __host__ __device__ int arrays() const { return D + sep + has4 + has1; }
+};
+
+__host__ __device__ inline LevelPlan plan_of(int D, uint32_t mask) {
+    LevelPlan p;
+    p.D = D;
+    p.sep = (mask & kPlanSep16) ? 1 : 0;
+    p.has4 = (mask & kPlanHas4) ? 1 : 0;
+    p.has1 = (mask & kPlanHas1) ? 1 : 0;
+    return p;
+}
+
+// r = min(r, the N blocks of a level at x, x - 16, ..., x - 16 (N - 1)): every read issued before the first is used (the
+// loop form kept one read in flight: k = 256, fifteen reads per cell quartet, 0.55 -> 0.64 ms).  Cells left of the array do
+// not exist: such a read repeats the leftmost one that does (min is idempotent), so no read is conditional.
+template <int N>
+__device__ __forceinline__ void fold_blocks_back(const uint32_t *hi, int x, uint4 &r) {
+    const int room = x & ~15;  // the furthest multiple of 16 this lane may step back
+    uint4 v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = *reinterpret_cast<const uint4 *>(hi + x - min(16 * i, room));
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        r.x = min(r.x, v[i].x);
+        r.y = min(r.y, v[i].y);
+        r.z = min(r.z, v[i].z);
+        r.w = min(r.w, v[i].w);
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void plan_clear(const SweepArgs &A, uint32_t *lds, uint32_t sent) {
+    const LevelPlan P = plan_of(A.nlev, A.lvmask);
+    const uint4 sv = make_uint4(sent, sent, sent, sent);
+    const int per = A.ls / 4;
+    for (int a = 0; a < P.arrays(); ++a) {
+        // (wave-uniform) a range slot no row writes to is never read; the separate target is written before it is read
+        const bool wanted = a < P.D ? ((A.lvmask >> a) & 1u) != 0 : !(P.sep && a == P.D);
+        if (!wanted) continue;
+        uint4 *p = reinterpret_cast<uint4 *>(lds + a * A.ls);
+        for (int i = threadIdx.x; i < per; i += T) p[i] = sv;
+    }
+    lds_barrier();
+}
+
+template <typename OutT, int T, int TOP>
+__device__ __forceinline__ void plan_fold_store(const SweepArgs &A, const Tile &t, uint32_t *lds) {
+    const int LS = A.ls, HL = A.hl, W = A.w;
+    const LevelPlan P = plan_of(A.nlev, A.lvmask);
+    const int cells = HL + W;
+    // every populated level above 16 into the blocks of 16, in ONE LDS pass: a block of 16 * 2^e at x covers the blocks
+    // of 16 at x, x + 16, ..., x + 16 (2^e - 1)
+    const int top = P.sep ? P.D - 1 : P.D - 2;  // last range slot above the blocks of 16
+    if (top >= 0) {
+        uint32_t *lo = lds + P.s16() * LS;
+        for (int x = 4 * threadIdx.x; x < cells; x += 4 * T) {
+            // (one 16-byte read whatever the plan: written as `sep ? ones : load` the compiler split it into four guarded
+            // 4-byte reads -- k = 256 0.55 -> 0.64 ms; a separate target holds nothing yet, what is read there is dropped)
+            uint4 r = *reinterpret_cast<const uint4 *>(lo + x);
+            if (P.sep) r = make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (int slot = top; slot >= 0; --slot) {
+                if (!((A.lvmask >> slot) & 1u)) continue;
+                const uint32_t *hi = lds + slot * LS;
+                switch (31 - A.ftop - slot) {  // log2 of this level's blocks (wave-uniform)
+                    case 5: fold_blocks_back<2>(hi, x, r); break;
+                    case 6: fold_blocks_back<4>(hi, x, r); break;
+                    default: fold_blocks_back<8>(hi, x, r); break;  // blocks of 128 (k - 1 <= 255)
+                }
+            }
+            *reinterpret_cast<uint4 *>(lo + x) = r;
+        }
+        lds_barrier();
+    }
+    // 16 -> 4 and 4 -> 1 in registers (r4_fold_store's last part; arrays that do not exist read as "no row")
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = T / 64;
+    constexpr int ctx = 4, valid = 64 - ctx;  // context lanes: 15 cells to the left
+    OutT *out = static_cast<OutT *>(A.out);
+    const int64_t ob = t.a - A.qs - HL;  // output index of cell 0
+    const int64_t o_lo = t.a - A.qs + t.x_lo, o_hi = t.a - A.qs + t.x_hi;
+    const bool aligned = (ob & 3) == 0;
+    // (arrays the plan does not have are read where the blocks of 16 are -- one unconditional 16-byte read each -- and
+    // replaced by "no row" afterwards)
+    const uint32_t *L16 = lds + P.s16() * LS, *L4 = lds + (P.has4 ? P.s4() : P.s16()) * LS,
+                   *L1 = lds + (P.has1 ? P.s1() : P.s16()) * LS;
+#define MEMO_DPP_MIN(dst, src) "v_min_u32_dpp " dst ", " src ", " dst " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define MEMO_DPP_MOV(dst, src) "v_mov_b32_dpp " dst ", " src " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    for (int base = wave * 4 * valid; base + 4 * ctx < cells; base += NW * 4 * valid) {
+        const int x0 = base + 4 * lane;             // this lane's cells x0 .. x0 + 3
+        const int xr = min(x0, LS - 4);             // (past the array: lanes whose results are dropped below)
+        const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+        uint4 R = *reinterpret_cast<const uint4 *>(L1 + xr);  // blocks of 1
+        uint4 M = *reinterpret_cast<const uint4 *>(L4 + xr);  // blocks of 4
+        if (!P.has1) R = ones;
+        if (!P.has4) M = ones;
+        {
+            // blocks of 16 -> blocks of 4: cells x - 4, x - 8, x - 12 are the same component 1, 2, 3 lanes left.
+            // B = min over two lanes in place, P = B one lane left; M = min(M, B, P one more lane left)
+            uint4 B = *reinterpret_cast<const uint4 *>(L16 + xr), Q;
+            asm("s_nop 1\n\t" MEMO_DPP_MIN("%4", "%4") MEMO_DPP_MIN("%5", "%5") MEMO_DPP_MIN("%6", "%6") MEMO_DPP_MIN("%7", "%7")
+                MEMO_DPP_MOV("%8", "%4") MEMO_DPP_MOV("%9", "%5") MEMO_DPP_MOV("%10", "%6") MEMO_DPP_MOV("%11", "%7")
+                "v_min_u32 %0, %4, %0\n\tv_min_u32 %1, %5, %1\n\tv_min_u32 %2, %6, %2\n\tv_min_u32 %3, %7, %3\n\t"
+                MEMO_DPP_MIN("%0", "%8") MEMO_DPP_MIN("%1", "%9") MEMO_DPP_MIN("%2", "%10") MEMO_DPP_MIN("%3", "%11")
+                : "+v"(M.x), "+v"(M.y), "+v"(M.z), "+v"(M.w), "+v"(B.x), "+v"(B.y), "+v"(B.z), "+v"(B.w),
+                  "=&v"(Q.x), "=&v"(Q.y), "=&v"(Q.z), "=&v"(Q.w));  // (Q of lane 0: whatever was there; a context lane)
+        }
+        // blocks of 4 -> positions: cell x takes the blocks at x, x - 1, x - 2, x - 3 (the last ones of the lane to the left)
+        asm("s_nop 1\n\t"
+            "v_min3_u32 %3, %3, %7, %6\n\tv_min3_u32 %3, %3, %5, %4\n\t"
+            "v_min3_u32 %2, %2, %6, %5\n\tv_min_u32 %2, %2, %4\n\t"
+            "v_min3_u32 %1, %1, %5, %4\n\tv_min_u32 %0, %0, %4\n\t"
+            MEMO_DPP_MIN("%2", "%7") MEMO_DPP_MIN("%1", "%7") MEMO_DPP_MIN("%0", "%7")
+            MEMO_DPP_MIN("%1", "%6") MEMO_DPP_MIN("%0", "%6") MEMO_DPP_MIN("%0", "%5")
+            : "+v"(R.x), "+v"(R.y), "+v"(R.z), "+v"(R.w) : "v"(M.x), "v"(M.y), "v"(M.z), "v"(M.w));
+        if (lane < ctx || x0 >= cells) continue;
+        const int64_t g = ob + x0;
+        if (aligned && g >= o_lo && g + 4 <= o_hi) {
+            if (sizeof(OutT) == 1 && TOP == 24) {  // the four top bytes, two v_perm_b32 and an or
+                *reinterpret_cast<uint32_t *>(out + g) = __builtin_amdgcn_perm(R.y, R.x, 0x0c0c0703u) |
+                                                         __builtin_amdgcn_perm(R.w, R.z, 0x07030c0cu);
+            } else {
+                if (TOP) R = make_uint4(R.x >> TOP, R.y >> TOP, R.z >> TOP, R.w >> TOP);
+                if (sizeof(OutT) == 1)
+                    *reinterpret_cast<uint32_t *>(out + g) = R.x | (R.y << 8) | (R.z << 16) | (R.w << 24);
+                else
+                    *reinterpret_cast<uint2 *>(out + g) = make_uint2(R.x | (R.y << 16), R.z | (R.w << 16));
+            }
+        } else {  // window edges, and windows that do not start on the tile grid's 4-position raster
+            const uint32_t v[4] = {R.x >> TOP, R.y >> TOP, R.z >> TOP, R.w >> TOP};
+            for (int i = 0; i < 4; ++i)
+                if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)v[i];
+        }
+    }
+#undef MEMO_DPP_MIN
+#undef MEMO_DPP_MOV
+}
+
+// ------------------------------------------------------------------------------------------
 // conservation, unclipped, MIXED levels: blocks of 1, 4, 16 and then doubling -- 32, 64, 128.
 //
 // What the radix-4 arrays cost is LDS atomics: an interval of n positions with 2S < n < 4S takes three or four
@@ -738,24 +896,32 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAV
 void sweep_conservation_mixed_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     static_assert(TOP == 0 || (!Rows::kAnnot16 && TOP == Rows::kTopShift), "the order rides in the word only in the 4-byte formats");
-    const int LS = A.ls, HL = A.hl, W = A.w, m = A.nlev;
+    const int LS = A.ls, HL = A.hl, W = A.w;
+    const LevelPlan P = plan_of(A.nlev, A.lvmask);
     Tile t;
     if (!locate_tile_w(A, t, W)) return;
     uint4 V[U];
     uint2 N[U];
     Rows::template issue<T, U>(A, t, 0, V, N);
     const uint32_t sent = (uint32_t)(A.ncols - 1);
-    halo_clear<T>(A, lds, TOP ? (sent << TOP) | ((1u << TOP) - 1u) : sent);
+#ifdef MEMO_OLD_MIXED  // (diagnostic builds: rounds 2-3's clear and fold, for the plan that has every array)
+    SweepArgs A2 = A;
+    A2.nlev = P.arrays();
+    halo_clear<T>(A2, lds, TOP ? (sent << TOP) | ((1u << TOP) - 1u) : sent);
+#else
+    plan_clear<T>(A, lds, TOP ? (sent << TOP) | ((1u << TOP) - 1u) : sent);
+#endif
 
     const int km1 = A.km1;
-    // slot of the blocks of 2^(31-f), f = clz(n) <= 27:  f - fmin, fmin = 30 - m (slot m-3 = blocks of 16 = f 27);
+    // slot of the blocks of 2^(31-f), f = clz(n) <= 27:  f - ftop (the range: see the level plan above);
     // LDS byte address of tile slot x there:  bias4 + f * 4 LS + 4 x
     const uint32_t ls4 = 4u * (uint32_t)LS;
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
-    const uint32_t bias4 = pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)(30 - m) * ls4));
+    const uint32_t bias4 = pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)A.ftop * ls4));
     const uint32_t top_bit = pin_vgpr((int)0x80000000u);
     const uint32_t key = pin_vgpr((int)Rows::tile_key(t.a));
-    uint32_t *const cells4 = lds + (m - 2) * LS + HL, *const cells1 = lds + (m - 1) * LS + HL;
+    // (rows of fewer than 16 positions exist only where the plan has arrays for them)
+    uint32_t *const cells4 = lds + P.s4() * LS + HL, *const cells1 = lds + P.s1() * LS + HL;
     auto scatter = [&](uint32_t w, uint32_t col) {
         if (MEMO_ROW_CMPX) {
             // The long intervals (n >= 16) as one branch-free block: v_cmpx narrows EXEC to "n > 0", then to "clz(n) < 28";
@@ -849,7 +1015,11 @@ void sweep_conservation_mixed_kernel(const SweepArgs A) {
     }
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
     __syncthreads();
-    r4_fold_store<OutT, T, TOP, true>(A, t, lds);
+#ifdef MEMO_OLD_MIXED
+    r4_fold_store<OutT, T, TOP, true>(A2, t, lds);
+#else
+    plan_fold_store<OutT, T, TOP>(A, t, lds);
+#endif
 }
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value
@@ -1014,6 +1184,38 @@ static int long_rows_conservation(const memo_index *ix, int64_t qs, int64_t qe, 
 // were made (memo_index.len_hist), so: many intervals under 16 positions (mixed would keep entering its slow path)
 // -> doubling up to seven levels (k <= 128; its fold runs in registers) and on dense indexes, else radix-4; radix-4
 // within 0.15 blocks per row of two (0.9 where mixed needs six arrays) -> radix-4; else mixed.
+// The level plan of the mixed arrays for k - 1 = km1 (see plan_of above): returns D, the slots of the doubling range; *ftop =
+// clz of the range's largest block size; *mask = populated slots | kPlanSep16 | kPlanHas4 | kPlanHas1.  `all`: every array a
+// k - 1 of this size can need (rounds 2-3; also what an index without an exact census gets).
+static int level_plan(const memo_index *ix, int km1, bool all, int *ftop, uint32_t *mask) {
+    all = all || !ix->len_seen_exact;
+    bool lv[32] = {false};
+    bool has4 = false, has1 = false;
+    for (int len = 0; len < km1 && len < 256; ++len) {
+        if (!all && !((ix->len_seen[len >> 5] >> (len & 31)) & 1u)) continue;  // no row of the index has this overlap
+        const int n = km1 - len;
+        if (n >= 16) lv[__builtin_clz((unsigned)n)] = true;
+        else if (n >= 4) has4 = true;
+        else has1 = true;
+    }
+    int top = 32, bot = -1;
+    for (int f = 0; f <= 27; ++f)
+        if (lv[f]) {
+            top = f < top ? f : top;
+            bot = f;
+        }
+    if (bot < 0) top = bot = 27, lv[27] = true;  // (no row of 16 positions or more: the blocks of 16 alone, which nobody writes)
+    uint32_t m = 0;
+    for (int f = top; f <= bot; ++f)
+        if (lv[f]) m |= 1u << (f - top);
+    if (bot < 27) m |= kPlanSep16;
+    if (has4) m |= kPlanHas4;
+    if (has1) m |= kPlanHas1;
+    *ftop = top;
+    *mask = m;
+    return bot - top + 1;
+}
+
 static int pick_levels(const memo_index *ix, int k, bool moderate) {
     const int km1 = k - 1, fallback = (km1 < 128 || !moderate) ? 2 : 3;
     if (!ix->len_hist_rows) return fallback;
@@ -1028,6 +1230,7 @@ static int pick_levels(const memo_index *ix, int k, bool moderate) {
     }
     if (rows <= 0) return fallback;
     if (small > 0.03 * rows) return fallback;
+    if (ix->len_seen_exact) return 4;  // mixed arrays, of which only the populated ones exist (level_plan): never more arrays than radix-4
     // (six mixed arrays from k = 130 up: on indexes of moderate density radix-4 stays ahead up to ~2.9 blocks per row --
     // config 3, k = 160: 2.5 blocks, 0.46 against 0.52 ms; k = 200: 3.1 blocks, level)
     return blocks4 <= (km1 >= 128 && moderate ? 2.9 : 2.15) * rows ? 3 : 4;
@@ -1142,18 +1345,24 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
         }
     }
-    // Mixed levels (sweep_conservation_mixed_kernel): 1, 4, 16, then doubling.  k - 1 >= 16 (three arrays or more).
+    // Mixed levels (sweep_conservation_mixed_kernel): 1, 4, 16, then doubling -- of which only the arrays some row of the index
+    // can write to exist (level_plan; the debug switch scatter = 4 asks for all of them, the layout of rounds 2-3).  k - 1 >= 16.
     if (levels == 4 && k - 1 >= 16) {
         const int bw = 1 << ix->bshift;
         const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + bw - 1 + 3) & ~3;
-        const int m = floor_log2((uint32_t)(k - 1)) - 1;  // blocks of 2^floor(log2(k-1)) .. 16, then 4 and 1
+        int ftop = 0;
+        uint32_t mask = 0;
+        const int D = level_plan(ix, k - 1, tune.scatter == 4, &ftop, &mask);
+        const int m = plan_of(D, mask).arrays();
         int ls = tune.tile_w ? tune.tile_w : (40 * 1024 / (4 * m)) & ~63;
         if (ls > 8192) ls = 8192;
         if (fmt == 12 && ls > 4096) ls = 4096;  // (12-bit start field: start - a < array size <= 2^12)
         while (!tune.tile_w && ls > 640 && (qe - qs) / (ls - hl - hr > bw ? ls - hl - hr : bw) < 4096) ls = (ls / 2) & ~3;
         const int tw = (ls - hl - hr) / bw * bw;
         if (tw >= bw && 2 * tw >= hl + hr && (size_t)m * (hl + tw + hr) * 4 <= 160 * 1024) {
-            A.nlev = m;
+            A.nlev = D;
+            A.lvmask = mask;
+            A.ftop = ftop;
             A.hl = hl;
             A.w = tw;
             A.ls = hl + tw + hr;
@@ -1166,6 +1375,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             if ((rc = use_words())) return rc;
             if ((rc = launch_tiles(kern, A, tw, 64 * waves, (size_t)m * A.ls * 4, st))) return rc;
             ix->last_sweep = 4;
+            ix->last_arrays = m;
             return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
         }
     }

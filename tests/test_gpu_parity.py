@@ -1113,7 +1113,7 @@ _C3_FNV = {}
     (False, "only", np.uint8, 101), (False, "keep", np.uint16, 101), (False, "only", np.uint8, 128), (True, "only", None, 101),
     (True, "dense", None, 31)],
     ids=["cons-int64-u16", "cons-packed-u16", "cons-packed-u8", "cons-packedonly-u8", "cons-dense-u8", "cons-dense-u16",
-         "memb-int64", "memb-packed", "cons-packedonly-u8-k101-mixed", "cons-packed-u16-k101-mixed", "cons-packedonly-u8-k128-radix4",
+         "memb-int64", "memb-packed", "cons-packedonly-u8-k101-mixed", "cons-packed-u16-k101-mixed", "cons-packedonly-u8-k128-mixed2",
          "memb-packedonly-k101", "memb-dense-planes3"])
 def test_config3_full_size_properties(membership, pack, dtype, k, memo, oracle):
     """configs 3/4 at full size: 100 genomes x 100 Mbp, 500 M rows, on the int64 columns AND on the
@@ -1156,7 +1156,9 @@ def test_config3_full_size_properties(membership, pack, dtype, k, memo, oracle):
         assert bad == 0, f"{bad} chunks of the whole-window result differ from the oracle"
         assert _C3_FNV.setdefault((membership, k), fnv) == fnv
         if not membership and pack in ("keep", "only"):   # the kernel family the library chose
-            assert ix.info()["last_sweep"] == {31: 2, 101: 4, 128: 3}[k]
+            assert ix.info()["last_sweep"] == {31: 2, 101: 4, 128: 4}[k]
+            if k > 64:        # the level plan: only the arrays some row can write to (k = 101: blocks of 64 and 32 + the fold's
+                assert ix.info()["last_level_arrays"] == {101: 3, 128: 2}[k]    # blocks of 16; k = 128: blocks of 64 + those)
         if pack == "dense":                               # a fact, not an inference: halo3 / planes3 answered
             assert ix.info()["last_sweep"] == (6 if membership else 5)
         rng = np.random.default_rng(3)
@@ -1868,8 +1870,11 @@ def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
     s = np.sort(rng.integers(1, length, m)).astype(np.int64)
     o = rng.integers(1, n_docs, m).astype(np.int64)
     cases = {
-        "uniform 0..59": (rng.integers(0, 60, m), {31: 2, 64: 2, 65: 2, 80: 4, 101: 4, 128: 3, 129: 3, 160: 3, 200: 4, 256: 4}),
-        "all 0": (np.zeros(m, np.int64), {65: 3, 101: 3, 200: 4}),   # n = k - 1: one length, radix-4 unless 2S < n
+        # (family, level arrays of the plan): mixed arrays wherever few intervals have fewer than 16 positions -- and of those
+        # only the ones some row can write to (+ the blocks of 16 the fold goes through)
+        "uniform 0..59": (rng.integers(0, 60, m), {31: 2, 64: 2, 65: 2, 80: (4, 3), 101: (4, 3), 128: (4, 2), 129: (4, 3), 160: (4, 3),
+                                                   200: (4, 2), 256: (4, 2)}),
+        "all 0": (np.zeros(m, np.int64), {65: (4, 2), 101: (4, 2), 200: (4, 2)}),   # n = k - 1: one length, one level
         "0..250": (rng.integers(0, 251, m), {101: 2, 200: 3, 256: 3}),  # many short intervals: doubling to k = 128, then radix-4
     }
     for name, (ov, want_by_k) in cases.items():
@@ -1887,7 +1892,10 @@ def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
                 for k, want in want_by_k.items():
                     qs, qe = 1000, 250_000
                     got = ix.conservation(qs, qe, k, n_docs)
-                    assert ix.info()["last_sweep"] == want, (name, way, k, ix.info()["last_sweep"])
+                    inf = ix.info()
+                    want_fam, want_arrays = want if isinstance(want, tuple) else (want, None)
+                    assert inf["last_sweep"] == want_fam, (name, way, k, inf["last_sweep"])
+                    assert want_arrays is None or inf["last_level_arrays"] == want_arrays, (name, way, k, inf["last_level_arrays"])
                     ref = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
                     assert np.array_equal(got, ref), (name, way, k)
 
