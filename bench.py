@@ -809,13 +809,18 @@ def main():
         }
         prof = os.path.join(ROOT, "profiles", "traffic.json")    # PMC passes are separate runs
         if os.path.exists(prof):
-            tj = json.load(open(prof)).get(f"{args.workload}_{args.rows}")
+            key = f"{args.workload}_{args.rows}" if host_rows is None else \
+                f"{os.path.basename(os.path.dirname(os.path.abspath(args.rows_file)))}_{'memb' if membership else 'cons'}_k{k}_{args.rows}"
+            tj = json.load(open(prof)).get(key)
             if tj and tj.get("result_bytes_per_position", b_out) == b_out and \
                     abs(tj.get("algorithmic_bytes", b_alg) - b_alg) <= 0.01 * b_alg:   # same kernel instantiation, same rows read
                 res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
                 res["roofline"]["traffic_source"] = (
                     "profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                     "(%s), not measured in this run" % tj.get("source", "tools/pmc_summary.py"))
+            elif tj:                                                    # (a stale entry must not vanish silently)
+                sys.stderr.write(f"bench.py: profiles/traffic.json[{key}] is for {tj.get('algorithmic_bytes')} algorithmic bytes / "
+                                 f"{tj.get('result_bytes_per_position')} B results, this run has {b_alg} / {b_out}: roofline.traffic left empty\n")
         if multi:
             # what the same run delivers when the result slices stay on their GPUs (no root):
             # every rank's sweep time from its own HIP events, slowest rank counts

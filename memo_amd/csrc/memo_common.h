@@ -75,9 +75,9 @@ struct memo_tuning {
     int no_views = 0;    // dense rows: 1 = never read a k-class view (A/B)
     int force_packed = 0;  // 1 = read the 4-byte rows even when the dense rows are resident and could answer (they are
                            //     the faster source for the conservation sweep: profiles/r02_dense_rows_ab.txt)
-    int row_order = 0;     // order of the 4-byte rows inside a bucket (memo_interleave.hip): 0 = the library's (kRowOrderDefault),
+    int row_order = 0;     // order of the 4-byte rows inside a bucket (memo_interleave.hip): 0 = the library's (by the kind of query),
                            //     1 = start order as packed, 2 = chunks of four dealt over the starts, 3 = the same with the rows of a
-                           //     start ordered by overlap mod 32
+                           //     start ordered by overlap mod 32 (the conservation order), 4 = dealt over annot mod 32 (membership)
 };
 
 // one chromosome's rows, resident in HBM (the opaque memo_index_t of the ABI)
@@ -106,7 +106,10 @@ struct memo_index {
     // for an order that spares a fraction of one sweep, so they are ordered by the FIFTH query that reads them (like the
     // k-class views), by memo_index_prepare, or by memo_index_pack on the finished index (order_words_now, memo_index.hip).
     int order_pending = 0;
-    int word_queries = 0;
+    // ... and rows in the conservation order (row_order 2) serve membership queries best in the membership order (3: dealt over
+    // annot mod 32) and the other way round: keep_row_order (memo_index.hip) switches by the fifth query of the other kind
+    int kind_queries = 0;        // queries of a kind that wants another order, since the last change
+    int order_switch_after = 4;  // ... how many of them it takes (four times as many after every switch)
     float pack_ms = 0.f;       // device time of the last memo_index_pack (census + packing kernel)
     uint32_t *p3 = nullptr;    // dense rows (memo_index_pack_dense): 16 bytes per 5 rows; annot <= 255 only
     // The dense rows may be FEWER than the index's rows: a row whose 6-bit length field is saturated (overlap >= 63, or
@@ -202,7 +205,7 @@ extern thread_local bool g_prepare_only;  // memo_index_prepare: the query path 
 extern thread_local bool g_side_alloc_fails;  // (AB library, memo_debug_fail_side_allocations: every side_alloc fails -- the test of kNoRoom)
 hipError_t side_alloc(void **p, size_t bytes);
 void drop_dense_views(memo_index *ix);
-int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows);  // k-class view of the words
+int packed_rows_for(memo_index *ix, int km1, bool membership, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows);  // k-class view of the words (+ their order)
 void drop_packed_views(memo_index *ix);
 inline uint64_t dense_groups_for(uint64_t padded) { return (padded + 4) / 5 + 64; }  // (+ one wave-load of slack: a wave reads its 64 groups whole)
 void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables derive from the dense rows and the bucket table
@@ -210,7 +213,7 @@ void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables der
 // over the bucket's starts, 2: the same with the rows of a start ordered by overlap mod 32), in place, queued on st
 int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshift, int fmt, int mode, hipStream_t st);
 constexpr int kRowOrderDefault = 2;  // interleave_words mode the product applies wherever 4-byte rows come into being
-int order_words_now(memo_index *ix);  // memo_index.hip: waits for the device, orders ix->pk in place, waits again
+int order_words_now(memo_index *ix, int mode);  // memo_index.hip: waits for the device, orders ix->pk in place, waits again
 inline int row_order_mode(const memo_index *ix) { return ix->tune.row_order ? ix->tune.row_order - 1 : kRowOrderDefault; }
 extern thread_local int g_last_one_shot_sweep;  // which kernel family answered this thread's last one-shot call
 }

@@ -58,9 +58,11 @@ int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32
 
 int memo_debug_row_order(memo_index_t *ix, int32_t order) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
-    if (order < 0 || order > 3) return fail(MEMO_EINVAL, "row order must be 0 (the library's), 1 (start order), 2 (chunks dealt over the starts) or 3 (+ by overlap mod 32)");
+    if (order < 0 || order > 4)
+        return fail(MEMO_EINVAL, "row order must be 0 (the library's), 1 (start order), 2 (chunks dealt over the starts), 3 (+ by overlap mod 32) "
+                                 "or 4 (dealt over annot mod 32: the membership order)");
     ix->tune.row_order = order;
-    return order_words_now(ix);  // (resident 4-byte rows: now; every later memo_index_pack: as asked)
+    return order_words_now(ix, row_order_mode(ix));  // (resident 4-byte rows: now; every later memo_index_pack: as asked)
 }
 
 int memo_debug_no_views(memo_index_t *ix, int32_t on) {

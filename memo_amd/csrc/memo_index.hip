@@ -846,19 +846,39 @@ static void keep_views_in_budget(memo_index *ix, memo_index::DenseView *views, i
     }
 }
 
-// The 4-byte rows of an index that came in through the builder or an import, brought into the query order (memo_interleave.hip).
-// In place: no sweep may be reading them, so the device is drained first (once per index: see memo_index::order_pending).
-int order_words_now(memo_index *ix) {
+// The 4-byte rows brought into a query order (memo_interleave.hip: 2 = the conservation order, 3 = the membership order, 0 =
+// start order).  In place: no sweep may be reading them, so the device is drained first (see memo_index::order_pending).
+int order_words_now(memo_index *ix, int mode) {
     ix->order_pending = 0;
-    const int mode = row_order_mode(ix);
+    if (mode == 3 && ix->bshift != 5) mode = 2;
     if (!ix->pk || !ix->rows || (ix->packed_fmt != 4 && ix->packed_fmt != 12) || mode == ix->row_order) return MEMO_OK;
     DeviceGuard guard(ix->device);
     HIP_TRY(hipDeviceSynchronize());
-    drop_packed_views(ix);  // (views are subsets in the old order; none exists before the fifth query, but a debug call may come late)
+    drop_packed_views(ix);  // (views are subsets in the old order)
     if (int rc = interleave_words(ix->pk, ix->boff, ix->nb, ix->bshift, ix->packed_fmt, mode, nullptr)) return rc;
     HIP_TRY(hipDeviceSynchronize());
     ix->row_order = mode;
     return MEMO_OK;
+}
+
+// Which order the 4-byte rows should be in for this kind of query, and whether it is time to bring them there: rows that came
+// in through the builder or an import wait for the fifth query that reads them (an index that answers one query should not
+// pay a pass over its rows); rows in the OTHER kind's order -- memo_index_pack leaves them in the conservation order, MEMO's
+// default query -- are re-ordered by the fifth query of this kind since the last change, then only after four times as many
+// (an index that serves both kinds settles on one order instead of flipping).  memo_index_prepare: now.
+static int keep_row_order(memo_index *ix, bool membership) {
+    if (!ix->pk || (ix->packed_fmt != 4 && ix->packed_fmt != 12)) return MEMO_OK;
+    const int want = ix->tune.row_order ? ix->tune.row_order - 1 : (membership && ix->bshift == 5 ? 3 : kRowOrderDefault);
+    if (want == ix->row_order) {
+        ix->order_pending = 0;
+        ix->kind_queries = 0;
+        return MEMO_OK;
+    }
+    const int after = ix->row_order == 0 ? 4 : ix->order_switch_after;  // (start order: nothing to lose by ordering)
+    if (!g_prepare_only && ++ix->kind_queries <= after) return MEMO_OK;
+    if (ix->row_order != 0 && ix->order_switch_after < (1 << 20)) ix->order_switch_after *= 4;
+    ix->kind_queries = 0;
+    return order_words_now(ix, want);
 }
 
 // the class of k - 1 = km1 for the 4-byte words: caps in steps of 2 up to 32 (an odd k -- 21, 31 -- gets exactly the rows that
@@ -882,9 +902,8 @@ static int view_slot(int km1, int *cap) {
 // The same k-class views for the 4-byte words (formats 4 and 12; what membership queries, k > 64 and indexes of more than 255
 // genomes read): the rows whose overlap is below the class's cap (2, 4 ... 32, 40 ... 64, 80 ... 128), with their own bucket table, built by the class's
 // fifth query when that spares a fifth of the rows.  BASELINE config 5 at k = 31 sweeps half of its 8.4 * 10^8 rows that way.
-int packed_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows) {
-    if (ix->order_pending && (g_prepare_only || ++ix->word_queries > 4))
-        if (int rc = order_words_now(ix)) return rc;
+int packed_rows_for(memo_index *ix, int km1, bool membership, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows) {
+    if (int rc = keep_row_order(ix, membership)) return rc;
     *pk = ix->pk;
     *boff = ix->boff;
     *rows = ix->rows;
@@ -1051,7 +1070,7 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
     if (!ix->finalized) return fail(MEMO_ENOTREADY, "index not finalized");
     if (!ix->has_wide) {  // packed already (a builder's or an imported index): bring its rows into the query order now
         if (!ix->packed_fmt) return fail(MEMO_EINVAL, "nothing to pack");
-        return ix->order_pending ? order_words_now(ix) : MEMO_OK;
+        return ix->order_pending ? order_words_now(ix, row_order_mode(ix)) : MEMO_OK;
     }
     if (ix->rows && ix->min_s < 0) return fail(MEMO_EINVAL, "rows with a negative start cannot be packed");
     DeviceGuard guard(ix->device);

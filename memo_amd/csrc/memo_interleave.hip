@@ -41,17 +41,31 @@ constexpr int kWaveQ = 16;            // wave path: chunk table for starts of up
 
 struct KeyCodec {
     int fmt12, mode, bshift;
+    int cshift;  // the class (what the chunks are dealt over) sits at key >> cshift: the start in its bucket (modes 0-2), annot mod 32 (mode 3)
     __device__ __forceinline__ uint32_t key(uint32_t w) const {
         const uint32_t start = fmt12 ? (w >> 8) & 0xFFFu : w & 0xFFFFu;
         const uint32_t ov = fmt12 ? w & 0xFFu : (w >> 16) & 0xFFu;
         const uint32_t annot = fmt12 ? w >> 20 : w >> 24;
+        const uint32_t s = start & ((1u << bshift) - 1u);
+        if (mode == 3)  // class = annot mod 32 | end in the bucket (9 bits) | annot | start in the bucket (bshift == 5)
+            return ((annot & 31u) << 26) | ((s + ov) << 17) | (annot << 5) | s;
         const uint32_t x = mode == 2 ? ((ov & 31u) << 3) | (ov >> 5) : ov;
-        return ((start & ((1u << bshift) - 1u)) << 20) | (x << 12) | annot;
+        return (s << 20) | (x << 12) | annot;
     }
     // high = the start field's bits above the bucket (the same for every row of a bucket)
     __device__ __forceinline__ uint32_t word(uint32_t k, uint32_t high) const {
-        const uint32_t start = high | (k >> 20), x = (k >> 12) & 0xFFu, annot = k & 0xFFFu;
-        const uint32_t ov = mode == 2 ? ((x & 7u) << 5) | (x >> 3) : x;
+        uint32_t start, ov, annot;
+        if (mode == 3) {
+            const uint32_t s = k & 31u;
+            start = high | s;
+            annot = (k >> 5) & 0xFFFu;
+            ov = ((k >> 17) & 0x1FFu) - s;
+        } else {
+            const uint32_t x = (k >> 12) & 0xFFu;
+            start = high | (k >> 20);
+            annot = k & 0xFFFu;
+            ov = mode == 2 ? ((x & 7u) << 5) | (x >> 3) : x;
+        }
         return fmt12 ? ov | (start << 8) | (annot << 20) : start | (ov << 16) | (annot << 24);
     }
     __device__ __forceinline__ uint32_t high_of(uint32_t w) const {
@@ -101,9 +115,9 @@ __device__ __forceinline__ void wave_bucket(uint32_t *__restrict__ words, int64_
         }
     }
     for (int e = lane; e < R; e += 64) {
-        const uint32_t s = key[e] >> 20;
-        if (e == 0 || (key[e - 1] >> 20) != s) first[s] = (uint32_t)e;
-        if (e == R - 1 || (key[e + 1] >> 20) != s) cnt[s] = (uint32_t)e + 1u;  // (its end, for now)
+        const uint32_t s = key[e] >> C.cshift;
+        if (e == 0 || (key[e - 1] >> C.cshift) != s) first[s] = (uint32_t)e;
+        if (e == R - 1 || (key[e + 1] >> C.cshift) != s) cnt[s] = (uint32_t)e + 1u;  // (its end, for now)
     }
     wave_sync();
     uint32_t c_mine = 0;
@@ -137,7 +151,7 @@ __device__ __forceinline__ void wave_bucket(uint32_t *__restrict__ words, int64_
         const uint32_t k = key[e];
         uint32_t pos = (uint32_t)e;  // mode 0: the sorted order itself
         if (C.mode) {
-            const uint32_t s = k >> 20, rank = (uint32_t)e - first[s];
+            const uint32_t s = k >> C.cshift, rank = (uint32_t)e - first[s];
             if (tabled) {
                 pos = table[32u * (rank >> 2) + s] + (rank & 3u);
             } else {
@@ -192,9 +206,9 @@ __device__ __forceinline__ void block_bucket(uint32_t *__restrict__ words, int64
         }
     }
     for (int i = tid; i < R; i += 256) {
-        const uint32_t s = key[i] >> 20;
-        if (i == 0 || (key[i - 1] >> 20) != s) first[s] = (uint32_t)i;
-        if (i == R - 1 || (key[i + 1] >> 20) != s) cnt[s] = (uint32_t)i + 1u;
+        const uint32_t s = key[i] >> C.cshift;
+        if (i == 0 || (key[i - 1] >> C.cshift) != s) first[s] = (uint32_t)i;
+        if (i == R - 1 || (key[i + 1] >> C.cshift) != s) cnt[s] = (uint32_t)i + 1u;
     }
     __syncthreads();
     for (int i = tid; i < S; i += 256)
@@ -204,7 +218,7 @@ __device__ __forceinline__ void block_bucket(uint32_t *__restrict__ words, int64
         const uint32_t k = key[i];
         uint32_t pos = (uint32_t)i;
         if (C.mode) {
-            const uint32_t s = k >> 20;
+            const uint32_t s = k >> C.cshift;
             const uint32_t rank = (uint32_t)i - first[s], q4 = rank & ~3u;
             pos = rank & 3u;
             for (int t = 0; t < S; ++t) {
@@ -222,7 +236,10 @@ __device__ __forceinline__ void block_bucket(uint32_t *__restrict__ words, int64
 }
 
 // mode 0: back to start order (start, overlap, annot); 1: chunks of four dealt over the starts, rows of a start by
-// (overlap, annot); 2: the same with the rows of a start by (overlap mod 32, overlap, annot)
+// (overlap, annot); 2: the same with the rows of a start by (overlap mod 32, overlap, annot); 3: the MEMBERSHIP order --
+// chunks of four dealt over the 32 classes of annot mod 32, the rows of a class by their end (then annot, start): a membership
+// sweep's ds_or goes to plane row `annot` (odd pitch: 32 consecutive residues are 32 banks) at the word of the run's first
+// bit, end - (k - 1), so the 32 lanes of a half-wave -- 32 residues, ends of one quantile of the bucket -- hit 32 banks
 __global__ __launch_bounds__(256) void interleave_buckets_kernel(uint32_t *__restrict__ words, const int64_t *__restrict__ boff,
                                                                  int64_t nbuckets, int bshift, int fmt12, int mode) {
     __shared__ uint32_t key[kMaxBucketRows];
@@ -233,6 +250,7 @@ __global__ __launch_bounds__(256) void interleave_buckets_kernel(uint32_t *__res
     C.fmt12 = fmt12;
     C.mode = mode;
     C.bshift = bshift;
+    C.cshift = mode == 3 ? 26 : 20;
     const int wave = threadIdx.x >> 6;
     // four buckets per workgroup and turn: one per wave when all four are small, else one after the other by everybody
     for (int64_t b0 = 4 * (int64_t)blockIdx.x; b0 < nbuckets; b0 += 4 * (int64_t)gridDim.x) {
@@ -258,6 +276,7 @@ __global__ __launch_bounds__(256) void interleave_buckets_kernel(uint32_t *__res
 // words: rows of formats 4 / 12, boff: their bucket table (nb entries, the last pinned to the row count).  Queued on st.
 int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshift, int fmt, int mode, hipStream_t st) {
     if (!words || !boff || nb < 2 || (fmt != 4 && fmt != 12) || bshift < 1 || bshift > 8) return MEMO_OK;
+    if (mode == 3 && bshift != 5) mode = 2;  // (the membership order's key is laid out for 32 starts per bucket)
     const int64_t nbuckets = (int64_t)nb - 1;
     const int64_t turns = (nbuckets + 3) / 4;
     const unsigned grid = (unsigned)(turns < 256 * 32 ? turns : 256 * 32);

@@ -1272,7 +1272,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         uint32_t *vpk = nullptr;
         int64_t *vboff = nullptr;
         uint64_t vrows = 0;
-        const int vrc = packed_rows_for(ix, k - 1, st_early, &vpk, &vboff, &vrows);
+        const int vrc = packed_rows_for(ix, k - 1, false, st_early, &vpk, &vboff, &vrows);
         if (vrc) return vrc;
         A.pk = vpk;
         A.boff = vboff;

@@ -463,7 +463,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         uint32_t *vpk = nullptr;
         int64_t *vboff = nullptr;
         uint64_t vrows = 0;
-        const int vrc = packed_rows_for(ix, k - 1, st, &vpk, &vboff, &vrows);
+        const int vrc = packed_rows_for(ix, k - 1, true, st, &vpk, &vboff, &vrows);
         if (vrc) return vrc;
         A.pk = vpk;
         A.boff = vboff;
