@@ -107,8 +107,8 @@ typedef struct memo_index_info {
                                when that spares a fifth of the rows and the device has room for it (see memo_index_prepare) */
     float last_view_ms;       /* device time of building that view, when the last sweep was the one that built it (else 0) */
     int32_t row_order;        /* order of the 4-byte rows inside a start bucket: 0 by start (as packed), 1 / 2 dealt round-robin
-                               over the bucket's starts in chunks of four (2: the rows of a start by overlap mod 32: what
-                               conservation queries want), 3 dealt over annot mod 32 (what membership queries want) -- the order
+                               over the bucket's starts in chunks of four (2: the rows of a start by overlap mod 32: the library's
+                               order), 3 dealt over annot mod 32 (A/B library only) -- the order
                                never changes a result, it spreads a wave's LDS atomics (memo_amd/csrc/memo_interleave.hip) */
     uint64_t side_bytes;      /* of device_bytes: what queries built on the side -- k-class views, tile tables, and buffers taken
                                out of service that wait for the device to drain (freed by the next memo_query_check) */

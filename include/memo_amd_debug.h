@@ -29,14 +29,14 @@ extern "C" {
  *   with views, 11 / 12 = as 6 / 7 with views;
  * scatter (conservation, packed rows): 1 = clip every interval to the tile, 2 = unclipped into doubling
  *   level arrays with a halo, 3 = unclipped into radix-4 level arrays, 4 = unclipped into mixed level arrays
- *   (blocks of 1, 4, 16, then doubling; k - 1 >= 16) -- 2, 3 and 4 only when every annot of the index is inside
- *   the result matrix, else 1. */
+ *   (blocks of 1, 4, 16, then doubling; k - 1 >= 16) with every array a k - 1 of that size can need (rounds 2-3), 5 = the mixed
+ *   arrays with the library's level plan (only the arrays some row of the index can write to) -- 2 .. 5 only when every annot of
+ *   the index is inside the result matrix, else 1. */
 int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32_t membership_algo,
                           int32_t row_source, int32_t scatter);
-/* Order of the 4-byte rows inside a start bucket (memo_amd/csrc/memo_interleave.hip): 0 = the library's choice (3 for
- * conservation, 4 for membership queries), 1 = start order (as the packers write them), 2 = chunks of four rows dealt round-robin
+/* Order of the 4-byte rows inside a start bucket (memo_amd/csrc/memo_interleave.hip): 0 = the library's choice (3), 1 = start order (as the packers write them), 2 = chunks of four rows dealt round-robin
  * over the bucket's starts, 3 = the same with the rows of a start ordered by overlap mod 32, 4 = chunks dealt over annot mod 32,
- * the rows of a class by their end.  Applied at once to resident 4-byte rows (their k-class views are dropped) and by every
+ * the rows of a class by their end (an order made for the membership planes; measured: 1 % -- profiles/r04_membership.txt).  Applied at once to resident 4-byte rows (their k-class views are dropped) and by every
  * later memo_index_pack of this index.  Results never depend on it. */
 int memo_debug_row_order(memo_index_t *ix, int32_t order);
 /* 1 = this index's sweeps read all the rows of their format even where a k-class view is resident (views already built stay:

@@ -75,7 +75,7 @@ struct memo_tuning {
     int no_views = 0;    // dense rows: 1 = never read a k-class view (A/B)
     int force_packed = 0;  // 1 = read the 4-byte rows even when the dense rows are resident and could answer (they are
                            //     the faster source for the conservation sweep: profiles/r02_dense_rows_ab.txt)
-    int row_order = 0;     // order of the 4-byte rows inside a bucket (memo_interleave.hip): 0 = the library's (by the kind of query),
+    int row_order = 0;     // order of the 4-byte rows inside a bucket (memo_interleave.hip): 0 = the library's (kRowOrderDefault),
                            //     1 = start order as packed, 2 = chunks of four dealt over the starts, 3 = the same with the rows of a
                            //     start ordered by overlap mod 32 (the conservation order), 4 = dealt over annot mod 32 (membership)
 };
@@ -106,10 +106,7 @@ struct memo_index {
     // for an order that spares a fraction of one sweep, so they are ordered by the FIFTH query that reads them (like the
     // k-class views), by memo_index_prepare, or by memo_index_pack on the finished index (order_words_now, memo_index.hip).
     int order_pending = 0;
-    // ... and rows in the conservation order (row_order 2) serve membership queries best in the membership order (3: dealt over
-    // annot mod 32) and the other way round: keep_row_order (memo_index.hip) switches by the fifth query of the other kind
-    int kind_queries = 0;        // queries of a kind that wants another order, since the last change
-    int order_switch_after = 4;  // ... how many of them it takes (four times as many after every switch)
+    int kind_queries = 0;        // queries that read the 4-byte rows while their ordering is pending
     float pack_ms = 0.f;       // device time of the last memo_index_pack (census + packing kernel)
     uint32_t *p3 = nullptr;    // dense rows (memo_index_pack_dense): 16 bytes per 5 rows; annot <= 255 only
     // The dense rows may be FEWER than the index's rows: a row whose 6-bit length field is saturated (overlap >= 63, or

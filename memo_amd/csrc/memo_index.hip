@@ -861,22 +861,17 @@ int order_words_now(memo_index *ix, int mode) {
     return MEMO_OK;
 }
 
-// Which order the 4-byte rows should be in for this kind of query, and whether it is time to bring them there: rows that came
-// in through the builder or an import wait for the fifth query that reads them (an index that answers one query should not
-// pay a pass over its rows); rows in the OTHER kind's order -- memo_index_pack leaves them in the conservation order, MEMO's
-// default query -- are re-ordered by the fifth query of this kind since the last change, then only after four times as many
-// (an index that serves both kinds settles on one order instead of flipping).  memo_index_prepare: now.
+// Is it time to bring the 4-byte rows into the query order?  Rows that came in through the builder or an import wait for the
+// fifth query that reads them (an index that answers one query should not pay a pass over its rows); memo_index_prepare: now.
+// (A membership order -- rows dealt over annot mod 32, interleave mode 3 -- was built and measured: config 4 at k = 101 0.870 ->
+// 0.863 ms, k = 31 0.528 -> 0.524: the planes kernel is not bound by its atomics' bank conflicts; profiles/r04_membership.txt.
+// One order serves both kinds of query; mode 3 stays reachable through memo_debug_row_order of the A/B library.)
 static int keep_row_order(memo_index *ix, bool membership) {
+    (void)membership;
     if (!ix->pk || (ix->packed_fmt != 4 && ix->packed_fmt != 12)) return MEMO_OK;
-    const int want = ix->tune.row_order ? ix->tune.row_order - 1 : (membership && ix->bshift == 5 ? 3 : kRowOrderDefault);
-    if (want == ix->row_order) {
-        ix->order_pending = 0;
-        ix->kind_queries = 0;
-        return MEMO_OK;
-    }
-    const int after = ix->row_order == 0 ? 4 : ix->order_switch_after;  // (start order: nothing to lose by ordering)
-    if (!g_prepare_only && ++ix->kind_queries <= after) return MEMO_OK;
-    if (ix->row_order != 0 && ix->order_switch_after < (1 << 20)) ix->order_switch_after *= 4;
+    const int want = row_order_mode(ix);
+    if (want == ix->row_order || !ix->order_pending) return MEMO_OK;
+    if (!g_prepare_only && ++ix->kind_queries <= 4) return MEMO_OK;
     ix->kind_queries = 0;
     return order_words_now(ix, want);
 }

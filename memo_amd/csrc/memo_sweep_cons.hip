@@ -1229,11 +1229,22 @@ static int pick_levels(const memo_index *ix, int k, bool moderate) {
         if (n < 16) small += w;
     }
     if (rows <= 0) return fallback;
-    if (small > 0.03 * rows) return fallback;
-    if (ix->len_seen_exact) return 4;  // mixed arrays, of which only the populated ones exist (level_plan): never more arrays than radix-4
-    // (six mixed arrays from k = 130 up: on indexes of moderate density radix-4 stays ahead up to ~2.9 blocks per row --
-    // config 3, k = 160: 2.5 blocks, 0.46 against 0.52 ms; k = 200: 3.1 blocks, level)
-    return blocks4 <= (km1 >= 128 && moderate ? 2.9 : 2.15) * rows ? 3 : 4;
+    // What decides (profiles/r04_large_k.txt): level arrays per tile against blocks per row -- and on an index of moderate density
+    // the arrays weigh more (rows built from sequences, 2 x 20 Mbp x 50 genomes, one more array costs what 0.3 blocks per row
+    // cost).  The mixed arrays take two blocks per row and exist only where some row can write (level_plan): with no more of them
+    // than radix-4's four they are the choice (BASELINE's generator at every k >= 65: two or three arrays).  Where the overlaps
+    // reach every level (rows built from sequences: five or six mixed arrays, seven or eight doubling ones) radix-4 arrays win
+    // while a row takes few blocks -- k = 101: 2.3 blocks per row, 0.185 ms against 0.204 doubling and 0.208 mixed; k = 128: 0.198
+    // against 0.228; k = 160: 0.248 against 0.272 mixed -- and lose beyond ~2.9 (k = 65: 0.181 against 0.168 doubling; k = 200:
+    // 0.284 against 0.279 mixed).  Many intervals under 16 positions keep the mixed arrays out (their slow path).
+    const bool few_small = small <= 0.03 * rows;
+    int ftop = 0;
+    uint32_t mask = 0;
+    const int planned = ix->len_seen_exact ? plan_of(level_plan(ix, km1, false, &ftop, &mask), mask).arrays() : 99;
+    if (few_small && planned <= 4) return 4;
+    if (moderate && blocks4 <= 2.9 * rows) return 3;
+    if (few_small) return ix->len_seen_exact || blocks4 > (km1 >= 128 && moderate ? 2.9 : 2.15) * rows ? 4 : 3;
+    return fallback;
 }
 
 #ifndef MEMO_TABLE_DEFAULT
@@ -1316,7 +1327,8 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // position: k = 101 0.89 vs 1.08, k = 256 1.14 vs 1.55 -- where a row's third and fourth block cost more LDS
     // atomics than the fold steps save.
     const bool moderate = (double)ix->rows < 12.0 * span;
-    const int levels = !halo || fmt == 3 ? 0 : tune.scatter >= 2 ? tune.scatter : (k - 1 >= 64 ? pick_levels(ix, k, moderate) : 2);
+    // (debug switch scatter = 5: the mixed arrays with the library's level plan, whatever pick_levels would say)
+    const int levels = !halo || fmt == 3 ? 0 : tune.scatter == 5 ? 4 : tune.scatter >= 2 ? tune.scatter : (k - 1 >= 64 ? pick_levels(ix, k, moderate) : 2);
     if (levels == 3) {
         const int bw = 1 << ix->bshift;
         const int hl = (k - 1 + 3) & ~3, hr = (k - 1 + bw - 1 + 3) & ~3;

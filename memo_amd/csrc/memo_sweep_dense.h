@@ -49,24 +49,31 @@ __device__ __forceinline__ void clear_levels(uint32_t lds_base, uint32_t sent) {
         clear_n<NLEV * 256 / T, 16 * T>(at, sv);
         return;
     }
-#ifdef MEMO_CLEAR_ADDTID
-    // A/B (round 4): ds_write_addtid_b32 -- address = M0 + offset + 4 * lane, no address VGPR -- stores 256 B per wave-instruction
-    // in 2 cycles of the LDS pipe where ds_write_b128 takes ~13 for 1 KiB (MI355X_MICROARCH.md, LDS): 4 NLEV instructions per wave
-    // instead of NLEV, 8 cycles per KiB instead of 13.  M0 is saved and restored inside the statement.
+#ifndef MEMO_CLEAR_B128  // (-DMEMO_CLEAR_B128: round 3's clear, one ds_write_b128 per lane and level, for A/B)
+    // ds_write_addtid_b32 -- address = M0 + offset + 4 * lane, no address VGPR -- stores 256 B per wave-instruction in 2 cycles of
+    // the LDS pipe where ds_write_b128 takes ~13 for 1 KiB (MI355X_MICROARCH.md, LDS): 4 NLEV instructions per wave instead of
+    // NLEV, 8 cycles per KiB instead of 13.  Config 3 on the k-class view, sustained: k = 31 0.2040 -> 0.1990 ms, k = 21 0.1680 ->
+    // 0.1635 (profiles/r04_view_levels.txt).  M0 is saved and restored inside the statement.
     {
         const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_base + (threadIdx.x >> 6) * 256u));
         uint32_t keep;
 #define MEMO_AT(off) "ds_write_addtid_b32 %2 offset:" #off "\n\t"
 #define MEMO_AT4(k) MEMO_AT(k) MEMO_AT(k + 1024) MEMO_AT(k + 2048) MEMO_AT(k + 3072)
+#define MEMO_AT_OPEN "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 1\n\t"  /* (a DS instruction that reads M0 needs wait states behind the s_mov: without them the first store of three waves in four went astray -- tools/addtid_probe.hip) */
+#define MEMO_AT_CLOSE "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(m0v), "v"(sent) : "memory"
+        if constexpr (NLEV == 1) asm volatile(MEMO_AT_OPEN MEMO_AT4(0) MEMO_AT_CLOSE);
+        if constexpr (NLEV == 2) asm volatile(MEMO_AT_OPEN MEMO_AT4(0) MEMO_AT4(4096) MEMO_AT_CLOSE);
+        if constexpr (NLEV == 3) asm volatile(MEMO_AT_OPEN MEMO_AT4(0) MEMO_AT4(4096) MEMO_AT4(8192) MEMO_AT_CLOSE);
+        if constexpr (NLEV == 4) asm volatile(MEMO_AT_OPEN MEMO_AT4(0) MEMO_AT4(4096) MEMO_AT4(8192) MEMO_AT4(12288) MEMO_AT_CLOSE);
         if constexpr (NLEV == 5)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" MEMO_AT4(0) MEMO_AT4(4096) MEMO_AT4(8192) MEMO_AT4(12288) MEMO_AT4(16384)
-                         "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(m0v), "v"(sent) : "memory");
-        if constexpr (NLEV == 4)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\t" MEMO_AT4(0) MEMO_AT4(4096) MEMO_AT4(8192) MEMO_AT4(12288)
-                         "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(m0v), "v"(sent) : "memory");
+            asm volatile(MEMO_AT_OPEN MEMO_AT4(0) MEMO_AT4(4096) MEMO_AT4(8192) MEMO_AT4(12288) MEMO_AT4(16384) MEMO_AT_CLOSE);
+        if constexpr (NLEV == 6)
+            asm volatile(MEMO_AT_OPEN MEMO_AT4(0) MEMO_AT4(4096) MEMO_AT4(8192) MEMO_AT4(12288) MEMO_AT4(16384) MEMO_AT4(20480) MEMO_AT_CLOSE);
+#undef MEMO_AT_CLOSE
+#undef MEMO_AT_OPEN
 #undef MEMO_AT4
 #undef MEMO_AT
-        if constexpr (NLEV == 5 || NLEV == 4) return;
+        return;
     }
 #endif
 #define MEMO_CLR(off) "ds_write_b128 %0, %1 offset:" #off "\n\t"

@@ -1875,7 +1875,8 @@ def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
         "uniform 0..59": (rng.integers(0, 60, m), {31: 2, 64: 2, 65: 2, 80: (4, 3), 101: (4, 3), 128: (4, 2), 129: (4, 3), 160: (4, 3),
                                                    200: (4, 2), 256: (4, 2)}),
         "all 0": (np.zeros(m, np.int64), {65: (4, 2), 101: (4, 2), 200: (4, 2)}),   # n = k - 1: one length, one level
-        "0..250": (rng.integers(0, 251, m), {101: 2, 200: 3, 256: 3}),  # many short intervals: doubling to k = 128, then radix-4
+        "0..250": (rng.integers(0, 251, m), {65: 2, 101: 3, 200: 3, 256: 3}),  # many short intervals, every level populated: radix-4's
+                                                                               # four arrays while a row takes few blocks, else doubling
     }
     for name, (ov, want_by_k) in cases.items():
         e = s + ov.astype(np.int64)

@@ -33,14 +33,29 @@ def main():
     ap.add_argument("--row-order", type=int, default=0,
                     help="order of the 4-byte rows inside a bucket (memo_debug_row_order): 0 library's, 1 start order, 2 chunks dealt "
                          "over the starts, 3 + by overlap mod 32")
+    ap.add_argument("--rows-file", default=None,
+                    help="an index from a file (.npz with start, end, annot, num_docs, length: tools/realistic_index.py) instead of the "
+                         "synthetic generator; the window is [0, length)")
+    ap.add_argument("--membership", action="store_true", help="with --rows-file: membership queries")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     num_docs, L, membership = WORKLOADS[a.workload]
     L = a.length or L
     from fractions import Fraction
     _lib.use_ab(True)
-    ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L, density=Fraction(a.density),
-                                      pack="only" if a.pack == "both" else a.pack)
+    if a.rows_file:
+        import memo_amd
+        z = np.load(a.rows_file)
+        num_docs, L, membership = int(z["num_docs"]), int(z["length"]), a.membership
+        ix = memo_amd.DeviceIndex.from_host(*(np.ascontiguousarray(z[c], dtype=np.int64) for c in ("start", "end", "annot")))
+        r0, r1 = 0, len(z["start"])
+        if a.pack:
+            ix.pack(keep_wide=(a.pack == "keep"))
+        if a.pack == "dense":
+            ix.pack_dense(keep_packed=False)
+    else:
+        ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L, density=Fraction(a.density),
+                                          pack="only" if a.pack == "both" else a.pack)
     if a.row_order:
         ix.debug_row_order(a.row_order)
     if a.pack == "both":
@@ -76,7 +91,9 @@ def main():
                                                     else (6 if ix.info()['packed_format'] == 6 else 4))
         b_alg = brow * (r1 - r0) + (4 * W if membership else (1 if a.u8 else 2)) * L
         t = np.array(times[v])
-        print(json.dumps({"variant": v, "workload": a.workload, "k": a.k, "row_bytes": brow, "ms_median": float(np.median(t)),
+        inf = ix.info()
+        print(json.dumps({"variant": v, "workload": a.rows_file or a.workload, "k": a.k, "row_bytes": brow, "ms_median": float(np.median(t)),
+                          "last_sweep": inf["last_sweep"], "last_rows_read": inf["last_rows_read"], "level_arrays": inf["last_level_arrays"],
                           "ms_min": float(t.min()), "ms_max": float(t.max()),
                           "frac_of_8TBs": b_alg / (float(np.median(t)) * 1e-3) / 8e12}))
 
