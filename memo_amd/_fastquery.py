@@ -20,9 +20,9 @@ import time
 
 from . import _lib
 
-VERSION = 2
+VERSION = 3
 HEADER_BYTES = 4096
-MAGIC = b"MEMOPK02"
+MAGIC = b"MEMOPK03"
 
 
 def _cache_path(in_file, record):       # (= memo_amd.cache.cache_path; restated here to keep NumPy out)
@@ -46,6 +46,12 @@ def _header_ok(head, file_bytes):       # (= memo_amd.cache.header_ok)
             if not (0 <= rows3 <= rows):
                 return False
             need += [(int(head["off_p3"]), 16 * ((rows3 + 4) // 5)), (int(head["off_boff3"]), 8 * nb)]
+        view = head.get("view")
+        if view is not None:
+            rows_v, cap = int(view["rows"]), int(view["cap"])
+            if head.get("off_p3") is None or not (0 <= rows_v <= int(head["rows3"])) or not (2 <= cap <= 32):
+                return False
+            need += [(int(view["off_p3"]), 16 * ((rows_v + 4) // 5)), (int(view["off_boff"]), 8 * nb)]
         return all(off >= HEADER_BYTES and size >= 0 and off + size <= total for off, size in need)
     except (KeyError, TypeError, ValueError):
         return False
@@ -124,11 +130,21 @@ def try_query(in_file, region, k, num_docs, out_file, membership):
             d1 = struct.unpack_from("<q", mm, head["off_boff3"] + 8 * b_hi)[0]
             dense = 0 <= d0 <= d1 <= head["rows3"] and bool(lib.memo_dense_rows_can_answer(
                 d1 - d0, lo, hi, head["max_annot"], k, num_docs, 1 if membership else 0))
+        off_g, off_t, viewed = head.get("off_p3"), head.get("off_boff3"), False
+        view = head.get("view")
+        if dense and view is not None and k - 1 <= view["cap"]:
+            # this k's class of the dense rows (the rows whose overlap is below the cap: all that can write at this k), when the
+            # cache was built for such a k: fewer rows to upload and sweep
+            v0 = struct.unpack_from("<q", mm, view["off_boff"] + 8 * b_lo)[0]
+            v1 = struct.unpack_from("<q", mm, view["off_boff"] + 8 * b_hi)[0]
+            if 0 <= v0 <= v1 <= view["rows"] and lib.memo_dense_rows_can_answer(v1 - v0, lo, hi, head["max_annot"], k, num_docs, 0):
+                d0, d1, off_g, off_t, viewed = v0, v1, view["off_p3"], view["off_boff"], True
         if dense:
             row_base = d0 // 5 * 5                # the slice starts with the group that holds row d0
+            n = d1 - d0
             _lib.check(lib.memo_index_import_dense(
-                d1 - row_base, device, shift, b_lo, base + head["off_p3"] + 16 * (row_base // 5),
-                base + head["off_boff3"] + 8 * b_lo, b_hi - b_lo + 2, row_base, lo, hi, head["max_annot"],
+                d1 - row_base, device, shift, b_lo, base + off_g + 16 * (row_base // 5),
+                base + off_t + 8 * b_lo, b_hi - b_lo + 2, row_base, lo, hi, head["max_annot"],
                 (base + head["off_long"]) if n_long else None, n_long, C.byref(ix)))
         else:
             _lib.check(lib.memo_index_import_packed(
@@ -167,5 +183,6 @@ def try_query(in_file, region, k, num_docs, out_file, membership):
     if os.environ.get("MEMO_TIMING"):
         sys.stderr.write("memo_query timing: region slice+upload %.3f s (from the sidecar cache, ctypes-only path), "
                          "sweep+download %.3f s, text+write %.3f s (%d rows as %s, %d positions)\n"
-                         % (t1 - t0, t2 - t1, t3 - t2, n, "dense rows (3.2 B)" if dense else "4-byte rows", L))
+                         % (t1 - t0, t2 - t1, t3 - t2, n, ("dense rows (3.2 B)" + (", the k-class view" if viewed else "")) if dense
+                            else "4-byte rows", L))
     return True

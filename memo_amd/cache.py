@@ -2,7 +2,7 @@
 
 `memo query` spends its wall clock decoding ZSTD Parquet pages (0.59 s of 0.93 s for a 2 * 10^7-position
 window of a 10^8-row index, profiles/r01_cli_timing_16decoders.txt); the sweep is 2 % of it.  The Parquet
-file stays the source of truth.  Beside it, `<index>.parquet.memo/<record>.v2.pk` keeps, per record
+file stays the source of truth.  Beside it, `<index>.parquet.memo/<record>.v3.pk` keeps, per record
 (chromosome), exactly what the GPU wants: the packed rows (4 B per row; + 2 B when an annot exceeds 4095),
 the dense rows (3.2 B per row, when every annot fits 8 bits: the benchmarked kernel's format),
 the start-bucket table and the few rows with end < start -- as produced by the library itself
@@ -16,8 +16,13 @@ temporary name and renamed, so a reader never sees a partial file.  Set MEMO_CAC
 write caches; MEMO_CACHE=read to read but never build.  A miss starts `python -m memo_amd.cache build`
 detached in the background (the query itself is answered from the Parquet file as before); MEMO_CACHE=sync
 builds it in-process after the answer is written instead (tests, batch jobs).  One builder per record at a
-time (an O_EXCL lock file); a record whose rows cannot be packed leaves a marker (`.v2.nocache`, keyed like the
+time (an O_EXCL lock file); a record whose rows cannot be packed leaves a marker (`.v3.nocache`, keyed like the
 cache) so that later queries neither rebuild nor respawn.
+
+v3 (round 4): beside the dense rows the file holds the k-class VIEW of them for the `-k` the cache was built for (the rows
+whose overlap is below the class's cap: all a conservation query with k - 1 <= cap can be touched by -- what a resident index
+builds by its class's fifth query, memo_index_info_t.last_rows_read) when that spares a fifth of the dense rows: a hit with
+such a k uploads and sweeps fewer rows (a cached `memo query` spends half of its wall clock on slice + upload).
 """
 import ctypes as C
 import json
@@ -30,9 +35,9 @@ import numpy as np
 from ._lib import MemoUnpackable, check, lib
 from .index import DeviceIndex, dense_rows_can_answer
 
-VERSION = 2
+VERSION = 3
 HEADER_BYTES = 4096
-MAGIC = b"MEMOPK02"
+MAGIC = b"MEMOPK03"
 LOCK_STALE_SECONDS = 3600.0
 
 
@@ -85,12 +90,56 @@ def header_ok(head, file_bytes):
             if not (0 <= rows3 <= rows):
                 return False
             need += [(int(head["off_p3"]), 16 * ((rows3 + 4) // 5)), (int(head["off_boff3"]), 8 * nb)]
+        view = head.get("view")
+        if view is not None:
+            rows_v, cap = int(view["rows"]), int(view["cap"])
+            if head.get("off_p3") is None or not (0 <= rows_v <= int(head["rows3"])) or not (2 <= cap <= 32):
+                return False
+            need += [(int(view["off_p3"]), 16 * ((rows_v + 4) // 5)), (int(view["off_boff"]), 8 * nb)]
         return all(off >= HEADER_BYTES and size >= 0 and off + size <= total for off, size in need)
     except (KeyError, TypeError, ValueError):
         return False
 
 
-def write(in_file, record, ix):
+def dense_view(p3, boff3, rows3, cap):
+    """the rows of exported dense groups (memo_index_export_dense; layout: memo_amd/csrc/memo_sweep.h, PackedRows3) whose 6-bit
+    overlap is below `cap`, as dense groups of their own with their own bucket table: (groups uint32[4 g], table int64, rows) --
+    what dense_filter builds on the device for a resident index.  None when that would spare less than a fifth of the rows."""
+    g = p3.reshape(-1, 4)
+    n = 5 * len(g)
+    B = np.empty(n, np.uint32)
+    A = np.empty(n, np.uint32)
+    for j in range(4):                       # dword j = B_j | X_j << 16 | A_j << 24
+        B[j::5] = g[:, j] & 0xFFFF
+        A[j::5] = g[:, j] >> 24
+    B[4::5] = ((g[:, 0] >> 16) & 0xFF) | (((g[:, 1] >> 16) & 0xFF) << 8)      # X_0 = B_4 & 255, X_1 = B_4 >> 8
+    A[4::5] = (g[:, 2] >> 16) & 0xFF                                          # X_2 = A_4
+    B, A = B[:rows3], A[:rows3]
+    keep = (B & 63) < cap
+    rows_v = int(keep.sum())
+    if rows_v * 5 > rows3 * 4:
+        return None
+    before = np.concatenate([np.zeros(1, np.int64), np.cumsum(keep, dtype=np.int64)])
+    table = before[boff3]                                                     # (entries are row numbers in [0, rows3])
+    pad = (-rows_v) % 5
+    Bv = np.concatenate([B[keep], np.full(pad, 63, np.uint32)])               # (rows behind the last one are never read by number)
+    Av = np.concatenate([A[keep], np.zeros(pad, np.uint32)])
+    out = np.empty((len(Bv) // 5, 4), np.uint32)
+    b4, a4 = Bv[4::5], Av[4::5]
+    out[:, 0] = Bv[0::5] | ((b4 & 255) << 16) | (Av[0::5] << 24)
+    out[:, 1] = Bv[1::5] | ((b4 >> 8) << 16) | (Av[1::5] << 24)
+    out[:, 2] = Bv[2::5] | (a4 << 16) | (Av[2::5] << 24)
+    out[:, 3] = Bv[3::5] | (Av[3::5] << 24)
+    return out.reshape(-1), table, rows_v
+
+
+def view_cap(k):
+    """the cap of the k class of the dense rows (classes of two: overlaps below 2, 4 ... 32), or None when k has no class"""
+    km1 = int(k) - 1
+    return 2 * ((km1 + 1) // 2) if 1 <= km1 <= 32 else None
+
+
+def write(in_file, record, ix, k=None):
     """ix: a packed DeviceIndex holding EVERY row of `record`.  Writes the cache file atomically: the 4- (6-) byte
     rows, the bucket table, the rows with end < start and -- when every annot fits 8 bits -- the DENSE rows too (3.2 B
     per row, memo_index_pack_dense: what the conservation sweep reads fastest, so that a cached `memo query -k 31`
@@ -112,17 +161,28 @@ def write(in_file, record, ix):
         p3 = np.empty(4 * ((rows3 + 4) // 5), np.uint32)
         boff3 = np.empty(nb, np.int64)                # the dense rows' own bucket table
         check(lib().memo_index_export_dense(ix._h, p3.ctypes.data, boff3.ctypes.data, longs.ctypes.data if n_long else None))
+    view, pv, boffv = None, np.empty(0, np.uint32), np.empty(0, np.int64)
+    cap = view_cap(k) if k is not None else None
+    if cap and rows3:
+        made = dense_view(p3, boff3, rows3, cap)
+        if made is not None:
+            pv, boffv, rows_v = made
+            view = {"cap": cap, "rows": rows_v}
     off_pk = HEADER_BYTES
     off_pa = _align(off_pk + pk.nbytes)
     off_p3 = _align(off_pa + pa.nbytes)
     off_boff3 = _align(off_p3 + p3.nbytes)
-    off_boff = _align(off_boff3 + boff3.nbytes)
+    off_pv = _align(off_boff3 + boff3.nbytes)
+    off_boffv = _align(off_pv + pv.nbytes)
+    off_boff = _align(off_boffv + boffv.nbytes)
     off_long = _align(off_boff + boff.nbytes)
     total = off_long + longs.nbytes
+    if view:
+        view.update(off_p3=off_pv, off_boff=off_boffv)
     head = {"version": VERSION, "record": record, "source": _source_key(in_file), "rows": rows, "format": fmt,
             "bucket_shift": inf["bucket_shift"], "buckets": nb, "min_start": inf["min_start"], "max_start": inf["max_start"],
             "max_annot": inf["max_annot"], "long_rows": n_long, "off_pk": off_pk, "off_pa": off_pa,
-            "off_p3": off_p3 if p3.nbytes else None, "off_boff3": off_boff3, "rows3": rows3, "off_boff": off_boff,
+            "off_p3": off_p3 if p3.nbytes else None, "off_boff3": off_boff3, "rows3": rows3, "view": view, "off_boff": off_boff,
             "off_long": off_long, "bytes": total}
     blob = MAGIC + json.dumps(head).encode()
     if len(blob) > HEADER_BYTES:
@@ -132,7 +192,8 @@ def write(in_file, record, ix):
     tmp = "%s.tmp.%d" % (path, os.getpid())
     with open(tmp, "wb") as fh:
         fh.write(blob.ljust(HEADER_BYTES, b"\0"))
-        for off, arr in ((off_pk, pk), (off_pa, pa), (off_p3, p3), (off_boff3, boff3), (off_boff, boff), (off_long, longs)):
+        for off, arr in ((off_pk, pk), (off_pa, pa), (off_p3, p3), (off_boff3, boff3), (off_pv, pv), (off_boffv, boffv), (off_boff, boff),
+                         (off_long, longs)):
             fh.seek(off)
             fh.write(memoryview(arr).cast("B"))
         fh.truncate(total)
@@ -198,9 +259,17 @@ def load_region(in_file, record, query_start, query_end, device=0, k=None, num_d
         cut3 = bucket_slice(head, lambda b: boff3[b], query_start, query_end, rows=head["rows3"])
         if cut3 is not None and dense_rows_can_answer(cut3[3] - cut3[2], lo, hi, head["max_annot"], k, num_docs, membership):
             _, _, d0, d1 = cut3
+            off_g, table_all = head["off_p3"], boff3
+            view = head.get("view")
+            if view is not None and k - 1 <= view["cap"]:          # this k's class of the dense rows: fewer rows to upload and sweep
+                boffv = mm[view["off_boff"]:view["off_boff"] + 8 * nb].view(np.int64)
+                cutv = bucket_slice(head, lambda b: boffv[b], query_start, query_end, rows=view["rows"])
+                if cutv is not None and dense_rows_can_answer(cutv[3] - cutv[2], lo, hi, head["max_annot"], k, num_docs, membership):
+                    _, _, d0, d1 = cutv
+                    off_g, table_all = view["off_p3"], boffv
             base = d0 // 5 * 5                       # the slice starts with the group that holds row d0
-            g = mm[head["off_p3"] + 16 * (base // 5):head["off_p3"] + 16 * ((d1 + 4) // 5)]
-            table3 = boff3[b_lo:b_hi + 1]
+            g = mm[off_g + 16 * (base // 5):off_g + 16 * ((d1 + 4) // 5)]
+            table3 = table_all[b_lo:b_hi + 1]
             check(lib().memo_index_import_dense(d1 - base, device, shift, b_lo, g.ctypes.data, table3.ctypes.data, len(table3) + 1,
                                                 base, lo, hi, head["max_annot"], longs.ctypes.data if n_long else None, n_long,
                                                 C.byref(h)))
@@ -271,7 +340,7 @@ def release_lock(in_file, record):
         pass
 
 
-def build(in_file, record, device=0, locked=False):
+def build(in_file, record, device=0, locked=False, k=None):
     """decode every row of `record` from the Parquet file, pack it with the library (the host packer only: rows it
     refuses are NOT uploaded as int64 columns -- 24 B per row of a whole chromosome for a cache that cannot be
     written), write the cache; a record that cannot be cached gets a marker so that no later query tries again.
@@ -293,12 +362,12 @@ def build(in_file, record, device=0, locked=False):
             if inf["packed_format"] not in (4, 6, 12) or inf["rows"] == 0:
                 _mark_uncacheable(in_file, record, "no rows" if inf["rows"] == 0 else "rows are not packed")
                 return None
-            return write(in_file, record, ix)
+            return write(in_file, record, ix, k=k)
     finally:
         release_lock(in_file, record)
 
 
-def build_in_background(in_file, record):
+def build_in_background(in_file, record, k=None):
     """a detached `python -m memo_amd.cache build` -- unless the record is known to be uncacheable or somebody
     (this user's other queries) is already building it"""
     import subprocess
@@ -308,6 +377,8 @@ def build_in_background(in_file, record):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     try:
+        if k is not None:
+            env["MEMO_CACHE_K"] = str(int(k))     # (the query's k: its class's view of the dense rows goes into the file too)
         subprocess.Popen([sys.executable, "-m", "memo_amd.cache", "build", in_file, record], env=env,
                          stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                          start_new_session=True)
@@ -321,7 +392,8 @@ if __name__ == "__main__":
     if len(sys.argv) >= 4 and sys.argv[1] == "build":
         dev = int(os.environ.get("MEMO_DEVICE", "0"))
         held = bool(os.environ.get("MEMO_CACHE_LOCKED")) and len(sys.argv) == 4
+        kk = int(os.environ["MEMO_CACHE_K"]) if os.environ.get("MEMO_CACHE_K", "").isdigit() else None
         for rec in sys.argv[3:]:
-            print(build(sys.argv[2], rec, dev, locked=held))
+            print(build(sys.argv[2], rec, dev, locked=held, k=kk))
     else:
         sys.exit("usage: python -m memo_amd.cache build INDEX.parquet RECORD [RECORD ...]")

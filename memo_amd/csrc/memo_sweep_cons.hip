@@ -776,12 +776,18 @@ __device__ __forceinline__ void plan_clear(const SweepArgs &A, uint32_t *lds, ui
     const LevelPlan P = plan_of(A.nlev, A.lvmask);
     const uint4 sv = make_uint4(sent, sent, sent, sent);
     const int per = A.ls / 4;
-    for (int a = 0; a < P.arrays(); ++a) {
-        // (wave-uniform) a range slot no row writes to is never read; the separate target is written before it is read
-        const bool wanted = a < P.D ? ((A.lvmask >> a) & 1u) != 0 : !(P.sep && a == P.D);
-        if (!wanted) continue;
-        uint4 *p = reinterpret_cast<uint4 *>(lds + a * A.ls);
-        for (int i = threadIdx.x; i < per; i += T) p[i] = sv;
+    // which arrays start at the sentinel: the populated slots of the range (one no row writes to is never read) and the blocks
+    // of 4 / of 1; the separate target of the fold is written before it is read.  (Unrolled over the eight arrays a plan can
+    // have, each behind a wave-uniform test: straight-line code the EXEC scan of tests/test_host_cpu.py can follow.)
+    uint32_t wanted = A.lvmask & ((1u << P.D) - 1u);
+    if (P.has4) wanted |= 1u << P.s4();
+    if (P.has1) wanted |= 1u << P.s1();
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        if ((wanted >> a) & 1u) {
+            uint4 *p = reinterpret_cast<uint4 *>(lds + a * A.ls);
+            for (int i = threadIdx.x; i < per; i += T) p[i] = sv;
+        }
     }
     lds_barrier();
 }

@@ -371,9 +371,9 @@ def main(args):
             if cache.uncacheable(*miss):                  # (read-only directory, full disk) is not an error
                 pass                                      # an earlier build found this record's rows unpackable
             elif cache.mode() == "sync":
-                cache.build(*miss, device=_device())
+                cache.build(*miss, device=_device(), k=None if membership_query else k)
             elif cache.mode() == "on":
-                cache.build_in_background(*miss)
+                cache.build_in_background(*miss, k=None if membership_query else k)
         except (OSError, RuntimeError) as exc:
             if os.environ.get("MEMO_TIMING"):
                 sys.stderr.write("memo_query: no sidecar cache written (%s)\n" % exc)

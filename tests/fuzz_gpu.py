@@ -2,7 +2,7 @@
 """Time-boxed differential fuzzing of the HIP path against the oracle (GPU box):
     python tests/fuzz_gpu.py --seconds 300 [--seed S]
 Random indexes (density, clumping, annots, overlaps incl. end < start), random windows, k, N,
-tile shapes, membership algorithms, row formats, scatters.  Exits non-zero on the first
+tile shapes, membership algorithms, row formats, scatters (incl. the level plan of the mixed arrays), row orders, memo_index_prepare.  Exits non-zero on the first
 mismatch and prints the case."""
 import argparse
 import os
@@ -73,7 +73,15 @@ while time.time() < t_end:
             ix.pack(keep_wide=True)
             if ix.info()["packed_format"] == 4 and rng.random() < 0.6:
                 ix.pack_dense(keep_packed=True)
-        k_pet = int(rng.choice([5, 9, 17, 31, 33]))               # (asked often enough for its class's view to be built)
+        if rng.random() < 0.5:                                     # the order of the 4-byte rows inside their buckets (memo_interleave.hip):
+            ix.debug_row_order(int(rng.integers(1, 5)))            #   start order, the two dealt orders, the membership order
+        k_pet = int(rng.choice([5, 9, 17, 31, 33, 101]))          # (asked often enough for its class's view to be built)
+        if rng.random() < 0.3:                                     # memo_index_prepare: the view / tile table / row order before the first query
+            try:
+                ix.prepare(k_pet, n_docs, membership=bool(rng.random() < 0.3), window_hint=int(rng.choice([0, 1000, length])))
+            except memo_amd.MemoError as exc:                      # (what the query itself would say: the dense rows alone cannot
+                if not (dense_only and ("needs the" in str(exc) or "dropped" in str(exc))):        # answer this k or this index)
+                    raise
         for _ in range(12):
             queries += 1
             k = k_pet if rng.random() < 0.45 else int(rng.choice(
@@ -84,7 +92,7 @@ while time.time() < t_end:
                 qs &= ~3                                                      # (the table-driven kernel wants the 4-position raster)
             qe = int(rng.integers(qs, length + 200))
             tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096, 1472, 1728])), int(rng.choice([0, 1, 4, 8])),
-                    int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])), int(rng.integers(0, 5)))
+                    int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])), int(rng.integers(0, 6)))
             if dense_only and tune[3] in (1, 3):
                 tune = tune[:3] + (0,) + tune[4:]                             # (no int64 columns / 4-byte rows to force)
             ix.debug_set_tuning(*tune)

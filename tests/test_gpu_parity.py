@@ -730,6 +730,21 @@ def test_sidecar_cache_round_trip(memo, oracle, tmp_path, monkeypatch):
         # the cache holds the dense rows where every annot fits 8 bits; a conservation query they can answer reads THEM
         assert ("dense rows (3.2 B)" if n_docs <= 255 else "4-byte rows") in err2, err2
         assert "dense rows (3.2 B)" in err1 if n_docs <= 255 else "4-byte rows" in err1, err1     # ... and so does the miss
+        if n_docs <= 255:
+            # v3: the miss ran with -k 31, so the file also holds that class's VIEW of the dense rows (overlaps below 30: three
+            # eighths of these rows) and a hit whose k fits the class uploads and sweeps only those
+            head = cache._open(path, record)[0]
+            assert head["view"]["cap"] == 30 and 0.3 < head["view"]["rows"] / head["rows3"] < 0.45
+            assert "the k-class view" in err2, err2
+            rows_hit = int(err2.split("(")[-1].split(" rows")[0])
+            text21, err21 = query(record, 1000, 60_000, 21, n_docs, "1")              # k - 1 = 20 <= 30: the same view serves it
+            assert "the k-class view" in err21
+            text33, err33 = query(record, 1000, 60_000, 33, n_docs, "1")              # k - 1 = 32 > 30: all the dense rows
+            assert "dense rows (3.2 B)" in err33 and "the k-class view" not in err33
+            assert int(err33.split("(")[-1].split(" rows")[0]) > 2 * rows_hit
+            for kk, tx in ((21, text21), (33, text33)):
+                assert tx == memo.emit_conservation(oracle.conservation(*oracle.filter_rows(s, e, o, 1000, 60_000, kk), 1000, 60_000, kk,
+                                                                        n_docs, literal=False))
         text2w, err2w = query(record, 1000, 60_000, 300, n_docs, "1")               # k > 256: not the fast path, not the cache
         assert "sidecar cache" not in err2w
         assert text2w == memo.emit_conservation(oracle.conservation(*oracle.filter_rows(s, e, o, 1000, 60_000, 300), 1000,
