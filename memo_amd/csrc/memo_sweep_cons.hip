@@ -479,35 +479,15 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
 // them, and three fold steps replace six or seven: 64 -> 16 as one LDS pass, 16 -> 4 and 4 -> 1 in registers
 // (DPP shifts only).  Used from k = 65 up; below that the doubling arrays are faster (see the launcher).
 // ------------------------------------------------------------------------------------------
-template <typename OutT, int T, int TOP, bool MIXED = false>
+template <typename OutT, int T, int TOP>
 __device__ __forceinline__ void r4_fold_store(const SweepArgs &A, const Tile &t, uint32_t *lds) {
     const int LS = A.ls, HL = A.hl, W = A.w, m = A.nlev;
     const int cells = HL + W;
-    // levels above 16 fold down through LDS (shifts of 16 cells and more are not a DPP's reach).
-    // Mixed levels: slot s < m - 3 holds blocks of 16 * 2^(m-3-s); ONE pass takes every one of them into the blocks
-    // of 16 (slot m-3): a block of 16 * 2^e at x covers the blocks of 16 at x, x + 16, ..., x + 16 (2^e - 1).
-    if (MIXED && m > 3) {
-        uint32_t *lo = lds + (m - 3) * LS;
-        for (int x = 4 * threadIdx.x; x < cells; x += 4 * T) {
-            uint4 r = *reinterpret_cast<const uint4 *>(lo + x);
-            for (int slot = m - 4; slot >= 0; --slot) {
-                const uint32_t *hi = lds + slot * LS;
-                const int reach = 16 << (m - 3 - slot);  // the size of this level's blocks
-                for (int back = 0; back < reach && back <= x; back += 16) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(hi + x - back);
-                    r.x = min(r.x, v.x);
-                    r.y = min(r.y, v.y);
-                    r.z = min(r.z, v.z);
-                    r.w = min(r.w, v.w);
-                }
-            }
-            *reinterpret_cast<uint4 *>(lo + x) = r;
-        }
-        lds_barrier();
-    }
+    // levels above 16 fold down through LDS (shifts of 16 cells and more are not a DPP's reach).  (The mixed arrays have a fold of
+    // their own since round 4: plan_fold_store.)
     // Radix-4 levels: slot s holds blocks of 4^(m-1-s); after this loop slot m-3 (blocks of 16) has everything
     // above it folded in
-    for (int slot = 0; !MIXED && slot + 3 < m; ++slot) {
+    for (int slot = 0; slot + 3 < m; ++slot) {
         const int S = 1 << (2 * (m - 2 - slot));  // size of the blocks being folded INTO (>= 16)
         const uint32_t *hi = lds + slot * LS;
         uint32_t *lo = lds + (slot + 1) * LS;
@@ -910,13 +890,7 @@ void sweep_conservation_mixed_kernel(const SweepArgs A) {
     uint2 N[U];
     Rows::template issue<T, U>(A, t, 0, V, N);
     const uint32_t sent = (uint32_t)(A.ncols - 1);
-#ifdef MEMO_OLD_MIXED  // (diagnostic builds: rounds 2-3's clear and fold, for the plan that has every array)
-    SweepArgs A2 = A;
-    A2.nlev = P.arrays();
-    halo_clear<T>(A2, lds, TOP ? (sent << TOP) | ((1u << TOP) - 1u) : sent);
-#else
     plan_clear<T>(A, lds, TOP ? (sent << TOP) | ((1u << TOP) - 1u) : sent);
-#endif
 
     const int km1 = A.km1;
     // slot of the blocks of 2^(31-f), f = clz(n) <= 27:  f - ftop (the range: see the level plan above);
@@ -1021,11 +995,7 @@ void sweep_conservation_mixed_kernel(const SweepArgs A) {
     }
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
     __syncthreads();
-#ifdef MEMO_OLD_MIXED
-    r4_fold_store<OutT, T, TOP, true>(A2, t, lds);
-#else
     plan_fold_store<OutT, T, TOP>(A, t, lds);
-#endif
 }
 
 // k <= 1: no row can write (casted_end >= start always), every position keeps its initial value

@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 4 diagnostic: the plan with every array (scatter 4) on this build against rounds 2-3's clear + fold (-DMEMO_OLD_MIXED build),
+# (the -DMEMO_OLD_MIXED diagnostic lived in memo_sweep_cons.hip from commit "Mixed level arrays follow an exact census" until the level plan's own
+# clear and fold had caught up -- profiles/r04_large_k.txt, item 3; this script is kept for the record of that run)
 # and the repeatability of one process's median (same build, same variant, five processes)
 TAG=${1:-r4plan2}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 run() {  # lib workload k pack extra...
