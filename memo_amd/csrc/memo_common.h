@@ -117,7 +117,8 @@ struct memo_index {
     int64_t *boff3 = nullptr;
     uint64_t rows3 = 0, padded3 = 0;
     // k-class views of the dense rows (dense_rows_for, memo_index.hip): the rows whose overlap is below 2 / 4 / ... / 32 -- all a
-    // query with k - 1 <= 2 / 4 / ... / 32 can be touched by -- with their own bucket table; built by the first query of the class
+    // query with k - 1 <= 2 / 4 / ... / 32 can be touched by -- with their own bucket table; built by memo_index_prepare or by the
+    // class's FIFTH query (build_after + 1), kept within the views' budget (memo_index_set_option: MEMO_OPT_VIEW_BUDGET_PCT)
     struct DenseView {
         int cap = 0, state = 0;  // state: 0 not looked at yet, 1 built, 2 not worth it (it would spare less than a fifth)
         int queries = 0;         // queries of this class since it was last looked at (a view is built by query build_after + 1)
