@@ -71,6 +71,11 @@ int memo_debug_no_views(memo_index_t *ix, int32_t on) {
     return MEMO_OK;
 }
 
+int memo_debug_view_colouring(int32_t on) {  // (views already built keep the order they have)
+    g_view_colouring = on ? 1 : 0;
+    return MEMO_OK;
+}
+
 int memo_debug_fail_side_allocations(int32_t on) {
     g_side_alloc_fails = on != 0;
     return MEMO_OK;

@@ -675,7 +675,7 @@ hipError_t side_alloc(void **p, size_t bytes) {
 
 static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_boff, uint64_t rows, uint64_t nb, int cap,
                         int min_tenths, hipStream_t st, uint32_t **out_p3, int64_t **out_boff, uint64_t *out_rows,
-                        uint64_t *out_padded, int len_shift = -1) {
+                        uint64_t *out_padded, int len_shift = -1, int colour_km1 = 0) {
     *out_p3 = nullptr;
     *out_boff = nullptr;
     if (!rows || rows >= ((uint64_t)1 << 38)) return MEMO_OK;
@@ -719,10 +719,14 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
                                words);
         } else {
             hipLaunchKernelGGL(dense_scatter_kernel, dim3(row_grid), dim3(256), 0, st, p3, rows, keep, local, blockpre, words);
-            hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, words, padded3, groups, p3n);
         }
         hipLaunchKernelGGL(dense_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, src_boff, nb, rows, total, keep, local,
                            blockpre, boff3);
+        if (len_shift < 0) {
+            // (a k-class view: which of its group's five places a row takes is chosen against LDS bank conflicts, memo_interleave.hip)
+            if (colour_km1 > 0 && g_view_colouring) (void)colour_view_words(words, boff3, nb, colour_km1, st);
+            hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, words, padded3, groups, p3n);
+        }
         err = hipGetLastError();
         if (err == hipSuccess) err = hipStreamSynchronize(st);
         if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
@@ -974,7 +978,7 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
             return fail(MEMO_EHIP, "hipEventCreate failed");
         }
         (void)hipEventRecord(e0, st);
-        const int rc = dense_filter(ix->device, *p3, *boff, *rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded);
+        const int rc = dense_filter(ix->device, *p3, *boff, *rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded, -1, cap);
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&v.build_ms, e0, e1);

@@ -271,6 +271,106 @@ __global__ __launch_bounds__(256) void interleave_buckets_kernel(uint32_t *__res
     }
 }
 
+
+// ---- the dense rows' k-class views: which of a group's five places a row takes --------------------------------------
+// The dense-row sweep (memo_sweep_dense.h: group_rows) gives a lane one 16-byte GROUP of five rows, and a wave's i-th row
+// instruction visits place i of 64 consecutive groups: the 32 rows of a half-wave are the rows 5 g + i of 32 consecutive
+// groups.  A row's two ds_min go to cell A = start - (k - 1) + overlap (first block) and cell B = start - 2^level (second
+// block) of its level's array (arrays are a multiple of 32 cells apart), and a half-wave's 32 atomics cost max(2, lanes on
+// the fullest of the 32 banks) cycles (profiles/r04_lds_atomics.txt).  What the k = 31 filter leaves of an interleaved
+// bucket costs 4.3 + 3.4 cycles per row instruction and half-wave by that model (both blocks near random), 2 + 2 being
+// the floor.  The order built here, per bucket of a view (one LANE per bucket: ~80 rows of BASELINE config 3):
+//   * the rows are taken in the order of A mod 32 (a counting sort) and given one of five COLOURS -- the place i = row
+//     number mod 5 -- greedily: the colour that has no row of the same A mod 32 yet, nor of the same B mod 32 (weights:
+//     a second row on a bank is free, a third is not), and room left (a colour has as many rows as the bucket has row
+//     numbers = i mod 5);
+//   * a colour's rows are laid down in the order they were taken: A mod 32 rises along the groups of a bucket, so that the
+//     pieces of two or three buckets that make up a half-wave's 32 groups (whatever group the tile began at) hold
+//     complementary ranges of A.
+// Model: 2.9 + 2.6 cycles (tools/view_order_model.py).  The levels are those of k - 1 = the class's cap: the odd k of the
+// class sees a few rows one level off (nothing but B's bank changes).  Buckets of more than 128 rows stay as they are.
+constexpr int kColourRows = 128;
+
+__global__ __launch_bounds__(64) void colour_view_kernel(uint32_t *__restrict__ words, const int64_t *__restrict__ boff, int64_t nbuckets,
+                                                         int km1) {
+    __shared__ uint32_t stage[kColourRows][64];
+    __shared__ uint8_t order[kColourRows][64];
+    __shared__ uint8_t cnt[32][64];
+    const int lane = threadIdx.x;
+    for (int64_t b0 = 64 * (int64_t)blockIdx.x; b0 < nbuckets; b0 += 64 * (int64_t)gridDim.x) {
+        const int64_t b = b0 + lane;
+        int64_t r0 = 0;
+        int R = 0;
+        if (b < nbuckets) {
+            r0 = boff[b];
+            const int64_t n = boff[b + 1] - r0;
+            R = n >= 6 && n <= kColourRows ? (int)n : 0;
+        }
+        for (int a = 0; a < 32; ++a) cnt[a][lane] = 0;
+        auto res_a = [&](uint32_t w) { return ((w & 1023u) + ((w >> 16) & 63u) - (uint32_t)km1) & 31u; };
+        for (int i = 0; i < R; ++i) {
+            const uint32_t w = words[r0 + i];
+            stage[i][lane] = w;
+            ++cnt[res_a(w)][lane];
+        }
+        {  // counts -> first places
+            int run = 0;
+            for (int a = 0; a < 32; ++a) {
+                const int c = cnt[a][lane];
+                cnt[a][lane] = (uint8_t)run;
+                run += c;
+            }
+        }
+        for (int i = 0; i < R; ++i) {
+            const uint32_t a = res_a(stage[i][lane]);
+            order[cnt[a][lane]++][lane] = (uint8_t)i;
+        }
+        // colours: place p = (row number) mod 5
+        uint32_t usedA[5], usedA2[5], usedB[5], usedB2[5];
+        int load[5], room[5];
+        int64_t at[5];
+        const int r0m = (int)(r0 % 5);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            usedA[c] = usedA2[c] = usedB[c] = usedB2[c] = 0u;
+            load[c] = 0;
+            const int skip = (c - r0m + 5) % 5;  // the bucket's first row number that is c mod 5: r0 + skip
+            at[c] = r0 + skip;
+            room[c] = R > skip ? (R - skip + 4) / 5 : 0;
+        }
+        for (int j = 0; j < R; ++j) {
+            const uint32_t w = stage[order[j][lane]][lane];
+            const uint32_t ov = (w >> 16) & 63u, s = w & 1023u;
+            const int n = km1 - (int)ov;  // (>= 1: the view holds the rows whose overlap is below the cap)
+            const uint32_t A = 1u << ((s + ov - (uint32_t)km1) & 31u);
+            const uint32_t B = 1u << ((s - (1u << (31 - __clz(n > 0 ? n : 1)))) & 31u);
+            int best = 0;
+            uint32_t bestp = 0xFFFFFFFFu;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                uint32_t p = (usedA[c] & A ? 4u : 0u) + (usedA2[c] & A ? 16u : 0u) + (usedB[c] & B ? 5u : 0u) + (usedB2[c] & B ? 16u : 0u);
+                p = (p << 8) + (uint32_t)load[c];
+                if (load[c] >= room[c]) p = 0xFFFFFFFEu;
+                if (p < bestp) {
+                    bestp = p;
+                    best = c;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                if (c == best) {
+                    usedA2[c] |= usedA[c] & A;
+                    usedB2[c] |= usedB[c] & B;
+                    usedA[c] |= A;
+                    usedB[c] |= B;
+                    words[at[c] + 5 * (int64_t)load[c]] = w;
+                    ++load[c];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // words: rows of formats 4 / 12, boff: their bucket table (nb entries, the last pinned to the row count).  Queued on st.
@@ -282,6 +382,18 @@ int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshi
     const unsigned grid = (unsigned)(turns < 256 * 32 ? turns : 256 * 32);
     hipLaunchKernelGGL(interleave_buckets_kernel, dim3(grid), dim3(256), 0, st, words, boff, nbuckets, bshift, fmt == 12 ? 1 : 0,
                        mode);
+    HIP_TRY(hipGetLastError());
+    return MEMO_OK;
+}
+
+// words: a dense view's rows as format-4 words (start mod 1024 | overlap << 16 | annot << 24) in bucket order, boff: the view's bucket
+// table (nb entries, the last pinned to the row count); km1 = the view's cap.  In place; queued on st.
+int colour_view_words(uint32_t *words, const int64_t *boff, uint64_t nb, int km1, hipStream_t st) {
+    if (!words || !boff || nb < 2 || km1 < 1 || km1 > 63) return MEMO_OK;
+    const int64_t nbuckets = (int64_t)nb - 1;
+    const int64_t turns = (nbuckets + 63) / 64;
+    const unsigned grid = (unsigned)(turns < 256 * 64 ? turns : 256 * 64);
+    hipLaunchKernelGGL(colour_view_kernel, dim3(grid), dim3(64), 0, st, words, boff, nbuckets, km1);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }

@@ -1880,6 +1880,45 @@ def test_row_order_inside_buckets_never_changes_a_result(memo, oracle, ab):
                     assert np.array_equal(gm, wm), (n_docs, order, k)
 
 
+def test_places_inside_a_dense_group_never_change_a_result(memo, oracle, ab):
+    """memo_interleave.hip, colour_view_kernel: the rows of a dense k-class view get their place inside their 16-byte group (and
+    their group inside the bucket) chosen against LDS bank conflicts.  Views built with and without it, on a ragged index
+    with empty stretches, a few buckets above the kernel's 128-row limit and windows that begin inside a bucket: the same rows
+    read, results equal to the oracle and to each other, every k of every class of two."""
+    rng = np.random.default_rng(43)
+    n_docs, length, m = 120, 90_000, 260_000
+    s = rng.integers(1, length, m)
+    s[:500] = rng.integers(30_016, 30_048, 500)          # one bucket of > 128 rows in the views: stays as it is
+    s[500:700] = rng.integers(50_000, 50_032, 200)
+    s[(s > 70_000) & (s < 72_000)] = 69_999              # an empty stretch
+    s = np.sort(s).astype(np.int64)
+    e = s + rng.integers(0, 64, m)
+    o = rng.integers(1, n_docs, m).astype(np.int64)
+    results = {}
+    try:
+        for colour in (1, 0, 1):
+            ab.check(ab.lib().memo_debug_view_colouring(colour))
+            with memo.DeviceIndex.from_host(s, e, o) as ix:
+                ix.pack(keep_wide=False)
+                ix.pack_dense(keep_packed=False)
+                for k in (2, 3, 8, 9, 16, 17, 21, 30, 31, 32, 33):
+                    ix.prepare(k, n_docs)
+                    for qs, qe in ((0, length + 50), (30_001, 50_017), (69_990, 72_100)):
+                        got = ix.conservation(qs, qe, k, n_docs)
+                        inf = ix.info()
+                        assert inf["last_sweep"] == 5, (k, inf["last_sweep"])
+                        key = (k, qs, qe)
+                        if key not in results:
+                            results[key] = (oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False),
+                                            inf["last_rows_read"])
+                        assert np.array_equal(got, results[key][0]), (colour, key)
+                        assert inf["last_rows_read"] == results[key][1], (colour, key)
+                    assert inf["last_rows_read"] < m                              # (a view was read)
+                ix.check()
+    finally:
+        ab.check(ab.lib().memo_debug_view_colouring(1))
+
+
 def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
     """k >= 65, unclipped conservation sweep: the library picks doubling / radix-4 / mixed level arrays from k and the
     overlap lengths it sampled when the packed rows were made (info.last_sweep says which ran); every choice is
