@@ -49,6 +49,7 @@ WORKLOADS = {
     "c4": (100, 100_000_000, True),
     "c5": (500, 1 << 25, False),
     "sparse": (10, 400_000_000, False),      # 0.5 rows per position (tuning experiments)
+    "c5h": (250, 1 << 25, False),            # config 5's 25 rows per position with annots that fit a byte (tools/ab.py --density 10/100)
 }
 
 
@@ -62,7 +63,7 @@ def parse():
     ap.add_argument("--wide", action="store_true", help="uint16 conservation results even when num_docs <= 255")
     ap.add_argument("--rows", default="auto", choices=["auto", "dense", "packed", "wide"],
                     help="row format the timed sweep reads: dense (memo_index_pack_dense, 3.2 B/row: conservation, "
-                         "k <= 64, num_docs <= 255), packed (memo_index_pack, 4-6 B/row), or the int64 columns as "
+                         "k <= 64, num_docs <= 511), packed (memo_index_pack, 4-6 B/row), or the int64 columns as "
                          "uploaded (24 B/row); auto = the fastest that can answer (dense where they can, else packed for k <= 256); at N=1 the "
                          "others are timed too")
     ap.add_argument("--plain-gather", action="store_true",
@@ -286,9 +287,12 @@ def main():
     from memo_amd import _lib
     if args.calibrate:
         _lib.use_ab(True)                   # the PMC calibration kernel lives in libmemo_amd_ab.so only
-    # the dense rows answer the unclipped conservation sweep only: k <= 64, num_docs <= 255, >= 1 row per position
+    # the dense rows answer the unclipped conservation sweep only: k <= 64, num_docs <= 511, >= 1 row per position
     # (membership reads them too when an index holds nothing else, 4 % slower than the 4-byte rows: not a bench format)
-    can_dense = (not membership) and k - 1 <= 63 and num_docs <= 255 and not args.wide and num_docs >= 20
+    # (256 .. 511 genomes -- BASELINE config 5 -- since round 4: the ninth annot bit in the group's spare byte, uint16 results, windows on
+    # the 4-position raster)
+    can_dense = (not membership) and k - 1 <= 63 and ((num_docs <= 255 and not args.wide) or (255 < num_docs <= 511 and qs % 4 == 0)) \
+        and num_docs >= 20
     if host_rows is not None:                # the library's own rule, on the rows the window sees
         from memo_amd.index import dense_rows_can_answer
         hs, _, ho = host_rows
@@ -297,7 +301,7 @@ def main():
     if args.rows == "auto":     # the fastest format that can answer: dense rows (back to back they are 13 % ahead of the
         args.rows = "wide" if k - 1 > 255 else ("dense" if can_dense else "packed")     # 4-byte rows: DESIGN.md section 7)
     if args.rows == "dense" and not can_dense:
-        raise SystemExit("--rows dense answers conservation with k <= 64 and num_docs <= 255 only")
+        raise SystemExit("--rows dense answers conservation with k <= 64 and num_docs <= 511 only")
     if k - 1 > 255:
         args.rows = "wide"                  # packed rows answer k <= 256 only
     # Resident indexes of the same rows, one per row format: the int64 columns as uploaded (24 B/row), the
@@ -786,7 +790,7 @@ def main():
                                          "`roofline` is priced on the rows read, other_row_formats has the same kernel on all the rows",
                        "result_bytes_per_position": b_out,
                        "row_format_choice": "--rows auto = the format that answers this query fastest: the dense rows where they "
-                                            "can (conservation, k <= 64, num_docs <= 255), else the 4- / 6-byte rows (k <= 256), "
+                                            "can (conservation, k <= 64, num_docs <= 511), else the 4- / 6-byte rows (k <= 256), "
                                             "else int64.  roofline is priced on the bytes of the format read (fewer bytes per row "
                                             "lower `frac` at the same speed); the other resident formats are timed in "
                                             "other_row_formats",

@@ -302,8 +302,8 @@ static int import_rows(uint64_t rows, int32_t device, int32_t bucket_shift, int6
     if (rows > ((uint64_t)1 << 40) || bucket_shift < 1 || bucket_shift > 8 || bucket_base < 0 || buckets < 2 ||
         (rows && !pk && !dense) || !boff || (n_long && !long_rows) || n_long > kMaxLongRows || max_annot > 65535)
         return fail(MEMO_EINVAL, "bad packed-index arguments");
-    if (dense && (max_annot > 255 || row_base % 5 || row_base < 0))
-        return fail(MEMO_EINVAL, "dense rows need every annot <= 255 and a row base that is a multiple of 5");
+    if (dense && (max_annot > 511 || row_base % 5 || row_base < 0))  // (256 .. 511: the ninth bit in the group's spare byte, memo_index.hip: pack3_rows_kernel)
+        return fail(MEMO_EINVAL, "dense rows need every annot <= 511 and a row base that is a multiple of 5");
     // boff: buckets - 1 entries of the (absolute) table the rows were cut from; the index's table is those minus
     // row_base, plus one entry pinned to `rows`
     const int64_t lead = boff[0] - row_base;  // rows of the slice in front of its first bucket (dense rows: up to 4)

@@ -121,20 +121,23 @@ __global__ void pack_rows_kernel(const int64_t *s, const int64_t *e, const int64
     }
 }
 
-// memo_index_pack_dense: 4-byte words -> dense rows, five per 16-byte group (layout: PackedRows3, memo_sweep.h)
-__global__ void pack3_rows_kernel(const uint32_t *pk, uint64_t padded, uint64_t groups, uint4 *p3) {
+// memo_index_pack_dense: 4-byte words -> dense rows, five per 16-byte group (layout: PackedRows3, memo_sweep.h).
+// f12: the words are format 12 (overlap | start << 8 | annot << 20) with annots of up to NINE bits: the ninth bit of row i's
+// annot goes to bit 16 + i of the group's last dword (the byte no row used while annots had eight)
+__global__ void pack3_rows_kernel(const uint32_t *pk, uint64_t padded, uint64_t groups, uint4 *p3, int f12) {
     for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < groups;
          g += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t w[5];
+        uint32_t B[5], A[5], hi = 0;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) w[i] = 5 * g + i < padded ? pk[5 * g + i] : 0u;
-        auto B = [](uint32_t x) {  // (start & 1023) << 6 | min(length, 63)
-            const uint32_t len = (x >> 16) & 0xFFu;
-            return ((x & 1023u) << 6) | (len > 63u ? 63u : len);
-        };
-        const uint32_t b4 = B(w[4]);
-        p3[g] = make_uint4(B(w[0]) | ((b4 & 0xFFu) << 16) | (w[0] & 0xFF000000u), B(w[1]) | ((b4 >> 8) << 16) | (w[1] & 0xFF000000u),
-                           B(w[2]) | ((w[4] >> 24) << 16) | (w[2] & 0xFF000000u), B(w[3]) | (w[3] & 0xFF000000u));
+        for (int i = 0; i < 5; ++i) {
+            const uint32_t x = 5 * g + i < padded ? pk[5 * g + i] : 0u;
+            const uint32_t len = f12 ? x & 0xFFu : (x >> 16) & 0xFFu, start = f12 ? x >> 8 : x, annot = f12 ? (x >> 20) & 0x1FFu : x >> 24;
+            B[i] = ((start & 1023u) << 6) | (len > 63u ? 63u : len);  // (start & 1023) << 6 | min(length, 63)
+            A[i] = annot & 0xFFu;
+            hi |= (annot >> 8) << i;
+        }
+        p3[g] = make_uint4(B[0] | ((B[4] & 0xFFu) << 16) | (A[0] << 24), B[1] | ((B[4] >> 8) << 16) | (A[1] << 24),
+                           B[2] | (A[4] << 16) | (A[2] << 24), B[3] | (hi << 16) | (A[3] << 24));
     }
 }
 
@@ -149,6 +152,7 @@ __device__ __forceinline__ void dense_row(const uint4 *p3, uint64_t r, uint32_t 
         case 3: B = g.w & 0xFFFFu; A = g.w >> 24; break;
         default: B = ((g.x >> 16) & 0xFFu) | (((g.y >> 16) & 0xFFu) << 8); A = (g.z >> 16) & 0xFFu; break;
     }
+    A |= ((g.w >> (16 + (int)(r % 5))) & 1u) << 8;  // (the ninth annot bit: indexes of 256 .. 511 genomes)
 }
 
 // keep[r / 32] bit r % 32 = row r stays; count[r / 32] = how many of the 32
@@ -223,15 +227,15 @@ __device__ __forceinline__ uint64_t kept_before(uint64_t r, const uint32_t *keep
     return blockpre[w >> 10] + local[w] + (uint32_t)__popc(keep[w] & ((1u << (r & 31)) - 1u));
 }
 
-// the rows that stay, as format-4 words (start mod 2^10 | length << 16 | annot << 24) at their new numbers: what
-// pack3_rows_kernel takes
+// the rows that stay, as format-4 words (start mod 2^10 | length << 16 | annot << 24; f12: as format-12 words, length | start
+// mod 2^10 << 8 | annot << 20 -- nine annot bits) at their new numbers: what pack3_rows_kernel takes
 __global__ __launch_bounds__(256) void dense_scatter_kernel(const uint4 *p3, uint64_t rows, const uint32_t *keep, const uint32_t *local,
-                                                            const uint64_t *blockpre, uint32_t *words) {
+                                                            const uint64_t *blockpre, uint32_t *words, int f12) {
     for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * 256) {
         if (!((keep[r >> 5] >> (r & 31)) & 1u)) continue;
         uint32_t B, A;
         dense_row(p3, r, B, A);
-        words[kept_before(r, keep, local, blockpre)] = (B >> 6) | ((B & 63u) << 16) | (A << 24);
+        words[kept_before(r, keep, local, blockpre)] = f12 ? (B & 63u) | ((B >> 6) << 8) | (A << 20) : (B >> 6) | ((B & 63u) << 16) | (A << 24);
     }
 }
 
@@ -675,7 +679,7 @@ hipError_t side_alloc(void **p, size_t bytes) {
 
 static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_boff, uint64_t rows, uint64_t nb, int cap,
                         int min_tenths, hipStream_t st, uint32_t **out_p3, int64_t **out_boff, uint64_t *out_rows,
-                        uint64_t *out_padded, int len_shift = -1, int colour_km1 = 0) {
+                        uint64_t *out_padded, int len_shift = -1, int colour_km1 = 0, int f12 = 0) {
     *out_p3 = nullptr;
     *out_boff = nullptr;
     if (!rows || rows >= ((uint64_t)1 << 38)) return MEMO_OK;
@@ -718,14 +722,14 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
             hipLaunchKernelGGL(packed_scatter_kernel, dim3(row_grid), dim3(256), 0, st, src_p3, rows, keep, local, blockpre,
                                words);
         } else {
-            hipLaunchKernelGGL(dense_scatter_kernel, dim3(row_grid), dim3(256), 0, st, p3, rows, keep, local, blockpre, words);
+            hipLaunchKernelGGL(dense_scatter_kernel, dim3(row_grid), dim3(256), 0, st, p3, rows, keep, local, blockpre, words, f12);
         }
         hipLaunchKernelGGL(dense_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, src_boff, nb, rows, total, keep, local,
                            blockpre, boff3);
         if (len_shift < 0) {
             // (a k-class view: which of its group's five places a row takes is chosen against LDS bank conflicts, memo_interleave.hip)
-            if (colour_km1 > 0 && g_view_colouring) (void)colour_view_words(words, boff3, nb, colour_km1, st);
-            hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, words, padded3, groups, p3n);
+            if (colour_km1 > 0 && g_view_colouring) (void)colour_view_words(words, boff3, nb, colour_km1, f12, st);
+            hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, words, padded3, groups, p3n, f12);
         }
         err = hipGetLastError();
         if (err == hipSuccess) err = hipStreamSynchronize(st);
@@ -758,7 +762,8 @@ int dense_compact(memo_index *ix) {
     uint32_t *p3n = nullptr;
     int64_t *boff3 = nullptr;
     uint64_t total = 0, padded3 = 0;
-    int rc = dense_filter(ix->device, ix->p3, ix->boff, ix->rows, ix->nb, 63, 1, nullptr, &p3n, &boff3, &total, &padded3);
+    int rc = dense_filter(ix->device, ix->p3, ix->boff, ix->rows, ix->nb, 63, 1, nullptr, &p3n, &boff3, &total, &padded3, -1, 0,
+                          ix->max_annot > 255 ? 1 : 0);
     if (rc == kNoRoom) rc = MEMO_OK;  // (no room for a second copy: every row stays)
     if (rc || !p3n) return rc;
     DeviceGuard guard(ix->device);
@@ -978,7 +983,8 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
             return fail(MEMO_EHIP, "hipEventCreate failed");
         }
         (void)hipEventRecord(e0, st);
-        const int rc = dense_filter(ix->device, *p3, *boff, *rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded, -1, cap);
+        const int rc = dense_filter(ix->device, *p3, *boff, *rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded, -1, cap,
+                                    ix->max_annot > 255 ? 1 : 0);
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&v.build_ms, e0, e1);
@@ -1152,14 +1158,14 @@ int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed) {
         }
         return MEMO_OK;
     }
-    if (ix->packed_fmt != 4 || !ix->pk)
-        return fail(MEMO_EINVAL, "dense rows are built from the 4-byte rows: memo_index_pack first, and every annot <= 255");
+    if (!ix->pk || (ix->packed_fmt != 4 && !(ix->packed_fmt == 12 && ix->max_annot <= 511)))
+        return fail(MEMO_EINVAL, "dense rows are built from the 4-byte rows: memo_index_pack first, and every annot <= 511");
     DeviceGuard guard(ix->device);
     hipStream_t st = nullptr;
     const uint64_t groups = dense_groups_for(ix->padded);
     HIP_TRY(hipMalloc(&ix->p3, groups * 16));
     hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, ix->pk, ix->padded, groups,
-                       reinterpret_cast<uint4 *>(ix->p3));
+                       reinterpret_cast<uint4 *>(ix->p3), ix->packed_fmt == 12 ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     ix->rows3 = ix->rows;

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void interleave_buckets_kernel(uint32_t *__res
 constexpr int kColourRows = 128;
 
 __global__ __launch_bounds__(64) void colour_view_kernel(uint32_t *__restrict__ words, const int64_t *__restrict__ boff, int64_t nbuckets,
-                                                         int km1) {
+                                                         int km1, int f12) {
     __shared__ uint32_t stage[kColourRows][64];
     __shared__ uint8_t order[kColourRows][64];
     __shared__ uint8_t cnt[32][64];
@@ -307,7 +307,10 @@ __global__ __launch_bounds__(64) void colour_view_kernel(uint32_t *__restrict__ 
             R = n >= 6 && n <= kColourRows ? (int)n : 0;
         }
         for (int a = 0; a < 32; ++a) cnt[a][lane] = 0;
-        auto res_a = [&](uint32_t w) { return ((w & 1023u) + ((w >> 16) & 63u) - (uint32_t)km1) & 31u; };
+        // (start mod 1024, overlap) of a word: format 4 (start | overlap << 16 | annot << 24) or, f12, format 12 (overlap | start << 8 | annot << 20)
+        auto start_of = [&](uint32_t w) { return (f12 ? w >> 8 : w) & 1023u; };
+        auto ov_of = [&](uint32_t w) { return (f12 ? w : w >> 16) & 63u; };
+        auto res_a = [&](uint32_t w) { return (start_of(w) + ov_of(w) - (uint32_t)km1) & 31u; };
         for (int i = 0; i < R; ++i) {
             const uint32_t w = words[r0 + i];
             stage[i][lane] = w;
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(64) void colour_view_kernel(uint32_t *__restrict__ 
         }
         for (int j = 0; j < R; ++j) {
             const uint32_t w = stage[order[j][lane]][lane];
-            const uint32_t ov = (w >> 16) & 63u, s = w & 1023u;
+            const uint32_t ov = ov_of(w), s = start_of(w);
             const int n = km1 - (int)ov;  // (>= 1: the view holds the rows whose overlap is below the cap)
             const uint32_t A = 1u << ((s + ov - (uint32_t)km1) & 31u);
             const uint32_t B = 1u << ((s - (1u << (31 - __clz(n > 0 ? n : 1)))) & 31u);
@@ -386,14 +389,14 @@ int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshi
     return MEMO_OK;
 }
 
-// words: a dense view's rows as format-4 words (start mod 1024 | overlap << 16 | annot << 24) in bucket order, boff: the view's bucket
-// table (nb entries, the last pinned to the row count); km1 = the view's cap.  In place; queued on st.
-int colour_view_words(uint32_t *words, const int64_t *boff, uint64_t nb, int km1, hipStream_t st) {
+// words: a dense view's rows as format-4 words (start mod 1024 | overlap << 16 | annot << 24; f12: format-12 words) in bucket order,
+// boff: the view's bucket table (nb entries, the last pinned to the row count); km1 = the view's cap.  In place; queued on st.
+int colour_view_words(uint32_t *words, const int64_t *boff, uint64_t nb, int km1, int f12, hipStream_t st) {
     if (!words || !boff || nb < 2 || km1 < 1 || km1 > 63) return MEMO_OK;
     const int64_t nbuckets = (int64_t)nb - 1;
     const int64_t turns = (nbuckets + 63) / 64;
     const unsigned grid = (unsigned)(turns < 256 * 64 ? turns : 256 * 64);
-    hipLaunchKernelGGL(colour_view_kernel, dim3(grid), dim3(64), 0, st, words, boff, nbuckets, km1);
+    hipLaunchKernelGGL(colour_view_kernel, dim3(grid), dim3(64), 0, st, words, boff, nbuckets, km1, f12);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }

@@ -1397,8 +1397,10 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             // (the dense rows may leave out the rows that can never write at k <= 64 -- memo_common.h: boff3 -- and then have
             // their own row numbers and bucket table; they answer only while they still hold a row per position)
             const uint64_t drows = ix->boff3 ? ix->rows3 : ix->rows;
-            const bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && top8 &&
-                               ((double)drows >= span || !ix->pk);
+            // 256 .. 511 genomes: the table-driven kernel's nine-bit form (memo_sweep_cons3t.hip: A9), uint16 results, or not the dense rows
+            const bool top9 = !top8 && num_docs <= 511 && ix->max_annot <= 511 && sizeof(OutT) == 2;
+            bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && (top8 || top9) &&
+                         ((double)drows >= span || !ix->pk);
             if (three) {  // the dense rows of this k's class (a view that leaves out the rows that cannot write at this k), or all
                 uint32_t *vp3 = nullptr;
                 int64_t *vboff = nullptr;
@@ -1409,7 +1411,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                 ix->last_rows_read = vrows;
             }
             ix->last_variant = 0;
-            if (three && g_persistent_launch && tune.persistent >= 2 && tune.persistent <= 4 && !g_prepare_only) {
+            if (three && top8 && g_persistent_launch && tune.persistent >= 2 && tune.persistent <= 4 && !g_prepare_only) {
                 // persistent workgroups (memo_sweep_cons3p.hip, AB library only: 17 - 50 % slower than a workgroup per tile,
                 // profiles/r03_persistent_sweep.txt); 1 = this query does not fit it
                 const int prc = g_persistent_launch(A, tw, (int)sizeof(OutT), ix->device, tune.persistent - 2, st);
@@ -1420,15 +1422,16 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
                 }
             }
-            if (three && (tune.persistent == 5 || (tune.persistent == 0 && MEMO_TABLE_DEFAULT))) {
+            if (three && (top9 || tune.persistent == 5 || (tune.persistent == 0 && MEMO_TABLE_DEFAULT))) {
                 // the tile's row slice from a table built once per (index, k): memo_sweep_cons3t.hip; 1 = does not fit
-                const int trc = launch_halo3t(ix, A, tw, (int)sizeof(OutT), st);
+                const int trc = launch_halo3t(ix, A, tw, (int)sizeof(OutT), st, top9);
                 if (trc < 0) return trc;
                 if (trc == MEMO_OK) {
                     ix->last_sweep = 5;
                     ix->last_variant = 2;
                     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
                 }
+                if (top9) three = false;  // (a window off the 4-position raster, no room for a tile table: the 4-byte rows if resident)
             }
             if (!three && fmt == 3) {
                 halo = false;  // (below: the int64 columns, or an error when they are gone too)

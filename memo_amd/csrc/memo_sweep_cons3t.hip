@@ -54,9 +54,12 @@ __global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase
 #endif
 
 // T = 256: four waves per tile (eight tiles = 32 waves per CU), the only form instantiated (T = 128 lost: see the launcher)
-template <int NLEV, typename OutT, int T>
+// A9: an index of 256 .. 511 genomes -- the order in the top NINE bits of a level cell (memo_sweep_dense.h: MEMO_ROW9_AT), uint16 results
+template <int NLEV, typename OutT, int T, bool A9 = false>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 : 4, 8)))
 void sweep_conservation_halo3t_kernel(const SweepArgs A) {
+    static_assert(!A9 || sizeof(OutT) == 2, "more than 255 genomes: uint16 results");
+    constexpr int SH = A9 ? 23 : 24;  // a cell = order << SH | tie-breaking bits
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int NW = T / 64, NL = kStageGroups / T;  // waves; 16-byte groups per lane and batch
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,7 +97,7 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     issue(0);
     const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds;
     const int HL = A.hl, W = A.w;
-    if (!(MEMO_T_ABLATE & 2)) clear_levels<NLEV, T>(lds_base, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
+    if (!(MEMO_T_ABLATE & 2)) clear_levels<NLEV, T>(lds_base, ((uint32_t)(A.ncols - 1) << SH) | ((1u << SH) - 1u));
     RowConst C;
     C.km1 = A.km1;
     C.status = A.status;
@@ -119,10 +122,10 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
         const uint32_t w_row0 = 5u * (gbase + (uint32_t)wave * 64u);
         if (w_row0 >= g.first && w_row0 + 5u * ((uint32_t)(NL - 1) * T + 64u) <= g.end) {
 #pragma unroll
-            for (int j = 0; j < NL; ++j) group_rows<false>(V[j], C, 0, 0);
+            for (int j = 0; j < NL; ++j) group_rows<false, A9>(V[j], C, 0, 0);
             continue;
         }
-        reg_pieces<T, NL>(V, tid, wave, gbase, gleft, g, C, span);
+        reg_pieces<T, NL, 0, A9>(V, tid, wave, gbase, gleft, g, C, span);
     }
     barrier_lds();  // (lgkmcnt(0): the ds_min above are invisible to the compiler)
 
@@ -158,7 +161,9 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
         if (lane < ctx || x0 >= cells) continue;
         const int64_t o = ob + x0;
         if (o >= o_lo && o + 4 <= o_hi) {
-            if constexpr (sizeof(OutT) == 1) {
+            if constexpr (A9) {
+                *reinterpret_cast<uint2 *>(out + o) = make_uint2((M.x >> 23) | ((M.y >> 23) << 16), (M.z >> 23) | ((M.w >> 23) << 16));
+            } else if constexpr (sizeof(OutT) == 1) {
                 *reinterpret_cast<uint32_t *>(out + o) = __builtin_amdgcn_perm(M.y, M.x, 0x0c0c0703u) |
                                                          __builtin_amdgcn_perm(M.w, M.z, 0x07030c0cu);
             } else {
@@ -166,7 +171,7 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
                                                                  __builtin_amdgcn_perm(M.w, M.z, 0x0c070c03u));
             }
         } else {
-            const uint32_t v[4] = {M.x >> 24, M.y >> 24, M.z >> 24, M.w >> 24};
+            const uint32_t v[4] = {M.x >> SH, M.y >> SH, M.z >> SH, M.w >> SH};
             for (int i = 0; i < 4; ++i)
                 if (o + i >= o_lo && o + i < o_hi) out[o + i] = (OutT)v[i];
         }
@@ -182,6 +187,18 @@ SweepKernel kernel_for(int nlev) {
         case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, OutT, T>;
         case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, OutT, T>;
         case 6: return (SweepKernel)sweep_conservation_halo3t_kernel<6, OutT, T>;
+    }
+    return nullptr;
+}
+
+SweepKernel kernel_for9(int nlev) {  // (256 .. 511 genomes)
+    switch (nlev) {
+        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, uint16_t, 256, true>;
+        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, uint16_t, 256, true>;
+        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, uint16_t, 256, true>;
+        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, uint16_t, 256, true>;
+        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, uint16_t, 256, true>;
+        case 6: return (SweepKernel)sweep_conservation_halo3t_kernel<6, uint16_t, 256, true>;
     }
     return nullptr;
 }
@@ -247,7 +264,8 @@ static int tile_table(memo_index *ix, const void *rows_of, const int64_t *boff, 
 
 // Launch the table-driven dense-row sweep if this query fits it (else return 1: the caller takes
 // sweep_conservation_halo3_kernel).  A: filled for the unclipped sweep (hl, w, ls, nlev, ncols); tw = tile width.
-int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStream_t st) {
+int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStream_t st, bool annot9) {
+    if (annot9 && elem_bytes != 2) return 1;
     if (!A.p3 || A.ls > kLS || A.nlev < 1 || A.nlev > 6 || A.km1 > 63 || A.qs < 0) return 1;
     const int64_t q = A.qs / tw, tile0 = q * tw;
     if ((tile0 - A.qs) & 3) return 1;  // the register fold needs the tile grid on the output's 4-position raster
@@ -269,7 +287,7 @@ int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStrea
     // what a wave does around its rows outweighs the rows: 7-9 % SLOWER on the k-class views of config 3 (0.217 against
     // 0.203 ms at k = 31, 0.168 against 0.154 at k = 17) and 1-4 % slower on all the rows; profiles/r03_views.txt.  Sixteen
     // waves per CU hide the scatter's LDS latency worse than thirty-two, whatever they save in instructions.)
-    SweepKernel kern = elem_bytes == 1 ? kernel_for<uint8_t, 256>(A.nlev) : kernel_for<uint16_t, 256>(A.nlev);
+    SweepKernel kern = annot9 ? kernel_for9(A.nlev) : (elem_bytes == 1 ? kernel_for<uint8_t, 256>(A.nlev) : kernel_for<uint16_t, 256>(A.nlev));
     if (!kern) return 1;
     if (g_prepare_only) return MEMO_OK;  // memo_index_prepare: the table is built, nothing is launched
     hipLaunchKernelGGL(kern, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(256), (size_t)A.nlev * 4096, st, A);

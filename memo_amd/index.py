@@ -104,7 +104,7 @@ class DeviceIndex:
         return self
 
     def pack_dense(self, keep_packed=True):
-        """build the dense rows (memo_index_pack_dense: five 24-bit rows per 16 bytes): k <= 64, annot <= 255"""
+        """build the dense rows (memo_index_pack_dense: five rows per 16 bytes): k <= 64, annot <= 511 (above 255: conservation only, uint16)"""
         check(lib().memo_index_pack_dense(self._h, 1 if keep_packed else 0))
         return self
 

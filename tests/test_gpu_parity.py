@@ -301,7 +301,7 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle, ab):
 def test_dense_rows_equal_packed_rows(n_docs, bucket_shift, keep_packed, keep_wide, memo, oracle, ab):
     """memo_index_pack_dense: 3 bytes per row (start mod 2^10, length saturated at 63, 8-bit annot).
     The unclipped conservation sweep reads them for k <= 64, level arrays of <= 1024 cells and
-    num_docs <= 255; every other query falls to the 4-byte rows / int64 columns -- or is refused when
+    num_docs <= 255 (<= 511 on the 4-position raster); every other query falls to the 4-byte rows / int64 columns -- or is refused when
     those were dropped.  Index longer than 2^10 and 2^16 positions: both start fields wrap inside it."""
     rng = np.random.default_rng(n_docs + bucket_shift)
     length = 200_000
@@ -321,7 +321,8 @@ def test_dense_rows_equal_packed_rows(n_docs, bucket_shift, keep_packed, keep_wi
                 want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
                 for source in (0, 3):                   # the library's choice (dense where they can answer) / the 4-byte rows
                     ix.debug_set_tuning(tile_w, waves, 0, source, 0)
-                    dense_can = k <= 64 and n_docs <= 255 and tile_w in (0, 1024, 512)
+                    # (256 .. 511 genomes: the table-driven kernel's nine-bit form, which wants the window's start on the 4-position raster)
+                    dense_can = k <= 64 and tile_w in (0, 1024, 512) and (n_docs <= 255 or (n_docs <= 511 and qs % 4 == 0))
                     answerable = keep_packed or keep_wide or dense_can
                     if not answerable:
                         with pytest.raises(memo.MemoError):
@@ -352,7 +353,7 @@ def test_dense_rows_equal_packed_rows(n_docs, bucket_shift, keep_packed, keep_wi
         if keep_wide:                                   # re-finalizing drops every packed copy
             ix.finalize(bucket_shift)
             assert ix.info()["dense_rows"] == 0 and ix.info()["packed_format"] == 0
-    s2, e2, o2 = _random_index(rng, 50_000, 30_000, 400, 80)                  # annots > 255: 6-byte rows, no dense form
+    s2, e2, o2 = _random_index(rng, 50_000, 30_000, 700, 80)                  # annots > 511: no dense form
     with memo.DeviceIndex.from_host(s2, e2, o2) as ix:
         ix.pack()
         with pytest.raises(memo.MemoError):
@@ -1917,6 +1918,65 @@ def test_places_inside_a_dense_group_never_change_a_result(memo, oracle, ab):
                 ix.check()
     finally:
         ab.check(ab.lib().memo_debug_view_colouring(1))
+
+
+def test_dense_rows_of_256_to_511_genomes(memo, oracle, ab):
+    """Indexes of 256 .. 511 genomes on the dense rows (the ninth annot bit in the group's spare byte; the table-driven kernel's
+    nine-bit form: memo_sweep_cons3t.hip, A9): conservation at every k class up to 64, views built and not, windows on and off the
+    4-position raster (off it: the 4-byte rows when they are resident, a clear error when they are not), membership and k > 64
+    through the 4-byte rows; an index whose annots would fit a byte asked with more than 255 genomes; equal to the oracle."""
+    rng = np.random.default_rng(47)
+    length = 70_000
+    for n_docs, top_annot, m in ((500, 499, 300_000), (511, 510, 160_000), (300, 200, 160_000)):
+        s = np.sort(rng.integers(1, length, m)).astype(np.int64)
+        e = s + rng.integers(0, 70, m)
+        o = rng.integers(1, top_annot + 1, m).astype(np.int64)
+        o[:4] = (top_annot, 1, 255 if top_annot > 255 else 1, 256 if top_annot > 256 else 1)
+        for keep_packed in (True, False):
+            with memo.DeviceIndex.from_host(s, e, o) as ix:
+                ix.pack(keep_wide=False)
+                assert ix.info()["packed_format"] == (12 if top_annot > 255 else 4)
+                ix.pack_dense(keep_packed=keep_packed)
+                assert ix.info()["dense_rows"] == 1
+                for k in (2, 3, 9, 21, 31, 32, 33, 48, 64):
+                    if k in (21, 33):
+                        ix.prepare(k, n_docs)
+                    for rep in range(6 if k == 9 else 1):                       # (the fifth query of a class builds its view)
+                        got = ix.conservation(0, length + 60, k, n_docs)
+                    inf = ix.info()
+                    assert (inf["last_sweep"], inf["last_variant"]) == (5, 2), (n_docs, k, inf["last_sweep"], inf["last_variant"])
+                    want = oracle.conservation(*oracle.filter_rows(s, e, o, 0, length + 60, k), 0, length + 60, k, n_docs, literal=False)
+                    assert np.array_equal(got, want), (n_docs, keep_packed, k)
+                    assert got.max() <= n_docs and (got == n_docs).any() == (want == n_docs).any()
+                    qs, qe = 20_004, 41_003                                     # on the raster at its start only
+                    got = ix.conservation(qs, qe, k, n_docs)
+                    assert ix.info()["last_sweep"] == 5
+                    assert np.array_equal(got, oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False))
+                    qs, qe = 20_001, 41_003                                     # off the raster
+                    if keep_packed:
+                        got = ix.conservation(qs, qe, k, n_docs)
+                        assert ix.info()["last_sweep"] != 5
+                        assert np.array_equal(got, oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False))
+                    else:
+                        with pytest.raises(memo.MemoError, match="needs the 4-byte rows"):
+                            ix.conservation(qs, qe, k, n_docs)
+                if keep_packed:
+                    for k in (31, 101):
+                        got = ix.membership(9_000, 19_000, k, n_docs)
+                        assert np.array_equal(got, oracle.membership(*oracle.filter_rows(s, e, o, 9_000, 19_000, k), 9_000, 19_000, k, n_docs,
+                                                                     literal=False))
+                    got = ix.conservation(0, length, 101, n_docs)
+                    assert np.array_equal(got, oracle.conservation(*oracle.filter_rows(s, e, o, 0, length, 101), 0, length, 101, n_docs, literal=False))
+                else:
+                    with pytest.raises(memo.MemoError):
+                        ix.membership(9_000, 19_000, 31, n_docs)
+                ix.check()
+    # 512 genomes and more: no dense rows
+    o = rng.integers(1, 600, m).astype(np.int64)
+    with memo.DeviceIndex.from_host(s, e, o) as ix:
+        ix.pack(keep_wide=False)
+        with pytest.raises(memo.MemoError, match="annot <= 511"):
+            ix.pack_dense()
 
 
 def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
