@@ -157,14 +157,15 @@ int memo_index_finalize(memo_index_t *ix, int32_t bucket_shift, int32_t allow_so
  * k <= 256 only and cannot be re-uploaded.  Needs 0 <= annot <= 65535 on every row. */
 int memo_index_pack(memo_index_t *ix, int32_t keep_wide);
 /* A denser copy of the packed rows: 24 bits per row, five rows per 16 bytes (3.2 B per row),
- *     (start mod 2^10) << 6 | min(end - start, 63)   +   annot (8 bits)
- * Exact for k <= 64 on the unclipped conservation sweep (level arrays of <= 1024 cells, num_docs <= 255), and its
- * fastest source: conservation queries read these rows wherever they are resident and can answer (BASELINE
- * config 3, launches back to back: 0.324 ms against 0.374 on the 4-byte rows at k = 31).  Membership queries
- * read them when the index holds no 4-byte rows (same limits; 4 % slower than on the 4-byte rows).  k > 64 and
- * more than 255 genomes need the 4-byte rows.  Needs memo_index_pack first and every annot <= 255.  keep_packed == 0 frees the 4-byte
- * rows: such an index holds 3.2 B per row and answers only what the dense rows (or, if still resident, the int64
- * columns) can. */
+ *     (start mod 2^10) << 6 | min(end - start, 63)   +   annot (8 bits; a ninth in the group's spare byte)
+ * Exact for k <= 64 on the unclipped conservation sweep (level arrays of <= 1024 cells), and its fastest source:
+ * conservation queries read these rows wherever they are resident and can answer (BASELINE config 3, launches back
+ * to back: 0.324 ms against 0.374 on the 4-byte rows at k = 31; config 5, 500 genomes: 0.27 against 0.33).  Up to 255
+ * genomes every window and both result widths; 256 .. 511 genomes (round 4) uint16 results of windows whose start is a
+ * multiple of four -- other windows of such an index, membership queries and k > 64 read the 4-byte rows.  Membership
+ * queries of up to 255 genomes read the dense rows when the index holds no 4-byte rows (4 % slower than on the 4-byte
+ * rows).  Needs memo_index_pack first and every annot <= 511.  keep_packed == 0 frees the 4-byte rows: such an index
+ * holds 3.2 B per row and answers only what the dense rows (or, if still resident, the int64 columns) can. */
 int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed);
 int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);  /* set info->struct_bytes first (see the struct) */
 /* Options of one index (queries never change a result with them).
