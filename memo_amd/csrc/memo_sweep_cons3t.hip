@@ -161,14 +161,21 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
         if (lane < ctx || x0 >= cells) continue;
         const int64_t o = ob + x0;
         if (o >= o_lo && o + 4 <= o_hi) {
+            // four results in one store, at whatever the window's start makes of the address: a window that begins off the
+            // 4-position raster stores 4 / 8 bytes at an address that is a multiple of the element size only.  Global memory takes
+            // that on gfx950 (unaligned access mode, what HSA asks of the global segment), at the same speed: config 3 from
+            // position 1 or 2: 0.185 ms, as from 0 (rounds 3-4 sent such windows to halo3: 0.295; profiles/r04_unaligned_windows.txt)
+            typedef uint32_t __attribute__((aligned(1))) u32_any;
+            typedef uint64_t __attribute__((aligned(2))) u64_any;
             if constexpr (A9) {
-                *reinterpret_cast<uint2 *>(out + o) = make_uint2((M.x >> 23) | ((M.y >> 23) << 16), (M.z >> 23) | ((M.w >> 23) << 16));
+                *reinterpret_cast<u64_any *>(out + o) = (uint64_t)((M.x >> 23) | ((M.y >> 23) << 16)) |
+                                                        ((uint64_t)((M.z >> 23) | ((M.w >> 23) << 16)) << 32);
             } else if constexpr (sizeof(OutT) == 1) {
-                *reinterpret_cast<uint32_t *>(out + o) = __builtin_amdgcn_perm(M.y, M.x, 0x0c0c0703u) |
-                                                         __builtin_amdgcn_perm(M.w, M.z, 0x07030c0cu);
+                *reinterpret_cast<u32_any *>(out + o) = __builtin_amdgcn_perm(M.y, M.x, 0x0c0c0703u) |
+                                                        __builtin_amdgcn_perm(M.w, M.z, 0x07030c0cu);
             } else {
-                *reinterpret_cast<uint2 *>(out + o) = make_uint2(__builtin_amdgcn_perm(M.y, M.x, 0x0c070c03u),
-                                                                 __builtin_amdgcn_perm(M.w, M.z, 0x0c070c03u));
+                *reinterpret_cast<u64_any *>(out + o) = (uint64_t)__builtin_amdgcn_perm(M.y, M.x, 0x0c070c03u) |
+                                                        ((uint64_t)__builtin_amdgcn_perm(M.w, M.z, 0x0c070c03u) << 32);
             }
         } else {
             const uint32_t v[4] = {M.x >> SH, M.y >> SH, M.z >> SH, M.w >> SH};
@@ -268,7 +275,9 @@ int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStrea
     if (annot9 && elem_bytes != 2) return 1;
     if (!A.p3 || A.ls > kLS || A.nlev < 1 || A.nlev > 6 || A.km1 > 63 || A.qs < 0) return 1;
     const int64_t q = A.qs / tw, tile0 = q * tw;
-    if ((tile0 - A.qs) & 3) return 1;  // the register fold needs the tile grid on the output's 4-position raster
+#ifdef MEMO_TABLE_RASTER_ONLY  // (A/B builds: rounds 3-4 took only windows whose start is a multiple of four -- aligned result stores)
+    if ((tile0 - A.qs) & 3) return 1;
+#endif
     const int64_t ntiles = ((A.qe - tile0) + tw - 1) / tw;
     if (ntiles + 8 >= ((int64_t)1 << 31) || q + ntiles >= ((int64_t)1 << 31)) return 1;
     const void *tab = nullptr;

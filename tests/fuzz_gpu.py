@@ -28,7 +28,7 @@ cases = queries = 0
 print("seed", a.seed, flush=True)
 while time.time() < t_end:
     cases += 1
-    n_docs = int(rng.choice([2, 5, 31, 32, 33, 64, 100, 255, 256, 257, 500, 1000]))
+    n_docs = int(rng.choice([2, 5, 31, 32, 33, 64, 100, 255, 256, 257, 500, 511, 512, 1000]))
     length = int(rng.choice([100, 3000, 50_000, 400_000]))
     m = int(rng.integers(0, int(rng.choice([50, 5000, 200_000]))))
     mode = int(rng.integers(0, 5))
@@ -66,12 +66,15 @@ while time.time() < t_end:
     else:
         made = memo_amd.DeviceIndex.from_host(s, e, o, bucket_shift=bshift)
     with made as ix:
+        def dense_fits():                                          # (format 12 with annots of nine bits: 256 .. 511 genomes)
+            inf = ix.info()
+            return inf["packed_format"] == 4 or (inf["packed_format"] == 12 and inf["max_annot"] <= 511)
         if via_builder and not dense_only:
-            if ix.info()["packed_format"] == 4 and rng.random() < 0.5:
+            if dense_fits() and rng.random() < 0.5:
                 ix.pack_dense(keep_packed=True)
         elif packable and rng.random() < 0.7:
             ix.pack(keep_wide=True)
-            if ix.info()["packed_format"] == 4 and rng.random() < 0.6:
+            if dense_fits() and rng.random() < 0.6:
                 ix.pack_dense(keep_packed=True)
         if rng.random() < 0.5:                                     # the order of the 4-byte rows inside their buckets (memo_interleave.hip):
             ix.debug_row_order(int(rng.integers(1, 5)))            #   start order, the two dealt orders, the membership order
@@ -90,7 +93,7 @@ while time.time() < t_end:
                 ([] if via_builder else [257, 1000])))                       # (a packed-only index answers k <= 256, dense rows k <= 64)
             qs = int(rng.integers(0, length))
             if rng.random() < 0.5:
-                qs &= ~3                                                      # (the table-driven kernel wants the 4-position raster)
+                qs &= ~3                                                      # (windows on the 4-position raster: aligned result stores)
             qe = int(rng.integers(qs, length + 200))
             tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096, 1472, 1728])), int(rng.choice([0, 1, 4, 8])),
                     int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])), int(rng.integers(0, 6)))

@@ -301,7 +301,7 @@ def test_packed_rows_equal_wide_rows(n_docs, keep_wide, memo, oracle, ab):
 def test_dense_rows_equal_packed_rows(n_docs, bucket_shift, keep_packed, keep_wide, memo, oracle, ab):
     """memo_index_pack_dense: 3 bytes per row (start mod 2^10, length saturated at 63, 8-bit annot).
     The unclipped conservation sweep reads them for k <= 64, level arrays of <= 1024 cells and
-    num_docs <= 255 (<= 511 on the 4-position raster); every other query falls to the 4-byte rows / int64 columns -- or is refused when
+    num_docs <= 511; every other query falls to the 4-byte rows / int64 columns -- or is refused when
     those were dropped.  Index longer than 2^10 and 2^16 positions: both start fields wrap inside it."""
     rng = np.random.default_rng(n_docs + bucket_shift)
     length = 200_000
@@ -321,8 +321,8 @@ def test_dense_rows_equal_packed_rows(n_docs, bucket_shift, keep_packed, keep_wi
                 want = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
                 for source in (0, 3):                   # the library's choice (dense where they can answer) / the 4-byte rows
                     ix.debug_set_tuning(tile_w, waves, 0, source, 0)
-                    # (256 .. 511 genomes: the table-driven kernel's nine-bit form, which wants the window's start on the 4-position raster)
-                    dense_can = k <= 64 and tile_w in (0, 1024, 512) and (n_docs <= 255 or (n_docs <= 511 and qs % 4 == 0))
+                    # (256 .. 511 genomes: the table-driven kernel's nine-bit form)
+                    dense_can = k <= 64 and tile_w in (0, 1024, 512) and n_docs <= 511
                     answerable = keep_packed or keep_wide or dense_can
                     if not answerable:
                         with pytest.raises(memo.MemoError):
@@ -1495,8 +1495,8 @@ def test_dense_row_sweep_variants(memo, oracle, ab):
                         assert np.array_equal(got, ref), (src, k, qs, qe, dt)
                         inf = ix.info()
                         assert inf["last_sweep"] == 5
-                        if variant == 2:      # (the persistent kernels decline short windows; the table kernel only windows
-                            assert inf["last_variant"] == (2 if qs % 4 == 0 else 0), (src, k, qs, qe, inf)    # off the raster)
+                        if variant == 2:      # (the persistent kernels decline short windows; the table kernel takes every window --
+                            assert inf["last_variant"] == 2, (src, k, qs, qe, inf)    # off the 4-position raster too, since late round 4)
                         else:
                             assert inf["last_variant"] in (0, 1)
             a, b = 3_000_000, 3_300_000
@@ -1923,8 +1923,8 @@ def test_places_inside_a_dense_group_never_change_a_result(memo, oracle, ab):
 def test_dense_rows_of_256_to_511_genomes(memo, oracle, ab):
     """Indexes of 256 .. 511 genomes on the dense rows (the ninth annot bit in the group's spare byte; the table-driven kernel's
     nine-bit form: memo_sweep_cons3t.hip, A9): conservation at every k class up to 64, views built and not, windows on and off the
-    4-position raster (off it: the 4-byte rows when they are resident, a clear error when they are not), membership and k > 64
-    through the 4-byte rows; an index whose annots would fit a byte asked with more than 255 genomes; equal to the oracle."""
+    4-position raster, membership and k > 64 through the 4-byte rows (refused when those were dropped); an index whose annots would
+    fit a byte asked with more than 255 genomes; equal to the oracle."""
     rng = np.random.default_rng(47)
     length = 70_000
     for n_docs, top_annot, m in ((500, 499, 300_000), (511, 510, 160_000), (300, 200, 160_000)):
@@ -1948,18 +1948,10 @@ def test_dense_rows_of_256_to_511_genomes(memo, oracle, ab):
                     want = oracle.conservation(*oracle.filter_rows(s, e, o, 0, length + 60, k), 0, length + 60, k, n_docs, literal=False)
                     assert np.array_equal(got, want), (n_docs, keep_packed, k)
                     assert got.max() <= n_docs and (got == n_docs).any() == (want == n_docs).any()
-                    qs, qe = 20_004, 41_003                                     # on the raster at its start only
-                    got = ix.conservation(qs, qe, k, n_docs)
-                    assert ix.info()["last_sweep"] == 5
-                    assert np.array_equal(got, oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False))
-                    qs, qe = 20_001, 41_003                                     # off the raster
-                    if keep_packed:
+                    for qs, qe in ((20_004, 41_003), (20_001, 41_003), (20_002, 20_009), (20_003, 41_000)):   # on and off the 4-position raster
                         got = ix.conservation(qs, qe, k, n_docs)
-                        assert ix.info()["last_sweep"] != 5
+                        assert (ix.info()["last_sweep"], ix.info()["last_variant"]) == (5, 2)
                         assert np.array_equal(got, oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False))
-                    else:
-                        with pytest.raises(memo.MemoError, match="needs the 4-byte rows"):
-                            ix.conservation(qs, qe, k, n_docs)
                 if keep_packed:
                     for k in (31, 101):
                         got = ix.membership(9_000, 19_000, k, n_docs)

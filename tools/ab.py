@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--u8", action="store_true")
     ap.add_argument("--length", type=int, default=0, help="query [0, length) instead of the whole pivot")
+    ap.add_argument("--qs", type=int, default=0, help="the window starts here (results of [qs, L))")
     ap.add_argument("--density", default="5/100", help="rows per genome and position")
     ap.add_argument("--pack", default=None, choices=[None, "keep", "only", "dense", "both"],
                     help="keep: int64 + 4-byte rows; only: 4-byte rows; dense: dense rows only; both: 4- and dense rows "
@@ -71,11 +72,11 @@ def main():
 
     def launch():
         if membership:
-            ix.membership_dev(0, L, a.k, num_docs, out, st.cuda_stream)
+            ix.membership_dev(a.qs, L, a.k, num_docs, out, st.cuda_stream)
         elif a.u8:
-            ix.conservation_u8_dev(0, L, a.k, num_docs, out, st.cuda_stream)
+            ix.conservation_u8_dev(a.qs, L, a.k, num_docs, out, st.cuda_stream)
         else:
-            ix.conservation_dev(0, L, a.k, num_docs, out, st.cuda_stream)
+            ix.conservation_dev(a.qs, L, a.k, num_docs, out, st.cuda_stream)
 
     for r in range(a.rounds + 1):
         for v in variants:
