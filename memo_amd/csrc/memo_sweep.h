@@ -46,6 +46,18 @@ struct SweepArgs {
     unsigned long long *stamps;  // diagnostic builds (-DMEMO_STAMPS): per-phase cycle sums
 };
 
+// Four results in one store, at whatever address the window's start makes of it: a window that begins off the 4-position
+// raster stores 4 / 8 bytes at an address that is a multiple of the element size only.  Global memory takes that on gfx950
+// (unaligned access mode, what HSA asks of the global segment) at the same speed -- config 3 from position 1 or 2: 0.185 ms,
+// as from 0; rounds 1-4 sent such windows to scalar stores or a slower kernel (0.295; profiles/r04_unaligned_windows.txt).
+// The types tell the compiler; the stores still come out as one global_store_dword / global_store_dwordx2 each.
+typedef uint32_t __attribute__((aligned(1))) u32_any;
+typedef uint64_t __attribute__((aligned(2))) u64_any;
+__device__ __forceinline__ void store_four(uint8_t *p, uint32_t v) { *reinterpret_cast<u32_any *>(p) = v; }
+__device__ __forceinline__ void store_four(uint16_t *p, uint32_t lo, uint32_t hi) {
+    *reinterpret_cast<u64_any *>(p) = (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
 // Diagnostic builds only (never in the product library): wave 0 of every workgroup stores the
 // shader cycles it spent in each phase of the conservation sweep to stamps[8 * block + phase]
 // (a buffer of its own, set with memo_debug_set_stamp_buffer; plain stores, no contention).

@@ -183,7 +183,7 @@ __device__ __forceinline__ void halo_fold_store_dpp(const SweepArgs &A, const Ti
     const int ctx = nlev <= 1 ? 0 : (nlev <= 3 ? 1 : 1 << (nlev - 3));  // context lanes at the left of a wave
     const int valid = 64 - ctx;
     OutT *out = static_cast<OutT *>(A.out);
-    const int64_t ob = t.a - A.qs - HL;  // output index of cell 0 (a multiple of 4 here)
+    const int64_t ob = t.a - A.qs - HL;  // output index of cell 0
     const int64_t o_lo = t.a - A.qs + t.x_lo, o_hi = t.a - A.qs + t.x_hi;
     for (int base = wave * 4 * valid; base + 4 * ctx < cells; base += NW * 4 * valid) {
         const int x0 = base + 4 * lane;             // this lane's cells x0 .. x0 + 3
@@ -199,15 +199,14 @@ __device__ __forceinline__ void halo_fold_store_dpp(const SweepArgs &A, const Ti
         if (lane < ctx || x0 >= cells) continue;
         const int64_t g = ob + x0;
         if (g >= o_lo && g + 4 <= o_hi) {
-            if (sizeof(OutT) == 1 && TOP == 24) {  // the four top bytes, two v_perm_b32 and an or
-                *reinterpret_cast<uint32_t *>(out + g) = __builtin_amdgcn_perm(M.y, M.x, 0x0c0c0703u) |
-                                                         __builtin_amdgcn_perm(M.w, M.z, 0x07030c0cu);
+            if constexpr (sizeof(OutT) == 1 && TOP == 24) {  // the four top bytes, two v_perm_b32 and an or
+                store_four(out + g, __builtin_amdgcn_perm(M.y, M.x, 0x0c0c0703u) | __builtin_amdgcn_perm(M.w, M.z, 0x07030c0cu));
             } else {
                 if (TOP) M = make_uint4(M.x >> TOP, M.y >> TOP, M.z >> TOP, M.w >> TOP);
-                if (sizeof(OutT) == 1)
-                    *reinterpret_cast<uint32_t *>(out + g) = M.x | (M.y << 8) | (M.z << 16) | (M.w << 24);
+                if constexpr (sizeof(OutT) == 1)
+                    store_four(out + g, M.x | (M.y << 8) | (M.z << 16) | (M.w << 24));
                 else
-                    *reinterpret_cast<uint2 *>(out + g) = make_uint2(M.x | (M.y << 16), M.z | (M.w << 16));
+                    store_four(out + g, M.x | (M.y << 16), M.z | (M.w << 16));
             }
         } else {
             const uint32_t v[4] = {M.x >> TOP, M.y >> TOP, M.z >> TOP, M.w >> TOP};
@@ -225,7 +224,7 @@ __device__ __forceinline__ void halo_fold_store_dpp(const SweepArgs &A, const Ti
 #endif
 template <typename OutT, int T, int TOP>
 __device__ __forceinline__ void halo_finish(const SweepArgs &A, const Tile &t, uint32_t *lds) {
-    if (MEMO_FOLD_REG && A.nlev <= MEMO_FOLD_DPP_LEVELS && ((t.a - A.qs) & 3) == 0)
+    if (MEMO_FOLD_REG && A.nlev <= MEMO_FOLD_DPP_LEVELS)  // (any window: store_four takes the address as it comes)
         halo_fold_store_dpp<OutT, T, TOP>(A, t, lds);
     else
         halo_fold_store<OutT, T, TOP>(A, t, lds);
@@ -518,7 +517,6 @@ __device__ __forceinline__ void r4_fold_store(const SweepArgs &A, const Tile &t,
     OutT *out = static_cast<OutT *>(A.out);
     const int64_t ob = t.a - A.qs - HL;  // output index of cell 0
     const int64_t o_lo = t.a - A.qs + t.x_lo, o_hi = t.a - A.qs + t.x_hi;
-    const bool aligned = (ob & 3) == 0;
 #define MEMO_DPP_MIN(dst, src) "v_min_u32_dpp " dst ", " src ", " dst " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
 #define MEMO_DPP_MOV(dst, src) "v_mov_b32_dpp " dst ", " src " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
     for (int base = wave * 4 * valid; base + 4 * ctx < cells; base += NW * 4 * valid) {
@@ -549,18 +547,17 @@ __device__ __forceinline__ void r4_fold_store(const SweepArgs &A, const Tile &t,
         }
         if (lane < ctx || x0 >= cells) continue;
         const int64_t g = ob + x0;
-        if (aligned && g >= o_lo && g + 4 <= o_hi) {
-            if (sizeof(OutT) == 1 && TOP == 24) {  // the four top bytes, two v_perm_b32 and an or
-                *reinterpret_cast<uint32_t *>(out + g) = __builtin_amdgcn_perm(R.y, R.x, 0x0c0c0703u) |
-                                                         __builtin_amdgcn_perm(R.w, R.z, 0x07030c0cu);
+        if (g >= o_lo && g + 4 <= o_hi) {
+            if constexpr (sizeof(OutT) == 1 && TOP == 24) {  // the four top bytes, two v_perm_b32 and an or
+                store_four(out + g, __builtin_amdgcn_perm(R.y, R.x, 0x0c0c0703u) | __builtin_amdgcn_perm(R.w, R.z, 0x07030c0cu));
             } else {
                 if (TOP) R = make_uint4(R.x >> TOP, R.y >> TOP, R.z >> TOP, R.w >> TOP);
-                if (sizeof(OutT) == 1)
-                    *reinterpret_cast<uint32_t *>(out + g) = R.x | (R.y << 8) | (R.z << 16) | (R.w << 24);
+                if constexpr (sizeof(OutT) == 1)
+                    store_four(out + g, R.x | (R.y << 8) | (R.z << 16) | (R.w << 24));
                 else
-                    *reinterpret_cast<uint2 *>(out + g) = make_uint2(R.x | (R.y << 16), R.z | (R.w << 16));
+                    store_four(out + g, R.x | (R.y << 16), R.z | (R.w << 16));
             }
-        } else {  // window edges, and windows that do not start on the tile grid's 4-position raster
+        } else {  // window edges
             const uint32_t v[4] = {R.x >> TOP, R.y >> TOP, R.z >> TOP, R.w >> TOP};
             for (int i = 0; i < 4; ++i)
                 if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)v[i];
@@ -807,7 +804,6 @@ __device__ __forceinline__ void plan_fold_store(const SweepArgs &A, const Tile &
     OutT *out = static_cast<OutT *>(A.out);
     const int64_t ob = t.a - A.qs - HL;  // output index of cell 0
     const int64_t o_lo = t.a - A.qs + t.x_lo, o_hi = t.a - A.qs + t.x_hi;
-    const bool aligned = (ob & 3) == 0;
     // (arrays the plan does not have are read where the blocks of 16 are -- one unconditional 16-byte read each -- and
     // replaced by "no row" afterwards)
     const uint32_t *L16 = lds + P.s16() * LS, *L4 = lds + (P.has4 ? P.s4() : P.s16()) * LS,
@@ -843,18 +839,17 @@ __device__ __forceinline__ void plan_fold_store(const SweepArgs &A, const Tile &
             : "+v"(R.x), "+v"(R.y), "+v"(R.z), "+v"(R.w) : "v"(M.x), "v"(M.y), "v"(M.z), "v"(M.w));
         if (lane < ctx || x0 >= cells) continue;
         const int64_t g = ob + x0;
-        if (aligned && g >= o_lo && g + 4 <= o_hi) {
-            if (sizeof(OutT) == 1 && TOP == 24) {  // the four top bytes, two v_perm_b32 and an or
-                *reinterpret_cast<uint32_t *>(out + g) = __builtin_amdgcn_perm(R.y, R.x, 0x0c0c0703u) |
-                                                         __builtin_amdgcn_perm(R.w, R.z, 0x07030c0cu);
+        if (g >= o_lo && g + 4 <= o_hi) {
+            if constexpr (sizeof(OutT) == 1 && TOP == 24) {  // the four top bytes, two v_perm_b32 and an or
+                store_four(out + g, __builtin_amdgcn_perm(R.y, R.x, 0x0c0c0703u) | __builtin_amdgcn_perm(R.w, R.z, 0x07030c0cu));
             } else {
                 if (TOP) R = make_uint4(R.x >> TOP, R.y >> TOP, R.z >> TOP, R.w >> TOP);
-                if (sizeof(OutT) == 1)
-                    *reinterpret_cast<uint32_t *>(out + g) = R.x | (R.y << 8) | (R.z << 16) | (R.w << 24);
+                if constexpr (sizeof(OutT) == 1)
+                    store_four(out + g, R.x | (R.y << 8) | (R.z << 16) | (R.w << 24));
                 else
-                    *reinterpret_cast<uint2 *>(out + g) = make_uint2(R.x | (R.y << 16), R.z | (R.w << 16));
+                    store_four(out + g, R.x | (R.y << 16), R.z | (R.w << 16));
             }
-        } else {  // window edges, and windows that do not start on the tile grid's 4-position raster
+        } else {  // window edges
             const uint32_t v[4] = {R.x >> TOP, R.y >> TOP, R.z >> TOP, R.w >> TOP};
             for (int i = 0; i < 4; ++i)
                 if (g + i >= o_lo && g + i < o_hi) out[g + i] = (OutT)v[i];

@@ -161,21 +161,12 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
         if (lane < ctx || x0 >= cells) continue;
         const int64_t o = ob + x0;
         if (o >= o_lo && o + 4 <= o_hi) {
-            // four results in one store, at whatever the window's start makes of the address: a window that begins off the
-            // 4-position raster stores 4 / 8 bytes at an address that is a multiple of the element size only.  Global memory takes
-            // that on gfx950 (unaligned access mode, what HSA asks of the global segment), at the same speed: config 3 from
-            // position 1 or 2: 0.185 ms, as from 0 (rounds 3-4 sent such windows to halo3: 0.295; profiles/r04_unaligned_windows.txt)
-            typedef uint32_t __attribute__((aligned(1))) u32_any;
-            typedef uint64_t __attribute__((aligned(2))) u64_any;
-            if constexpr (A9) {
-                *reinterpret_cast<u64_any *>(out + o) = (uint64_t)((M.x >> 23) | ((M.y >> 23) << 16)) |
-                                                        ((uint64_t)((M.z >> 23) | ((M.w >> 23) << 16)) << 32);
+            if constexpr (A9) {  // (store_four, memo_sweep.h: the address is whatever the window's start makes of it)
+                store_four(out + o, (M.x >> 23) | ((M.y >> 23) << 16), (M.z >> 23) | ((M.w >> 23) << 16));
             } else if constexpr (sizeof(OutT) == 1) {
-                *reinterpret_cast<u32_any *>(out + o) = __builtin_amdgcn_perm(M.y, M.x, 0x0c0c0703u) |
-                                                        __builtin_amdgcn_perm(M.w, M.z, 0x07030c0cu);
+                store_four(out + o, __builtin_amdgcn_perm(M.y, M.x, 0x0c0c0703u) | __builtin_amdgcn_perm(M.w, M.z, 0x07030c0cu));
             } else {
-                *reinterpret_cast<u64_any *>(out + o) = (uint64_t)__builtin_amdgcn_perm(M.y, M.x, 0x0c070c03u) |
-                                                        ((uint64_t)__builtin_amdgcn_perm(M.w, M.z, 0x0c070c03u) << 32);
+                store_four(out + o, __builtin_amdgcn_perm(M.y, M.x, 0x0c070c03u), __builtin_amdgcn_perm(M.w, M.z, 0x0c070c03u));
             }
         } else {
             const uint32_t v[4] = {M.x >> SH, M.y >> SH, M.z >> SH, M.w >> SH};
