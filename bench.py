@@ -289,10 +289,8 @@ def main():
         _lib.use_ab(True)                   # the PMC calibration kernel lives in libmemo_amd_ab.so only
     # the dense rows answer the unclipped conservation sweep only: k <= 64, num_docs <= 511, >= 1 row per position
     # (membership reads them too when an index holds nothing else, 4 % slower than the 4-byte rows: not a bench format)
-    # (256 .. 511 genomes -- BASELINE config 5 -- since round 4: the ninth annot bit in the group's spare byte, uint16 results, windows on
-    # the 4-position raster)
-    can_dense = (not membership) and k - 1 <= 63 and ((num_docs <= 255 and not args.wide) or (255 < num_docs <= 511 and qs % 4 == 0)) \
-        and num_docs >= 20
+    # (256 .. 511 genomes -- BASELINE config 5 -- since round 4: the ninth annot bit in the group's spare byte, uint16 results)
+    can_dense = (not membership) and k - 1 <= 63 and ((num_docs <= 255 and not args.wide) or 255 < num_docs <= 511) and num_docs >= 20
     if host_rows is not None:                # the library's own rule, on the rows the window sees
         from memo_amd.index import dense_rows_can_answer
         hs, _, ho = host_rows

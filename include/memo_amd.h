@@ -161,8 +161,8 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide);
  * Exact for k <= 64 on the unclipped conservation sweep (level arrays of <= 1024 cells), and its fastest source:
  * conservation queries read these rows wherever they are resident and can answer (BASELINE config 3, launches back
  * to back: 0.324 ms against 0.374 on the 4-byte rows at k = 31; config 5, 500 genomes: 0.27 against 0.33).  Up to 255
- * genomes every window and both result widths; 256 .. 511 genomes (round 4) uint16 results of windows whose start is a
- * multiple of four -- other windows of such an index, membership queries and k > 64 read the 4-byte rows.  Membership
+ * genomes both result widths; 256 .. 511 genomes (round 4) uint16 results -- membership queries and k > 64 of such an
+ * index read the 4-byte rows.  Membership
  * queries of up to 255 genomes read the dense rows when the index holds no 4-byte rows (4 % slower than on the 4-byte
  * rows).  Needs memo_index_pack first and every annot <= 511.  keep_packed == 0 frees the 4-byte rows: such an index
  * holds 3.2 B per row and answers only what the dense rows (or, if still resident, the int64 columns) can. */

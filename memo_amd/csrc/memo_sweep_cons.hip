@@ -1426,7 +1426,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                     ix->last_variant = 2;
                     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
                 }
-                if (top9) three = false;  // (a window off the 4-position raster, no room for a tile table: the 4-byte rows if resident)
+                if (top9) three = false;  // (no room for a tile table, a negative window start: the 4-byte rows if resident)
             }
             if (!three && fmt == 3) {
                 halo = false;  // (below: the int64 columns, or an error when they are gone too)
