@@ -1030,7 +1030,14 @@ __global__ __launch_bounds__(256) void len_seen_kernel(const uint32_t *__restric
         if (r + 3 < rows) flag[(v.w >> shift) & 255u] = 1u;
     }
     __syncthreads();
-    if (flag[threadIdx.x]) atomicOr(&seen[threadIdx.x >> 5], 1u << (threadIdx.x & 31));
+    // one atomic per word and workgroup (a flag per thread was 60 atomics per workgroup on the same two words of HBM: 5 * 10^5 of
+    // them, one after the other in the L2 -- 5.0 of this pass's 5.0 ms on 5 * 10^8 rows)
+    const unsigned long long b = __ballot(flag[threadIdx.x] != 0);
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned int lo = (unsigned int)b, hi = (unsigned int)(b >> 32), w = threadIdx.x >> 5;
+        if (lo) atomicOr(&seen[w], lo);
+        if (hi) atomicOr(&seen[w + 1], hi);
+    }
 }
 }  // namespace
 
@@ -1056,7 +1063,7 @@ int memo_len_census(memo_index *ix) {
     if (err == hipSuccess) err = hipMemsetAsync(d_hist, 0, 32, nullptr);
     if (err == hipSuccess) {
         const uint64_t wg = (ix->rows + 1023) / 1024;
-        hipLaunchKernelGGL(len_seen_kernel, dim3((unsigned)(wg < 8192 ? wg : 8192)), dim3(256), 0, nullptr, ix->pk, ix->rows,
+        hipLaunchKernelGGL(len_seen_kernel, dim3((unsigned)(wg < 4096 ? wg : 4096)), dim3(256), 0, nullptr, ix->pk, ix->rows,
                            ix->packed_fmt == 12 ? 0 : 16, d_hist);
         err = hipGetLastError();
     }

@@ -1471,6 +1471,46 @@ def test_config5_shard_packed_rows(memo, oracle):
                 assert np.array_equal(ix.conservation(a + 3, b - 11, k, n), want[3:-11])
 
 
+def test_config5_shard_dense_rows(memo, oracle):
+    """the same shard of config 5 on the DENSE rows (500 genomes: nine-bit annots, memo_sweep_cons3t.hip A9): what `bench.py
+    --workload c5 --k 21 / 31` times since round 4.  The whole 2^25-position shard against the oracle before and after the
+    k-class view exists, a window that begins off a multiple of four, sampled sub-windows, k = 64 (every row, six level arrays)."""
+    from memo_amd import synth
+    n, L = 500, 1 << 25
+    pivot = 8 * L
+    qs, qe = 3 * L, 4 * L
+    num, den = synth.rows_per_position(n)
+    ix, (r0, r1) = synth.device_index(qs, qe, 64, n, pivot, pack="dense")
+    with ix:
+        inf = ix.info()
+        assert inf["dense_rows"] == 1 and inf["has_wide"] == 0 and inf["max_annot"] > 255
+        assert inf["device_bytes"] < 3.3 * (r1 - r0) + (64 << 20)
+        rng = np.random.default_rng(10)
+        for k in (21, 31, 64):
+            full = ix.conservation(qs, qe, k, n)
+            inf = ix.info()
+            assert (inf["last_sweep"], inf["last_variant"]) == (5, 2) and full.dtype == np.uint16 and full.max() <= n
+            bad, fnv = oracle.synth_window_compare(full, qs, qe, k, n, pivot)   # the WHOLE shard, all the dense rows
+            assert bad == 0, (k, bad)
+            if k != 64:           # the benchmarked regime: the k-class view (memo_index_prepare builds it), whole shard
+                ix.prepare(k, n)
+                again = ix.conservation(qs, qe, k, n)
+                inf = ix.info()
+                assert inf["last_rows_read"] < 0.6 * (r1 - r0) and (inf["last_sweep"], inf["last_variant"]) == (5, 2), (k, inf)
+                bad2, fnv2 = oracle.synth_window_compare(again, qs, qe, k, n, pivot)
+                assert bad2 == 0 and fnv2 == fnv, (k, bad2)
+                off = ix.conservation(qs + 1, qe - 2, k, n)                     # off the 4-position raster: the same kernel
+                assert ix.info()["last_variant"] == 2 and np.array_equal(off, full[1:-2])
+            for a in [qs, qe - 200_000] + [int(x) for x in rng.integers(qs, qe - 200_000, 2)]:
+                b = a + 200_000
+                sr0, sr1 = synth.shard_rows(a, b, k, num, den, pivot)
+                s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
+                want = oracle.conservation(s, e, o, a, b, k, n, literal=False)
+                assert np.array_equal(full[a - qs:b - qs], want), (k, a)
+                assert np.array_equal(ix.conservation(a + 3, b - 11, k, n), want[3:-11])
+        ix.check()
+
+
 def test_dense_row_sweep_variants(memo, oracle, ab):
     """The dense rows are swept by sweep_conservation_halo3t_kernel (the tile's row slice from the index's tile table;
     memo_sweep_cons3t.hip) wherever the query fits it; the round-2 kernel (every wave works its tile out) answers the

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--u8", action="store_true")
     ap.add_argument("--length", type=int, default=0, help="query [0, length) instead of the whole pivot")
     ap.add_argument("--qs", type=int, default=0, help="the window starts here (results of [qs, L))")
+    ap.add_argument("--num-docs", type=int, default=0, help="this many genomes instead of the workload's (same rows per genome and position)")
     ap.add_argument("--density", default="5/100", help="rows per genome and position")
     ap.add_argument("--pack", default=None, choices=[None, "keep", "only", "dense", "both"],
                     help="keep: int64 + 4-byte rows; only: 4-byte rows; dense: dense rows only; both: 4- and dense rows "
@@ -42,6 +43,7 @@ def main():
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     num_docs, L, membership = WORKLOADS[a.workload]
+    num_docs = a.num_docs or num_docs
     L = a.length or L
     from fractions import Fraction
     _lib.use_ab(True)
