@@ -81,6 +81,19 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+constexpr uint32_t kCountedClass = 96;  // rows of one class a row's place is counted through (longer classes: the sort)
+
+// the place of row e (key k) among the c rows of its class, which lie at key[f .. f + c) in any order: the rows with a smaller
+// key, or an equal one further left
+__device__ __forceinline__ uint32_t counted_rank(const uint32_t *key, uint32_t f, uint32_t c, uint32_t e, uint32_t k) {
+    uint32_t rank = 0;
+    for (uint32_t j = f; j < f + c; ++j) {
+        const uint32_t z = key[j];
+        rank += (z < k || (z == k && j < e)) ? 1u : 0u;
+    }
+    return rank;
+}
+
 // ---- one wave, one bucket of at most 256 rows, 32 starts (the default bucket width) -------------------------------
 __device__ __forceinline__ void wave_bucket(uint32_t *__restrict__ words, int64_t r0, int R, const KeyCodec &C, uint32_t *key /*[256]*/,
                                             uint32_t *first /*[32]*/, uint32_t *cnt /*[32]*/, uint32_t *table /*[kWaveQ * 32]*/) {
@@ -100,20 +113,30 @@ __device__ __forceinline__ void wave_bucket(uint32_t *__restrict__ words, int64_
     high = (uint32_t)__builtin_amdgcn_readfirstlane((int)high);  // (lane 0 always holds a row: R >= 2)
     if (lane < 32) cnt[lane] = 0;
     wave_sync();
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int c = lane; c < (P >> 1); c += 64) {
-                const int lo = 2 * c - (c & (stride - 1)), hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const uint32_t a = key[lo], z = key[hi];
-                if ((a > z) == up) {
-                    key[lo] = z;
-                    key[hi] = a;
+    // Rows as memo_index_pack leaves them come grouped by class already (start order): then a row's place in its class is
+    // COUNTED (the rows of its class with a smaller key: a handful of LDS reads) instead of sorting the bucket -- config 3's
+    // 5 * 10^8 rows: 14.2 ms of ordering pass with the sort (profiles/r04_pack_pass.txt).  Rows that were dealt before (a change of order) take the sort.
+    bool in_order = true;
+    for (int e = lane; e < R; e += 64)
+        if (e && (key[e - 1] >> C.cshift) > (key[e] >> C.cshift)) in_order = false;
+    bool grouped = __ballot(!in_order) == 0ull;
+    auto sort_keys = [&]() {
+        for (int size = 2; size <= P; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int c = lane; c < (P >> 1); c += 64) {
+                    const int lo = 2 * c - (c & (stride - 1)), hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const uint32_t a = key[lo], z = key[hi];
+                    if ((a > z) == up) {
+                        key[lo] = z;
+                        key[hi] = a;
+                    }
                 }
+                wave_sync();
             }
-            wave_sync();
         }
-    }
+    };
+    if (!grouped) sort_keys();
     for (int e = lane; e < R; e += 64) {
         const uint32_t s = key[e] >> C.cshift;
         if (e == 0 || (key[e - 1] >> C.cshift) != s) first[s] = (uint32_t)e;
@@ -129,6 +152,10 @@ __device__ __forceinline__ void wave_bucket(uint32_t *__restrict__ words, int64_
     uint32_t maxc = c_mine;
     for (int off = 16; off > 0; off >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, off, 64));
     maxc = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxc);
+    if (grouped && maxc > kCountedClass) {  // (a class too long to count through: the sort; the classes stay where they are)
+        sort_keys();
+        grouped = false;
+    }
     const bool tabled = C.mode != 0 && maxc <= 4u * kWaveQ;
     if (tabled) {
         // where every chunk (pass q, start s) begins: an exclusive scan of the chunk sizes in (q, s) order, two passes at a time
@@ -150,9 +177,13 @@ __device__ __forceinline__ void wave_bucket(uint32_t *__restrict__ words, int64_
     for (int e = lane; e < R; e += 64) {
         const uint32_t k = key[e];
         uint32_t pos = (uint32_t)e;  // mode 0: the sorted order itself
-        if (C.mode) {
-            const uint32_t s = k >> C.cshift, rank = (uint32_t)e - first[s];
-            if (tabled) {
+        if (C.mode || grouped) {
+            const uint32_t s = k >> C.cshift;
+            uint32_t rank = (uint32_t)e - first[s];
+            if (grouped) rank = counted_rank(key, first[s], cnt[s], (uint32_t)e, k);
+            if (!C.mode) {
+                pos = first[s] + rank;
+            } else if (tabled) {
                 pos = table[32u * (rank >> 2) + s] + (rank & 3u);
             } else {
                 const uint32_t q4 = rank & ~3u;
@@ -191,36 +222,55 @@ __device__ __forceinline__ void block_bucket(uint32_t *__restrict__ words, int64
     for (int i = tid; i < S; i += 256) cnt[i] = 0;
     __syncthreads();
     const uint32_t high = *shared_high;
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int c = tid; c < (P >> 1); c += 256) {
-                const int lo = 2 * c - (c & (stride - 1)), hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const uint32_t a = key[lo], z = key[hi];
-                if ((a > z) == up) {
-                    key[lo] = z;
-                    key[hi] = a;
+    bool in_order = true;  // (as in wave_bucket: rows that come grouped by class are counted into place, not sorted)
+    for (int i = tid; i < R; i += 256)
+        if (i && (key[i - 1] >> C.cshift) > (key[i] >> C.cshift)) in_order = false;
+    bool grouped = __syncthreads_and(in_order ? 1 : 0) != 0;
+    auto sort_keys = [&]() {
+        for (int size = 2; size <= P; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int c = tid; c < (P >> 1); c += 256) {
+                    const int lo = 2 * c - (c & (stride - 1)), hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const uint32_t a = key[lo], z = key[hi];
+                    if ((a > z) == up) {
+                        key[lo] = z;
+                        key[hi] = a;
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
-    }
+    };
+    if (!grouped) sort_keys();
     for (int i = tid; i < R; i += 256) {
         const uint32_t s = key[i] >> C.cshift;
         if (i == 0 || (key[i - 1] >> C.cshift) != s) first[s] = (uint32_t)i;
         if (i == R - 1 || (key[i + 1] >> C.cshift) != s) cnt[s] = (uint32_t)i + 1u;
     }
     __syncthreads();
+    uint32_t longest = 0;
     for (int i = tid; i < S; i += 256)
-        if (cnt[i]) cnt[i] -= first[i];
+        if (cnt[i]) {
+            cnt[i] -= first[i];
+            longest = longest > cnt[i] ? longest : cnt[i];
+        }
+    if (grouped && !__syncthreads_and(longest <= kCountedClass ? 1 : 0)) {
+        sort_keys();
+        grouped = false;
+    }
     __syncthreads();
     for (int i = tid; i < R; i += 256) {
         const uint32_t k = key[i];
         uint32_t pos = (uint32_t)i;
-        if (C.mode) {
+        if (C.mode || grouped) {
             const uint32_t s = k >> C.cshift;
-            const uint32_t rank = (uint32_t)i - first[s], q4 = rank & ~3u;
+            const uint32_t rank = grouped ? counted_rank(key, first[s], cnt[s], (uint32_t)i, k) : (uint32_t)i - first[s], q4 = rank & ~3u;
             pos = rank & 3u;
+            if (!C.mode) {
+                words[r0 + first[s] + rank] = C.word(k, high);
+                continue;
+            }
             for (int t = 0; t < S; ++t) {
                 const uint32_t c = cnt[t];
                 pos += c < q4 ? c : q4;  // rows of start t in earlier passes
