@@ -109,11 +109,12 @@ def dense_view(p3, boff3, rows3, cap):
     n = 5 * len(g)
     B = np.empty(n, np.uint32)
     A = np.empty(n, np.uint32)
+    hi = (g[:, 3] >> 16) & 0x1F              # X_3: the ninth annot bit of rows 0 .. 4 (indexes of 256 .. 511 genomes)
     for j in range(4):                       # dword j = B_j | X_j << 16 | A_j << 24
         B[j::5] = g[:, j] & 0xFFFF
-        A[j::5] = g[:, j] >> 24
+        A[j::5] = (g[:, j] >> 24) | (((hi >> j) & 1) << 8)
     B[4::5] = ((g[:, 0] >> 16) & 0xFF) | (((g[:, 1] >> 16) & 0xFF) << 8)      # X_0 = B_4 & 255, X_1 = B_4 >> 8
-    A[4::5] = (g[:, 2] >> 16) & 0xFF                                          # X_2 = A_4
+    A[4::5] = ((g[:, 2] >> 16) & 0xFF) | (((hi >> 4) & 1) << 8)               # X_2 = A_4
     B, A = B[:rows3], A[:rows3]
     keep = (B & 63) < cap
     rows_v = int(keep.sum())
@@ -126,10 +127,11 @@ def dense_view(p3, boff3, rows3, cap):
     Av = np.concatenate([A[keep], np.zeros(pad, np.uint32)])
     out = np.empty((len(Bv) // 5, 4), np.uint32)
     b4, a4 = Bv[4::5], Av[4::5]
-    out[:, 0] = Bv[0::5] | ((b4 & 255) << 16) | (Av[0::5] << 24)
-    out[:, 1] = Bv[1::5] | ((b4 >> 8) << 16) | (Av[1::5] << 24)
-    out[:, 2] = Bv[2::5] | (a4 << 16) | (Av[2::5] << 24)
-    out[:, 3] = Bv[3::5] | (Av[3::5] << 24)
+    hi = sum(((Av[j::5] >> 8) & 1) << j for j in range(5)).astype(np.uint32)
+    out[:, 0] = Bv[0::5] | ((b4 & 255) << 16) | ((Av[0::5] & 255) << 24)
+    out[:, 1] = Bv[1::5] | ((b4 >> 8) << 16) | ((Av[1::5] & 255) << 24)
+    out[:, 2] = Bv[2::5] | ((a4 & 255) << 16) | ((Av[2::5] & 255) << 24)
+    out[:, 3] = Bv[3::5] | (hi << 16) | ((Av[3::5] & 255) << 24)
     return out.reshape(-1), table, rows_v
 
 
@@ -141,7 +143,7 @@ def view_cap(k):
 
 def write(in_file, record, ix, k=None):
     """ix: a packed DeviceIndex holding EVERY row of `record`.  Writes the cache file atomically: the 4- (6-) byte
-    rows, the bucket table, the rows with end < start and -- when every annot fits 8 bits -- the DENSE rows too (3.2 B
+    rows, the bucket table, the rows with end < start and -- when every annot fits 9 bits -- the DENSE rows too (3.2 B
     per row, memo_index_pack_dense: what the conservation sweep reads fastest, so that a cached `memo query -k 31`
     runs the benchmarked kernel)."""
     inf = ix.info()
@@ -155,7 +157,7 @@ def write(in_file, record, ix, k=None):
     check(lib().memo_index_export_packed(ix._h, pk.ctypes.data, pa.ctypes.data if fmt == 6 else None, boff.ctypes.data,
                                          longs.ctypes.data if n_long else None))
     p3, boff3, rows3 = np.empty(0, np.uint32), np.empty(0, np.int64), 0
-    if fmt == 4 and rows:
+    if (fmt == 4 or (fmt == 12 and inf["max_annot"] <= 511)) and rows:   # (annots of up to nine bits fit the dense rows)
         ix.pack_dense(keep_packed=True)
         rows3 = ix.info()["dense_row_count"]          # (fewer than rows when the rows that never write at k <= 64 were left out)
         p3 = np.empty(4 * ((rows3 + 4) // 5), np.uint32)

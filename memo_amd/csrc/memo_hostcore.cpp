@@ -9,7 +9,7 @@
 // long_rows_*_kernel), the largest annot, and the start-bucket table -- built from the sorted starts as they stream
 // by, no search.
 //
-// Rows that cannot be packed (unsorted, negative start, annot outside [0, 4095] -- outside [0, 255] for the dense
+// Rows that cannot be packed (unsorted, negative start, annot outside [0, 4095] -- outside [0, 511] for the dense
 // rows --, coordinates beyond +-2^61) make the builder return MEMO_EUNPACKABLE; the caller then takes the next way in
 // (dense -> 4-byte words -> memo_index_upload + memo_index_finalize + memo_index_pack, which sorts on the device, knows
 // the 6-byte format for larger annots and handles every legal input).
@@ -344,6 +344,7 @@ struct RowScan {
         res.max_annot = top;
         res.bad = bad;
         res.wide_annot = wide;
+        res.over511 = top > 511u ? 1 : 0;
     }
 };
 
@@ -395,7 +396,7 @@ static inline __attribute__((always_inline)) void scan_piece_body(const int64_t 
         if (FMT == 3) {
             const uint32_t l6 = len > 63u ? 63u : (uint32_t)len;
             W[i] = (((uint32_t)s & 1023u) << 6) | l6;
-            A8[i] = (uint32_t)a & 0xFFu;
+            A8[i] = (uint32_t)a & 0x1FFu;  // (nine bits: the ninth goes to the group's spare byte, dense_group)
         } else {
             const uint32_t l8 = len > 255u ? 255u : (uint32_t)len;
             const uint32_t a12 = (uint32_t)a & 0xFFFu;
@@ -491,6 +492,7 @@ static void scan_block(const PackArgs &A, uint64_t i0, uint64_t i1, int64_t prev
     res.max_annot = top;
     res.bad = bad;
     res.wide_annot = f.annot_or > 255u ? 1 : 0;
+    res.over511 = f.annot_or > 511u ? 1 : 0;
 }
 
 // rows [i0, i1) -> words (format 4 or 12), pk[i] for row i.  end < start (handled by long_rows_*_kernel) packs as
@@ -511,11 +513,15 @@ inline uint32_t dense_b(int64_t s, int64_t len) {
 
 // five rows -> one 16-byte group (PackedRows3, memo_sweep.h): dword j = B_j | X_j << 16 | A_j << 24, the fifth row in
 // the spare bytes X
+// (annots of nine bits -- indexes of 256 .. 511 genomes --: the ninth bit of row i at bit 16 + i of the last dword, the byte no
+// row used; memo_index.hip: pack3_rows_kernel builds the same on the device)
 inline void dense_group(const uint32_t *B, const uint32_t *Aa, uint32_t *out) {
-    out[0] = B[0] | ((B[4] & 0xFFu) << 16) | (Aa[0] << 24);
-    out[1] = B[1] | ((B[4] >> 8) << 16) | (Aa[1] << 24);
-    out[2] = B[2] | ((Aa[4] & 0xFFu) << 16) | (Aa[2] << 24);
-    out[3] = B[3] | (Aa[3] << 24);
+    const uint32_t hi = ((Aa[0] >> 8) & 1u) | (((Aa[1] >> 8) & 1u) << 1) | (((Aa[2] >> 8) & 1u) << 2) | (((Aa[3] >> 8) & 1u) << 3) |
+                        (((Aa[4] >> 8) & 1u) << 4);
+    out[0] = B[0] | ((B[4] & 0xFFu) << 16) | ((Aa[0] & 0xFFu) << 24);
+    out[1] = B[1] | ((B[4] >> 8) << 16) | ((Aa[1] & 0xFFu) << 24);
+    out[2] = B[2] | ((Aa[4] & 0xFFu) << 16) | ((Aa[2] & 0xFFu) << 24);
+    out[3] = B[3] | (hi << 16) | ((Aa[3] & 0xFFu) << 24);
 }
 
 // rows [i0, i0 + 5 * groups) -> groups at out (4 dwords each)
@@ -526,7 +532,7 @@ void pack_dense(const PackArgs &A, uint64_t i0, uint64_t groups, int64_t prev_st
         uint32_t *o = out + 4 * ((at - i0) / 5);
         for (int j = 0; j + 5 <= n; j += 5, o += 4) dense_group(W + j, A8 + j, o);
     });
-    if (res.wide_annot) res.bad |= 16;
+    if (res.over511) res.bad |= 16;
 }
 
 const char *bad_message(int bad) {
@@ -534,7 +540,7 @@ const char *bad_message(int bad) {
            : bad & 2  ? "rows with a negative start cannot be packed"
            : bad & 4  ? "rows with an annot outside [0, 4095] do not fit the one-word formats"
            : bad & 8  ? "rows have coordinates beyond +-2^61"
-                      : "rows with an annot above 255 do not fit the dense rows: take the 4-byte rows";
+                      : "rows with an annot above 511 do not fit the dense rows: take the 4-byte rows";
 }
 
 int merge_results(memo_builder *b, std::vector<BlockResult> &res) {
@@ -610,11 +616,11 @@ int carry_rows(memo_builder *b, const PackArgs &A, uint64_t i0, uint64_t i1) {
         uint32_t a12;
         scan.row(A, i, res[0], s, len, a12);
         b->carry_b[b->carry_n] = dense_b(s, len);
-        b->carry_a[b->carry_n] = a12 & 0xFFu;
+        b->carry_a[b->carry_n] = a12 & 0x1FFu;
         ++b->carry_n;
     }
     scan.finish(res[0]);
-    if (scan.wide) res[0].bad |= 16;
+    if (scan.top > 511u) res[0].bad |= 16;
     if (res[0].bad) { b->why = res[0].bad; return builder_fail(b, MEMO_EUNPACKABLE, bad_message(res[0].bad)); }
     return merge_results(b, res);
 }

@@ -83,8 +83,9 @@ int upload_pipelined_core(int device, void *dev, const void *host, size_t bytes)
 // ---- the builder ------------------------------------------------------------------------------------------
 struct BlockResult {  // what one worker task found in its rows
     uint64_t max_annot = 0;
-    int bad = 0;  // 1 unsorted, 2 negative start, 4 annot outside [0, 4095], 8 wild coordinate, 16 annot > 255 (dense rows)
-    int wide_annot = 0;
+    int bad = 0;  // 1 unsorted, 2 negative start, 4 annot outside [0, 4095], 8 wild coordinate, 16 annot > 511 (dense rows)
+    int wide_annot = 0;  // some annot > 255 (the one-word rows go to format 12)
+    int over511 = 0;     // some annot > 511 (no dense rows: nine annot bits per row, memo_index.hip: pack3_rows_kernel)
     std::vector<int64_t> long_rows;  // (start, end, annot) triples with end < start
 };
 

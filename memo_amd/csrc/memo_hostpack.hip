@@ -408,10 +408,11 @@ int memo_index_import_dense(uint64_t rows, int32_t device, int32_t bucket_shift,
 
 // One rule for "the dense rows alone can answer this query" (memo_sweep_cons.hip, query_conservation: the unclipped
 // sweep on PackedRows3), for callers that choose the row format before they build or import an index: conservation,
-// 2 <= k <= 64, at most 255 genomes, every annot inside the result matrix, at least one row per position.
+// 2 <= k <= 64, at most 511 genomes (above 255: uint16 results, the nine-bit form of the table-driven kernel), every annot inside
+// the result matrix, at least one row per position.
 int memo_dense_rows_can_answer(uint64_t rows, int64_t min_start, int64_t max_start, uint64_t max_annot, int32_t k,
                                int32_t num_docs, int32_t membership) {
-    if (membership || k < 2 || k - 1 > 63 || num_docs < 1 || num_docs > 255 || max_annot > (uint64_t)num_docs || !rows)
+    if (membership || k < 2 || k - 1 > 63 || num_docs < 1 || num_docs > 511 || max_annot > (uint64_t)num_docs || !rows)
         return 0;
     const double span = (double)max_start - (double)min_start + 1.0;  // (as query_conservation judges "dense enough")
     return (double)rows >= span ? 1 : 0;

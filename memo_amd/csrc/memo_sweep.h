@@ -438,7 +438,9 @@ struct PackedRows3 {
     // g(b, data): the row's B field is the low half of b (the high half is other rows' business), data a word with
     // its annot in the top byte.  Rows outside [r0, r1) get the dead field (start = a, length 63: never writes when
     // k - 1 <= 63).
-    template <int T, int U, typename G>
+    // A9 (indexes of 256 .. 511 genomes): data carries the order in its top NINE bits -- (ninth annot bit, from bit 16 + i of the
+    // group's last dword : the dword) >> 1
+    template <int T, int U, typename G, bool A9 = false>
     static __device__ __forceinline__ void consume(const SweepArgs &A, const Tile &t, uint32_t batch, uint4 (&V)[U], G g) {
         uint64_t g0;
         uint32_t ng, first, end;
@@ -466,6 +468,15 @@ struct PackedRows3 {
                 if (!in(1)) V[u].y = (V[u].y & 0xFFFF0000u) | dead;
                 if (!in(2)) V[u].z = (V[u].z & 0xFFFF0000u) | dead;
                 if (!in(3)) V[u].w = (V[u].w & 0xFFFF0000u) | dead;
+            }
+            if constexpr (A9) {
+                const uint32_t hi = V[u].w >> 16;
+                g(V[u].x, __builtin_amdgcn_alignbit(hi, V[u].x, 1));
+                g(V[u].y, __builtin_amdgcn_alignbit(hi >> 1, V[u].y, 1));
+                g(V[u].z, __builtin_amdgcn_alignbit(hi >> 2, V[u].z, 1));
+                g(V[u].w, __builtin_amdgcn_alignbit(hi >> 3, V[u].w, 1));
+                g(__builtin_amdgcn_perm(V[u].y, V[u].x, 0x0c0c0602u), __builtin_amdgcn_alignbit(hi >> 4, V[u].z << 8, 1));
+                continue;
             }
             g(V[u].x, V[u].x);
             g(V[u].y, V[u].y);

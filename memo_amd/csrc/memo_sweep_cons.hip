@@ -368,9 +368,11 @@ void sweep_conservation_halo_kernel(const SweepArgs A) {
 // runs at 2.36 GHz), i.e. what it executes per row.  Moving the arithmetic out of the row loop into a per-tile table
 // indexed by the length (64 entries of two LDS offsets: 4 VALU per row fewer, one ds_read_b64 more) made it slower
 // (0.46 ms: every row then waits for an LDS round trip).
-template <int U, int T, typename OutT>
+template <int U, int T, typename OutT, bool A9 = false>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MEMO_HALO_WAVES, 8)))
 void sweep_conservation_halo3_kernel(const SweepArgs A) {
+    static_assert(!A9 || sizeof(OutT) == 2, "more than 255 genomes: uint16 results");
+    constexpr int TOP = A9 ? 23 : 24;  // a cell = order << TOP | tie-breaking bits
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     using Rows = PackedRows3;
     const int LS = A.ls, HL = A.hl, W = A.w;
@@ -394,7 +396,7 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
         if (sx + vx == 0xFFFFFFF0u) atomicOr(A.status, 64);  // (keeps them alive)
     }
 #endif
-    halo_clear<T>(A, lds, ((uint32_t)(A.ncols - 1) << 24) | 0x00FFFFFFu);
+    halo_clear<T>(A, lds, ((uint32_t)(A.ncols - 1) << TOP) | ((1u << TOP) - 1u));
 
     const int km1 = A.km1;
     const uint32_t ls4 = 4u * (uint32_t)LS;
@@ -456,13 +458,13 @@ void sweep_conservation_halo3_kernel(const SweepArgs A) {
         asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(b), "v"(a10s));
         scatter(r, data);
     };
-    Rows::template consume<T, U>(A, t, 0, V, g);
+    Rows::template consume<T, U, decltype(g), A9>(A, t, 0, V, g);
     for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
         Rows::template issue<T, U>(A, t, b, V);
-        Rows::template consume<T, U>(A, t, b, V, g);
+        Rows::template consume<T, U, decltype(g), A9>(A, t, b, V, g);
     }
     lds_barrier();  // waits for lgkmcnt(0): the ds_min above are invisible to the compiler
-    halo_finish<OutT, T, 24>(A, t, lds);
+    halo_finish<OutT, T, TOP>(A, t, lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1126,7 +1128,13 @@ static SweepKernel mixed_kernel(int waves) {
 }
 
 template <typename OutT>
-static SweepKernel halo3_kernel(int waves) {
+static SweepKernel halo3_kernel(int waves, bool annot9) {
+    if constexpr (sizeof(OutT) == 2) {
+        if (annot9)  // (256 .. 511 genomes)
+            return waves == 8   ? (SweepKernel)sweep_conservation_halo3_kernel<PackedRows3::kLoads, 512, OutT, true>
+                   : waves == 4 ? (SweepKernel)sweep_conservation_halo3_kernel<PackedRows3::kLoads, 256, OutT, true>
+                                : (SweepKernel)sweep_conservation_halo3_kernel<PackedRows3::kLoads, 64, OutT, true>;
+    }
     return waves == 8   ? (SweepKernel)sweep_conservation_halo3_kernel<PackedRows3::kLoads, 512, OutT>
            : waves == 4 ? (SweepKernel)sweep_conservation_halo3_kernel<PackedRows3::kLoads, 256, OutT>
                         : (SweepKernel)sweep_conservation_halo3_kernel<PackedRows3::kLoads, 64, OutT>;
@@ -1394,7 +1402,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             const uint64_t drows = ix->boff3 ? ix->rows3 : ix->rows;
             // 256 .. 511 genomes: the table-driven kernel's nine-bit form (memo_sweep_cons3t.hip: A9), uint16 results, or not the dense rows
             const bool top9 = !top8 && num_docs <= 511 && ix->max_annot <= 511 && sizeof(OutT) == 2;
-            bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && (top8 || top9) &&
+            const bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && (top8 || top9) &&
                          ((double)drows >= span || !ix->pk);
             if (three) {  // the dense rows of this k's class (a view that leaves out the rows that cannot write at this k), or all
                 uint32_t *vp3 = nullptr;
@@ -1417,7 +1425,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
                 }
             }
-            if (three && (top9 || tune.persistent == 5 || (tune.persistent == 0 && MEMO_TABLE_DEFAULT))) {
+            if (three && (tune.persistent == 5 || (tune.persistent == 0 && MEMO_TABLE_DEFAULT))) {
                 // the tile's row slice from a table built once per (index, k): memo_sweep_cons3t.hip; 1 = does not fit
                 const int trc = launch_halo3t(ix, A, tw, (int)sizeof(OutT), st, top9);
                 if (trc < 0) return trc;
@@ -1426,12 +1434,11 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                     ix->last_variant = 2;
                     return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
                 }
-                if (top9) three = false;  // (no room for a tile table, a negative window start: the 4-byte rows if resident)
             }
             if (!three && fmt == 3) {
                 halo = false;  // (below: the int64 columns, or an error when they are gone too)
             } else {
-            SweepKernel kern = three      ? halo3_kernel<OutT>(waves)
+            SweepKernel kern = three      ? halo3_kernel<OutT>(waves, top9)  // (no tile table: no room, a negative window start)
                                : fmt == 4 ? (top8 ? halo_kernel<PackedRows<false, false>, OutT, 24>(waves)
                                                   : halo_kernel<PackedRows<false, false>, OutT, 0>(waves))
                                : fmt == 12 ? (num_docs <= 4095 ? halo_kernel<PackedRows<false, false, true>, OutT, 20>(waves)

@@ -56,7 +56,7 @@ while time.time() < t_end:
     via_builder = packable and m > 0 and int(o.max()) <= 4095 and int(o.min()) >= 0 and rng.random() < 0.4
     # ... a third of those as DENSE rows straight from the host packer (five rows per 16 bytes; such an index answers k <= 64
     # only, may leave out the rows that can never write, and builds k-class views and tile tables behind its queries)
-    dense_only = via_builder and int(o.max()) <= 255 and n_docs <= 255 and rng.random() < 0.4
+    dense_only = via_builder and int(o.max()) <= 511 and n_docs <= 511 and rng.random() < 0.4      # (annots of up to nine bits)
     if via_builder:
         cuts = [0] + sorted(int(x) for x in rng.integers(0, m, int(rng.integers(0, 4)))) + [m]
         with memo_amd.IndexBuilder(m + int(rng.integers(0, 100)), bucket_shift=bshift, dense=dense_only) as b:

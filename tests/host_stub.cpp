@@ -231,7 +231,9 @@ static void verify(const memo_builder *b, const Rows &r, uint64_t n) {
                 gotB = ((g[0] >> 16) & 0xFFu) | (((g[1] >> 16) & 0xFFu) << 8);
                 gotA = (g[2] >> 16) & 0xFFu;
             }
+            gotA |= ((g[3] >> (16 + j)) & 1u) << 8;  // the ninth annot bit: bit 16 + j of the group's last dword
             CHECK(gotB == B && gotA == (uint32_t)a);
+            CHECK(((g[3] >> 21) & 7u) == 0);  // (the byte's other three bits stay clear)
         } else {
             const uint32_t l8 = len > 255 ? 255u : (uint32_t)len;
             const uint32_t want = b->fmt == 12 ? l8 | (((uint32_t)s & 0xFFFu) << 8) | ((uint32_t)a << 20)
@@ -247,7 +249,7 @@ static void verify(const memo_builder *b, const Rows &r, uint64_t n) {
 }
 
 static void run_builder(bool dense, uint64_t n, uint64_t seed, int late_wide_at, int long_every) {
-    Rows r = make_rows(n, seed, dense ? 255 : 200, dense ? -1 : late_wide_at, long_every);
+    Rows r = make_rows(n, seed, dense ? (seed % 2 ? 511 : 255) : 200, dense ? -1 : late_wide_at, long_every);   // (dense rows: annots of up to nine bits)
     memo_builder *b = new_builder(n, dense);
     std::mt19937_64 rng(seed ^ 0x55);
     uint64_t at = 0;
@@ -286,7 +288,7 @@ int main() {
             free_builder(b);
         }
         Rows w = make_rows(1000, 4, 100);
-        w.a[999] = 300;
+        w.a[999] = 512;
         memo_builder *b = new_builder(1000, true);
         CHECK(builder_push_core(b, w.s.data(), w.e.data(), w.a.data(), 1000) == MEMO_EUNPACKABLE);
         free_builder(b);

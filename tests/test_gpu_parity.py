@@ -462,7 +462,8 @@ def test_builder_equals_int64_upload(n_rows, n_docs, pieces, memo, oracle):
                 ix.conservation(0, 1000, 300, n_docs)               # k > 256 needs the int64 columns
 
 
-@pytest.mark.parametrize("n_rows,n_docs,pieces", [(300_003, 90, 1), (300_001, 255, 9), (9_500_002, 200, 3), (6, 5, 1), (4, 5, 2)])
+@pytest.mark.parametrize("n_rows,n_docs,pieces", [(300_003, 90, 1), (300_001, 255, 9), (9_500_002, 200, 3), (6, 5, 1), (4, 5, 2),
+                                                  (300_002, 500, 7), (300_004, 511, 2)])      # (annots of nine bits)
 def test_dense_builder_equals_device_packing(n_rows, n_docs, pieces, memo, oracle, ab):
     """memo_builder_create_rows(MEMO_ROWS_DENSE): rows narrowed on the host straight to the dense format (five rows per
     16 bytes; PCIe carries 3.2 B per row), pushed in ragged pieces that end inside a group -- the groups, bucket table
@@ -515,13 +516,17 @@ def test_dense_builder_equals_device_packing(n_rows, n_docs, pieces, memo, oracl
                     assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want_v), (k, qs, qe)
                     assert ix.info()["last_sweep"] == 5
                 qe2 = min(qe, qs + 20_000)
-                wantb = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe2, 31), qs, qe2, 31, n_docs, literal=False)
-                assert np.array_equal(ix.membership(qs, qe2, 31, n_docs), wantb) and ix.info()["last_sweep"] == 6
+                if n_docs <= 255:
+                    wantb = oracle.membership(*oracle.filter_rows(s, e, o, qs, qe2, 31), qs, qe2, 31, n_docs, literal=False)
+                    assert np.array_equal(ix.membership(qs, qe2, 31, n_docs), wantb) and ix.info()["last_sweep"] == 6
+                else:                                                # (bit planes on the dense rows: up to 255 genomes)
+                    with pytest.raises(memo.MemoError):
+                        ix.membership(qs, qe2, 31, n_docs)
                 with pytest.raises(memo.MemoError):
                     ix.conservation(0, 1000, 101, n_docs)            # k > 64 needs the 4-byte rows
-    # an annot above 255 is refused: the caller starts over with the 4-byte rows
+    # an annot above 511 is refused: the caller starts over with the 4-byte rows
     o2 = o.copy()
-    o2[-1] = 300
+    o2[-1] = 512
     with memo.IndexBuilder(n_rows, dense=True) as b:
         with pytest.raises(memo.MemoUnpackable):
             b.push(s, e, o2)
@@ -701,7 +706,7 @@ def test_sidecar_cache_round_trip(memo, oracle, tmp_path, monkeypatch):
     from memo_amd import cache, memo_query as mq
     rng = np.random.default_rng(12)
     tabs, cols = [], {}
-    for name, n, n_docs in (("chrA", 700_000, 60), ("chr B/2", 250_000, 700)):         # formats 4 and 12
+    for name, n, n_docs in (("chrA", 700_000, 60), ("chr B/2", 250_000, 700), ("chrC", 450_000, 400)):   # formats 4, 12 and 12 with annots of nine bits
         s, e, o = _random_index(rng, n, 150_000, n_docs, 80)
         neg = rng.random(n) < 0.001
         e[neg] = s[neg] - rng.integers(1, 500, int(neg.sum()))                        # a few rows with end < start
@@ -728,10 +733,10 @@ def test_sidecar_cache_round_trip(memo, oracle, tmp_path, monkeypatch):
         assert os.path.exists(cache.cache_path(path, record))
         text2, err2 = query(record, 1000, 60_000, 31, n_docs, "1")                  # hit
         assert text2 == text0 and "from the sidecar cache, ctypes-only path" in err2
-        # the cache holds the dense rows where every annot fits 8 bits; a conservation query they can answer reads THEM
-        assert ("dense rows (3.2 B)" if n_docs <= 255 else "4-byte rows") in err2, err2
-        assert "dense rows (3.2 B)" in err1 if n_docs <= 255 else "4-byte rows" in err1, err1     # ... and so does the miss
-        if n_docs <= 255:
+        # the cache holds the dense rows where every annot fits 9 bits; a conservation query they can answer reads THEM
+        assert ("dense rows (3.2 B)" if n_docs <= 511 else "4-byte rows") in err2, err2
+        assert "dense rows (3.2 B)" in err1 if n_docs <= 511 else "4-byte rows" in err1, err1     # ... and so does the miss
+        if n_docs <= 511:
             # v3: the miss ran with -k 31, so the file also holds that class's VIEW of the dense rows (overlaps below 30: three
             # eighths of these rows) and a hit whose k fits the class uploads and sweeps only those
             head = cache._open(path, record)[0]
@@ -792,7 +797,7 @@ def test_sidecar_cache_round_trip(memo, oracle, tmp_path, monkeypatch):
                 assert ix.cache == "hit"
                 assert np.array_equal(ix.conservation(qs, qe, k, n_docs), want), (record, qs, qe, k)
                 inf = ix.info()
-                if n_docs <= 255 and k <= 64 and inf["rows"] >= inf["max_start"] - inf["min_start"] + 1 and inf["rows"]:
+                if n_docs <= 511 and k <= 64 and inf["rows"] >= inf["max_start"] - inf["min_start"] + 1 and inf["rows"]:
                     assert inf["dense_rows"] == 1 and inf["last_sweep"] == 5, (inf, k)
                 else:
                     assert inf["dense_rows"] == 0
@@ -1961,8 +1966,8 @@ def test_places_inside_a_dense_group_never_change_a_result(memo, oracle, ab):
 
 
 def test_dense_rows_of_256_to_511_genomes(memo, oracle, ab):
-    """Indexes of 256 .. 511 genomes on the dense rows (the ninth annot bit in the group's spare byte; the table-driven kernel's
-    nine-bit form: memo_sweep_cons3t.hip, A9): conservation at every k class up to 64, views built and not, windows on and off the
+    """Indexes of 256 .. 511 genomes on the dense rows (the ninth annot bit in the group's spare byte; the nine-bit forms of the
+    table-driven kernel and of the one without a table: memo_sweep_cons3t.hip / memo_sweep_cons.hip, A9): conservation at every k class up to 64, views built and not, windows on and off the
     4-position raster, membership and k > 64 through the 4-byte rows (refused when those were dropped); an index whose annots would
     fit a byte asked with more than 255 genomes; equal to the oracle."""
     rng = np.random.default_rng(47)
@@ -1992,6 +1997,13 @@ def test_dense_rows_of_256_to_511_genomes(memo, oracle, ab):
                         got = ix.conservation(qs, qe, k, n_docs)
                         assert (ix.info()["last_sweep"], ix.info()["last_variant"]) == (5, 2)
                         assert np.array_equal(got, oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False))
+                    # the kernel without a tile table (what a negative window start or a device without room for the table gets): nine bits too
+                    for qs, qe, source in ((-70, 9_001, 0), (20_001, 41_003, 5), (0, length + 60, 5)):
+                        ix.debug_set_tuning(0, 0, 0, source, 0)
+                        got = ix.conservation(qs, qe, k, n_docs)
+                        assert (ix.info()["last_sweep"], ix.info()["last_variant"]) == (5, 0), (k, qs, source)
+                        assert np.array_equal(got, oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False))
+                    ix.debug_set_tuning()
                 if keep_packed:
                     for k in (31, 101):
                         got = ix.membership(9_000, 19_000, k, n_docs)
