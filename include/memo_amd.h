@@ -202,7 +202,7 @@ int memo_index_prepare(memo_index_t *ix, int32_t k, int32_t num_docs, int32_t me
 int memo_index_export_packed(memo_index_t *ix, uint32_t *pk, uint16_t *pa, int64_t *boff, int64_t *long_rows);
 /* The same for the DENSE rows (five per 16 bytes; memo_index_pack_dense, or a memo_builder_create_rows(...,
  * MEMO_ROWS_DENSE) index): _export copies ceil(rows / 5) groups, the bucket table and the rows with end < start;
- * _import builds a finalized index that holds the dense rows only (3.2 B per row: conservation, k <= 64, <= 255
+ * _import builds a finalized index that holds the dense rows only (3.2 B per row: conservation, k <= 64, <= 511
  * genomes -- memo_dense_rows_can_answer) from such arrays, or from a slice of them: `groups` points at the group
  * that holds row `row_base` (a multiple of 5), `rows` counts from row_base, and the first table entry may lie up to
  * 4 rows behind row_base (the bucket's first row sits inside that group).  So that `memo query` reads the
@@ -213,7 +213,7 @@ int memo_index_import_dense(uint64_t rows, int32_t device, int32_t bucket_shift,
                             int64_t min_start, int64_t max_start, uint64_t max_annot, const int64_t *long_rows,
                             uint64_t n_long, memo_index_t **out);
 /* 1 when an index that holds ONLY the dense rows answers this query (the unclipped conservation sweep on them:
- * conservation, 2 <= k <= 64, num_docs <= 255, every annot <= num_docs, at least one row per pivot position between
+ * conservation, 2 <= k <= 64, num_docs <= 511, every annot <= num_docs, at least one row per pivot position between
  * min_start and max_start), else 0.  Pure host arithmetic; the one rule the one-shot form, memo_amd/memo_query.py and
  * the cache use to choose the row format BEFORE they build or import an index. */
 int memo_dense_rows_can_answer(uint64_t rows, int64_t min_start, int64_t max_start, uint64_t max_annot, int32_t k,
@@ -237,11 +237,11 @@ void memo_index_destroy(memo_index_t *ix);
  * Nothing of the caller's memory is referenced after _push returns.  One builder per thread.
  * memo_builder_create_rows(..., MEMO_ROWS_DENSE) narrows the rows to the DENSE format instead (five rows per 16
  * bytes: 3.2 B per row on the link and in HBM, the fastest source of the conservation sweep) for callers that know
- * their queries fit it (memo_dense_rows_can_answer); a row with an annot > 255 makes _push return MEMO_EUNPACKABLE
+ * their queries fit it (memo_dense_rows_can_answer); a row with an annot > 511 makes _push return MEMO_EUNPACKABLE
  * there too: start over with MEMO_ROWS_PACKED. */
 typedef struct memo_builder memo_builder_t;
 #define MEMO_ROWS_PACKED 0 /* one 32-bit word per row (formats 4 / 12): every query with k <= 256 */
-#define MEMO_ROWS_DENSE 1  /* five 24-bit rows per 16 bytes: conservation, k <= 64, <= 255 genomes */
+#define MEMO_ROWS_DENSE 1  /* five rows per 16 bytes: conservation, k <= 64, <= 511 genomes (membership: <= 255) */
 int memo_builder_create(uint64_t max_rows, int32_t device, int32_t bucket_shift, memo_builder_t **out);
 int memo_builder_create_rows(uint64_t max_rows, int32_t device, int32_t bucket_shift, int32_t row_format,
                              memo_builder_t **out);
