@@ -26,7 +26,8 @@ extern "C" {
  *   whose rows go into registers at the head of a tile / one tile ahead, 8 = the dense rows with one workgroup per
  *   tile that reads its row slice from the index's tile table (memo_sweep_cons3t.hip); 4 .. 7 read all the dense rows,
  *   0 and 8 the k-class view of them where one pays (memo_index_info_t.last_rows_read), 9 = as 0 without views, 10 = as 5
- *   with views, 11 / 12 = as 6 / 7 with views;
+ *   with views, 11 / 12 = as 6 / 7 with views, 13 = as 0 with the "this row writes" test kept in the row blocks even where the
+ *   view holds exactly the rows that write (cap = k - 1; round 4);
  * scatter (conservation, packed rows): 1 = clip every interval to the tile, 2 = unclipped into doubling
  *   level arrays with a halo, 3 = unclipped into radix-4 level arrays, 4 = unclipped into mixed level arrays
  *   (blocks of 1, 4, 16, then doubling; k - 1 >= 16) with every array a k - 1 of that size can need (rounds 2-3), 5 = the mixed

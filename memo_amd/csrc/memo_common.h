@@ -73,6 +73,7 @@ struct memo_tuning {
                          //   2 / 3 / 4 = persistent workgroups (sweep_conservation_halo3p_kernel) wherever the query fits: rows by
                          //   LDS-DMA / into registers at the head of a tile / into registers one tile ahead
     int no_views = 0;    // dense rows: 1 = never read a k-class view (A/B)
+    int no_all_write = 0;  // dense rows: 1 = the row blocks keep their "this row writes" test on a view of exactly the writing rows (A/B)
     int force_packed = 0;  // 1 = read the 4-byte rows even when the dense rows are resident and could answer (they are
                            //     the faster source for the conservation sweep: profiles/r02_dense_rows_ab.txt)
     int row_order = 0;     // order of the 4-byte rows inside a bucket (memo_interleave.hip): 0 = the library's (kRowOrderDefault),
@@ -191,7 +192,7 @@ struct memo_index {
 namespace memo {
 void drop_dense(memo_index *ix);       // frees the dense rows, their bucket table and the tile tables
 int dense_compact(memo_index *ix);     // memo_index.hip: leave the rows that can never write out of the dense rows (see boff3)
-int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows);  // ... or a k-class view
+int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows, int *view_cap = nullptr);  // ... or a k-class view
 constexpr int kNoRoom = 1;  // (internal) the device has no memory for a view / tile table: run without it
 constexpr size_t kMaxTileTables = 64;
 void retire(memo_index *ix, void *p, uint64_t bytes);  // memo_index.hip: out of service now, freed once the device has drained

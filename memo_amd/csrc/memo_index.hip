@@ -963,7 +963,8 @@ int packed_rows_for(memo_index *ix, int km1, bool membership, hipStream_t st, ui
 // memo_query.py:49 drops it per query; here it is dropped once per index and class) when that spares a fifth of the rows or
 // more, else the dense rows themselves.  A view is built by the fifth query of its class (a few ms for 5 * 10^8 rows: one pass
 // over the dense rows, timed in view.build_ms) and kept with the index; MEMO_DENSE_VIEWS=0 turns them off.
-int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows) {
+int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows, int *view_cap) {
+    if (view_cap) *view_cap = 0;  // (the cap of the view handed out: its rows are exactly those with overlap < cap)
     *p3 = ix->p3;
     *boff = ix->boff3 ? ix->boff3 : ix->boff;
     *rows = ix->boff3 ? ix->rows3 : ix->rows;
@@ -1009,6 +1010,7 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
         *p3 = v.p3;
         *boff = v.boff;
         *rows = v.rows;
+        if (view_cap) *view_cap = v.cap;
     }
     return MEMO_OK;
 }

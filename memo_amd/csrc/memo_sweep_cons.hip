@@ -1404,11 +1404,12 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             const bool top9 = !top8 && num_docs <= 511 && ix->max_annot <= 511 && sizeof(OutT) == 2;
             const bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && (top8 || top9) &&
                          ((double)drows >= span || !ix->pk);
+            int view_cap = 0;  // (a view whose cap is k - 1 holds exactly the rows that write at this k: the table-driven kernel's row blocks drop their test)
             if (three) {  // the dense rows of this k's class (a view that leaves out the rows that cannot write at this k), or all
                 uint32_t *vp3 = nullptr;
                 int64_t *vboff = nullptr;
                 uint64_t vrows = 0;
-                if ((rc = dense_rows_for(ix, k - 1, st, &vp3, &vboff, &vrows))) return rc;
+                if ((rc = dense_rows_for(ix, k - 1, st, &vp3, &vboff, &vrows, &view_cap))) return rc;
                 A.p3 = vp3;
                 A.boff = vboff;
                 ix->last_rows_read = vrows;
@@ -1427,7 +1428,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             }
             if (three && (tune.persistent == 5 || (tune.persistent == 0 && MEMO_TABLE_DEFAULT))) {
                 // the tile's row slice from a table built once per (index, k): memo_sweep_cons3t.hip; 1 = does not fit
-                const int trc = launch_halo3t(ix, A, tw, (int)sizeof(OutT), st, top9);
+                const int trc = launch_halo3t(ix, A, tw, (int)sizeof(OutT), st, top9, view_cap == k - 1 && !tune.no_all_write);
                 if (trc < 0) return trc;
                 if (trc == MEMO_OK) {
                     ix->last_sweep = 5;

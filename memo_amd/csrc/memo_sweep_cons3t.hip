@@ -55,7 +55,8 @@ __global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase
 
 // T = 256: four waves per tile (eight tiles = 32 waves per CU), the only form instantiated (T = 128 lost: see the launcher)
 // A9: an index of 256 .. 511 genomes -- the order in the top NINE bits of a level cell (memo_sweep_dense.h: MEMO_ROW9_AT), uint16 results
-template <int NLEV, typename OutT, int T, bool A9 = false>
+// AW: the row source is a k-class view whose cap is this k - 1 -- every row of it writes, the row blocks carry no test (memo_sweep_dense.h)
+template <int NLEV, typename OutT, int T, bool A9 = false, bool AW = false>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 : 4, 8)))
 void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     static_assert(!A9 || sizeof(OutT) == 2, "more than 255 genomes: uint16 results");
@@ -122,10 +123,10 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
         const uint32_t w_row0 = 5u * (gbase + (uint32_t)wave * 64u);
         if (w_row0 >= g.first && w_row0 + 5u * ((uint32_t)(NL - 1) * T + 64u) <= g.end) {
 #pragma unroll
-            for (int j = 0; j < NL; ++j) group_rows<false, A9>(V[j], C, 0, 0);
+            for (int j = 0; j < NL; ++j) group_rows<false, A9, AW>(V[j], C, 0, 0);
             continue;
         }
-        reg_pieces<T, NL, 0, A9>(V, tid, wave, gbase, gleft, g, C, span);
+        reg_pieces<T, NL, 0, A9, AW>(V, tid, wave, gbase, gleft, g, C, span);
     }
     barrier_lds();  // (lgkmcnt(0): the ds_min above are invisible to the compiler)
 
@@ -176,29 +177,23 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     }
 }
 
-template <typename OutT, int T>
+template <typename OutT, int T, bool A9, bool AW>
 SweepKernel kernel_for(int nlev) {
     switch (nlev) {
-        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, OutT, T>;
-        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, OutT, T>;
-        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, OutT, T>;
-        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, OutT, T>;
-        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, OutT, T>;
-        case 6: return (SweepKernel)sweep_conservation_halo3t_kernel<6, OutT, T>;
+        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, OutT, T, A9, AW>;
+        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, OutT, T, A9, AW>;
+        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, OutT, T, A9, AW>;
+        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, OutT, T, A9, AW>;
+        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, OutT, T, A9, AW>;
+        case 6: return (SweepKernel)sweep_conservation_halo3t_kernel<6, OutT, T, A9, AW>;
     }
     return nullptr;
 }
 
-SweepKernel kernel_for9(int nlev) {  // (256 .. 511 genomes)
-    switch (nlev) {
-        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, uint16_t, 256, true>;
-        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, uint16_t, 256, true>;
-        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, uint16_t, 256, true>;
-        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, uint16_t, 256, true>;
-        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, uint16_t, 256, true>;
-        case 6: return (SweepKernel)sweep_conservation_halo3t_kernel<6, uint16_t, 256, true>;
-    }
-    return nullptr;
+template <bool AW>
+SweepKernel kernel_of(int nlev, int elem_bytes, bool annot9) {  // (256 .. 511 genomes: nine-bit orders, uint16 results)
+    return annot9 ? kernel_for<uint16_t, 256, true, AW>(nlev)
+                  : (elem_bytes == 1 ? kernel_for<uint8_t, 256, false, AW>(nlev) : kernel_for<uint16_t, 256, false, AW>(nlev));
 }
 
 }  // namespace
@@ -262,7 +257,7 @@ static int tile_table(memo_index *ix, const void *rows_of, const int64_t *boff, 
 
 // Launch the table-driven dense-row sweep if this query fits it (else return 1: the caller takes
 // sweep_conservation_halo3_kernel).  A: filled for the unclipped sweep (hl, w, ls, nlev, ncols); tw = tile width.
-int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStream_t st, bool annot9) {
+int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStream_t st, bool annot9, bool all_write) {
     if (annot9 && elem_bytes != 2) return 1;
     if (!A.p3 || A.ls > kLS || A.nlev < 1 || A.nlev > 6 || A.km1 > 63 || A.qs < 0) return 1;
     const int64_t q = A.qs / tw, tile0 = q * tw;
@@ -287,7 +282,7 @@ int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStrea
     // what a wave does around its rows outweighs the rows: 7-9 % SLOWER on the k-class views of config 3 (0.217 against
     // 0.203 ms at k = 31, 0.168 against 0.154 at k = 17) and 1-4 % slower on all the rows; profiles/r03_views.txt.  Sixteen
     // waves per CU hide the scatter's LDS latency worse than thirty-two, whatever they save in instructions.)
-    SweepKernel kern = annot9 ? kernel_for9(A.nlev) : (elem_bytes == 1 ? kernel_for<uint8_t, 256>(A.nlev) : kernel_for<uint16_t, 256>(A.nlev));
+    SweepKernel kern = all_write ? kernel_of<true>(A.nlev, elem_bytes, annot9) : kernel_of<false>(A.nlev, elem_bytes, annot9);
     if (!kern) return 1;
     if (g_prepare_only) return MEMO_OK;  // memo_index_prepare: the table is built, nothing is launched
     hipLaunchKernelGGL(kern, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(256), (size_t)A.nlev * 4096, st, A);

@@ -138,11 +138,16 @@ struct RowConst {
 // block might have (none here: an SALU write of EXEC needs no wait states before a VALU that only uses it as its mask).
 // operands: %0-%3 temporaries; %4-%7 the group's dwords; %8 / %9 row 4's field and order word; %10 a10s, %11 km1 (SGPR),
 // %12 ls4 (SGPR), %13 bias4, %14 top_bit; masked form: %15 tmp, %16 span (SGPR)
-#define MEMO_ROW3_AT(B, D)                               \
+// TEST / DONE: "v_cmpx_lt_i32 vcc, 0, %0" + the s_mov that restores EXEC -- or nothing where every row is known to write (AW: a
+// k-class view whose cap is this query's k - 1 holds exactly the rows with overlap < k - 1: one vector and one scalar instruction
+// per row less)
+#define MEMO_ROW3_TEST "v_cmpx_lt_i32 vcc, 0, %0\n\t"
+#define MEMO_ROW3_DONE "s_mov_b64 exec, -1\n\t"
+#define MEMO_ROW3_AT_(B, D, TEST, DONE)                  \
     "v_sub_u16 %3, " B ", %10\n\t"                       \
     "v_and_b32 %0, 63, %3\n\t"                           \
     "v_sub_u32 %0, %11, %0\n\t"                          \
-    "v_cmpx_lt_i32 vcc, 0, %0\n\t"                       \
+    TEST                                                 \
     "v_ffbh_u32 %1, %0\n\t"                              \
     "v_bfe_u32 %3, %3, 6, 10\n\t"                        \
     "v_mad_u32_u24 %2, %1, %12, %13\n\t"                 \
@@ -152,19 +157,22 @@ struct RowConst {
     "v_lshl_add_u32 %2, %1, 2, %2\n\t"                   \
     "ds_min_u32 %3, " D "\n\t"                           \
     "ds_min_u32 %2, " D "\n\t"                           \
-    "s_mov_b64 exec, -1\n\t"
+    DONE
+#define MEMO_ROW3_AT(B, D) MEMO_ROW3_AT_(B, D, MEMO_ROW3_TEST, MEMO_ROW3_DONE)
+#define MEMO_ROW3_AW(B, D) MEMO_ROW3_AT_(B, D, "", "")              /* every row writes, every lane holds a row */
+#define MEMO_ROW3_AWM(B, D) MEMO_ROW3_AT_(B, D, "", MEMO_ROW3_DONE)  /* ... behind a mask by row number */
 #define MEMO_ROW3_MASK(I) "v_add_u32 %0, %15, " #I "\n\tv_cmpx_gt_u32 vcc, %16, %0\n\t"
 
 // Indexes of 256 .. 511 genomes (A9): the ninth bit of row i's annot sits at bit 16 + i of the group's last dword
 // (pack3_rows_kernel), and a level cell holds the order in its top NINE bits: the data of a row's two ds_min is
 // (ninth bit : dword) >> 1 -- two more vector instructions per row.  operands as above, shifted by one: %4 the data.
-#define MEMO_ROW9_AT(B, D, SH)                           \
+#define MEMO_ROW9_AT_(B, D, SH, TEST, DONE)              \
     "v_lshrrev_b32 %4, " SH ", %8\n\t"                   \
     "v_alignbit_b32 %4, %4, " D ", 1\n\t"                \
     "v_sub_u16 %3, " B ", %11\n\t"                       \
     "v_and_b32 %0, 63, %3\n\t"                           \
     "v_sub_u32 %0, %12, %0\n\t"                          \
-    "v_cmpx_lt_i32 vcc, 0, %0\n\t"                       \
+    TEST                                                 \
     "v_ffbh_u32 %1, %0\n\t"                              \
     "v_bfe_u32 %3, %3, 6, 10\n\t"                        \
     "v_mad_u32_u24 %2, %1, %13, %14\n\t"                 \
@@ -174,73 +182,86 @@ struct RowConst {
     "v_lshl_add_u32 %2, %1, 2, %2\n\t"                   \
     "ds_min_u32 %3, %4\n\t"                              \
     "ds_min_u32 %2, %4\n\t"                              \
-    "s_mov_b64 exec, -1\n\t"
+    DONE
+#define MEMO_ROW9_AT(B, D, SH) MEMO_ROW9_AT_(B, D, SH, MEMO_ROW3_TEST, MEMO_ROW3_DONE)
+#define MEMO_ROW9_AW(B, D, SH) MEMO_ROW9_AT_(B, D, SH, "", "")
+#define MEMO_ROW9_AWM(B, D, SH) MEMO_ROW9_AT_(B, D, SH, "", MEMO_ROW3_DONE)
 #define MEMO_ROW9_MASK(I) "v_add_u32 %0, %16, " #I "\n\tv_cmpx_gt_u32 vcc, %17, %0\n\t"
 
-template <bool MASKED, bool A9 = false>
+#define MEMO_G3_OUT : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+#define MEMO_G3_IN "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w), "v"(b4), "v"(d4), "v"(C.a10s), "s"(C.km1), "s"(C.ls4), "v"(C.bias4), "v"(C.top_bit)
+#define MEMO_G9_OUT : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
+// AW: every row of this source writes at this k (see MEMO_ROW3_TEST)
+template <bool MASKED, bool A9 = false, bool AW = false>
 __device__ __forceinline__ void group_rows(const uint4 &V, const RowConst &C, uint32_t tmp, uint32_t span) {
     const uint32_t b4 = __builtin_amdgcn_perm(V.y, V.x, 0x0c0c0602u), d4 = V.z << 8;
     uint32_t r0, r1, r2, r3;
     MEMO_EXEC_ALL_ONES(C.status);
     if constexpr (A9) {
         uint32_t r4;
-        if constexpr (MASKED) {
+        if constexpr (MASKED && AW) {
+            asm volatile(MEMO_ROW9_MASK(0) MEMO_ROW9_AWM("%5", "%5", "16") MEMO_ROW9_MASK(1) MEMO_ROW9_AWM("%6", "%6", "17")
+                         MEMO_ROW9_MASK(2) MEMO_ROW9_AWM("%7", "%7", "18") MEMO_ROW9_MASK(3) MEMO_ROW9_AWM("%8", "%8", "19")
+                         MEMO_ROW9_MASK(4) MEMO_ROW9_AWM("%9", "%10", "20")
+                         MEMO_G9_OUT : MEMO_G3_IN, "v"(tmp), "s"(span) : "memory", "vcc");
+        } else if constexpr (MASKED) {
             asm volatile(MEMO_ROW9_MASK(0) MEMO_ROW9_AT("%5", "%5", "16") MEMO_ROW9_MASK(1) MEMO_ROW9_AT("%6", "%6", "17")
                          MEMO_ROW9_MASK(2) MEMO_ROW9_AT("%7", "%7", "18") MEMO_ROW9_MASK(3) MEMO_ROW9_AT("%8", "%8", "19")
                          MEMO_ROW9_MASK(4) MEMO_ROW9_AT("%9", "%10", "20")
-                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
-                         : "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w), "v"(b4), "v"(d4), "v"(C.a10s), "s"(C.km1), "s"(C.ls4), "v"(C.bias4),
-                           "v"(C.top_bit), "v"(tmp), "s"(span)
-                         : "memory", "vcc");
+                         MEMO_G9_OUT : MEMO_G3_IN, "v"(tmp), "s"(span) : "memory", "vcc");
+        } else if constexpr (AW) {
+            asm volatile(MEMO_ROW9_AW("%5", "%5", "16") MEMO_ROW9_AW("%6", "%6", "17") MEMO_ROW9_AW("%7", "%7", "18")
+                         MEMO_ROW9_AW("%8", "%8", "19") MEMO_ROW9_AW("%9", "%10", "20")
+                         MEMO_G9_OUT : MEMO_G3_IN : "memory");
         } else {
             asm volatile(MEMO_ROW9_AT("%5", "%5", "16") MEMO_ROW9_AT("%6", "%6", "17") MEMO_ROW9_AT("%7", "%7", "18")
                          MEMO_ROW9_AT("%8", "%8", "19") MEMO_ROW9_AT("%9", "%10", "20")
-                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
-                         : "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w), "v"(b4), "v"(d4), "v"(C.a10s), "s"(C.km1), "s"(C.ls4), "v"(C.bias4),
-                           "v"(C.top_bit)
-                         : "memory", "vcc");
+                         MEMO_G9_OUT : MEMO_G3_IN : "memory", "vcc");
         }
+    } else if constexpr (MASKED && AW) {
+        asm volatile(MEMO_ROW3_MASK(0) MEMO_ROW3_AWM("%4", "%4") MEMO_ROW3_MASK(1) MEMO_ROW3_AWM("%5", "%5")
+                     MEMO_ROW3_MASK(2) MEMO_ROW3_AWM("%6", "%6") MEMO_ROW3_MASK(3) MEMO_ROW3_AWM("%7", "%7")
+                     MEMO_ROW3_MASK(4) MEMO_ROW3_AWM("%8", "%9")
+                     MEMO_G3_OUT : MEMO_G3_IN, "v"(tmp), "s"(span) : "memory", "vcc");
     } else if constexpr (MASKED) {
         asm volatile(MEMO_ROW3_MASK(0) MEMO_ROW3_AT("%4", "%4") MEMO_ROW3_MASK(1) MEMO_ROW3_AT("%5", "%5")
                      MEMO_ROW3_MASK(2) MEMO_ROW3_AT("%6", "%6") MEMO_ROW3_MASK(3) MEMO_ROW3_AT("%7", "%7")
                      MEMO_ROW3_MASK(4) MEMO_ROW3_AT("%8", "%9")
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-                     : "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w), "v"(b4), "v"(d4), "v"(C.a10s), "s"(C.km1), "s"(C.ls4), "v"(C.bias4),
-                       "v"(C.top_bit), "v"(tmp), "s"(span)
-                     : "memory", "vcc");
+                     MEMO_G3_OUT : MEMO_G3_IN, "v"(tmp), "s"(span) : "memory", "vcc");
+    } else if constexpr (AW) {
+        asm volatile(MEMO_ROW3_AW("%4", "%4") MEMO_ROW3_AW("%5", "%5") MEMO_ROW3_AW("%6", "%6") MEMO_ROW3_AW("%7", "%7")
+                     MEMO_ROW3_AW("%8", "%9")
+                     MEMO_G3_OUT : MEMO_G3_IN : "memory");
     } else {
         asm volatile(MEMO_ROW3_AT("%4", "%4") MEMO_ROW3_AT("%5", "%5") MEMO_ROW3_AT("%6", "%6") MEMO_ROW3_AT("%7", "%7")
                      MEMO_ROW3_AT("%8", "%9")
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-                     : "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w), "v"(b4), "v"(d4), "v"(C.a10s), "s"(C.km1), "s"(C.ls4), "v"(C.bias4),
-                       "v"(C.top_bit)
-                     : "memory", "vcc");
+                     MEMO_G3_OUT : MEMO_G3_IN : "memory", "vcc");
     }
 }
 
 // the J-th group of a lane, already in registers (MODE 1 / 2)
-template <int J, int T = 256, bool A9 = false>
+template <int J, int T = 256, bool A9 = false, bool AW = false>
 __device__ __forceinline__ bool reg_piece(const uint4 &V, int tid, int wave, uint32_t gbase, uint32_t gleft, const Geo &g,
                                           const RowConst &C, uint32_t span) {
     const uint32_t pg = (uint32_t)(J * T + wave * 64);
     if (pg >= gleft) return false;
     const uint32_t row0 = 5u * (gbase + pg);
     if (row0 >= g.first && row0 + 320u <= g.end) {
-        group_rows<false, A9>(V, C, 0, 0);
+        group_rows<false, A9, AW>(V, C, 0, 0);
     } else {
         const uint32_t tmp = 5u * (gbase + (uint32_t)(J * T + tid)) - g.first;
-        group_rows<true, A9>(V, C, tmp, span);
+        group_rows<true, A9, AW>(V, C, tmp, span);
     }
     return true;
 }
 
 // the NL groups of a lane, one after the other, until the tile's groups end
-template <int T, int NL, int J = 0, bool A9 = false>
+template <int T, int NL, int J = 0, bool A9 = false, bool AW = false>
 __device__ __forceinline__ void reg_pieces(const uint4 (&V)[NL], int tid, int wave, uint32_t gbase, uint32_t gleft, const Geo &g,
                                            const RowConst &C, uint32_t span) {
     if constexpr (J < NL) {
-        if (reg_piece<J, T, A9>(V[J], tid, wave, gbase, gleft, g, C, span))
-            reg_pieces<T, NL, J + 1, A9>(V, tid, wave, gbase, gleft, g, C, span);
+        if (reg_piece<J, T, A9, AW>(V[J], tid, wave, gbase, gleft, g, C, span))
+            reg_pieces<T, NL, J + 1, A9, AW>(V, tid, wave, gbase, gleft, g, C, span);
     }
 }
 

@@ -96,7 +96,7 @@ while time.time() < t_end:
                 qs &= ~3                                                      # (windows on the 4-position raster: aligned result stores)
             qe = int(rng.integers(qs, length + 200))
             tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096, 1472, 1728])), int(rng.choice([0, 1, 4, 8])),
-                    int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])), int(rng.integers(0, 6)))
+                    int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13])), int(rng.integers(0, 6)))
             if dense_only and tune[3] in (1, 3):
                 tune = tune[:3] + (0,) + tune[4:]                             # (no int64 columns / 4-byte rows to force)
             ix.debug_set_tuning(*tune)
