@@ -44,7 +44,7 @@ int memo_debug_row_order(memo_index_t *ix, int32_t order);
  * bench.py times the same index with and without); 0 = back to the library's choice.  (The product switch is
  * memo_index_set_option(MEMO_OPT_VIEWS), which also drops the views.) */
 int memo_debug_no_views(memo_index_t *ix, int32_t on);
-/* the process's later builds of a dense k-class view: 0 = the rows keep the order the filter leaves them in, 1 (the default) = the
+/* this THREAD's later builds of a dense k-class view: 0 = the rows keep the order the filter leaves them in, 1 (the default) = the
  * place of a row inside its 16-byte group is chosen against LDS bank conflicts (memo_interleave.hip: colour_view_kernel).
  * Results never depend on it. */
 int memo_debug_view_colouring(int32_t on);

@@ -212,7 +212,7 @@ void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables der
 // over the bucket's starts, 2: the same with the rows of a start ordered by overlap mod 32), in place, queued on st
 int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshift, int fmt, int mode, hipStream_t st);
 int colour_view_words(uint32_t *words, const int64_t *boff, uint64_t nb, int km1, int f12, hipStream_t st);  // (memo_interleave.hip)
-extern int g_view_colouring;  // 1: the dense rows' k-class views get their rows' places inside a group chosen against bank conflicts (memo_debug_view_colouring of the AB library turns it off)
+extern thread_local int g_view_colouring;  // 1: the dense rows' k-class views get their rows' places inside a group chosen against bank conflicts (memo_debug_view_colouring of the AB library turns it off)
 constexpr int kRowOrderDefault = 2;  // interleave_words mode the product applies wherever 4-byte rows come into being
 int order_words_now(memo_index *ix, int mode);  // memo_index.hip: waits for the device, orders ix->pk in place, waits again
 inline int row_order_mode(const memo_index *ix) { return ix->tune.row_order ? ix->tune.row_order - 1 : kRowOrderDefault; }
