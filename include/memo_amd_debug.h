@@ -48,6 +48,10 @@ int memo_debug_no_views(memo_index_t *ix, int32_t on);
  * place of a row inside its 16-byte group is chosen against LDS bank conflicts (memo_interleave.hip: colour_view_kernel).
  * Results never depend on it. */
 int memo_debug_view_colouring(int32_t on);
+/* this THREAD's later conservation queries on dense rows (k - 1 <= 31, up to 255 genomes, buckets of 32 positions): 1 = the k-class
+ * view is built as groups of SIX rows that carry their bucket (2.67 B per row; memo_interleave.hip: six_view_kernel) and swept by the
+ * table-driven kernel's form for them (info.last_variant 3); 0 (the default) = five-row groups.  Round 4 experiment. */
+int memo_debug_six_views(int32_t on);
 /* this THREAD's later calls: every device allocation for a view or a tile table fails (the test of the no-memory path) */
 int memo_debug_fail_side_allocations(int32_t on);
 /* this thread's later memo_index_pack_dense / dense builders keep the rows that can never write at k <= 64 in the dense rows */

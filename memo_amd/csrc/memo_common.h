@@ -136,6 +136,7 @@ struct memo_index {
     uint64_t view_clock = 0;
     uint64_t view_builds = 0;     // views built over the index's lifetime (memo_index_info_t.view_builds)
     DenseView views[16];          // classes of two: overlaps below 2, 4, 6 ... 32
+    DenseView views6[16];         // the same classes as groups of SIX rows that carry their bucket (memo_interleave.hip: six_view_kernel; A/B, round 4)
     DenseView pviews[24];         // the same for the 4-byte words (caps 2 .. 32 by 2, .. 64 by 8, .. 128 by 16; `p3` holds words there): packed_rows_for
     uint64_t last_rows_read = 0;  // rows of the row source the last sweep read (info.last_rows_read)
     float last_view_ms = 0.f;     // device time of the view build, when the last sweep's view was built by it (else 0)
@@ -192,7 +193,12 @@ struct memo_index {
 namespace memo {
 void drop_dense(memo_index *ix);       // frees the dense rows, their bucket table and the tile tables
 int dense_compact(memo_index *ix);     // memo_index.hip: leave the rows that can never write out of the dense rows (see boff3)
-int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows, int *view_cap = nullptr);  // ... or a k-class view
+int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows, int *view_cap = nullptr,
+                   bool six = false);  // ... or a k-class view (six: as groups of six rows, or nothing: *view_cap stays 0)
+extern thread_local int g_six_views;  // (AB library, memo_debug_six_views: the table-driven kernel reads six-row views where it can)
+void six_counts(const int64_t *boff, uint64_t nb, uint32_t *count, hipStream_t st);
+void six_view_fill(const uint32_t *words, const int64_t *boff, const uint32_t *glocal, const uint64_t *gblock, uint64_t nb, int64_t bbase,
+                   int km1, int f12, uint32_t *groups, int64_t *boff6, hipStream_t st);
 constexpr int kNoRoom = 1;  // (internal) the device has no memory for a view / tile table: run without it
 constexpr size_t kMaxTileTables = 64;
 void retire(memo_index *ix, void *p, uint64_t bytes);  // memo_index.hip: out of service now, freed once the device has drained

@@ -77,6 +77,11 @@ int memo_debug_view_colouring(int32_t on) {  // (views already built keep the or
     return MEMO_OK;
 }
 
+int memo_debug_six_views(int32_t on) {
+    g_six_views = on ? 1 : 0;
+    return MEMO_OK;
+}
+
 int memo_debug_fail_side_allocations(int32_t on) {
     g_side_alloc_fails = on != 0;
     return MEMO_OK;

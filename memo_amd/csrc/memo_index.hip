@@ -679,7 +679,7 @@ hipError_t side_alloc(void **p, size_t bytes) {
 
 static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_boff, uint64_t rows, uint64_t nb, int cap,
                         int min_tenths, hipStream_t st, uint32_t **out_p3, int64_t **out_boff, uint64_t *out_rows,
-                        uint64_t *out_padded, int len_shift = -1, int colour_km1 = 0, int f12 = 0) {
+                        uint64_t *out_padded, int len_shift = -1, int colour_km1 = 0, int f12 = 0, int64_t six_bbase = -1) {
     *out_p3 = nullptr;
     *out_boff = nullptr;
     if (!rows || rows >= ((uint64_t)1 << 38)) return MEMO_OK;
@@ -711,7 +711,8 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
         if (err == hipSuccess) err = hipStreamSynchronize(st);
         if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
         if (total + rows / 10 * (uint64_t)min_tenths > rows) break;  // too few would go
-        const uint64_t padded3 = ((total + 15) & ~(uint64_t)15) + kPadRows, groups = dense_groups_for(padded3);
+        uint64_t padded3 = ((total + 15) & ~(uint64_t)15) + kPadRows;
+        const uint64_t groups = dense_groups_for(padded3);
         err = side_alloc((void **)&words, padded3 * 4);
         if (err == hipSuccess) err = hipMemsetAsync(words, 0, padded3 * 4, st);
         if (err == hipSuccess && len_shift < 0) err = side_alloc((void **)&p3n, groups * 16);
@@ -726,7 +727,48 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
         }
         hipLaunchKernelGGL(dense_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, src_boff, nb, rows, total, keep, local,
                            blockpre, boff3);
-        if (len_shift < 0) {
+        if (len_shift < 0 && six_bbase >= 0) {
+            // six rows per 16 bytes, groups that end at bucket boundaries and carry their bucket (memo_interleave.hip: six_view_kernel):
+            // groups per bucket -> their prefix sums (the scan above, on nb - 1 counts) -> the groups and their table
+            const uint64_t nbk = nb - 1, nblk6 = (nbk + 1023) >> 10;
+            uint32_t *gcount = nullptr;
+            uint64_t *gblock = nullptr;
+            hipError_t e6 = side_alloc((void **)&gcount, nbk * 4 + 4);
+            if (e6 == hipSuccess) e6 = side_alloc((void **)&gblock, (nblk6 + 1) * 8);
+            uint64_t total6 = 0;
+            if (e6 == hipSuccess) {
+                six_counts(boff3, nb, gcount, st);
+                hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblk6), dim3(256), 0, st, gcount, nbk, gcount, gblock);
+                hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, gblock, nblk6);
+                e6 = hipGetLastError();
+                if (e6 == hipSuccess) e6 = hipMemcpyAsync(&total6, gblock + nblk6, 8, hipMemcpyDeviceToHost, st);
+                if (e6 == hipSuccess) e6 = hipStreamSynchronize(st);
+            }
+            uint4 *g6 = nullptr;
+            int64_t *boff6 = nullptr;
+            if (e6 == hipSuccess) e6 = side_alloc((void **)&g6, (total6 + 64) * 16);
+            if (e6 == hipSuccess) e6 = side_alloc((void **)&boff6, nb * 8);
+            if (e6 == hipSuccess) e6 = hipMemsetAsync(g6, 0, (total6 + 64) * 16, st);
+            if (e6 == hipSuccess) {
+                six_view_fill(words, boff3, gcount, gblock, nb, six_bbase, colour_km1, f12, reinterpret_cast<uint32_t *>(g6), boff6, st);
+                e6 = hipGetLastError();
+                if (e6 == hipSuccess) e6 = hipStreamSynchronize(st);
+            }
+            (void)hipFree(gcount);
+            (void)hipFree(gblock);
+            if (e6 == hipSuccess) {
+                (void)hipFree(p3n);
+                (void)hipFree(boff3);
+                p3n = g6;
+                boff3 = boff6;
+                padded3 = 6 * total6;
+            } else {
+                (void)hipFree(g6);
+                (void)hipFree(boff6);
+            }
+            if (e6 == hipErrorOutOfMemory) { rc = kNoRoom; break; }
+            if (e6 != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter (six): %s", hipGetErrorString(e6)); break; }
+        } else if (len_shift < 0) {
             // (a k-class view: which of its group's five places a row takes is chosen against LDS bank conflicts, memo_interleave.hip)
             if (colour_km1 > 0 && g_view_colouring) (void)colour_view_words(words, boff3, nb, colour_km1, f12, st);
             hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, words, padded3, groups, p3n, f12);
@@ -812,6 +854,11 @@ static void retire_view(memo_index *ix, memo_index::DenseView &v, bool dense) {
 
 void drop_dense_views(memo_index *ix) {
     for (memo_index::DenseView &v : ix->views) {
+        (void)hipFree(v.p3);
+        (void)hipFree(v.boff);
+        v = memo_index::DenseView();
+    }
+    for (memo_index::DenseView &v : ix->views6) {
         (void)hipFree(v.p3);
         (void)hipFree(v.boff);
         v = memo_index::DenseView();
@@ -963,15 +1010,17 @@ int packed_rows_for(memo_index *ix, int km1, bool membership, hipStream_t st, ui
 // memo_query.py:49 drops it per query; here it is dropped once per index and class) when that spares a fifth of the rows or
 // more, else the dense rows themselves.  A view is built by the fifth query of its class (a few ms for 5 * 10^8 rows: one pass
 // over the dense rows, timed in view.build_ms) and kept with the index; MEMO_DENSE_VIEWS=0 turns them off.
-int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows, int *view_cap) {
+int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows, int *view_cap, bool six) {
     if (view_cap) *view_cap = 0;  // (the cap of the view handed out: its rows are exactly those with overlap < cap)
     *p3 = ix->p3;
     *boff = ix->boff3 ? ix->boff3 : ix->boff;
     *rows = ix->boff3 ? ix->rows3 : ix->rows;
     ix->last_view_ms = 0.f;
     if (!ix->views_on || ix->tune.no_views || km1 > 32 || km1 < 1) return MEMO_OK;
+    if (six && (ix->bshift != 5 || ix->max_annot > 255 || km1 > 31)) return MEMO_OK;  // (5-bit starts and overlaps, 8-bit annots)
     const int slot = (km1 + 1) / 2 - 1, cap = 2 * (slot + 1);  // classes of two: k - 1 <= 2, 4, 6 ... 32 (an odd k: exactly its rows)
-    memo_index::DenseView &v = ix->views[slot];
+    if (six && cap > 31 && km1 != 31) return MEMO_OK;
+    memo_index::DenseView &v = six ? ix->views6[slot] : ix->views[slot];
     // a view costs about as much as fifty sweeps of config 3: it is built by the class's FIFTH query, not its first -- an index
     // that answers one query (the one-shot forms, `memo query`) never builds one
     if (v.state == 0 && !g_prepare_only && ++v.queries <= v.build_after) return MEMO_OK;
@@ -985,7 +1034,7 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
         }
         (void)hipEventRecord(e0, st);
         const int rc = dense_filter(ix->device, *p3, *boff, *rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded, -1, cap,
-                                    ix->max_annot > 255 ? 1 : 0);
+                                    ix->max_annot > 255 ? 1 : 0, six ? ix->bbase : -1);
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&v.build_ms, e0, e1);
@@ -1001,7 +1050,7 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
         if (v.state == 1) {
             ++ix->view_builds;
             ix->last_view_ms = v.build_ms;
-            keep_views_in_budget(ix, ix->views, (int)(sizeof(ix->views) / sizeof(ix->views[0])), &v,
+            keep_views_in_budget(ix, six ? ix->views6 : ix->views, (int)(sizeof(ix->views) / sizeof(ix->views[0])), &v,
                                  dense_groups_for(ix->boff3 ? ix->padded3 : ix->padded) * 16, true);
         }
     }
@@ -1221,6 +1270,10 @@ static void fill_info(const memo_index *ix, memo_index_info_t *info) {
         side += v.p3 ? dense_groups_for(v.padded) * 16 + ix->nb * 8 : 0;
         info->views_resident += v.p3 ? 1 : 0;
     }
+    for (const memo_index::DenseView &v : ix->views6) {
+        side += v.p3 ? dense_groups_for(v.padded) * 16 + ix->nb * 8 : 0;
+        info->views_resident += v.p3 ? 1 : 0;
+    }
     for (const memo_index::DenseView &v : ix->pviews) {
         side += v.p3 ? v.padded * 4 + ix->nb * 8 : 0;
         info->views_resident += v.p3 ? 1 : 0;
@@ -1255,7 +1308,8 @@ int memo_index_set_option(memo_index_t *ix, int32_t option, int64_t value) {
         if (!value) {
             DeviceGuard guard(ix->device);
             HIP_TRY(hipDeviceSynchronize());
-            for (memo_index::DenseView &v : ix->views)
+            for (int kind = 0; kind < 2; ++kind)
+            for (memo_index::DenseView &v : (kind ? ix->views6 : ix->views))
                 if (v.p3) {  // (their tile tables go with them)
                     for (size_t i = 0; i < ix->ttabs.size();)
                         if (ix->ttabs[i].rows_of == v.p3) {

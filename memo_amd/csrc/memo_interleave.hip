@@ -424,6 +424,140 @@ __global__ __launch_bounds__(64) void colour_view_kernel(uint32_t *__restrict__ 
     }
 }
 
+
+// ---- six rows per 16 bytes: a k-class view whose groups carry their bucket (round 4, A/B: memo_debug_six_views) ------------------
+// A view row needs 5 + 5 + 8 bits -- start inside its 32-position bucket, overlap (below the cap: <= 31), annot -- once its group
+// says which bucket it is in and groups end at bucket boundaries: 2.67 B per row instead of 3.2.  Layout of a group (dword j = row j's
+// ten bits | 14 bits of rows 4 / 5 and the bucket | row j's annot on top, so that rows 0 .. 3 are their dword as the ds_min operand):
+//   dword 0 = lo_0 | lo_4 << 10 | a_0 << 24      dword 1 = lo_1 | a_4 << 10 | a_1 << 24
+//   dword 2 = lo_2 | a_5 << 10 | bucket mod 32 << 18 | a_2 << 24      dword 3 = lo_3 | lo_5 << 10 | a_3 << 24
+//   lo = start mod 32 | overlap << 5.   Places a bucket leaves empty hold a row of annot 255 (it writes; no result can see it).
+// The places are coloured as in colour_view_kernel, with six colours.  One lane per bucket; buckets of fewer than 6 or more than
+// kSixRows rows keep their order.  Needs buckets of 32 positions and annots of eight bits.
+constexpr int kSixRows = 96;
+
+struct SixRow {
+    uint32_t lo, a;
+};
+__device__ __forceinline__ SixRow six_of(uint32_t w, int f12) {
+    const uint32_t start = (f12 ? w >> 8 : w) & 31u, ov = (f12 ? w : w >> 16) & 63u, annot = f12 ? (w >> 20) & 0xFFu : w >> 24;
+    SixRow r;
+    r.lo = start | ((ov > 31u ? 31u : ov) << 5);
+    r.a = annot;
+    return r;
+}
+__device__ __forceinline__ uint4 six_group(const SixRow (&r)[6], uint32_t bucket5) {
+    return make_uint4(r[0].lo | (r[4].lo << 10) | (r[0].a << 24), r[1].lo | (r[4].a << 10) | (r[1].a << 24),
+                      r[2].lo | (r[5].a << 10) | (bucket5 << 18) | (r[2].a << 24), r[3].lo | (r[5].lo << 10) | (r[3].a << 24));
+}
+
+__global__ __launch_bounds__(64) void six_view_kernel(const uint32_t *__restrict__ words, const int64_t *__restrict__ boff,
+                                                      const uint32_t *__restrict__ glocal, const uint64_t *__restrict__ gblock,
+                                                      int64_t nbuckets, int64_t bbase, int km1, int f12, uint4 *__restrict__ groups,
+                                                      int64_t *__restrict__ boff6) {
+    __shared__ uint32_t stage[kSixRows][64];
+    __shared__ uint32_t placed[kSixRows + 6][64];
+    __shared__ uint8_t order[kSixRows][64];
+    __shared__ uint8_t cnt[32][64];
+    const int lane = threadIdx.x;
+    // a place a bucket leaves empty: a row at the bucket's first position with overlap 0 and annot 255 -- it WRITES (the kernels' AW
+    // form has no test), but nothing a result can see: no genome has order 255 unless num_docs is 255, the sentinel itself
+    const uint32_t pad = f12 ? (255u << 20) : (255u << 24);
+    for (int64_t b0 = 64 * (int64_t)blockIdx.x; b0 < nbuckets; b0 += 64 * (int64_t)gridDim.x) {
+        const int64_t b = b0 + lane;
+        if (b >= nbuckets) continue;  // (no barrier below: every lane works on its own columns)
+        const int64_t r0 = boff[b], n64 = boff[b + 1] - r0;
+        const uint64_t g0 = gblock[b >> 10] + glocal[b];
+        boff6[b] = (int64_t)(6 * g0);
+        if (b == nbuckets - 1) boff6[nbuckets] = (int64_t)(6 * (g0 + (uint64_t)((n64 + 5) / 6)));
+        if (n64 <= 0) continue;
+        const uint32_t bucket5 = (uint32_t)((b + bbase) & 31);
+        const int64_t ng = (n64 + 5) / 6;
+        if (n64 < 6 || n64 > kSixRows) {  // as they come
+            for (int64_t j = 0; j < ng; ++j) {
+                SixRow r[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) r[c] = six_of(6 * j + c < n64 ? words[r0 + 6 * j + c] : pad, f12);
+                groups[g0 + (uint64_t)j] = six_group(r, bucket5);
+            }
+            continue;
+        }
+        const int R = (int)n64, NG = (int)ng;
+        auto start_of = [&](uint32_t w) { return (f12 ? w >> 8 : w) & 1023u; };
+        auto ov_of = [&](uint32_t w) { return (f12 ? w : w >> 16) & 63u; };
+        auto res_a = [&](uint32_t w) { return (start_of(w) + ov_of(w) - (uint32_t)km1) & 31u; };
+        for (int a = 0; a < 32; ++a) cnt[a][lane] = 0;
+        for (int i = 0; i < R; ++i) {
+            const uint32_t w = words[r0 + i];
+            stage[i][lane] = w;
+            ++cnt[res_a(w)][lane];
+        }
+        {
+            int run = 0;
+            for (int a = 0; a < 32; ++a) {
+                const int c = cnt[a][lane];
+                cnt[a][lane] = (uint8_t)run;
+                run += c;
+            }
+        }
+        for (int i = 0; i < R; ++i) {
+            const uint32_t a = res_a(stage[i][lane]);
+            order[cnt[a][lane]++][lane] = (uint8_t)i;
+        }
+        for (int i = 0; i < 6 * NG; ++i) placed[i][lane] = pad;
+        uint32_t usedA[6], usedA2[6], usedB[6], usedB2[6];
+        int load[6], room[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            usedA[c] = usedA2[c] = usedB[c] = usedB2[c] = 0u;
+            load[c] = 0;
+            room[c] = (R - c + 5) / 6;  // places c, c + 6, ... below R
+        }
+        for (int j = 0; j < R; ++j) {
+            const uint32_t w = stage[order[j][lane]][lane];
+            const uint32_t ov = ov_of(w), s = start_of(w);
+            const int n = km1 - (int)ov;
+            const uint32_t A = 1u << ((s + ov - (uint32_t)km1) & 31u);
+            const uint32_t B = 1u << ((s - (1u << (31 - __clz(n > 0 ? n : 1)))) & 31u);
+            int best = 0;
+            uint32_t bestp = 0xFFFFFFFFu;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                uint32_t p = (usedA[c] & A ? 4u : 0u) + (usedA2[c] & A ? 16u : 0u) + (usedB[c] & B ? 5u : 0u) + (usedB2[c] & B ? 16u : 0u);
+                p = (p << 8) + (uint32_t)load[c];
+                if (load[c] >= room[c]) p = 0xFFFFFFFEu;
+                if (p < bestp) {
+                    bestp = p;
+                    best = c;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                if (c == best) {
+                    usedA2[c] |= usedA[c] & A;
+                    usedB2[c] |= usedB[c] & B;
+                    usedA[c] |= A;
+                    usedB[c] |= B;
+                    placed[6 * load[c] + c][lane] = w;
+                    ++load[c];
+                }
+            }
+        }
+        for (int j = 0; j < NG; ++j) {
+            SixRow r[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) r[c] = six_of(placed[6 * j + c][lane], f12);
+            groups[g0 + (uint64_t)j] = six_group(r, bucket5);
+        }
+    }
+}
+
+// groups of six per bucket: count[b] = ceil(rows of bucket b / 6) (what the two-level scan of memo_index.hip takes)
+__global__ void six_counts_kernel(const int64_t *__restrict__ boff, int64_t nbuckets, uint32_t *__restrict__ count) {
+    const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (b < nbuckets) count[b] = (uint32_t)((boff[b + 1] - boff[b] + 5) / 6);
+}
+
 }  // namespace
 
 // words: rows of formats 4 / 12, boff: their bucket table (nb entries, the last pinned to the row count).  Queued on st.
@@ -449,6 +583,20 @@ int colour_view_words(uint32_t *words, const int64_t *boff, uint64_t nb, int km1
     hipLaunchKernelGGL(colour_view_kernel, dim3(grid), dim3(64), 0, st, words, boff, nbuckets, km1, f12);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
+}
+
+// the two halves of a six-row view's build around memo_index.hip's scan: the groups every bucket needs, then the groups themselves
+void six_counts(const int64_t *boff, uint64_t nb, uint32_t *count, hipStream_t st) {
+    const int64_t nbuckets = (int64_t)nb - 1;
+    hipLaunchKernelGGL(six_counts_kernel, dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st, boff, nbuckets, count);
+}
+void six_view_fill(const uint32_t *words, const int64_t *boff, const uint32_t *glocal, const uint64_t *gblock, uint64_t nb, int64_t bbase,
+                   int km1, int f12, uint32_t *groups, int64_t *boff6, hipStream_t st) {
+    const int64_t nbuckets = (int64_t)nb - 1;
+    const int64_t turns = (nbuckets + 63) / 64;
+    const unsigned grid = (unsigned)(turns < 256 * 64 ? turns : 256 * 64);
+    hipLaunchKernelGGL(six_view_kernel, dim3(grid), dim3(64), 0, st, words, boff, glocal, gblock, nbuckets, bbase, km1, f12,
+                       reinterpret_cast<uint4 *>(groups), boff6);
 }
 
 }  // namespace memo

@@ -574,7 +574,8 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
 // memo_sweep_cons3p.hip (linked into libmemo_amd_ab.so only: an experiment that lost, kept for A/B): the persistent
 // dense-row sweep registers itself here; 1 = this query does not fit it (take the tile-per-workgroup kernel)
 // memo_sweep_cons3t.hip: the table-driven dense-row sweep; 1 = this query does not fit it
-int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStream_t st, bool annot9 = false, bool all_write = false);
+int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStream_t st, bool annot9 = false, bool all_write = false,
+                  bool six = false);
 using PersistentLaunch = int (*)(SweepArgs &A, int tw, int elem_bytes, int device, int mode, hipStream_t st);
 extern PersistentLaunch g_persistent_launch;
 int pick_rows(const memo_index *ix, int32_t k, int &fmt);

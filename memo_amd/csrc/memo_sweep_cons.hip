@@ -1405,6 +1405,28 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             const bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && (top8 || top9) &&
                          ((double)drows >= span || !ix->pk);
             int view_cap = 0;  // (a view whose cap is k - 1 holds exactly the rows that write at this k: the table-driven kernel's row blocks drop their test)
+            if (three && top8 && g_six_views && (tune.persistent == 0 || tune.persistent == 5) && !tune.no_views) {
+                // A/B (memo_debug_six_views): the class's view as groups of SIX rows that carry their bucket (memo_interleave.hip:
+                // six_view_kernel), 2.67 B per row, on the table-driven kernel; anything it cannot take goes the regular way below
+                uint32_t *p6 = nullptr;
+                int64_t *b6 = nullptr;
+                uint64_t r6 = 0;
+                int cap6 = 0;
+                if ((rc = dense_rows_for(ix, k - 1, st, &p6, &b6, &r6, &cap6, true))) return rc;
+                if (cap6) {
+                    SweepArgs A6 = A;
+                    A6.p3 = p6;
+                    A6.boff = b6;
+                    const int trc = launch_halo3t(ix, A6, tw, (int)sizeof(OutT), st, false, cap6 == k - 1 && !tune.no_all_write, true);
+                    if (trc < 0) return trc;
+                    if (trc == MEMO_OK) {
+                        ix->last_rows_read = r6;
+                        ix->last_sweep = 5;
+                        ix->last_variant = 3;
+                        return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
+                    }
+                }
+            }
             if (three) {  // the dense rows of this k's class (a view that leaves out the rows that cannot write at this k), or all
                 uint32_t *vp3 = nullptr;
                 int64_t *vboff = nullptr;

@@ -26,8 +26,10 @@ struct TileDesc {  // 32 bytes
 };
 
 // tile T covers pivot positions [T * w, (T + 1) * w); its rows: T * w <= start < roundup((T + 1) * w + k - 1, bucket)
+// rpg: rows per group -- 5 (g0 a multiple of 8 groups: 128-byte loads), or 6: groups that end at bucket boundaries (six_view_kernel),
+// the slice is whole groups from its first one
 __global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase, int bshift, int w, int km1, int64_t ntab,
-                                  TileDesc *out) {
+                                  TileDesc *out, int rpg) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= ntab) return;
     const int64_t a = t * w, last = nb - 1, lim = a + w + km1;
@@ -35,13 +37,13 @@ __global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase
     b0 = b0 < 0 ? 0 : (b0 > last ? last : b0);
     b1 = b1 < 0 ? 0 : (b1 > last ? last : b1);
     const uint64_t r0 = a <= 0 ? 0 : (uint64_t)boff[b0], r1 = (uint64_t)boff[b1];
-    const uint64_t g0 = (r0 / 5) & ~(uint64_t)7, g1 = (r1 + 4) / 5;
+    const uint64_t g0 = rpg == 6 ? r0 / 6 : (r0 / 5) & ~(uint64_t)7, g1 = (r1 + (uint64_t)rpg - 1) / (uint64_t)rpg;
     TileDesc d;
     d.g0_lo = (uint32_t)g0;
     d.g0_hi = (uint32_t)(g0 >> 32);
-    d.ng = r1 - 5 * g0 >= 0xFFFF0000ull ? 0xFFFFFFFFu : (uint32_t)(g1 - g0);
-    d.first = (uint32_t)(r0 - 5 * g0);
-    d.end = (uint32_t)(r1 - 5 * g0);
+    d.ng = r1 - (uint64_t)rpg * g0 >= 0xFFFF0000ull ? 0xFFFFFFFFu : (uint32_t)(g1 - g0);
+    d.first = (uint32_t)(r0 - (uint64_t)rpg * g0);
+    d.end = (uint32_t)(r1 - (uint64_t)rpg * g0);
     d.pad[0] = d.pad[1] = d.pad[2] = 0;
     out[t] = d;
 }
@@ -56,10 +58,12 @@ __global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase
 // T = 256: four waves per tile (eight tiles = 32 waves per CU), the only form instantiated (T = 128 lost: see the launcher)
 // A9: an index of 256 .. 511 genomes -- the order in the top NINE bits of a level cell (memo_sweep_dense.h: MEMO_ROW9_AT), uint16 results
 // AW: the row source is a k-class view whose cap is this k - 1 -- every row of it writes, the row blocks carry no test (memo_sweep_dense.h)
-template <int NLEV, typename OutT, int T, bool A9 = false, bool AW = false>
+// SIX: the row source is a view in groups of six rows that carry their bucket (memo_interleave.hip: six_view_kernel; A/B)
+template <int NLEV, typename OutT, int T, bool A9 = false, bool AW = false, bool SIX = false>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 : 4, 8)))
 void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     static_assert(!A9 || sizeof(OutT) == 2, "more than 255 genomes: uint16 results");
+    static_assert(!(A9 && SIX), "six-row groups hold eight-bit annots");
     constexpr int SH = A9 ? 23 : 24;  // a cell = order << SH | tie-breaking bits
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int NW = T / 64, NL = kStageGroups / T;  // waves; 16-byte groups per lane and batch
@@ -106,6 +110,13 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     C.bias4 = (uint32_t)pin_vgpr((int)(lds_base + 4u * (uint32_t)HL - (uint32_t)(32 - NLEV) * C.ls4));
     C.top_bit = (uint32_t)pin_vgpr((int)0x80000000u);
     C.a10s = (uint32_t)pin_vgpr((int)(((tabs * (uint32_t)W) & 1023u) << 6));
+    SixConst C6;
+    C6.km1 = A.km1;
+    C6.status = A.status;
+    C6.ls4 = C.ls4;
+    C6.bias4 = C.bias4;
+    C6.top_bit = C.top_bit;
+    C6.nega = (uint32_t)pin_vgpr((int)((0u - tabs * (uint32_t)W) & 1023u));
     const uint32_t span = g.end - g.first;
     barrier_lds();  // the level arrays are clear
 
@@ -119,6 +130,10 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
         }
         const uint32_t gbase = batch * kStageGroups;
         const uint32_t gleft = g.ng > gbase ? g.ng - gbase : 0;
+        if constexpr (SIX) {
+            six_pieces<T, NL, AW>(V, lane, wave, gleft, C6);
+            continue;
+        }
         // a wave whose four pieces (64 groups each, 256 apart) all lie inside the slice: twenty rows, not one test
         const uint32_t w_row0 = 5u * (gbase + (uint32_t)wave * 64u);
         if (w_row0 >= g.first && w_row0 + 5u * ((uint32_t)(NL - 1) * T + 64u) <= g.end) {
@@ -196,6 +211,18 @@ SweepKernel kernel_of(int nlev, int elem_bytes, bool annot9) {  // (256 .. 511 g
                   : (elem_bytes == 1 ? kernel_for<uint8_t, 256, false, AW>(nlev) : kernel_for<uint16_t, 256, false, AW>(nlev));
 }
 
+template <typename OutT, bool AW>
+SweepKernel kernel_six(int nlev) {
+    switch (nlev) {
+        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, OutT, 256, false, AW, true>;
+        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, OutT, 256, false, AW, true>;
+        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, OutT, 256, false, AW, true>;
+        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, OutT, 256, false, AW, true>;
+        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, OutT, 256, false, AW, true>;
+    }
+    return nullptr;
+}
+
 }  // namespace
 
 namespace memo {
@@ -211,7 +238,7 @@ void drop_tile_tables(memo_index *ix) {  // (callers have the device drained: pa
 // (round 3 kept four and rebuilt, behind a hipDeviceSynchronize, on the fifth: ADVICE r03); past kMaxTileTables the least
 // recently used one is retired (memo_common.h: no wait on the query path)
 static int tile_table(memo_index *ix, const void *rows_of, const int64_t *boff, int w, int km1, hipStream_t st, const void **tab,
-                      int64_t *ntab) {
+                      int64_t *ntab, int rpg) {
     memo_index::TileTable *slot = nullptr;
     for (memo_index::TileTable &t : ix->ttabs)
         if (t.d && t.w == w && t.km1 == km1 && t.rows_of == rows_of) slot = &t;
@@ -231,7 +258,7 @@ static int tile_table(memo_index *ix, const void *rows_of, const int64_t *boff, 
         if (aerr == hipErrorOutOfMemory) return kNoRoom;  // (the caller takes the kernel that needs no table)
         HIP_TRY(aerr);
         hipLaunchKernelGGL(tile_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, boff, (int64_t)ix->nb, ix->bbase,
-                           ix->bshift, w, km1, n, static_cast<TileDesc *>(d));
+                           ix->bshift, w, km1, n, static_cast<TileDesc *>(d), rpg);
         hipError_t err = hipGetLastError();
         // complete before this call returns: the next query may come on another stream, and nothing would order its sweep
         // behind this kernel (once per index, tile width and k: some tens of microseconds)
@@ -257,8 +284,9 @@ static int tile_table(memo_index *ix, const void *rows_of, const int64_t *boff, 
 
 // Launch the table-driven dense-row sweep if this query fits it (else return 1: the caller takes
 // sweep_conservation_halo3_kernel).  A: filled for the unclipped sweep (hl, w, ls, nlev, ncols); tw = tile width.
-int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStream_t st, bool annot9, bool all_write) {
+int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStream_t st, bool annot9, bool all_write, bool six) {
     if (annot9 && elem_bytes != 2) return 1;
+    if (six && (annot9 || A.nlev > 5 || ix->bshift != 5)) return 1;
     if (!A.p3 || A.ls > kLS || A.nlev < 1 || A.nlev > 6 || A.km1 > 63 || A.qs < 0) return 1;
     const int64_t q = A.qs / tw, tile0 = q * tw;
 #ifdef MEMO_TABLE_RASTER_ONLY  // (A/B builds: rounds 3-4 took only windows whose start is a multiple of four -- aligned result stores)
@@ -268,7 +296,7 @@ int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStrea
     if (ntiles + 8 >= ((int64_t)1 << 31) || q + ntiles >= ((int64_t)1 << 31)) return 1;
     const void *tab = nullptr;
     int64_t ntab = 0;
-    const int rc = tile_table(ix, A.p3, A.boff, tw, A.km1, st, &tab, &ntab);
+    const int rc = tile_table(ix, A.p3, A.boff, tw, A.km1, st, &tab, &ntab, six ? 6 : 5);
     if (rc) return rc;
     A.tile0 = tile0;
     A.ntiles = ntiles;
@@ -283,6 +311,9 @@ int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStrea
     // 0.203 ms at k = 31, 0.168 against 0.154 at k = 17) and 1-4 % slower on all the rows; profiles/r03_views.txt.  Sixteen
     // waves per CU hide the scatter's LDS latency worse than thirty-two, whatever they save in instructions.)
     SweepKernel kern = all_write ? kernel_of<true>(A.nlev, elem_bytes, annot9) : kernel_of<false>(A.nlev, elem_bytes, annot9);
+    if (six)
+        kern = elem_bytes == 1 ? (all_write ? kernel_six<uint8_t, true>(A.nlev) : kernel_six<uint8_t, false>(A.nlev))
+                               : (all_write ? kernel_six<uint16_t, true>(A.nlev) : kernel_six<uint16_t, false>(A.nlev));
     if (!kern) return 1;
     if (g_prepare_only) return MEMO_OK;  // memo_index_prepare: the table is built, nothing is launched
     hipLaunchKernelGGL(kern, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(256), (size_t)A.nlev * 4096, st, A);

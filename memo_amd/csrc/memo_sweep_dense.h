@@ -239,6 +239,71 @@ __device__ __forceinline__ void group_rows(const uint4 &V, const RowConst &C, ui
     }
 }
 
+// ---- groups of SIX rows that carry their bucket (memo_interleave.hip: six_view_kernel; A/B, round 4) -----------------------------
+// A row's ten bits (start mod 32 | overlap << 5) are the low bits of LO, its ds_min operand D has its annot on top; BIAS = the level
+// arrays' bias + 4 * the cell of the group's bucket.  operands: %0-%3 temporaries; %4-%9 LO of rows 0 .. 5; %10-%15 their D;
+// %16 BIAS; %17 km1 (SGPR), %18 ls4 (SGPR), %19 top_bit; masked form: %20 the lane's group number, %21 groups left (SGPR)
+#define MEMO_ROW6_AT_(LO, D, TEST, DONE)                 \
+    "v_bfe_u32 %0, " LO ", 5, 5\n\t"                     \
+    "v_sub_u32 %0, %17, %0\n\t"                          \
+    TEST                                                 \
+    "v_ffbh_u32 %1, %0\n\t"                              \
+    "v_and_b32 %3, 31, " LO "\n\t"                       \
+    "v_mad_u32_u24 %2, %1, %18, %16\n\t"                 \
+    "v_lshl_add_u32 %2, %3, 2, %2\n\t"                   \
+    "v_mad_i32_i24 %3, %0, -4, %2\n\t"                   \
+    "v_ashrrev_i32 %1, %1, %19\n\t"                      \
+    "v_lshl_add_u32 %2, %1, 2, %2\n\t"                   \
+    "ds_min_u32 %3, " D "\n\t"                           \
+    "ds_min_u32 %2, " D "\n\t"                           \
+    DONE
+#define MEMO_ROW6_MASK "v_cmpx_gt_u32 vcc, %21, %20\n\t"
+#define MEMO_SIX_ROWS(PRE, TEST, DONE)                                                                                          \
+    PRE MEMO_ROW6_AT_("%4", "%10", TEST, DONE) PRE MEMO_ROW6_AT_("%5", "%11", TEST, DONE) PRE MEMO_ROW6_AT_("%6", "%12", TEST, DONE) \
+    PRE MEMO_ROW6_AT_("%7", "%13", TEST, DONE) PRE MEMO_ROW6_AT_("%8", "%14", TEST, DONE) PRE MEMO_ROW6_AT_("%9", "%15", TEST, DONE)
+
+struct SixConst {
+    uint32_t nega, bias4, top_bit;  // VGPRs: -(tile start mod 1024), the level arrays' bias, 0x80000000
+    int km1;                        // SGPRs
+    uint32_t ls4;
+    int *status;
+};
+
+// lg: the lane's group number inside the piece's count, left: groups of the slice left at this piece (MASKED: lanes past it do nothing)
+template <bool MASKED, bool AW>
+__device__ __forceinline__ void group_rows6(const uint4 &V, const SixConst &C, uint32_t lg, uint32_t left) {
+    const uint32_t lo4 = V.x >> 10, d4 = V.y << 14, lo5 = V.w >> 10, d5 = V.z << 14;
+    // the cell of the bucket's first position in the tile's arrays: (bucket mod 32) * 32 - tile start, mod 1024
+    const uint32_t cell = (__builtin_amdgcn_ubfe(V.z, 18, 5) * 32u + C.nega) & 1023u;
+    const uint32_t bias = C.bias4 + 4u * cell;
+    uint32_t r0, r1, r2, r3;
+    MEMO_EXEC_ALL_ONES(C.status);
+#define MEMO_SIX_IN "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w), "v"(lo4), "v"(lo5), "v"(V.x), "v"(V.y), "v"(V.z), "v"(V.w), "v"(d4), "v"(d5), \
+                    "v"(bias), "s"(C.km1), "s"(C.ls4), "v"(C.top_bit)
+    if constexpr (MASKED && AW) {
+        asm volatile(MEMO_SIX_ROWS(MEMO_ROW6_MASK, "", MEMO_ROW3_DONE) MEMO_G3_OUT : MEMO_SIX_IN, "v"(lg), "s"(left) : "memory", "vcc");
+    } else if constexpr (MASKED) {
+        asm volatile(MEMO_SIX_ROWS(MEMO_ROW6_MASK, MEMO_ROW3_TEST, MEMO_ROW3_DONE) MEMO_G3_OUT : MEMO_SIX_IN, "v"(lg), "s"(left) : "memory", "vcc");
+    } else if constexpr (AW) {
+        asm volatile(MEMO_SIX_ROWS("", "", "") MEMO_G3_OUT : MEMO_SIX_IN : "memory");
+    } else {
+        asm volatile(MEMO_SIX_ROWS("", MEMO_ROW3_TEST, MEMO_ROW3_DONE) MEMO_G3_OUT : MEMO_SIX_IN : "memory", "vcc");
+    }
+#undef MEMO_SIX_IN
+}
+
+// the NL groups of a lane (group J * T + tid of the batch), until the slice's groups end: a piece wholly inside runs unmasked
+template <int T, int NL, bool AW, int J = 0>
+__device__ __forceinline__ void six_pieces(const uint4 (&V)[NL], int lane, int wave, uint32_t gleft, const SixConst &C) {
+    if constexpr (J < NL) {
+        const uint32_t pg = (uint32_t)(J * T + wave * 64);
+        if (pg >= gleft) return;
+        if (pg + 64u <= gleft) group_rows6<false, AW>(V[J], C, 0, 0);
+        else group_rows6<true, AW>(V[J], C, pg + (uint32_t)lane, gleft);
+        six_pieces<T, NL, AW, J + 1>(V, lane, wave, gleft, C);
+    }
+}
+
 // the J-th group of a lane, already in registers (MODE 1 / 2)
 template <int J, int T = 256, bool A9 = false, bool AW = false>
 __device__ __forceinline__ bool reg_piece(const uint4 &V, int tid, int wave, uint32_t gbase, uint32_t gleft, const Geo &g,

@@ -2023,6 +2023,42 @@ def test_dense_rows_of_256_to_511_genomes(memo, oracle, ab):
             ix.pack_dense()
 
 
+def test_six_row_views_experiment(memo, oracle, ab):
+    """memo_debug_six_views (A/B library only; round-4 experiment, off in the product): the dense k-class views as groups of SIX rows that
+    carry their bucket (memo_interleave.hip: six_view_kernel; 2.67 B per row) on the table-driven kernel's form for them
+    (info.last_variant 3).  Ragged index with an empty stretch and a bucket above the builder's 96-row limit, every k class it takes
+    (k - 1 <= 31), windows that begin inside a bucket, both result types: equal to the oracle and to the five-row views."""
+    rng = np.random.default_rng(61)
+    n_docs, length, m = 120, 90_000, 260_000
+    s = rng.integers(1, length, m)
+    s[:500] = rng.integers(30_016, 30_048, 500)
+    s[(s > 70_000) & (s < 72_000)] = 69_999
+    s = np.sort(s).astype(np.int64)
+    e = s + rng.integers(0, 64, m)
+    o = rng.integers(1, n_docs, m).astype(np.int64)
+    want = {}
+    try:
+        for six in (1, 0):
+            ab.check(ab.lib().memo_debug_six_views(six))
+            with memo.DeviceIndex.from_host(s, e, o) as ix:
+                ix.pack(keep_wide=False)
+                ix.pack_dense(keep_packed=False)
+                for k in (2, 3, 9, 17, 21, 30, 31, 32, 33):
+                    ix.prepare(k, n_docs)
+                    for qs, qe in ((0, length + 50), (30_001, 50_017), (69_990, 72_100), (5, 7)):
+                        for dt in (np.uint8, np.uint16):
+                            got = ix.conservation(qs, qe, k, n_docs, dtype=dt)
+                            inf = ix.info()
+                            assert inf["last_sweep"] == 5 and inf["last_variant"] == (3 if six and k <= 32 else 2), (six, k, inf["last_variant"])
+                            key = (k, qs, qe)
+                            if key not in want:
+                                want[key] = oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs, literal=False)
+                            assert np.array_equal(got, want[key].astype(dt)), (six, key, dt)
+                ix.check()
+    finally:
+        ab.check(ab.lib().memo_debug_six_views(0))
+
+
 def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):
     """k >= 65, unclipped conservation sweep: the library picks doubling / radix-4 / mixed level arrays from k and the
     overlap lengths it sampled when the packed rows were made (info.last_sweep says which ran); every choice is
