@@ -45,8 +45,9 @@ int memo_debug_row_order(memo_index_t *ix, int32_t order);
  * memo_index_set_option(MEMO_OPT_VIEWS), which also drops the views.) */
 int memo_debug_no_views(memo_index_t *ix, int32_t on);
 /* this THREAD's later builds of a dense k-class view: 0 = the rows keep the order the filter leaves them in, 1 (the default) = the
- * place of a row inside its 16-byte group is chosen against LDS bank conflicts (memo_interleave.hip: colour_view_kernel).
- * Results never depend on it. */
+ * place of a row inside its 16-byte group is chosen against LDS bank conflicts (memo_interleave.hip: colour_view_kernel), 2 = the
+ * same with the groups ended at bucket boundaries (aligned_view_kernel<5>: places a bucket leaves empty hold a copy of one of its rows;
+ * measured level with 1, kept for A/B).  Results never depend on it. */
 int memo_debug_view_colouring(int32_t on);
 /* this THREAD's later conservation queries on dense rows (k - 1 <= 31, up to 255 genomes, buckets of 32 positions): 1 = the k-class
  * view is built as groups of SIX rows that carry their bucket (2.67 B per row; memo_interleave.hip: six_view_kernel) and swept by the

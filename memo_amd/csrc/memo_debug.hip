@@ -73,7 +73,7 @@ int memo_debug_no_views(memo_index_t *ix, int32_t on) {
 }
 
 int memo_debug_view_colouring(int32_t on) {  // (views already built keep the order they have)
-    g_view_colouring = on ? 1 : 0;
+    g_view_colouring = on == 2 ? 2 : (on ? 1 : 0);  // (2: rows placed AND groups ended at bucket boundaries: an experiment that bought nothing)
     return MEMO_OK;
 }
 

@@ -679,7 +679,7 @@ hipError_t side_alloc(void **p, size_t bytes) {
 
 static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_boff, uint64_t rows, uint64_t nb, int cap,
                         int min_tenths, hipStream_t st, uint32_t **out_p3, int64_t **out_boff, uint64_t *out_rows,
-                        uint64_t *out_padded, int len_shift = -1, int colour_km1 = 0, int f12 = 0, int64_t six_bbase = -1) {
+                        uint64_t *out_padded, int len_shift = -1, int colour_km1 = 0, int f12 = 0, int aligned_rpg = 0, int64_t bbase = 0) {
     *out_p3 = nullptr;
     *out_boff = nullptr;
     if (!rows || rows >= ((uint64_t)1 << 38)) return MEMO_OK;
@@ -727,9 +727,10 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
         }
         hipLaunchKernelGGL(dense_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, src_boff, nb, rows, total, keep, local,
                            blockpre, boff3);
-        if (len_shift < 0 && six_bbase >= 0) {
-            // six rows per 16 bytes, groups that end at bucket boundaries and carry their bucket (memo_interleave.hip: six_view_kernel):
-            // groups per bucket -> their prefix sums (the scan above, on nb - 1 counts) -> the groups and their table
+        if (len_shift < 0 && aligned_rpg) {
+            // a k-class view whose groups (five rows, or -- A/B -- six that carry their bucket) end at bucket boundaries, the place of a
+            // row inside its group chosen against LDS bank conflicts (memo_interleave.hip: aligned_view_kernel): groups per bucket ->
+            // their prefix sums (the scan above, on nb - 1 counts) -> the groups and their table
             const uint64_t nbk = nb - 1, nblk6 = (nbk + 1023) >> 10;
             uint32_t *gcount = nullptr;
             uint64_t *gblock = nullptr;
@@ -737,7 +738,7 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
             if (e6 == hipSuccess) e6 = side_alloc((void **)&gblock, (nblk6 + 1) * 8);
             uint64_t total6 = 0;
             if (e6 == hipSuccess) {
-                six_counts(boff3, nb, gcount, st);
+                six_counts(boff3, nb, gcount, aligned_rpg, st);
                 hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblk6), dim3(256), 0, st, gcount, nbk, gcount, gblock);
                 hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, gblock, nblk6);
                 e6 = hipGetLastError();
@@ -750,7 +751,8 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
             if (e6 == hipSuccess) e6 = side_alloc((void **)&boff6, nb * 8);
             if (e6 == hipSuccess) e6 = hipMemsetAsync(g6, 0, (total6 + 64) * 16, st);
             if (e6 == hipSuccess) {
-                six_view_fill(words, boff3, gcount, gblock, nb, six_bbase, colour_km1, f12, reinterpret_cast<uint32_t *>(g6), boff6, st);
+                six_view_fill(words, boff3, gcount, gblock, nb, bbase, colour_km1, f12, reinterpret_cast<uint32_t *>(g6), boff6, aligned_rpg,
+                              g_view_colouring, st);
                 e6 = hipGetLastError();
                 if (e6 == hipSuccess) e6 = hipStreamSynchronize(st);
             }
@@ -761,7 +763,7 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
                 (void)hipFree(boff3);
                 p3n = g6;
                 boff3 = boff6;
-                padded3 = 6 * total6;
+                padded3 = (uint64_t)aligned_rpg * total6;
             } else {
                 (void)hipFree(g6);
                 (void)hipFree(boff6);
@@ -1033,8 +1035,10 @@ int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64
             return fail(MEMO_EHIP, "hipEventCreate failed");
         }
         (void)hipEventRecord(e0, st);
+        // (five-row groups that end at bucket boundaries -- aligned_view_kernel<5>, memo_debug_view_colouring 2 -- were measured and
+        // bought nothing: profiles/r04_view_levels.txt; the product's views keep their rows back to back)
         const int rc = dense_filter(ix->device, *p3, *boff, *rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded, -1, cap,
-                                    ix->max_annot > 255 ? 1 : 0, six ? ix->bbase : -1);
+                                    ix->max_annot > 255 ? 1 : 0, six ? 6 : (ix->bshift == 5 && g_view_colouring == 2 ? 5 : 0), ix->bbase);
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&v.build_ms, e0, e1);

@@ -451,34 +451,61 @@ __device__ __forceinline__ uint4 six_group(const SixRow (&r)[6], uint32_t bucket
                       r[2].lo | (r[5].a << 10) | (bucket5 << 18) | (r[2].a << 24), r[3].lo | (r[5].lo << 10) | (r[3].a << 24));
 }
 
-__global__ __launch_bounds__(64) void six_view_kernel(const uint32_t *__restrict__ words, const int64_t *__restrict__ boff,
+// the same six words as a group of FIVE rows (PackedRows3: memo_index.hip, pack3_rows_kernel) -- r[5] unused
+__device__ __forceinline__ uint4 five_group(const uint32_t (&w)[6], int f12) {
+    uint32_t B[5], A[5], hi = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const uint32_t x = w[i];
+        const uint32_t len = f12 ? x & 0xFFu : (x >> 16) & 0xFFu, start = f12 ? x >> 8 : x, annot = f12 ? (x >> 20) & 0x1FFu : x >> 24;
+        B[i] = ((start & 1023u) << 6) | (len > 63u ? 63u : len);
+        A[i] = annot & 0xFFu;
+        hi |= (annot >> 8) << i;
+    }
+    return make_uint4(B[0] | ((B[4] & 0xFFu) << 16) | (A[0] << 24), B[1] | ((B[4] >> 8) << 16) | (A[1] << 24),
+                      B[2] | (A[4] << 16) | (A[2] << 24), B[3] | (hi << 16) | (A[3] << 24));
+}
+
+// P = 6: the six-row groups above.  P = 5 (A/B, memo_debug_view_colouring 2; measured level with the product's back-to-back views): the
+// five-row groups of PackedRows3, ending at bucket boundaries like the six-row ones.  A place a bucket leaves empty holds a COPY of one of the bucket's rows: min and
+// and are idempotent, every kernel that reads the view may sweep it.
+template <int P>
+__global__ __launch_bounds__(64) void aligned_view_kernel(const uint32_t *__restrict__ words, const int64_t *__restrict__ boff,
                                                       const uint32_t *__restrict__ glocal, const uint64_t *__restrict__ gblock,
                                                       int64_t nbuckets, int64_t bbase, int km1, int f12, uint4 *__restrict__ groups,
-                                                      int64_t *__restrict__ boff6) {
+                                                      int64_t *__restrict__ boff6, int colour) {
     __shared__ uint32_t stage[kSixRows][64];
     __shared__ uint32_t placed[kSixRows + 6][64];
     __shared__ uint8_t order[kSixRows][64];
     __shared__ uint8_t cnt[32][64];
     const int lane = threadIdx.x;
-    // a place a bucket leaves empty: a row at the bucket's first position with overlap 0 and annot 255 -- it WRITES (the kernels' AW
-    // form has no test), but nothing a result can see: no genome has order 255 unless num_docs is 255, the sentinel itself
-    const uint32_t pad = f12 ? (255u << 20) : (255u << 24);
     for (int64_t b0 = 64 * (int64_t)blockIdx.x; b0 < nbuckets; b0 += 64 * (int64_t)gridDim.x) {
         const int64_t b = b0 + lane;
         if (b >= nbuckets) continue;  // (no barrier below: every lane works on its own columns)
         const int64_t r0 = boff[b], n64 = boff[b + 1] - r0;
         const uint64_t g0 = gblock[b >> 10] + glocal[b];
-        boff6[b] = (int64_t)(6 * g0);
-        if (b == nbuckets - 1) boff6[nbuckets] = (int64_t)(6 * (g0 + (uint64_t)((n64 + 5) / 6)));
+        boff6[b] = (int64_t)(P * g0);
+        if (b == nbuckets - 1) boff6[nbuckets] = (int64_t)(P * (g0 + (uint64_t)((n64 + P - 1) / P)));
         if (n64 <= 0) continue;
         const uint32_t bucket5 = (uint32_t)((b + bbase) & 31);
-        const int64_t ng = (n64 + 5) / 6;
-        if (n64 < 6 || n64 > kSixRows) {  // as they come
-            for (int64_t j = 0; j < ng; ++j) {
+        const int64_t ng = (n64 + P - 1) / P;
+        const uint32_t pad = words[r0 + n64 - 1];  // (a place the bucket leaves empty: a copy of its last row)
+        auto emit = [&](uint64_t g, const uint32_t (&w)[6]) {
+            if constexpr (P == 6) {
                 SixRow r[6];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) r[c] = six_of(6 * j + c < n64 ? words[r0 + 6 * j + c] : pad, f12);
-                groups[g0 + (uint64_t)j] = six_group(r, bucket5);
+                for (int c = 0; c < 6; ++c) r[c] = six_of(w[c], f12);
+                groups[g] = six_group(r, bucket5);
+            } else {
+                groups[g] = five_group(w, f12);
+            }
+        };
+        if (n64 < 6 || n64 > kSixRows || !colour) {  // as they come
+            for (int64_t j = 0; j < ng; ++j) {
+                uint32_t w[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) w[c] = c < P && P * j + c < n64 ? words[r0 + P * j + c] : pad;
+                emit(g0 + (uint64_t)j, w);
             }
             continue;
         }
@@ -504,14 +531,13 @@ __global__ __launch_bounds__(64) void six_view_kernel(const uint32_t *__restrict
             const uint32_t a = res_a(stage[i][lane]);
             order[cnt[a][lane]++][lane] = (uint8_t)i;
         }
-        for (int i = 0; i < 6 * NG; ++i) placed[i][lane] = pad;
-        uint32_t usedA[6], usedA2[6], usedB[6], usedB2[6];
-        int load[6], room[6];
+        for (int i = 0; i < P * NG; ++i) placed[i][lane] = pad;
+        uint32_t usedA[P], usedA2[P], usedB[P], usedB2[P];
+        int load[P];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < P; ++c) {
             usedA[c] = usedA2[c] = usedB[c] = usedB2[c] = 0u;
             load[c] = 0;
-            room[c] = (R - c + 5) / 6;  // places c, c + 6, ... below R
         }
         for (int j = 0; j < R; ++j) {
             const uint32_t w = stage[order[j][lane]][lane];
@@ -522,40 +548,40 @@ __global__ __launch_bounds__(64) void six_view_kernel(const uint32_t *__restrict
             int best = 0;
             uint32_t bestp = 0xFFFFFFFFu;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
+            for (int c = 0; c < P; ++c) {
                 uint32_t p = (usedA[c] & A ? 4u : 0u) + (usedA2[c] & A ? 16u : 0u) + (usedB[c] & B ? 5u : 0u) + (usedB2[c] & B ? 16u : 0u);
                 p = (p << 8) + (uint32_t)load[c];
-                if (load[c] >= room[c]) p = 0xFFFFFFFEu;
+                if (load[c] >= NG) p = 0xFFFFFFFEu;  // (a colour holds one row of every group)
                 if (p < bestp) {
                     bestp = p;
                     best = c;
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
+            for (int c = 0; c < P; ++c) {
                 if (c == best) {
                     usedA2[c] |= usedA[c] & A;
                     usedB2[c] |= usedB[c] & B;
                     usedA[c] |= A;
                     usedB[c] |= B;
-                    placed[6 * load[c] + c][lane] = w;
+                    placed[P * load[c] + c][lane] = w;
                     ++load[c];
                 }
             }
         }
         for (int j = 0; j < NG; ++j) {
-            SixRow r[6];
+            uint32_t w[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) r[c] = six_of(placed[6 * j + c][lane], f12);
-            groups[g0 + (uint64_t)j] = six_group(r, bucket5);
+            for (int c = 0; c < 6; ++c) w[c] = c < P ? placed[P * j + c][lane] : pad;
+            emit(g0 + (uint64_t)j, w);
         }
     }
 }
 
 // groups of six per bucket: count[b] = ceil(rows of bucket b / 6) (what the two-level scan of memo_index.hip takes)
-__global__ void six_counts_kernel(const int64_t *__restrict__ boff, int64_t nbuckets, uint32_t *__restrict__ count) {
+__global__ void six_counts_kernel(const int64_t *__restrict__ boff, int64_t nbuckets, uint32_t *__restrict__ count, int rpg) {
     const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (b < nbuckets) count[b] = (uint32_t)((boff[b + 1] - boff[b] + 5) / 6);
+    if (b < nbuckets) count[b] = (uint32_t)((boff[b + 1] - boff[b] + rpg - 1) / rpg);
 }
 
 }  // namespace
@@ -586,17 +612,21 @@ int colour_view_words(uint32_t *words, const int64_t *boff, uint64_t nb, int km1
 }
 
 // the two halves of a six-row view's build around memo_index.hip's scan: the groups every bucket needs, then the groups themselves
-void six_counts(const int64_t *boff, uint64_t nb, uint32_t *count, hipStream_t st) {
+void six_counts(const int64_t *boff, uint64_t nb, uint32_t *count, int rpg, hipStream_t st) {
     const int64_t nbuckets = (int64_t)nb - 1;
-    hipLaunchKernelGGL(six_counts_kernel, dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st, boff, nbuckets, count);
+    hipLaunchKernelGGL(six_counts_kernel, dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st, boff, nbuckets, count, rpg);
 }
 void six_view_fill(const uint32_t *words, const int64_t *boff, const uint32_t *glocal, const uint64_t *gblock, uint64_t nb, int64_t bbase,
-                   int km1, int f12, uint32_t *groups, int64_t *boff6, hipStream_t st) {
+                   int km1, int f12, uint32_t *groups, int64_t *boff6, int rpg, int colour, hipStream_t st) {
     const int64_t nbuckets = (int64_t)nb - 1;
     const int64_t turns = (nbuckets + 63) / 64;
     const unsigned grid = (unsigned)(turns < 256 * 64 ? turns : 256 * 64);
-    hipLaunchKernelGGL(six_view_kernel, dim3(grid), dim3(64), 0, st, words, boff, glocal, gblock, nbuckets, bbase, km1, f12,
-                       reinterpret_cast<uint4 *>(groups), boff6);
+    if (rpg == 6)
+        hipLaunchKernelGGL(aligned_view_kernel<6>, dim3(grid), dim3(64), 0, st, words, boff, glocal, gblock, nbuckets, bbase, km1, f12,
+                           reinterpret_cast<uint4 *>(groups), boff6, colour);
+    else
+        hipLaunchKernelGGL(aligned_view_kernel<5>, dim3(grid), dim3(64), 0, st, words, boff, glocal, gblock, nbuckets, bbase, km1, f12,
+                           reinterpret_cast<uint4 *>(groups), boff6, colour);
 }
 
 }  // namespace memo

@@ -19,15 +19,14 @@ using namespace memo::dense;
 namespace {
 
 struct TileDesc {  // 32 bytes
-    uint32_t g0_lo, g0_hi;  // first group of the slice (a multiple of 8)
+    uint32_t g0_lo, g0_hi;  // first group of the slice (five-row groups: a multiple of 8)
     uint32_t ng;            // groups; 0xFFFFFFFF: more than 2^32 rows reach this tile (unsupported)
     uint32_t first, end;    // rows [first, end) of the slice, counted from row 5 * g0
     uint32_t pad[3];
 };
 
 // tile T covers pivot positions [T * w, (T + 1) * w); its rows: T * w <= start < roundup((T + 1) * w + k - 1, bucket)
-// rpg: rows per group -- 5 (g0 a multiple of 8 groups: 128-byte loads), or 6: groups that end at bucket boundaries (six_view_kernel),
-// the slice is whole groups from its first one
+// rpg: rows per group -- 5, or 6 (A/B: groups that carry their bucket)
 __global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase, int bshift, int w, int km1, int64_t ntab,
                                   TileDesc *out, int rpg) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -37,6 +36,8 @@ __global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase
     b0 = b0 < 0 ? 0 : (b0 > last ? last : b0);
     b1 = b1 < 0 ? 0 : (b1 > last ? last : b1);
     const uint64_t r0 = a <= 0 ? 0 : (uint64_t)boff[b0], r1 = (uint64_t)boff[b1];
+    // (five-row groups: from the 128-byte line that holds the slice's first group -- a wave's 1 KiB load is eight whole lines;
+    // six-row groups end at bucket boundaries: the slice is whole groups from its first one)
     const uint64_t g0 = rpg == 6 ? r0 / 6 : (r0 / 5) & ~(uint64_t)7, g1 = (r1 + (uint64_t)rpg - 1) / (uint64_t)rpg;
     TileDesc d;
     d.g0_lo = (uint32_t)g0;

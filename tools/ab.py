@@ -39,6 +39,7 @@ def main():
                     help="an index from a file (.npz with start, end, annot, num_docs, length: tools/realistic_index.py) instead of the "
                          "synthetic generator; the window is [0, length)")
     ap.add_argument("--membership", action="store_true", help="with --rows-file: membership queries")
+    ap.add_argument("--aligned-views", action="store_true", help="dense views whose five-row groups end at bucket boundaries (memo_debug_view_colouring 2)")
     ap.add_argument("--six", action="store_true", help="dense k-class views as groups of six rows (memo_debug_six_views 1)")
     ap.add_argument("--no-colour", action="store_true", help="dense k-class views keep the order the filter leaves (memo_debug_view_colouring 0)")
     ap.add_argument("variants", nargs="+")
@@ -52,6 +53,8 @@ def main():
         _lib.lib().memo_debug_view_colouring(0)
     if a.six:
         _lib.lib().memo_debug_six_views(1)
+    if a.aligned_views:
+        _lib.lib().memo_debug_view_colouring(2)
     if a.rows_file:
         import memo_amd
         z = np.load(a.rows_file)
