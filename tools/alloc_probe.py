@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--trials", type=int, default=6)
     ap.add_argument("--launches", type=int, default=3000)
     ap.add_argument("--u8", action="store_true")
+    ap.add_argument("--pack", default="only", choices=["only", "dense"])
     ap.add_argument("--same-place", action="store_true", help="no dummy allocations: every trial reuses the freed blocks")
     a = ap.parse_args()
     num_docs, L, membership = WORKLOADS[a.workload]
@@ -35,7 +36,7 @@ def main():
     for trial in range(a.trials):
         if not a.same_place:
             pads.append(torch.empty(((trial * 37 + 5) << 20) + trial * 4096, dtype=torch.uint8, device="cuda"))
-        ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L, pack="only")
+        ix, (r0, r1) = synth.device_index(0, L, a.k, num_docs, L, pack=a.pack)
         ix.prepare(a.k, num_docs, False, L)
         fn = ix.conservation_u8_dev if a.u8 else ix.conservation_dev
         blocks = []
