@@ -196,8 +196,8 @@ int dense_compact(memo_index *ix);     // memo_index.hip: leave the rows that ca
 int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows, int *view_cap = nullptr,
                    bool six = false);  // ... or a k-class view (six: as groups of six rows, or nothing: *view_cap stays 0)
 extern thread_local int g_six_views;  // (AB library, memo_debug_six_views: the table-driven kernel reads six-row views where it can)
-void six_counts(const int64_t *boff, uint64_t nb, uint32_t *count, int rpg, hipStream_t st);
-void six_view_fill(const uint32_t *words, const int64_t *boff, const uint32_t *glocal, const uint64_t *gblock, uint64_t nb, int64_t bbase,
+void aligned_group_counts(const int64_t *boff, uint64_t nb, uint32_t *count, int rpg, hipStream_t st);
+void aligned_view_fill(const uint32_t *words, const int64_t *boff, const uint32_t *glocal, const uint64_t *gblock, uint64_t nb, int64_t bbase,
                    int km1, int f12, uint32_t *groups, int64_t *boff6, int rpg, int colour, hipStream_t st);
 constexpr int kNoRoom = 1;  // (internal) the device has no memory for a view / tile table: run without it
 constexpr size_t kMaxTileTables = 64;

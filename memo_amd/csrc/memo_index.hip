@@ -738,7 +738,7 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
             if (e6 == hipSuccess) e6 = side_alloc((void **)&gblock, (nblk6 + 1) * 8);
             uint64_t total6 = 0;
             if (e6 == hipSuccess) {
-                six_counts(boff3, nb, gcount, aligned_rpg, st);
+                aligned_group_counts(boff3, nb, gcount, aligned_rpg, st);
                 hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblk6), dim3(256), 0, st, gcount, nbk, gcount, gblock);
                 hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, gblock, nblk6);
                 e6 = hipGetLastError();
@@ -751,7 +751,7 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
             if (e6 == hipSuccess) e6 = side_alloc((void **)&boff6, nb * 8);
             if (e6 == hipSuccess) e6 = hipMemsetAsync(g6, 0, (total6 + 64) * 16, st);
             if (e6 == hipSuccess) {
-                six_view_fill(words, boff3, gcount, gblock, nb, bbase, colour_km1, f12, reinterpret_cast<uint32_t *>(g6), boff6, aligned_rpg,
+                aligned_view_fill(words, boff3, gcount, gblock, nb, bbase, colour_km1, f12, reinterpret_cast<uint32_t *>(g6), boff6, aligned_rpg,
                               g_view_colouring, st);
                 e6 = hipGetLastError();
                 if (e6 == hipSuccess) e6 = hipStreamSynchronize(st);

@@ -579,7 +579,7 @@ __global__ __launch_bounds__(64) void aligned_view_kernel(const uint32_t *__rest
 }
 
 // groups of six per bucket: count[b] = ceil(rows of bucket b / 6) (what the two-level scan of memo_index.hip takes)
-__global__ void six_counts_kernel(const int64_t *__restrict__ boff, int64_t nbuckets, uint32_t *__restrict__ count, int rpg) {
+__global__ void group_counts_kernel(const int64_t *__restrict__ boff, int64_t nbuckets, uint32_t *__restrict__ count, int rpg) {
     const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (b < nbuckets) count[b] = (uint32_t)((boff[b + 1] - boff[b] + rpg - 1) / rpg);
 }
@@ -612,11 +612,11 @@ int colour_view_words(uint32_t *words, const int64_t *boff, uint64_t nb, int km1
 }
 
 // the two halves of a six-row view's build around memo_index.hip's scan: the groups every bucket needs, then the groups themselves
-void six_counts(const int64_t *boff, uint64_t nb, uint32_t *count, int rpg, hipStream_t st) {
+void aligned_group_counts(const int64_t *boff, uint64_t nb, uint32_t *count, int rpg, hipStream_t st) {
     const int64_t nbuckets = (int64_t)nb - 1;
-    hipLaunchKernelGGL(six_counts_kernel, dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st, boff, nbuckets, count, rpg);
+    hipLaunchKernelGGL(group_counts_kernel, dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st, boff, nbuckets, count, rpg);
 }
-void six_view_fill(const uint32_t *words, const int64_t *boff, const uint32_t *glocal, const uint64_t *gblock, uint64_t nb, int64_t bbase,
+void aligned_view_fill(const uint32_t *words, const int64_t *boff, const uint32_t *glocal, const uint64_t *gblock, uint64_t nb, int64_t bbase,
                    int km1, int f12, uint32_t *groups, int64_t *boff6, int rpg, int colour, hipStream_t st) {
     const int64_t nbuckets = (int64_t)nb - 1;
     const int64_t turns = (nbuckets + 63) / 64;
