@@ -351,6 +351,7 @@ def main():
     ix = indexes[args.rows]
     fmt_bytes = {"wide": 24, "packed": 6 if packed_fmt == 6 else 4, "dense": 3.2}
     row_bytes = fmt_bytes[args.rows]
+    view_bytes = {}                          # per format: bytes per row of the k-class VIEW the sweep reads, where they differ
     W = (num_docs + 31) // 32
     # result element: membership = W uint32 words; conservation = uint8 when num_docs <= 255 (the
     # same at every N; it also halves what the slices put on xGMI), else uint16
@@ -381,27 +382,58 @@ def main():
     # builds their k-class VIEW (the rows whose overlap is below the class's cap -- 2, 4, 6 ... 32 --: all that can write at this k; memo_query.py:49
     # drops the others per query, the library once per index and class -- memo_index_info_t.last_rows_read) and the tile
     # table; both stay with the index.  What each format's sweep reads is what its roofline is priced on.
-    view_pass = None
+    view_pass = place_pass = None
+    unplaced = None                          # the headline sweep on the view BEFORE its rows were placed (what a query-built view is at first)
     full_rows = {}
     prepared = {}
     for f, ixf in indexes.items():
         if f != "wide":
             # memo_index_prepare: the k-class view and the tile table NOW (a host that sweeps one k over many windows calls it
-            # once; without it the class's fifth query builds the view on the way) -- timed on the device by the library
+            # once; without it the view is built by the query that finds it has become worth its pass: MEMO_OPT_BUILD_COST_PCT)
+            # -- timed on the device by the library.  Dense rows: in the two steps a sequence of queries would take -- first the
+            # view with its rows in the order they come (MEMO_OPT_VIEW_PLACES 0), then again with the rows' places inside their
+            # groups chosen against LDS bank conflicts -- each timed, and the sweep on the first timed too.
+            if f == "dense" and f == args.rows and not membership:
+                ixf.set_option(5, 0)
             prepared[f] = ixf.prepare(k, num_docs, membership)
             inf = ixf.info()
             if f == args.rows and inf["last_view_ms"] > 0:
                 view_pass = {"what": "k-class view of the rows the sweep reads (rows whose overlap is below the class's cap: all that can "
-                                     "write at this k), built by memo_index_prepare (else: by the fifth query of its class) -- one pass over "
-                                     "the rows + their bucket table -- once per index and class, kept",
+                                     "write at this k), built by memo_index_prepare (else: by the query that finds the class's queries "
+                                     "have lost more to its absence than it costs) -- count, scan, one fused pass over "
+                                     "the rows -- once per index and class, kept",
                              "ms": float(inf["last_view_ms"]), "rows_in": int(inf["dense_row_count"] if f == "dense" else inf["rows"]),
                              "rows_kept": int(inf["last_rows_read"]), "device_bytes_taken_by_prepare": int(prepared[f])}
+            if f == "dense" and f == args.rows and not membership:
+                ixf.set_option(5, 1)
+                if view_pass:
+                    if world == 1 and not args.force_dist and not args.headline_only:
+                        # the sweep on the view as a sequence of queries first gets it (300 launches, the last 100 timed)
+                        ev_ = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(300)]
+                        for a_, b_ in ev_:
+                            a_.record(stream)
+                            launch(outs[0], ixf)
+                            b_.record(stream)
+                        torch.cuda.synchronize()
+                        ms_u = sorted(a_.elapsed_time(b_) for a_, b_ in ev_[200:])
+                        unplaced = {"kernel_ms_median": float(ms_u[len(ms_u) // 2]), "rows_read": int(ixf.info()["last_rows_read"])}
+                    ixf.prepare(k, num_docs, membership)
+                    inf = ixf.info()
+                    if inf["last_view_ms"] > 0:
+                        place_pass = {"what": "the same view built again with the place of every row inside its 16-byte group chosen against LDS "
+                                              "bank conflicts (memo_view.hip: view_place_bucket) -- by memo_index_prepare at once, by queries "
+                                              "once the class's queries have lost to the plain view what this pass costs (MEMO_OPT_VIEW_PLACES)",
+                                      "ms": float(inf["last_view_ms"])}
         launch(outs[0], ixf)
         torch.cuda.synchronize()
         inf = ixf.info()
         full_rows[f] = int(inf["dense_row_count"]) if f == "dense" else rows
         if inf["last_rows_read"]:
             rows_read[f] = int(inf["last_rows_read"])
+        if f == "dense" and inf.get("last_view_rows_per_group") == 6:
+            view_bytes[f] = 16.0 / 6.0               # a view of six rows per group: bytes per row (slot) the sweep reads
+            if f == args.rows:
+                row_bytes = view_bytes[f]
     # What travels to rank 0.  A slice's own xGMI link is what bounds N > 1, so uint8
     # conservation slices go in a lossless transport coding: "runs" (one bit per position + a byte per change of
     # value, memo_transport_runs_*), "dense" (2 bits per position + a nibble per value outside 1..3,
@@ -639,6 +671,9 @@ def main():
         if which == "dense" and not membership:
             inf = indexes[which].info()
             if inf["last_sweep"] == 5:
+                if inf["last_variant"] == 3:
+                    return ("sweep_conservation_halo3t_kernel<..., SIX> (a k-class view of the dense rows as groups of six rows that carry their "
+                            "bucket: 2.67 B per row; the tile's row slice from the index's tile table)")
                 return ("sweep_conservation_halo3t_kernel<...> (dense rows, five per 16 bytes; the tile's row slice from the index's tile table)"
                         if inf["last_variant"] == 2 else "sweep_conservation_halo3_kernel<...> (PackedRows3: five rows per 16 bytes)")
             return {1: "sweep_conservation_kernel<", 2: "sweep_conservation_halo_kernel<"}.get(inf["last_sweep"], "?<") + "...> (the dense rows could not answer)"
@@ -690,20 +725,40 @@ def main():
     if others and args.rows != "wide" and rows_read[args.rows] != full_rows[args.rows]:
         # the same kernel on ALL the rows of the headline format (MEMO_OPT_VIEWS off: no k-class view), for the record: what round 2 timed
         legs.append((args.rows, args.rows + ", all rows (no k-class view)", full_rows[args.rows]))
+    if others and args.rows == "dense" and view_bytes.get("dense"):
+        # the view of FIVE rows per group (MEMO_OPT_VIEW_ROWS 5: rounds 3-4's headline; 3.2 B per row, no padding), for the record
+        legs.append(("dense", "dense, the k-class view as groups of five rows (MEMO_OPT_VIEW_ROWS 5)", -5))
+    if others and not membership and narrow:
+        legs.append((args.rows, args.rows + ", uint16 results (memo_query_conservation_dev: the ABI's primary result type)", -16))
     for which, label, all_rows in legs:
-        ob = fmt_bytes[which]
-        if all_rows:
+        ob = fmt_bytes[which] if all_rows and all_rows > 0 else view_bytes.get(which, fmt_bytes[which])
+        fn2, out2, b_out2, read2 = (lambda: launch(outs[0], indexes[which])), None, b_out, None
+        if all_rows and all_rows > 0:
             indexes[which].set_option(1, 0)         # MEMO_OPT_VIEWS = 0: the views go, every sweep reads all the rows
+        elif all_rows == -5:
+            indexes[which].set_option(4, 5)
+            indexes[which].prepare(k, num_docs, membership)
+            ob = fmt_bytes[which]
+        elif all_rows == -16:
+            out2 = torch.empty(L, dtype=torch.int16, device=dev)
+            b_out2 = 2
+            fn2 = lambda: indexes[which].conservation_dev(qs, qe_mine, k, num_docs, out2, stream.cuda_stream)
         try:
-            settle(lambda: launch(outs[0], indexes[which]))
-            ms2 = per_step(lambda: launch(outs[0], indexes[which]), max(args.steps, 20))
+            settle(fn2)
+            ms2 = per_step(fn2, max(args.steps, 20))
             indexes[which].check(stream.cuda_stream)
             name2 = kernel_name(which)
+            read2 = int(indexes[which].info()["last_rows_read"]) or None
         finally:
-            if all_rows:
+            if all_rows and all_rows > 0:
                 indexes[which].set_option(1, 1)
                 indexes[which].prepare(k, num_docs, membership)     # (the headline's view again)
-        alg2 = ob * (all_rows or rows_read[which]) + b_out * L
+            elif all_rows == -5:
+                indexes[which].set_option(4, 0)
+                indexes[which].prepare(k, num_docs, membership)
+        if all_rows and all_rows < 0:
+            all_rows = read2
+        alg2 = ob * (all_rows or rows_read[which]) + b_out2 * L
         med2 = float(np.median(ms2))
         other.append({"rows": label, "row_bytes": ob, "rows_read": all_rows or rows_read[which], "kernel": name2,
                       "kernel_ms": float(np.mean(ms2)),
@@ -775,16 +830,20 @@ def main():
                                      else "3.2 B/row (five 24-bit rows per 16 bytes: start mod 2^10, length saturated at 63, 8-bit "
                                           "order) built once per index by memo_index_pack + memo_index_pack_dense" +
                                           ("" if rows_read.get("dense", rows) == rows else
-                                           f"; the sweep reads the k-class view of them: the {rows_read['dense']} rows whose overlap is below "
+                                           f"; the sweep reads the k-class view of them: the rows whose overlap is below "
                                            f"{2 * (k // 2)} -- the others cannot write at k = {k} "
-                                           "(memo_query.py:49 drops them per query) -- built once per index and class by memo_index_prepare (else "
-                                           "by the class's fifth query), timed in dense_view_pass; `roofline` is priced on the rows read; other_row_formats has the same "
-                                           "kernel on all the dense rows"),
+                                           "(memo_query.py:49 drops them per query) -- " +
+                                           (f"as groups of SIX rows that carry their bucket (16 B per 6 rows; every bucket padded to whole groups with "
+                                            f"copies of one of its rows: {rows_read['dense']} places in all), " if view_bytes.get("dense") else
+                                            f"{rows_read['dense']} rows, ") +
+                                           "built once per index and class by memo_index_prepare (else by the query that finds the view has become "
+                                           "worth its pass), timed in dense_view_pass / dense_view_place_pass; `roofline` is priced on the bytes read; "
+                                           "other_row_formats has the same kernel on all the dense rows and on the view of five rows per group"),
                        "row_bytes": row_bytes, "rows_read": rows_read[args.rows],
                        "rows_read_note": None if args.rows == "wide" or rows_read[args.rows] == full_rows.get(args.rows) else
                                          f"the sweep reads the k-class view of the {args.rows} rows: the {rows_read[args.rows]} of "
                                          f"{full_rows.get(args.rows)} rows that can write at k = {k} (memo_query.py:49 drops the others per "
-                                         "query; the library once per index and class -- memo_index_prepare, else the class's fifth query: dense_view_pass); "
+                                         "query; the library once per index and class -- memo_index_prepare, else the query that finds the view worth its pass: dense_view_pass); "
                                          "`roofline` is priced on the rows read, other_row_formats has the same kernel on all the rows",
                        "result_bytes_per_position": b_out,
                        "row_format_choice": "--rows auto = the format that answers this query fastest: the dense rows where they "
@@ -793,6 +852,7 @@ def main():
                                             "lower `frac` at the same speed); the other resident formats are timed in "
                                             "other_row_formats",
                        "row_format_pass": pack_pass, "dense_format_pass": dense_pass, "dense_view_pass": view_pass,
+                       "dense_view_place_pass": place_pass,
                        "clock_ramp": {"what": "untimed headline launches before the warm-up steps, in batches of 20 until two "
                                               "batches in a row are within 1 % of the one before them", **ramp},
                        "sharding": f"window split into {world} contiguous sub-windows, slices gathered to rank 0 "
@@ -834,15 +894,22 @@ def main():
             res["other_row_formats"] = other
             allr = [o for o in other if "all rows" in o["rows"]]
             if allr and view_pass:     # what the same resident index delivers BEFORE its k-class view exists, next to `value`
-                gain_ms = allr[0]["kernel_ms_median"] - kern_ms
+                first_ms = unplaced["kernel_ms_median"] if unplaced else kern_ms     # the sweep on the view as queries first get it
+                gain_ms = allr[0]["kernel_ms_median"] - first_ms
                 res["resident_index_without_view"] = {
                     "value": allr[0]["query_positions_per_s"], "unit": "query-positions/s", "kernel_ms_median": allr[0]["kernel_ms_median"],
                     "frac": allr[0]["frac"], "rows_read": allr[0]["rows_read"],
                     "view_build_ms": view_pass["ms"],
                     "view_amortised_after_queries": (view_pass["ms"] / gain_ms) if gain_ms > 0 else None,
-                    "note": "`value` holds for a resident index once memo_index_prepare (or the fifth query of the k class) has built the "
-                            "class's view of the rows; this is the same kernel on all the rows of the same format -- the first four queries "
-                            "of a class, and every query of an index that answers one (the one-shot forms, `memo query`)"}
+                    "sweep_on_the_view_before_its_rows_are_placed": unplaced,
+                    "places_build_ms": place_pass["ms"] if place_pass else None,
+                    "places_amortised_after_queries": (place_pass["ms"] / (first_ms - kern_ms)) if (place_pass and unplaced and first_ms > kern_ms) else None,
+                    "note": "`value` holds for a resident index once memo_index_prepare has built the class's view of the rows with the rows' "
+                            "places chosen.  A sequence of queries gets there in two steps, each taken by the query that finds the step has "
+                            "paid for itself (ski rental: MEMO_OPT_BUILD_COST_PCT): first the view (view_build_ms, after "
+                            "view_amortised_after_queries whole-window queries of the class: until then this -- the same kernel on all the "
+                            "rows of the same format, also what every query of an index that answers one gets: the one-shot forms, `memo "
+                            "query`), then the same view with its rows placed (places_build_ms, places_amortised_after_queries)"}
         if world == 1 and args.cpu_sample > 0:
             def gpu_slice(S):
                 h = out[:S].cpu().numpy()

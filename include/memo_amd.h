@@ -64,11 +64,14 @@ extern "C" {
 typedef struct memo_index memo_index_t; /* one chromosome's rows, resident in HBM */
 
 /* Versioned: the CALLER sets struct_bytes = sizeof(memo_index_info_t) as it compiled it (a binder built against an older
- * header has a shorter struct); memo_index_get_info writes no more than that many bytes -- whole leading fields of the layout
- * below, which only ever grows at its end -- and puts the number of bytes it wrote back into struct_bytes, its own layout
- * version into `version`.  struct_bytes below 16 (never set) is MEMO_EINVAL.  (Rounds 1-3 had no such field, and every round
- * grew the struct: a round-2 binder would have had its stack overwritten by round 3's library.) */
-#define MEMO_INDEX_INFO_VERSION 4
+ * header has a shorter struct); memo_index_get_info_v5 writes no more than that many bytes -- whole leading fields of the layout
+ * below, which only ever grows at its end (a size that ends inside a field is rounded down to the field's start) -- and puts
+ * the number of bytes it wrote back into struct_bytes, its own layout version into `version`.  struct_bytes below 16 (never
+ * set) is MEMO_EINVAL.  The entry point carries the version of the FIRST layout that began with struct_bytes in its name:
+ * rounds 1-3 had no such field (every round grew the struct: a round-2 binder would have had its stack overwritten by round
+ * 3's library), and a binder that still passes one of those structs must fail when it looks the symbol up, not read its own
+ * garbage as a size -- so `memo_index_get_info` is a macro for C callers and not an exported name. */
+#define MEMO_INDEX_INFO_VERSION 5
 typedef struct memo_index_info {
     uint32_t struct_bytes;  /* in: sizeof of the caller's struct; out: bytes written */
     uint32_t version;       /* out: MEMO_INDEX_INFO_VERSION of the library */
@@ -117,6 +120,11 @@ typedef struct memo_index_info {
     uint64_t view_builds;     /* k-class views built over the index's lifetime: a service can watch it for thrashing */
     int32_t last_level_arrays; /* last_sweep == 4: level arrays the sweep allocated per tile -- only those some row of the index can
                                write to at this k (which overlaps occur in the index is known exactly since its rows were packed) */
+    int32_t last_view_placed; /* the view the last sweep read has its rows placed inside their groups against LDS bank conflicts (a second
+                               pass over the rows, decided like the first: MEMO_OPT_VIEW_PLACES) */
+    uint64_t view_placings;   /* dense views (re)built with their rows placed, over the index's lifetime */
+    int32_t last_view_rows_per_group; /* rows per 16-byte group of the dense rows the last sweep read: 5, or 6 (a view whose groups carry
+                               their bucket: 2.67 B per row; last_rows_read then counts the places a bucket leaves empty too) */
     int32_t reserved;
 } memo_index_info_t;
 
@@ -167,7 +175,8 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide);
  * rows).  Needs memo_index_pack first and every annot <= 511.  keep_packed == 0 frees the 4-byte rows: such an index
  * holds 3.2 B per row and answers only what the dense rows (or, if still resident, the int64 columns) can. */
 int memo_index_pack_dense(memo_index_t *ix, int32_t keep_packed);
-int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);  /* set info->struct_bytes first (see the struct) */
+int memo_index_get_info_v5(const memo_index_t *ix, memo_index_info_t *info);  /* set info->struct_bytes first (see the struct) */
+#define memo_index_get_info memo_index_get_info_v5
 /* Options of one index (queries never change a result with them).
  *   MEMO_OPT_VIEWS            1 (default): queries may build k-class views of the rows (memo_index_info_t.last_rows_read);
  *                             0: never -- resident views are dropped (the call waits for the device), every sweep reads all
@@ -175,9 +184,27 @@ int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info);  /* se
  *   MEMO_OPT_VIEW_BUDGET_PCT  the views of ONE row source (the dense rows; the 4-byte words) together stay within this many
  *                             percent of that row source's own bytes; past it the least recently used view is dropped (its
  *                             class is then rebuilt only after four times as many queries as the last time).  Default 200:
- *                             a long-lived index that holds both row sources can grow to three times their bytes.  0 .. 1600. */
+ *                             a long-lived index that holds both row sources can grow to three times their bytes.  0 .. 1600.
+ *   MEMO_OPT_BUILD_COST_PCT   when a query builds a view (or brings rows that came in start order into the query order): every query
+ *                             of a k class that runs without its view adds what the view would have saved it (the rows of its window
+ *                             the view leaves out x what a sweep pays per row); the view is built by the query that finds the sum has
+ *                             reached this many percent of what the pass is estimated to cost (calibrated, then measured by the
+ *                             index's own last pass).  100 (the default) is the ski-rental rule: never more than twice what knowing
+ *                             the future would have cost; ten whole-chromosome queries build nothing, two hundred build one view,
+ *                             ten thousand 10-kbp windows build nothing.  0: the first query of a class builds (what a test wants);
+ *                             0 .. 100000.  memo_index_prepare builds at once whatever this says.
+ *   MEMO_OPT_VIEW_ROWS        rows per 16-byte group of the views of the dense rows: 0 (default) the library's choice -- 6 (groups that
+ *                             carry their bucket: 2.67 B per row) where they apply and the view holds enough rows per bucket, else 5;
+ *                             5 or 6: that kind wherever it applies.  Results never depend on it.
+ *   MEMO_OPT_VIEW_PLACES      1 (default): a dense view is built a second time, the places of its rows inside their 16-byte groups chosen
+ *                             against LDS bank conflicts (2-4 % of a sweep; the pass costs twice the plain one), once the class's
+ *                             queries have lost to the plain view what that costs (MEMO_OPT_BUILD_COST_PCT applies) -- or at once by
+ *                             memo_index_prepare; 0: never (views keep their rows in the order they come in). */
 #define MEMO_OPT_VIEWS 1
 #define MEMO_OPT_VIEW_BUDGET_PCT 2
+#define MEMO_OPT_BUILD_COST_PCT 3
+#define MEMO_OPT_VIEW_ROWS 4
+#define MEMO_OPT_VIEW_PLACES 5
 int memo_index_set_option(memo_index_t *ix, int32_t option, int64_t value);
 /* Build NOW what queries of one kind would otherwise build on the way: the k-class view of the rows such a query reads (else
  * built inside the class's fifth query, on the caller's stream, with a wait for it) and the tile table of the table-driven
@@ -208,6 +235,15 @@ int memo_index_export_packed(memo_index_t *ix, uint32_t *pk, uint16_t *pa, int64
  * 4 rows behind row_base (the bucket's first row sits inside that group).  So that `memo query` reads the
  * benchmarked row format straight from its sidecar cache. */
 int memo_index_export_dense(memo_index_t *ix, void *groups, int64_t *boff, int64_t *long_rows);
+/* The resident k-class VIEW of the dense rows that conservation queries with this k read (memo_index_info_t.last_rows_read;
+ * memo_index_prepare builds it): the rows whose overlap is below *cap -- what memo_init keeps per query at any k - 1 <= cap
+ * (memo_query.py:49) -- as groups of 5 rows (PackedRows3, the view's rows back to back: what memo_index_import_dense takes, so the
+ * CLI's cache stores the view the device built instead of rebuilding it on the host) or of 6 rows that carry their bucket (groups end at
+ * bucket boundaries, a place a bucket leaves empty holds a copy of one of its rows; memo_amd/csrc/memo_view.hip).  *rows: the
+ * view's rows (0: no such view is resident), *group_count: its 16-byte groups, boff: info.buckets entries in units of the view's
+ * (rows_per_group 6: padded) row numbers.  groups == boff == NULL: the sizes only. */
+int memo_index_export_view(memo_index_t *ix, int32_t k, int32_t rows_per_group, void *groups, int64_t *boff, uint64_t *rows,
+                           uint64_t *group_count, int32_t *cap);
 int memo_index_import_dense(uint64_t rows, int32_t device, int32_t bucket_shift, int64_t bucket_base,
                             const void *groups, const int64_t *boff, uint64_t buckets, int64_t row_base,
                             int64_t min_start, int64_t max_start, uint64_t max_annot, const int64_t *long_rows,

@@ -49,10 +49,14 @@ int memo_debug_no_views(memo_index_t *ix, int32_t on);
  * same with the groups ended at bucket boundaries (aligned_view_kernel<5>: places a bucket leaves empty hold a copy of one of its rows;
  * measured level with 1, kept for A/B).  Results never depend on it. */
 int memo_debug_view_colouring(int32_t on);
-/* this THREAD's later conservation queries on dense rows (k - 1 <= 31, up to 255 genomes, buckets of 32 positions): 1 = the k-class
- * view is built as groups of SIX rows that carry their bucket (2.67 B per row; memo_interleave.hip: six_view_kernel) and swept by the
- * table-driven kernel's form for them (info.last_variant 3); 0 (the default) = five-row groups.  Round 4 experiment. */
+/* this THREAD's later conservation queries on dense rows: which kind of k-class view they build and read where views of SIX rows per
+ * group apply (k - 1 <= 31, up to 255 genomes, buckets of 32 positions; memo_view.hip; info.last_variant 3): 1 = six wherever they apply,
+ * 0 = five always, -1 (the default) = the library's choice (MEMO_OPT_VIEW_ROWS of the index, else six where the view holds enough rows
+ * per bucket for the padding of every bucket to whole groups not to matter). */
 int memo_debug_six_views(int32_t on);
+/* this THREAD's later builds of a dense k-class view: 1 = round 4's builder (keep bits, scatter, places chosen by one lane per bucket,
+ * packing: five kernels), 0 (the default) = count, scan and one fused pass (memo_view.hip).  The two write the same bytes. */
+int memo_debug_view_builder(int32_t legacy);
 /* this THREAD's later calls: every device allocation for a view or a tile table fails (the test of the no-memory path) */
 int memo_debug_fail_side_allocations(int32_t on);
 /* this thread's later memo_index_pack_dense / dense builders keep the rows that can never write at k <= 64 in the dense rows */

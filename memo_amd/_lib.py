@@ -37,7 +37,7 @@ class MemoUnpackable(MemoError):
 
 
 class IndexInfo(C.Structure):
-    """memo_index_info_t (include/memo_amd.h): versioned -- set struct_bytes before memo_index_get_info"""
+    """memo_index_info_t (include/memo_amd.h): versioned -- set struct_bytes before memo_index_get_info_v5"""
     _fields_ = [("struct_bytes", C.c_uint32), ("version", C.c_uint32),
                 ("rows", C.c_uint64), ("min_start", C.c_int64), ("max_start", C.c_int64),
                 ("device", C.c_int32), ("bucket_shift", C.c_int32), ("buckets", C.c_uint64),
@@ -47,7 +47,8 @@ class IndexInfo(C.Structure):
                 ("bucket_base", C.c_int64), ("last_sweep", C.c_int32), ("last_variant", C.c_int32), ("dense_row_count", C.c_uint64), ("last_rows_read", C.c_uint64),
                 ("last_view_ms", C.c_float), ("row_order", C.c_int32), ("side_bytes", C.c_uint64),
                 ("views_resident", C.c_int32), ("tile_tables_resident", C.c_int32), ("view_builds", C.c_uint64),
-                ("last_level_arrays", C.c_int32), ("reserved", C.c_int32)]
+                ("last_level_arrays", C.c_int32), ("last_view_placed", C.c_int32), ("view_placings", C.c_uint64),
+                ("last_view_rows_per_group", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol the product headers declare: name -> (restype, argtypes)
@@ -64,13 +65,14 @@ SYMBOLS = {
     "memo_index_finalize": (C.c_int, [_P, _I32, _I32]),
     "memo_index_pack": (C.c_int, [_P, _I32]),
     "memo_index_pack_dense": (C.c_int, [_P, _I32]),
-    "memo_index_get_info": (C.c_int, [_P, C.POINTER(IndexInfo)]),
+    "memo_index_get_info_v5": (C.c_int, [_P, C.POINTER(IndexInfo)]),
     "memo_index_set_option": (C.c_int, [_P, _I32, _I64]),
     "memo_index_prepare": (C.c_int, [_P, _I32, _I32, _I32, _I64, _P, C.POINTER(_U64)]),
     "memo_index_export_packed": (C.c_int, [_P, _P, _P, _P, _P]),
     "memo_index_import_packed": (C.c_int, [_U64, _I32, _I32, _I64, _P, _P, _P, _U64, _I64, _I64, _I64, _U64, _P, _U64,
                                            C.POINTER(_P)]),
     "memo_index_export_dense": (C.c_int, [_P, _P, _P, _P]),
+    "memo_index_export_view": (C.c_int, [_P, _I32, _I32, _P, _P, _P, _P, _P]),
     "memo_index_import_dense": (C.c_int, [_U64, _I32, _I32, _I64, _P, _P, _U64, _I64, _I64, _I64, _U64, _P, _U64,
                                           C.POINTER(_P)]),
     "memo_dense_rows_can_answer": (C.c_int, [_U64, _I64, _I64, _U64, _I32, _I32, _I32]),
@@ -131,6 +133,7 @@ DEBUG_SYMBOLS = {
     "memo_debug_no_views": (C.c_int, [_P, _I32]),
     "memo_debug_view_colouring": (C.c_int, [_I32]),
     "memo_debug_six_views": (C.c_int, [_I32]),
+    "memo_debug_view_builder": (C.c_int, [_I32]),
     "memo_debug_fail_side_allocations": (C.c_int, [_I32]),
     "memo_debug_dense_keep_all": (C.c_int, [_I32]),
     "memo_debug_one_shot_way": (C.c_int, [_I32]),

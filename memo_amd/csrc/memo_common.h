@@ -104,10 +104,13 @@ struct memo_index {
     int row_order = 0;         // how the 4-byte rows are ordered inside a bucket: 0 = by start (as packed), 1 / 2 = interleave_words modes
     // Rows that came in through memo_builder_* or memo_index_import_packed are in start order (or in whatever order their
     // file holds): an index that answers one query -- the one-shot forms, `memo query` -- should not pay a pass over its rows
-    // for an order that spares a fraction of one sweep, so they are ordered by the FIFTH query that reads them (like the
-    // k-class views), by memo_index_prepare, or by memo_index_pack on the finished index (order_words_now, memo_index.hip).
+    // for an order that spares a fraction of one sweep.  They are ordered once the queries that read them have lost to the
+    // start order what the ordering pass costs (order_due, memo_view.hip: the same ski-rental rule as the views), by
+    // memo_index_prepare, or by memo_index_pack on the finished index.
     int order_pending = 0;
-    int kind_queries = 0;        // queries that read the 4-byte rows while their ordering is pending
+    double order_lost_ns = 0;    // what the queries so far would have saved on rows in the query order (estimate)
+    int order_backoff = 1;       // (x 4 after an ordering that found no room for its second copy)
+    double order_ns_per_row = 0;  // measured by the last ordering pass (0: the calibrated constant)
     float pack_ms = 0.f;       // device time of the last memo_index_pack (census + packing kernel)
     uint32_t *p3 = nullptr;    // dense rows (memo_index_pack_dense): 16 bytes per 5 rows; annot <= 255 only
     // The dense rows may be FEWER than the index's rows: a row whose 6-bit length field is saturated (overlap >= 63, or
@@ -117,14 +120,20 @@ struct memo_index {
     // its own bucket table; boff3 == nullptr: the dense rows are the index's rows, numbered alike (rows3 == rows).
     int64_t *boff3 = nullptr;
     uint64_t rows3 = 0, padded3 = 0;
-    // k-class views of the dense rows (dense_rows_for, memo_index.hip): the rows whose overlap is below 2 / 4 / ... / 32 -- all a
-    // query with k - 1 <= 2 / 4 / ... / 32 can be touched by -- with their own bucket table; built by memo_index_prepare or by the
-    // class's FIFTH query (build_after + 1), kept within the views' budget (memo_index_set_option: MEMO_OPT_VIEW_BUDGET_PCT)
+    // k-class views of the dense rows (dense_rows_for, memo_view.hip): the rows whose overlap is below 2 / 4 / ... / 32 -- all a
+    // query with k - 1 <= 2 / 4 / ... / 32 can be touched by -- with their own bucket table; built by memo_index_prepare, or by the
+    // query that finds that its class's queries have by now paid more for the rows a view would have spared them than the view costs
+    // (view_due: ski rental), kept within the views' budget (memo_index_set_option: MEMO_OPT_VIEW_BUDGET_PCT)
     struct DenseView {
         int cap = 0, state = 0;  // state: 0 not looked at yet, 1 built, 2 not worth it (it would spare less than a fifth)
-        int queries = 0;         // queries of this class since it was last looked at (a view is built by query build_after + 1)
-        int build_after = 4;     // ... the fifth at first; four times as many after every eviction or failed allocation (back-off:
-                                 //   a service that cycles through more classes than the budget holds must not rebuild all the time)
+        double lost_ns = 0;      // what this class's queries since it was last looked at would have saved with the view (estimate)
+        int backoff = 1;         // the view is due when lost_ns reaches backoff x its estimated cost: x 4 after every eviction or failed
+                                 //   allocation (a service that cycles through more classes than the budget holds must not rebuild all the time)
+        int seen = 0;            // queries of the class since it was last looked at ...
+        int ask_after = 0;       // ... of which this many must pass before it is looked at again: 0, then 16, 64 ... after evictions (what
+                                 //   keeps the back-off alive when MEMO_OPT_BUILD_COST_PCT is 0 and every cost is nothing)
+        int placed = 0;          // dense views: the rows' places inside their groups were chosen against LDS bank conflicts (memo_view.hip):
+        double unplaced_ns = 0;  //   a second pass, decided like the first -- what the class's queries on the view as it is have lost to that
         uint32_t *p3 = nullptr;
         int64_t *boff = nullptr;
         uint64_t rows = 0, padded = 0;
@@ -133,13 +142,19 @@ struct memo_index {
     };
     int views_on = 1;             // memo_index_set_option(MEMO_OPT_VIEWS)
     int view_budget_pct = 200;    // memo_index_set_option(MEMO_OPT_VIEW_BUDGET_PCT)
+    int build_cost_pct = 100;     // memo_index_set_option(MEMO_OPT_BUILD_COST_PCT): a view / the ordering is due at this share of its cost
+    int view_rows = 0;            // memo_index_set_option(MEMO_OPT_VIEW_ROWS): 0 the library's choice, 5 / 6 rows per group of a dense view
+    int view_places = 1;          // memo_index_set_option(MEMO_OPT_VIEW_PLACES): 0 the rows of a dense view keep the order they come in
+    uint64_t view_placings = 0;   // dense views rebuilt with their rows placed (memo_index_info_t.view_placings)
+    double view_ns_per_row[3] = {0, 0, 0};  // measured by the last view build ([0] dense rows, [1] 4-byte words, [2] dense rows with places; 0: the calibrated constant)
     uint64_t view_clock = 0;
     uint64_t view_builds = 0;     // views built over the index's lifetime (memo_index_info_t.view_builds)
     DenseView views[16];          // classes of two: overlaps below 2, 4, 6 ... 32
-    DenseView views6[16];         // the same classes as groups of SIX rows that carry their bucket (memo_interleave.hip: six_view_kernel; A/B, round 4)
+    DenseView views6[16];         // the same classes as groups of SIX rows that carry their bucket (memo_view.hip; what the table-driven sweep reads where it can)
     DenseView pviews[24];         // the same for the 4-byte words (caps 2 .. 32 by 2, .. 64 by 8, .. 128 by 16; `p3` holds words there): packed_rows_for
     uint64_t last_rows_read = 0;  // rows of the row source the last sweep read (info.last_rows_read)
     float last_view_ms = 0.f;     // device time of the view build, when the last sweep's view was built by it (else 0)
+    int last_view_placed = 0, last_view_rpg = 5;  // (memo_index_info_t: of the dense rows the last sweep read)
     uint64_t max_annot = 0;    // largest annot of the packed rows
     // Sampled histogram of the packed rows' overlap field (min(end - start, 255)): with it the length n = k - 1 -
     // overlap of a row's interval is known in distribution for any k, which is what the choice between the level
@@ -193,9 +208,11 @@ struct memo_index {
 namespace memo {
 void drop_dense(memo_index *ix);       // frees the dense rows, their bucket table and the tile tables
 int dense_compact(memo_index *ix);     // memo_index.hip: leave the rows that can never write out of the dense rows (see boff3)
-int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows, int *view_cap = nullptr,
-                   bool six = false);  // ... or a k-class view (six: as groups of six rows, or nothing: *view_cap stays 0)
-extern thread_local int g_six_views;  // (AB library, memo_debug_six_views: the table-driven kernel reads six-row views where it can)
+// ... or a k-class view of them (memo_view.hip); window: the query's length (what a view would save this query decides when it is built);
+// allow_six: the caller reads views of six rows per group too (*rpg says which kind it got: 5 or 6)
+int dense_rows_for(memo_index *ix, int km1, int64_t window, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows,
+                   int *view_cap = nullptr, bool allow_six = false, int *rpg = nullptr);
+extern thread_local int g_six_views;  // (AB library, memo_debug_six_views: -1 the library's choice, 0 five rows per group always, 1 six wherever they apply)
 void aligned_group_counts(const int64_t *boff, uint64_t nb, uint32_t *count, int rpg, hipStream_t st);
 void aligned_view_fill(const uint32_t *words, const int64_t *boff, const uint32_t *glocal, const uint64_t *gblock, uint64_t nb, int64_t bbase,
                    int km1, int f12, uint32_t *groups, int64_t *boff6, int rpg, int colour, hipStream_t st);
@@ -210,7 +227,7 @@ extern thread_local bool g_prepare_only;  // memo_index_prepare: the query path 
 extern thread_local bool g_side_alloc_fails;  // (AB library, memo_debug_fail_side_allocations: every side_alloc fails -- the test of kNoRoom)
 hipError_t side_alloc(void **p, size_t bytes);
 void drop_dense_views(memo_index *ix);
-int packed_rows_for(memo_index *ix, int km1, bool membership, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows);  // k-class view of the words (+ their order)
+int packed_rows_for(memo_index *ix, int km1, int64_t window, bool membership, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows);  // k-class view of the words (+ their order)
 void drop_packed_views(memo_index *ix);
 inline uint64_t dense_groups_for(uint64_t padded) { return (padded + 4) / 5 + 64; }  // (+ one wave-load of slack: a wave reads its 64 groups whole)
 void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables derive from the dense rows and the bucket table
@@ -218,6 +235,7 @@ void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables der
 // over the bucket's starts, 2: the same with the rows of a start ordered by overlap mod 32), in place, queued on st
 int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshift, int fmt, int mode, hipStream_t st);
 int colour_view_words(uint32_t *words, const int64_t *boff, uint64_t nb, int km1, int f12, hipStream_t st);  // (memo_interleave.hip)
+extern thread_local int g_view_builder;  // (AB library, memo_debug_view_builder: 1 = round 4's five-kernel view builder, kept one round for the bit-for-bit check)
 extern thread_local int g_view_colouring;  // 1: the dense rows' k-class views get their rows' places inside a group chosen against bank conflicts (memo_debug_view_colouring of the AB library turns it off)
 constexpr int kRowOrderDefault = 2;  // interleave_words mode the product applies wherever 4-byte rows come into being
 int order_words_now(memo_index *ix, int mode);  // memo_index.hip: waits for the device, orders ix->pk in place, waits again

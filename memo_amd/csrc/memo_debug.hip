@@ -77,8 +77,13 @@ int memo_debug_view_colouring(int32_t on) {  // (views already built keep the or
     return MEMO_OK;
 }
 
+int memo_debug_view_builder(int32_t legacy) {
+    g_view_builder = legacy ? 1 : 0;
+    return MEMO_OK;
+}
+
 int memo_debug_six_views(int32_t on) {
-    g_six_views = on ? 1 : 0;
+    g_six_views = on < 0 ? -1 : (on ? 1 : 0);
     return MEMO_OK;
 }
 

@@ -5,6 +5,7 @@
 // (:28-36, :45): three int64 columns, kept in HBM so that many windows reuse one upload.
 #include <chrono>
 #include <cstdarg>
+#include <cstddef>
 #include <new>
 
 #include "memo_common.h"
@@ -141,134 +142,6 @@ __global__ void pack3_rows_kernel(const uint32_t *pk, uint64_t padded, uint64_t 
     }
 }
 
-// ---- dense_compact: the rows whose length field is saturated (they can never write at k <= 64) leave the dense rows ----
-// field and annot of dense row r (PackedRows3, memo_sweep.h)
-__device__ __forceinline__ void dense_row(const uint4 *p3, uint64_t r, uint32_t &B, uint32_t &A) {
-    const uint4 g = p3[r / 5];
-    switch ((int)(r % 5)) {
-        case 0: B = g.x & 0xFFFFu; A = g.x >> 24; break;
-        case 1: B = g.y & 0xFFFFu; A = g.y >> 24; break;
-        case 2: B = g.z & 0xFFFFu; A = g.z >> 24; break;
-        case 3: B = g.w & 0xFFFFu; A = g.w >> 24; break;
-        default: B = ((g.x >> 16) & 0xFFu) | (((g.y >> 16) & 0xFFu) << 8); A = (g.z >> 16) & 0xFFu; break;
-    }
-    A |= ((g.w >> (16 + (int)(r % 5))) & 1u) << 8;  // (the ninth annot bit: indexes of 256 .. 511 genomes)
-}
-
-// keep[r / 32] bit r % 32 = row r stays; count[r / 32] = how many of the 32
-// (grid-stride over whole waves: a launch cannot have 2^32 work-items, and an index can have more rows than that)
-__global__ __launch_bounds__(256) void dense_keep_kernel(const uint4 *p3, uint64_t rows, uint32_t cap, uint32_t *keep, uint32_t *count) {
-    const uint64_t top = (rows + 255) & ~(uint64_t)255;
-    for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < top; r += (uint64_t)gridDim.x * 256) {
-        uint32_t B = 63, A = 0;
-        if (r < rows) dense_row(p3, r, B, A);
-        const unsigned long long m = __ballot(r < rows && (B & 63u) < cap);
-        const int lane = threadIdx.x & 63;
-        if ((lane & 31) == 0 && (r >> 5) < ((rows + 31) >> 5)) {
-            const uint32_t half = (uint32_t)(m >> (lane & 32));
-            keep[r >> 5] = half;
-            count[r >> 5] = (uint32_t)__popc(half);
-        }
-    }
-}
-
-// two-level exclusive scan of count[] (n entries): local[i] = prefix inside i's block of 1024, blocksum[b] = the block's total
-__global__ __launch_bounds__(256) void scan_local_kernel(const uint32_t *count, uint64_t n, uint32_t *local, uint64_t *blocksum) {
-    __shared__ uint32_t part[256];
-    const uint64_t base = blockIdx.x * (uint64_t)1024 + 4 * threadIdx.x;
-    uint32_t v[4], sum = 0;
-    for (int i = 0; i < 4; ++i) {
-        v[i] = base + i < n ? count[base + i] : 0;
-        sum += v[i];
-    }
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t add = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - sum;
-    for (int i = 0; i < 4; ++i) {
-        if (base + i < n) local[base + i] = run;
-        run += v[i];
-    }
-    if (threadIdx.x == 255) blocksum[blockIdx.x] = part[255];
-}
-
-// exclusive scan of blocksum[] in place (one workgroup; nb entries), total -> blocksum[nb]
-__global__ __launch_bounds__(1024) void scan_blocks_kernel(uint64_t *blocksum, uint64_t nb) {
-    __shared__ uint64_t part[1024];
-    __shared__ uint64_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint64_t at = 0; at < nb; at += 1024) {
-        const uint64_t i = at + threadIdx.x;
-        const uint64_t v = i < nb ? blocksum[i] : 0;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            const uint64_t add = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
-            __syncthreads();
-            part[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if (i < nb) blocksum[i] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += part[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) blocksum[nb] = carry;
-}
-
-__device__ __forceinline__ uint64_t kept_before(uint64_t r, const uint32_t *keep, const uint32_t *local, const uint64_t *blockpre) {
-    const uint64_t w = r >> 5;
-    return blockpre[w >> 10] + local[w] + (uint32_t)__popc(keep[w] & ((1u << (r & 31)) - 1u));
-}
-
-// the rows that stay, as format-4 words (start mod 2^10 | length << 16 | annot << 24; f12: as format-12 words, length | start
-// mod 2^10 << 8 | annot << 20 -- nine annot bits) at their new numbers: what pack3_rows_kernel takes
-__global__ __launch_bounds__(256) void dense_scatter_kernel(const uint4 *p3, uint64_t rows, const uint32_t *keep, const uint32_t *local,
-                                                            const uint64_t *blockpre, uint32_t *words, int f12) {
-    for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * 256) {
-        if (!((keep[r >> 5] >> (r & 31)) & 1u)) continue;
-        uint32_t B, A;
-        dense_row(p3, r, B, A);
-        words[kept_before(r, keep, local, blockpre)] = f12 ? (B & 63u) | ((B >> 6) << 8) | (A << 20) : (B >> 6) | ((B & 63u) << 16) | (A << 24);
-    }
-}
-
-// boff3[b] = rows that stay among the first boff[b] rows; the last entry is pinned to the total
-__global__ void dense_table_kernel(const int64_t *boff, uint64_t nb, uint64_t rows, uint64_t total, const uint32_t *keep,
-                                   const uint32_t *local, const uint64_t *blockpre, int64_t *boff3) {
-    const uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    const uint64_t r = (uint64_t)boff[b];
-    boff3[b] = (b == nb - 1 || r >= rows) ? (int64_t)total : (int64_t)kept_before(r, keep, local, blockpre);
-}
-
-// the same for the 4-byte words (formats 4 and 12): keep the rows whose overlap byte is below cap
-__global__ __launch_bounds__(256) void packed_keep_kernel(const uint32_t *pk, uint64_t rows, int len_shift, uint32_t cap, uint32_t *keep,
-                                                          uint32_t *count) {
-    const uint64_t top = (rows + 255) & ~(uint64_t)255;
-    for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < top; r += (uint64_t)gridDim.x * 256) {
-        const uint32_t len = r < rows ? (pk[r] >> len_shift) & 0xFFu : 255u;
-        const unsigned long long m = __ballot(r < rows && len < cap);
-        const int lane = threadIdx.x & 63;
-        if ((lane & 31) == 0 && (r >> 5) < ((rows + 31) >> 5)) {
-            const uint32_t half = (uint32_t)(m >> (lane & 32));
-            keep[r >> 5] = half;
-            count[r >> 5] = (uint32_t)__popc(half);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void packed_scatter_kernel(const uint32_t *pk, uint64_t rows, const uint32_t *keep, const uint32_t *local,
-                                                             const uint64_t *blockpre, uint32_t *out) {
-    for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * 256)
-        if ((keep[r >> 5] >> (r & 31)) & 1u) out[kept_before(r, keep, local, blockpre)] = pk[r];
-}
 
 // boff[b] = lower_bound(start, b << shift); the last bucket is pinned to `rows`
 __global__ void bucket_table_kernel(const int64_t *s, uint64_t rows, int64_t *boff, uint64_t nb,
@@ -662,414 +535,25 @@ __global__ __launch_bounds__(256) void len_census_kernel(const uint32_t *__restr
 }
 }  // namespace
 
-namespace memo {
-// The rows of `src` (dense groups, bucket table, row count) whose length field is below `cap`, as dense rows of their own
-// with their own bucket table -- or nothing (out->p3 stays NULL) when fewer than min_tenths tenths of the rows would go.
-// A row with length >= cap cannot write at any k with k - 1 <= cap.  Synchronous on stream `st`.
-// len_shift >= 0: src_p3 / out_p3 are 4-byte WORDS (formats 4 / 12: the overlap byte sits at bit len_shift) instead of dense groups.
-// Device memory for what a query builds on the side (views, tile tables).  These are optimisations: when the device has no
-// room for them the query runs on the rows it has (callers see kNoRoom, not an error).  memo_debug_fail_side_allocations (AB
-// library) makes every such allocation fail: the test of that path.
-hipError_t side_alloc(void **p, size_t bytes) {
-    if (g_side_alloc_fails) return hipErrorOutOfMemory;  // (memo_debug_fail_side_allocations of the AB library)
-    const hipError_t err = hipMalloc(p, bytes);
-    if (err == hipErrorOutOfMemory) (void)hipGetLastError();  // (not sticky: later calls are clean)
-    return err;
-}
-
-static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_boff, uint64_t rows, uint64_t nb, int cap,
-                        int min_tenths, hipStream_t st, uint32_t **out_p3, int64_t **out_boff, uint64_t *out_rows,
-                        uint64_t *out_padded, int len_shift = -1, int colour_km1 = 0, int f12 = 0, int aligned_rpg = 0, int64_t bbase = 0) {
-    *out_p3 = nullptr;
-    *out_boff = nullptr;
-    if (!rows || rows >= ((uint64_t)1 << 38)) return MEMO_OK;
-    DeviceGuard guard(device);
-    const uint64_t n32 = (rows + 31) >> 5, nblk = (n32 + 1023) >> 10;
-    const unsigned row_grid = (unsigned)((rows + 255) / 256 < ((uint64_t)1 << 20) ? (rows + 255) / 256 : (uint64_t)1 << 20);
-    uint32_t *keep = nullptr, *local = nullptr, *words = nullptr;
-    uint64_t *blockpre = nullptr;
-    uint4 *p3n = nullptr;
-    int64_t *boff3 = nullptr;
-    int rc = MEMO_OK;
-    do {
-        hipError_t err = side_alloc((void **)&keep, n32 * 4 + 4);
-        if (err == hipSuccess) err = side_alloc((void **)&local, n32 * 4);
-        if (err == hipSuccess) err = side_alloc((void **)&blockpre, (nblk + 1) * 8);
-        if (err == hipErrorOutOfMemory) { rc = kNoRoom; break; }
-        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
-        const uint4 *p3 = reinterpret_cast<const uint4 *>(src_p3);
-        if (len_shift >= 0)
-            hipLaunchKernelGGL(packed_keep_kernel, dim3(row_grid), dim3(256), 0, st, src_p3, rows, len_shift, (uint32_t)cap,
-                               keep, local);
-        else
-            hipLaunchKernelGGL(dense_keep_kernel, dim3(row_grid), dim3(256), 0, st, p3, rows, (uint32_t)cap, keep, local);
-        hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblk), dim3(256), 0, st, local, n32, local, blockpre);
-        hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, blockpre, nblk);
-        uint64_t total = 0;
-        err = hipGetLastError();
-        if (err == hipSuccess) err = hipMemcpyAsync(&total, blockpre + nblk, 8, hipMemcpyDeviceToHost, st);
-        if (err == hipSuccess) err = hipStreamSynchronize(st);
-        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
-        if (total + rows / 10 * (uint64_t)min_tenths > rows) break;  // too few would go
-        uint64_t padded3 = ((total + 15) & ~(uint64_t)15) + kPadRows;
-        const uint64_t groups = dense_groups_for(padded3);
-        err = side_alloc((void **)&words, padded3 * 4);
-        if (err == hipSuccess) err = hipMemsetAsync(words, 0, padded3 * 4, st);
-        if (err == hipSuccess && len_shift < 0) err = side_alloc((void **)&p3n, groups * 16);
-        if (err == hipSuccess) err = side_alloc((void **)&boff3, nb * 8);
-        if (err == hipErrorOutOfMemory) { rc = kNoRoom; break; }
-        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
-        if (len_shift >= 0) {
-            hipLaunchKernelGGL(packed_scatter_kernel, dim3(row_grid), dim3(256), 0, st, src_p3, rows, keep, local, blockpre,
-                               words);
-        } else {
-            hipLaunchKernelGGL(dense_scatter_kernel, dim3(row_grid), dim3(256), 0, st, p3, rows, keep, local, blockpre, words, f12);
-        }
-        hipLaunchKernelGGL(dense_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, src_boff, nb, rows, total, keep, local,
-                           blockpre, boff3);
-        if (len_shift < 0 && aligned_rpg) {
-            // a k-class view whose groups (five rows, or -- A/B -- six that carry their bucket) end at bucket boundaries, the place of a
-            // row inside its group chosen against LDS bank conflicts (memo_interleave.hip: aligned_view_kernel): groups per bucket ->
-            // their prefix sums (the scan above, on nb - 1 counts) -> the groups and their table
-            const uint64_t nbk = nb - 1, nblk6 = (nbk + 1023) >> 10;
-            uint32_t *gcount = nullptr;
-            uint64_t *gblock = nullptr;
-            hipError_t e6 = side_alloc((void **)&gcount, nbk * 4 + 4);
-            if (e6 == hipSuccess) e6 = side_alloc((void **)&gblock, (nblk6 + 1) * 8);
-            uint64_t total6 = 0;
-            if (e6 == hipSuccess) {
-                aligned_group_counts(boff3, nb, gcount, aligned_rpg, st);
-                hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblk6), dim3(256), 0, st, gcount, nbk, gcount, gblock);
-                hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, gblock, nblk6);
-                e6 = hipGetLastError();
-                if (e6 == hipSuccess) e6 = hipMemcpyAsync(&total6, gblock + nblk6, 8, hipMemcpyDeviceToHost, st);
-                if (e6 == hipSuccess) e6 = hipStreamSynchronize(st);
-            }
-            uint4 *g6 = nullptr;
-            int64_t *boff6 = nullptr;
-            if (e6 == hipSuccess) e6 = side_alloc((void **)&g6, (total6 + 64) * 16);
-            if (e6 == hipSuccess) e6 = side_alloc((void **)&boff6, nb * 8);
-            if (e6 == hipSuccess) e6 = hipMemsetAsync(g6, 0, (total6 + 64) * 16, st);
-            if (e6 == hipSuccess) {
-                aligned_view_fill(words, boff3, gcount, gblock, nb, bbase, colour_km1, f12, reinterpret_cast<uint32_t *>(g6), boff6, aligned_rpg,
-                              g_view_colouring, st);
-                e6 = hipGetLastError();
-                if (e6 == hipSuccess) e6 = hipStreamSynchronize(st);
-            }
-            (void)hipFree(gcount);
-            (void)hipFree(gblock);
-            if (e6 == hipSuccess) {
-                (void)hipFree(p3n);
-                (void)hipFree(boff3);
-                p3n = g6;
-                boff3 = boff6;
-                padded3 = (uint64_t)aligned_rpg * total6;
-            } else {
-                (void)hipFree(g6);
-                (void)hipFree(boff6);
-            }
-            if (e6 == hipErrorOutOfMemory) { rc = kNoRoom; break; }
-            if (e6 != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter (six): %s", hipGetErrorString(e6)); break; }
-        } else if (len_shift < 0) {
-            // (a k-class view: which of its group's five places a row takes is chosen against LDS bank conflicts, memo_interleave.hip)
-            if (colour_km1 > 0 && g_view_colouring) (void)colour_view_words(words, boff3, nb, colour_km1, f12, st);
-            hipLaunchKernelGGL(pack3_rows_kernel, dim3(4096), dim3(256), 0, st, words, padded3, groups, p3n, f12);
-        }
-        err = hipGetLastError();
-        if (err == hipSuccess) err = hipStreamSynchronize(st);
-        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
-        if (len_shift >= 0) {
-            *out_p3 = words;  // (the compacted words are the result)
-            words = nullptr;
-        } else {
-            *out_p3 = reinterpret_cast<uint32_t *>(p3n);
-        }
-        *out_boff = boff3;
-        *out_rows = total;
-        *out_padded = padded3;
-        p3n = nullptr;
-        boff3 = nullptr;
-    } while (0);
-    (void)hipFree(keep);
-    (void)hipFree(local);
-    (void)hipFree(blockpre);
-    (void)hipFree(words);
-    (void)hipFree(p3n);
-    (void)hipFree(boff3);
-    return rc;
-}
-
-// ix->p3 holds every row of the index (rows3 == rows, no boff3).  When more than a tenth of them can never write at
-// k <= 64 (6-bit length field saturated), rebuild the dense rows without them, with a bucket table of their own.
-int dense_compact(memo_index *ix) {
-    if (!ix->p3 || ix->boff3 || !ix->rows || g_dense_keep_all) return MEMO_OK;
-    uint32_t *p3n = nullptr;
-    int64_t *boff3 = nullptr;
-    uint64_t total = 0, padded3 = 0;
-    int rc = dense_filter(ix->device, ix->p3, ix->boff, ix->rows, ix->nb, 63, 1, nullptr, &p3n, &boff3, &total, &padded3, -1, 0,
-                          ix->max_annot > 255 ? 1 : 0);
-    if (rc == kNoRoom) rc = MEMO_OK;  // (no room for a second copy: every row stays)
-    if (rc || !p3n) return rc;
-    DeviceGuard guard(ix->device);
-    drop_tile_tables(ix);
-    (void)hipFree(ix->p3);
-    ix->p3 = p3n;
-    ix->boff3 = boff3;
-    ix->rows3 = total;
-    ix->padded3 = padded3;
-    return MEMO_OK;
-}
-
-thread_local bool g_dense_keep_all = false;   // (AB library: memo_debug_dense_keep_all)
-thread_local int g_one_shot_way = 0;          // (AB library: memo_debug_one_shot_way: 1 = int64 columns, 2 = 4-byte words)
-
-void retire(memo_index *ix, void *p, uint64_t bytes) {
-    if (!p) return;
-    memo_index::Retired r;
-    r.p = p;
-    r.bytes = bytes;
-    ix->retired.push_back(r);
-    ix->retired_bytes += bytes;
-}
-
-void flush_retired(memo_index *ix) {
-    for (memo_index::Retired &r : ix->retired) (void)hipFree(r.p);
-    ix->retired.clear();
-    ix->retired_bytes = 0;
-}
-
-static void retire_view(memo_index *ix, memo_index::DenseView &v, bool dense) {
-    for (size_t i = 0; i < ix->ttabs.size();) {  // the tile tables made for it go with it (a later allocation may land on its address)
-        if (ix->ttabs[i].rows_of == v.p3) {
-            retire(ix, ix->ttabs[i].d, (uint64_t)ix->ttabs[i].n * 32);
-            ix->ttabs.erase(ix->ttabs.begin() + (long)i);
-        } else {
-            ++i;
-        }
-    }
-    retire(ix, v.p3, dense ? dense_groups_for(v.padded) * 16 : v.padded * 4);
-    retire(ix, v.boff, ix->nb * 8);
-    const int again = v.build_after < (1 << 16) ? v.build_after * 4 : v.build_after;  // back-off: see DenseView
-    v = memo_index::DenseView();
-    v.build_after = again;
-}
-
-void drop_dense_views(memo_index *ix) {
-    for (memo_index::DenseView &v : ix->views) {
-        (void)hipFree(v.p3);
-        (void)hipFree(v.boff);
-        v = memo_index::DenseView();
-    }
-    for (memo_index::DenseView &v : ix->views6) {
-        (void)hipFree(v.p3);
-        (void)hipFree(v.boff);
-        v = memo_index::DenseView();
-    }
-}
-
-void drop_packed_views(memo_index *ix) {
-    for (memo_index::DenseView &v : ix->pviews) {
-        (void)hipFree(v.p3);
-        (void)hipFree(v.boff);
-        v = memo_index::DenseView();
-    }
-}
-
-// All the views of one row source together may take view_budget_pct percent (200 by default: memo_index_set_option) of the bytes
-// of the rows they are views of (sixteen classes of the dense rows would come to 4.5 times on BASELINE's generator); past that
-// the least recently used view is RETIRED -- with the tile tables made for it -- and its class starts counting queries again,
-// towards a threshold four times the last one (a service that cycles through more classes than the budget holds settles on
-// the classes that fit and reads all the rows for the others, instead of rebuilding a view every few queries: ADVICE r03).
-// Nothing is waited for here: a sweep queued on any of the caller's streams may still read the view, so its buffers go to
-// the index's retire list (memo_common.h) -- unless that list has itself grown past the budget: then the device is drained.
-static void keep_views_in_budget(memo_index *ix, memo_index::DenseView *views, int n, const memo_index::DenseView *fresh,
-                                 uint64_t base_bytes, bool dense) {
-    auto bytes_of = [&](const memo_index::DenseView &v) -> uint64_t {
-        return v.p3 ? (dense ? dense_groups_for(v.padded) * 16 : v.padded * 4) + ix->nb * 8 : 0;
-    };
-    const uint64_t budget = base_bytes / 100 * (uint64_t)ix->view_budget_pct;
-    for (;;) {
-        uint64_t total = 0;
-        memo_index::DenseView *lru = nullptr;
-        for (int i = 0; i < n; ++i) {
-            total += bytes_of(views[i]);
-            if (views[i].p3 && &views[i] != fresh && (!lru || views[i].stamp < lru->stamp)) lru = &views[i];
-        }
-        if (total <= budget || !lru) break;
-        retire_view(ix, *lru, dense);
-    }
-    if (ix->retired_bytes > budget + base_bytes) {  // (rare: many evictions and no memo_query_check in between)
-        (void)hipDeviceSynchronize();
-        flush_retired(ix);
-    }
-}
-
-// The 4-byte rows brought into a query order (memo_interleave.hip: 2 = the conservation order, 3 = the membership order, 0 =
-// start order).  In place: no sweep may be reading them, so the device is drained first (see memo_index::order_pending).
-int order_words_now(memo_index *ix, int mode) {
-    ix->order_pending = 0;
-    if (mode == 3 && ix->bshift != 5) mode = 2;
-    if (!ix->pk || !ix->rows || (ix->packed_fmt != 4 && ix->packed_fmt != 12) || mode == ix->row_order) return MEMO_OK;
-    DeviceGuard guard(ix->device);
-    HIP_TRY(hipDeviceSynchronize());
-    drop_packed_views(ix);  // (views are subsets in the old order)
-    if (int rc = interleave_words(ix->pk, ix->boff, ix->nb, ix->bshift, ix->packed_fmt, mode, nullptr)) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    ix->row_order = mode;
-    return MEMO_OK;
-}
-
-// Is it time to bring the 4-byte rows into the query order?  Rows that came in through the builder or an import wait for the
-// fifth query that reads them (an index that answers one query should not pay a pass over its rows); memo_index_prepare: now.
-// (A membership order -- rows dealt over annot mod 32, interleave mode 3 -- was built and measured: config 4 at k = 101 0.870 ->
-// 0.863 ms, k = 31 0.528 -> 0.524: the planes kernel is not bound by its atomics' bank conflicts; profiles/r04_membership.txt.
-// One order serves both kinds of query; mode 3 stays reachable through memo_debug_row_order of the A/B library.)
-static int keep_row_order(memo_index *ix, bool membership) {
-    (void)membership;
-    if (!ix->pk || (ix->packed_fmt != 4 && ix->packed_fmt != 12)) return MEMO_OK;
-    const int want = row_order_mode(ix);
-    if (want == ix->row_order || !ix->order_pending) return MEMO_OK;
-    if (!g_prepare_only && ++ix->kind_queries <= 4) return MEMO_OK;
-    ix->kind_queries = 0;
-    return order_words_now(ix, want);
-}
-
-// the class of k - 1 = km1 for the 4-byte words: caps in steps of 2 up to 32 (an odd k -- 21, 31 -- gets exactly the rows that
-// can write), of 8 up to 64, of 16 up to 128 (twenty-four classes)
-static int view_slot(int km1, int *cap) {
-    if (km1 <= 32) {
-        *cap = 2 * ((km1 + 1) / 2);
-        return *cap / 2 - 1;
-    }
-    if (km1 <= 64) {
-        *cap = 8 * ((km1 + 7) / 8);
-        return 16 + (*cap - 40) / 8;
-    }
-    if (km1 <= 128) {
-        *cap = 16 * ((km1 + 15) / 16);
-        return 20 + (*cap - 80) / 16;
-    }
-    return -1;
-}
-
-// The same k-class views for the 4-byte words (formats 4 and 12; what membership queries, k > 64 and indexes of more than 255
-// genomes read): the rows whose overlap is below the class's cap (2, 4 ... 32, 40 ... 64, 80 ... 128), with their own bucket table, built by the class's
-// fifth query when that spares a fifth of the rows.  BASELINE config 5 at k = 31 sweeps half of its 8.4 * 10^8 rows that way.
-int packed_rows_for(memo_index *ix, int km1, bool membership, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows) {
-    if (int rc = keep_row_order(ix, membership)) return rc;
-    *pk = ix->pk;
-    *boff = ix->boff;
-    *rows = ix->rows;
-    ix->last_view_ms = 0.f;
-    if (!ix->views_on || ix->tune.no_views || km1 < 1 || !ix->pk || (ix->packed_fmt != 4 && ix->packed_fmt != 12)) return MEMO_OK;
-    int cap = 0;
-    const int slot = view_slot(km1, &cap);
-    if (slot < 0) return MEMO_OK;
-    memo_index::DenseView &v = ix->pviews[slot];
-    if (v.state == 0 && !g_prepare_only && ++v.queries <= v.build_after) return MEMO_OK;
-    if (v.state == 0) {
-        DeviceGuard guard(ix->device);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        HIP_TRY(hipEventCreate(&e0));
-        if (hipEventCreate(&e1) != hipSuccess) {
-            (void)hipEventDestroy(e0);
-            return fail(MEMO_EHIP, "hipEventCreate failed");
-        }
-        (void)hipEventRecord(e0, st);
-        int rc = dense_filter(ix->device, ix->pk, ix->boff, ix->rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded,
-                              ix->packed_fmt == 12 ? 0 : 16);
-        // (what the filter leaves of an interleaved bucket is no longer dealt evenly: the view's buckets are ordered again)
-        if (!rc && v.p3 && ix->row_order) rc = interleave_words(v.p3, v.boff, ix->nb, ix->bshift, ix->packed_fmt, ix->row_order, st);
-        (void)hipEventRecord(e1, st);
-        (void)hipEventSynchronize(e1);
-        (void)hipEventElapsedTime(&v.build_ms, e0, e1);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)
-        v.cap = cap;
-        v.state = v.p3 ? 1 : (rc == kNoRoom ? 0 : 2);
-        if (rc == kNoRoom) {  // (the pressure may pass: look again, but not every fifth query)
-            v.queries = 0;
-            if (v.build_after < (1 << 16)) v.build_after *= 4;
-        }
-        if (v.state == 1) {
-            ++ix->view_builds;
-            ix->last_view_ms = v.build_ms;
-            keep_views_in_budget(ix, ix->pviews, (int)(sizeof(ix->pviews) / sizeof(ix->pviews[0])), &v, ix->rows * 4, false);
-        }
-    }
-    if (v.state == 1) {
-        v.stamp = ++ix->view_clock;
-        *pk = v.p3;
-        *boff = v.boff;
-        *rows = v.rows;
-    }
-    return MEMO_OK;
-}
-
-// The dense rows a conservation / membership sweep with k - 1 = km1 should read: the k-class VIEW that leaves out the rows
-// whose overlap is cap or more (cap = 2, 4, 6 ... 32, the smallest that is >= km1: such a row cannot write at this k --
-// memo_query.py:49 drops it per query; here it is dropped once per index and class) when that spares a fifth of the rows or
-// more, else the dense rows themselves.  A view is built by the fifth query of its class (a few ms for 5 * 10^8 rows: one pass
-// over the dense rows, timed in view.build_ms) and kept with the index; MEMO_DENSE_VIEWS=0 turns them off.
-int dense_rows_for(memo_index *ix, int km1, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows, int *view_cap, bool six) {
-    if (view_cap) *view_cap = 0;  // (the cap of the view handed out: its rows are exactly those with overlap < cap)
-    *p3 = ix->p3;
-    *boff = ix->boff3 ? ix->boff3 : ix->boff;
-    *rows = ix->boff3 ? ix->rows3 : ix->rows;
-    ix->last_view_ms = 0.f;
-    if (!ix->views_on || ix->tune.no_views || km1 > 32 || km1 < 1) return MEMO_OK;
-    if (six && (ix->bshift != 5 || ix->max_annot > 255 || km1 > 31)) return MEMO_OK;  // (5-bit starts and overlaps, 8-bit annots)
-    const int slot = (km1 + 1) / 2 - 1, cap = 2 * (slot + 1);  // classes of two: k - 1 <= 2, 4, 6 ... 32 (an odd k: exactly its rows)
-    if (six && cap > 31 && km1 != 31) return MEMO_OK;
-    memo_index::DenseView &v = six ? ix->views6[slot] : ix->views[slot];
-    // a view costs about as much as fifty sweeps of config 3: it is built by the class's FIFTH query, not its first -- an index
-    // that answers one query (the one-shot forms, `memo query`) never builds one
-    if (v.state == 0 && !g_prepare_only && ++v.queries <= v.build_after) return MEMO_OK;
-    if (v.state == 0) {
-        DeviceGuard guard(ix->device);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        HIP_TRY(hipEventCreate(&e0));
-        if (hipEventCreate(&e1) != hipSuccess) {
-            (void)hipEventDestroy(e0);
-            return fail(MEMO_EHIP, "hipEventCreate failed");
-        }
-        (void)hipEventRecord(e0, st);
-        // (five-row groups that end at bucket boundaries -- aligned_view_kernel<5>, memo_debug_view_colouring 2 -- were measured and
-        // bought nothing: profiles/r04_view_levels.txt; the product's views keep their rows back to back)
-        const int rc = dense_filter(ix->device, *p3, *boff, *rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded, -1, cap,
-                                    ix->max_annot > 255 ? 1 : 0, six ? 6 : (ix->bshift == 5 && g_view_colouring == 2 ? 5 : 0), ix->bbase);
-        (void)hipEventRecord(e1, st);
-        (void)hipEventSynchronize(e1);
-        (void)hipEventElapsedTime(&v.build_ms, e0, e1);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)
-        v.cap = cap;
-        v.state = v.p3 ? 1 : (rc == kNoRoom ? 0 : 2);
-        if (rc == kNoRoom) {
-            v.queries = 0;
-            if (v.build_after < (1 << 16)) v.build_after *= 4;
-        }
-        if (v.state == 1) {
-            ++ix->view_builds;
-            ix->last_view_ms = v.build_ms;
-            keep_views_in_budget(ix, six ? ix->views6 : ix->views, (int)(sizeof(ix->views) / sizeof(ix->views[0])), &v,
-                                 dense_groups_for(ix->boff3 ? ix->padded3 : ix->padded) * 16, true);
-        }
-    }
-    if (v.state == 1) {
-        v.stamp = ++ix->view_clock;
-        *p3 = v.p3;
-        *boff = v.boff;
-        *rows = v.rows;
-        if (view_cap) *view_cap = v.cap;
-    }
-    return MEMO_OK;
-}
-}  // namespace memo
 
 namespace {
+// the same for dense rows: one workgroup per sampled block of 256 groups (1280 rows)
+__global__ __launch_bounds__(256) void dense_census_kernel(const uint4 *__restrict__ p3, uint64_t rows, uint64_t step,
+                                                           unsigned int *__restrict__ hist) {
+    __shared__ unsigned int h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t g = (uint64_t)blockIdx.x * step * 256 + threadIdx.x;
+    if (5 * g < rows) {
+        const uint4 v = p3[g];
+        const uint32_t len[5] = {v.x & 63u, v.y & 63u, v.z & 63u, v.w & 63u, (v.x >> 16) & 63u};
+        for (int i = 0; i < 5; ++i)
+            if (5 * g + i < rows) atomicAdd(&h[len[i]], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
 // which overlap values (min(end - start, 255)) occur among ALL the rows: one pass, a flag per value in LDS (plain stores: lanes
 // that hit the same flag merge), the workgroup's flags or-ed into eight words in HBM
 __global__ __launch_bounds__(256) void len_seen_kernel(const uint32_t *__restrict__ pk, uint64_t rows, int shift,
@@ -1101,9 +585,37 @@ int memo_len_census(memo_index *ix) {
     ix->len_seen_exact = 0;
     for (unsigned int &c : ix->len_seen) c = 0;
     for (unsigned int &c : ix->len_hist) c = 0;
-    if (!ix->pk || !ix->rows || (ix->packed_fmt != 4 && ix->packed_fmt != 6 && ix->packed_fmt != 12)) return MEMO_OK;
+    if (!ix->rows) return MEMO_OK;
     DeviceGuard guard(ix->device);
     unsigned int *d_hist = nullptr;
+    if (!ix->pk && ix->p3) {
+        // an index that holds the dense rows only (the builder's dense way in, memo_index_import_dense): the same sampled
+        // histogram from their 6-bit overlap fields (63 = "63 or more") -- what the rule that decides when a k-class view is
+        // worth its pass (memo_view.hip: view_due) estimates the view's size from
+        const uint64_t drows = ix->boff3 ? ix->rows3 : ix->rows, groups = (drows + 4) / 5;
+        if (!groups) return MEMO_OK;
+        HIP_TRY(hipMalloc(&d_hist, sizeof(ix->len_hist)));
+        const uint64_t blocks = (groups + 255) / 256, step = blocks / 4096 + 1, grid = (blocks + step - 1) / step;
+        hipError_t err = hipMemsetAsync(d_hist, 0, sizeof(ix->len_hist), nullptr);
+        if (err == hipSuccess) {
+            hipLaunchKernelGGL(dense_census_kernel, dim3((unsigned)grid), dim3(256), 0, nullptr, reinterpret_cast<const uint4 *>(ix->p3),
+                               drows, step, d_hist);
+            err = hipGetLastError();
+        }
+        if (err == hipSuccess) err = hipMemcpy(ix->len_hist, d_hist, sizeof(ix->len_hist), hipMemcpyDeviceToHost);
+        (void)hipFree(d_hist);
+        if (err != hipSuccess) return fail(MEMO_EHIP, "overlap census: %s", hipGetErrorString(err));
+        for (unsigned int c : ix->len_hist) ix->len_hist_rows += c;
+        // (the histogram is of the dense rows: when rows that never write were left out of them, scale it to the index's rows so
+        // that shares are shares of ix->rows, as they are for an index with 4-byte rows)
+        if (ix->boff3 && ix->len_hist_rows) {
+            const double gone = (double)(ix->rows - ix->rows3) / (double)ix->rows3;
+            ix->len_hist[255] += (unsigned int)(gone * (double)ix->len_hist_rows);
+            ix->len_hist_rows += (unsigned int)(gone * (double)ix->len_hist_rows);
+        }
+        return MEMO_OK;
+    }
+    if (!ix->pk || (ix->packed_fmt != 4 && ix->packed_fmt != 6 && ix->packed_fmt != 12)) return MEMO_OK;
     HIP_TRY(hipMalloc(&d_hist, sizeof(ix->len_hist)));
     const uint64_t blocks = (ix->rows + 1023) / 1024, step = blocks / 4096 + 1, grid = (blocks + step - 1) / step;
     hipError_t err = hipMemsetAsync(d_hist, 0, sizeof(ix->len_hist), nullptr);
@@ -1288,17 +800,33 @@ static void fill_info(const memo_index *ix, memo_index_info_t *info) {
     info->device_bytes += side;
     info->view_builds = ix->view_builds;
     info->last_level_arrays = ix->last_arrays;
+    info->view_placings = ix->view_placings;
+    info->last_view_placed = ix->last_view_placed;
+    info->last_view_rows_per_group = ix->last_view_rpg;
 }
 
-int memo_index_get_info(const memo_index_t *ix, memo_index_info_t *info) {
+int memo_index_get_info_v5(const memo_index_t *ix, memo_index_info_t *info) {
     if (!ix || !info) return fail(MEMO_EINVAL, "NULL argument");
     const uint32_t have = info->struct_bytes;
     if (have < 16)
         return fail(MEMO_EINVAL, "memo_index_info_t.struct_bytes = %u: set it to sizeof(memo_index_info_t) before the call", have);
     memo_index_info_t full;
     fill_info(ix, &full);
-    // whole leading fields only: a caller's (older, shorter) struct ends at a field boundary of this layout
-    const uint32_t n = have < sizeof full ? have : (uint32_t)sizeof full;
+    // whole leading fields only: a size that ends inside a field is rounded down to where that field begins
+#define MEMO_INFO_FIELD(f) (uint32_t) offsetof(memo_index_info_t, f)
+    static const uint32_t starts[] = {
+        MEMO_INFO_FIELD(struct_bytes), MEMO_INFO_FIELD(version), MEMO_INFO_FIELD(rows), MEMO_INFO_FIELD(min_start), MEMO_INFO_FIELD(max_start),
+        MEMO_INFO_FIELD(device), MEMO_INFO_FIELD(bucket_shift), MEMO_INFO_FIELD(buckets), MEMO_INFO_FIELD(was_sorted), MEMO_INFO_FIELD(finalized),
+        MEMO_INFO_FIELD(device_bytes), MEMO_INFO_FIELD(packed_format), MEMO_INFO_FIELD(has_wide), MEMO_INFO_FIELD(pack_ms), MEMO_INFO_FIELD(dense_rows),
+        MEMO_INFO_FIELD(long_rows), MEMO_INFO_FIELD(max_annot), MEMO_INFO_FIELD(bucket_base), MEMO_INFO_FIELD(last_sweep), MEMO_INFO_FIELD(last_variant),
+        MEMO_INFO_FIELD(dense_row_count), MEMO_INFO_FIELD(last_rows_read), MEMO_INFO_FIELD(last_view_ms), MEMO_INFO_FIELD(row_order),
+        MEMO_INFO_FIELD(side_bytes), MEMO_INFO_FIELD(views_resident), MEMO_INFO_FIELD(tile_tables_resident), MEMO_INFO_FIELD(view_builds),
+        MEMO_INFO_FIELD(last_level_arrays), MEMO_INFO_FIELD(last_view_placed), MEMO_INFO_FIELD(view_placings),
+        MEMO_INFO_FIELD(last_view_rows_per_group), MEMO_INFO_FIELD(reserved), (uint32_t)sizeof(memo_index_info_t)};
+#undef MEMO_INFO_FIELD
+    uint32_t n = 0;
+    for (uint32_t s : starts)
+        if (s <= have && s > n) n = s;
     full.struct_bytes = n;
     memcpy(info, &full, n);
     return MEMO_OK;
@@ -1332,6 +860,21 @@ int memo_index_set_option(memo_index_t *ix, int32_t option, int64_t value) {
     if (option == MEMO_OPT_VIEW_BUDGET_PCT) {
         if (value < 0 || value > 1600) return fail(MEMO_EINVAL, "MEMO_OPT_VIEW_BUDGET_PCT takes 0 .. 1600");
         ix->view_budget_pct = (int)value;
+        return MEMO_OK;
+    }
+    if (option == MEMO_OPT_BUILD_COST_PCT) {
+        if (value < 0 || value > 100000) return fail(MEMO_EINVAL, "MEMO_OPT_BUILD_COST_PCT takes 0 .. 100000");
+        ix->build_cost_pct = (int)value;
+        return MEMO_OK;
+    }
+    if (option == MEMO_OPT_VIEW_PLACES) {
+        if (value != 0 && value != 1) return fail(MEMO_EINVAL, "MEMO_OPT_VIEW_PLACES takes 0 or 1");
+        ix->view_places = (int)value;
+        return MEMO_OK;
+    }
+    if (option == MEMO_OPT_VIEW_ROWS) {
+        if (value != 0 && value != 5 && value != 6) return fail(MEMO_EINVAL, "MEMO_OPT_VIEW_ROWS takes 0 (the library's choice), 5 or 6");
+        ix->view_rows = (int)value;
         return MEMO_OK;
     }
     return fail(MEMO_EINVAL, "unknown index option %d", option);

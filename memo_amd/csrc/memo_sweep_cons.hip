@@ -1255,14 +1255,14 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     int fmt;
     if ((rc = pick_rows(ix, k, fmt))) return rc;
     hipStream_t st_early = static_cast<hipStream_t>(stream);
-    // the 4-byte words a sweep reads: the k-class view of them where one exists or is due (packed_rows_for, memo_index.hip)
+    // the 4-byte words a sweep reads: the k-class view of them where one exists or is due (packed_rows_for, memo_view.hip)
     auto use_words = [&]() -> int {
         ix->last_rows_read = ix->rows;  // (6-byte rows and the int64 columns have no views)
         if (fmt != 4 && fmt != 12) return MEMO_OK;
         uint32_t *vpk = nullptr;
         int64_t *vboff = nullptr;
         uint64_t vrows = 0;
-        const int vrc = packed_rows_for(ix, k - 1, false, st_early, &vpk, &vboff, &vrows);
+        const int vrc = packed_rows_for(ix, k - 1, qe - qs, false, st_early, &vpk, &vboff, &vrows);
         if (vrc) return vrc;
         A.pk = vpk;
         A.boff = vboff;
@@ -1405,59 +1405,45 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             const bool three = ix->p3 && (!ix->pk || !tune.force_packed) && k - 1 <= 63 && A.ls <= 1024 && (top8 || top9) &&
                          ((double)drows >= span || !ix->pk);
             int view_cap = 0;  // (a view whose cap is k - 1 holds exactly the rows that write at this k: the table-driven kernel's row blocks drop their test)
-            if (three && top8 && g_six_views && (tune.persistent == 0 || tune.persistent == 5) && !tune.no_views) {
-                // A/B (memo_debug_six_views): the class's view as groups of SIX rows that carry their bucket (memo_interleave.hip:
-                // six_view_kernel), 2.67 B per row, on the table-driven kernel; anything it cannot take goes the regular way below
-                uint32_t *p6 = nullptr;
-                int64_t *b6 = nullptr;
-                uint64_t r6 = 0;
-                int cap6 = 0;
-                if ((rc = dense_rows_for(ix, k - 1, st, &p6, &b6, &r6, &cap6, true))) return rc;
-                if (cap6) {
-                    SweepArgs A6 = A;
-                    A6.p3 = p6;
-                    A6.boff = b6;
-                    const int trc = launch_halo3t(ix, A6, tw, (int)sizeof(OutT), st, false, cap6 == k - 1 && !tune.no_all_write, true);
-                    if (trc < 0) return trc;
-                    if (trc == MEMO_OK) {
-                        ix->last_rows_read = r6;
-                        ix->last_sweep = 5;
-                        ix->last_variant = 3;
-                        return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
-                    }
-                }
-            }
-            if (three) {  // the dense rows of this k's class (a view that leaves out the rows that cannot write at this k), or all
+            int rpg = 5;       // rows per 16-byte group of the source handed out: 5, or 6 (a view whose groups carry their bucket: memo_view.hip)
+            ix->last_variant = 0;
+            // the dense rows of this k's class (a view that leaves out the rows that cannot write at this k), or all of them.  Views of
+            // six rows per group are for the table-driven kernel alone: a query it cannot take (a negative window start, no room for
+            // the tile table) asks again for five-row groups.
+            const bool table = three && (tune.persistent == 5 || (tune.persistent == 0 && MEMO_TABLE_DEFAULT));
+            for (int attempt = 0; three && attempt < 2; ++attempt) {
+                const bool can_six = attempt == 0 && table && top8 && A.nlev <= 5 && qs >= 0;
                 uint32_t *vp3 = nullptr;
                 int64_t *vboff = nullptr;
                 uint64_t vrows = 0;
-                if ((rc = dense_rows_for(ix, k - 1, st, &vp3, &vboff, &vrows, &view_cap))) return rc;
+                if ((rc = dense_rows_for(ix, k - 1, qe - qs, st, &vp3, &vboff, &vrows, &view_cap, can_six, &rpg))) return rc;
                 A.p3 = vp3;
                 A.boff = vboff;
                 ix->last_rows_read = vrows;
-            }
-            ix->last_variant = 0;
-            if (three && top8 && g_persistent_launch && tune.persistent >= 2 && tune.persistent <= 4 && !g_prepare_only) {
-                // persistent workgroups (memo_sweep_cons3p.hip, AB library only: 17 - 50 % slower than a workgroup per tile,
-                // profiles/r03_persistent_sweep.txt); 1 = this query does not fit it
-                const int prc = g_persistent_launch(A, tw, (int)sizeof(OutT), ix->device, tune.persistent - 2, st);
-                if (prc < 0) return prc;
-                if (prc == MEMO_OK) {
-                    ix->last_sweep = 5;
-                    ix->last_variant = 1;
-                    return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
+                if (attempt == 0 && top8 && g_persistent_launch && tune.persistent >= 2 && tune.persistent <= 4 && !g_prepare_only) {
+                    // persistent workgroups (memo_sweep_cons3p.hip, AB library only: 17 - 50 % slower than a workgroup per tile,
+                    // profiles/r03_persistent_sweep.txt); 1 = this query does not fit it
+                    const int prc = g_persistent_launch(A, tw, (int)sizeof(OutT), ix->device, tune.persistent - 2, st);
+                    if (prc < 0) return prc;
+                    if (prc == MEMO_OK) {
+                        ix->last_sweep = 5;
+                        ix->last_variant = 1;
+                        return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
+                    }
                 }
-            }
-            if (three && (tune.persistent == 5 || (tune.persistent == 0 && MEMO_TABLE_DEFAULT))) {
-                // the tile's row slice from a table built once per (index, k): memo_sweep_cons3t.hip; 1 = does not fit
-                const int trc = launch_halo3t(ix, A, tw, (int)sizeof(OutT), st, top9, view_cap == k - 1 && !tune.no_all_write);
-                if (trc < 0) return trc;
-                if (trc == MEMO_OK) {
-                    ix->last_sweep = 5;
-                    ix->last_variant = 2;
-                    return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
+                if (table) {
+                    // the tile's row slice from a table built once per (index, k): memo_sweep_cons3t.hip; 1 = does not fit
+                    const int trc = launch_halo3t(ix, A, tw, (int)sizeof(OutT), st, top9, view_cap == k - 1 && !tune.no_all_write, rpg == 6);
+                    if (trc < 0) return trc;
+                    if (trc == MEMO_OK) {
+                        ix->last_sweep = 5;
+                        ix->last_variant = rpg == 6 ? 3 : 2;
+                        return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
+                    }
                 }
+                if (rpg != 6) break;  // (five-row groups: the kernel without a table takes them)
             }
+            if (three && rpg == 6) return fail(MEMO_EHIP, "a six-row view reached a sweep that cannot read it");
             if (!three && fmt == 3) {
                 halo = false;  // (below: the int64 columns, or an error when they are gone too)
             } else {

@@ -456,14 +456,14 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     A.nwords = nw;
     int fmt;
     if ((rc = pick_rows(ix, k, fmt))) return rc;
-    // the 4-byte words a sweep reads: the k-class view of them where one exists or is due (packed_rows_for, memo_index.hip)
+    // the 4-byte words a sweep reads: the k-class view of them where one exists or is due (packed_rows_for, memo_view.hip)
     auto use_words = [&]() -> int {
         ix->last_rows_read = ix->rows;
         if (fmt != 4 && fmt != 12) return MEMO_OK;
         uint32_t *vpk = nullptr;
         int64_t *vboff = nullptr;
         uint64_t vrows = 0;
-        const int vrc = packed_rows_for(ix, k - 1, true, st, &vpk, &vboff, &vrows);
+        const int vrc = packed_rows_for(ix, k - 1, qe - qs, true, st, &vpk, &vboff, &vrows);
         if (vrc) return vrc;
         A.pk = vpk;
         A.boff = vboff;
@@ -493,7 +493,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                 uint32_t *vp3 = nullptr;
                 int64_t *vboff = nullptr;
                 uint64_t vrows = 0;
-                if ((rc = dense_rows_for(ix, k - 1, st, &vp3, &vboff, &vrows))) return rc;
+                if ((rc = dense_rows_for(ix, k - 1, qe - qs, st, &vp3, &vboff, &vrows))) return rc;
                 A.p3 = vp3;
                 A.boff = vboff;
                 ix->last_rows_read = vrows;

@@ -111,7 +111,7 @@ class DeviceIndex:
     def info(self):
         inf = _lib.IndexInfo()
         inf.struct_bytes = C.sizeof(inf)           # the versioned struct: the library writes no more than this
-        check(lib().memo_index_get_info(self._h, C.byref(inf)))
+        check(lib().memo_index_get_info_v5(self._h, C.byref(inf)))
         return {k: getattr(inf, k) for k, _ in inf._fields_}
 
     def prepare(self, k, num_docs, membership=False, window_hint=0, stream=None):
@@ -122,8 +122,22 @@ class DeviceIndex:
                                        C.byref(taken)))
         return taken.value
 
+    def export_view(self, k, rows_per_group=5):
+        """memo_index_export_view: (groups uint32[4 g], table int64[buckets], rows, cap) of the resident k-class view of the dense
+        rows, or None when there is none (memo_index_prepare builds it)"""
+        rows, ng, cap = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        check(lib().memo_index_export_view(self._h, int(k), int(rows_per_group), None, None, C.byref(rows), C.byref(ng), C.byref(cap)))
+        if not rows.value:
+            return None
+        groups = np.empty(4 * ng.value, np.uint32)
+        table = np.empty(self.info()["buckets"], np.int64)
+        check(lib().memo_index_export_view(self._h, int(k), int(rows_per_group), groups.ctypes.data, table.ctypes.data, C.byref(rows),
+                                           C.byref(ng), C.byref(cap)))
+        return groups, table, rows.value, cap.value
+
     def set_option(self, option, value):
-        """memo_index_set_option: 1 = MEMO_OPT_VIEWS (0 / 1), 2 = MEMO_OPT_VIEW_BUDGET_PCT"""
+        """memo_index_set_option: 1 = MEMO_OPT_VIEWS (0 / 1), 2 = MEMO_OPT_VIEW_BUDGET_PCT, 3 = MEMO_OPT_BUILD_COST_PCT (100: ski rental; 0: the
+        first query of a class builds), 4 = MEMO_OPT_VIEW_ROWS (0 / 5 / 6), 5 = MEMO_OPT_VIEW_PLACES (0 / 1)"""
         check(lib().memo_index_set_option(self._h, int(option), int(value)))
         return self
 

@@ -1195,18 +1195,24 @@ def test_config3_full_size_properties(membership, pack, dtype, k, memo, oracle):
             assert full.min() >= 1 and full.max() == n
         if pack and k == 31:
             # THE SCOREBOARD INSTANTIATION: what bench.py times is the sweep on the k-class VIEW of the
-            # rows -- built by the class's fifth query -- read through the tile table.  The whole window again, until the
-            # library reads the view, and THAT result against the oracle over all 10^8 positions (not a sub-window, not an
-            # inference from the all-rows result).
-            again = np.empty_like(full)
-            whole_window(again, times=6)
-            inf = ix.info()
-            assert inf["last_rows_read"] < r1 - r0 and abs(inf["last_rows_read"] / (r1 - r0) - 0.5) < 0.01, inf
-            assert inf["views_resident"] >= 1
-            if pack == "dense" and not membership:
-                assert inf["last_sweep"] == 5 and inf["last_variant"] == 2 and inf["tile_tables_resident"] >= 1, inf
-            bad2, fnv2 = oracle.synth_window_compare(again, 0, L, k, n, L, membership=membership)
-            assert bad2 == 0 and fnv2 == fnv, f"{bad2} chunks of the view's whole-window result differ from the oracle"
+            # rows -- memo_index_prepare builds it, as bench.py does (queries build it once it has become worth its pass:
+            # test_views_are_built_when_they_have_paid_for_themselves) -- read through the tile table.  The whole window again,
+            # and THAT result against the oracle over all 10^8 positions (not a sub-window, not an inference from the all-rows
+            # result).  Dense rows, conservation: the library's choice is the view of SIX rows per group (round 5; asserted), and the
+            # view of five (MEMO_OPT_VIEW_ROWS 5: bench.py's other_row_formats line) is checked the same way.
+            for view_rows in ((0, 5) if pack == "dense" and not membership else (0,)):
+                ix.set_option(4, view_rows)
+                ix.prepare(k, n, membership)
+                again = np.empty_like(full)
+                whole_window(again, times=1)
+                inf = ix.info()
+                six = pack == "dense" and not membership and view_rows == 0
+                assert inf["last_rows_read"] < r1 - r0 and abs(inf["last_rows_read"] / (r1 - r0) - (0.516 if six else 0.5)) < 0.01, inf
+                assert inf["views_resident"] >= 1
+                if pack == "dense" and not membership:
+                    assert inf["last_sweep"] == 5 and inf["last_variant"] == (3 if six else 2) and inf["tile_tables_resident"] >= 1, inf
+                bad2, fnv2 = oracle.synth_window_compare(again, 0, L, k, n, L, membership=membership)
+                assert bad2 == 0 and fnv2 == fnv, f"{bad2} chunks of the view's whole-window result differ from the oracle ({view_rows})"
 
 
 # ---------------------------------------------------------------------------------------
@@ -1459,9 +1465,9 @@ def test_config5_shard_packed_rows(memo, oracle):
             assert ix.info()["last_rows_read"] == r1 - r0 or k != 21
             bad, fnv = oracle.synth_window_compare(full, qs, qe, k, n, pivot)   # the WHOLE 2^25-position shard
             assert bad == 0, (k, bad)
-            if k in (21, 31):     # the benchmarked regime: the k-class view of the words (built by the fifth query), whole shard
-                for _ in range(5):
-                    again = ix.conservation(qs, qe, k, n)
+            if k in (21, 31):     # the benchmarked regime: the k-class view of the words (memo_index_prepare builds it), whole shard
+                ix.prepare(k, n)
+                again = ix.conservation(qs, qe, k, n)
                 inf = ix.info()
                 assert inf["last_rows_read"] < r1 - r0 and abs(inf["last_rows_read"] / (r1 - r0) - (k - 1) / 60) < 0.01, (k, inf)
                 bad2, fnv2 = oracle.synth_window_compare(again, qs, qe, k, n, pivot)
@@ -1553,6 +1559,8 @@ def test_dense_row_sweep_variants(memo, oracle, ab):
     # spares a fifth of them (here: overlaps uniform in 0 .. 59, so every class does); row_source 9 reads them all
     ix, (r0, r1) = synth.device_index(0, 2_000_000, 64, n, 2_000_000, pack="dense")
     with ix:
+        ix.set_option(3, 0)       # MEMO_OPT_BUILD_COST_PCT 0: the first query of a class builds its view
+        ix.set_option(4, 5)       # MEMO_OPT_VIEW_ROWS 5: five rows per group (the views of six: test_six_row_views)
         for k, cap in ((2, 2), (5, 4), (6, 6), (9, 8), (10, 10), (17, 16), (18, 18), (21, 20), (22, 22), (30, 30), (31, 30), (32, 32),
                        (33, 32), (34, None), (64, None)):
             ix.debug_set_tuning(0, 0, 0, 9, 0)
@@ -1561,7 +1569,7 @@ def test_dense_row_sweep_variants(memo, oracle, ab):
             assert inf["last_rows_read"] == inf["dense_row_count"] == r1 - r0
             for src in (0, 10):
                 ix.debug_set_tuning(0, 0, 0, src, 0)
-                for _ in range(6 if src == 0 else 1):                # (a view is built by the fifth query of its class)
+                for _ in range(2 if src == 0 else 1):
                     assert np.array_equal(ix.conservation(0, 2_000_000, k, n, dtype=np.uint8), ref), (k, src)
                 inf = ix.info()
                 if cap is None:
@@ -1591,6 +1599,7 @@ def test_packed_k_class_views(n, memo, oracle, ab):
     num, den = synth.rows_per_position(n)
     with ix:
         assert ix.info()["packed_format"] == (4 if n <= 255 else 12)
+        ix.set_option(3, 0)       # MEMO_OPT_BUILD_COST_PCT 0: the first query of a class builds its view
         for k, cap in ((4, 4), (7, 6), (9, 8), (17, 16), (21, 20), (31, 30), (33, 32), (34, 40), (50, 56), (64, 64), (65, 64), (101, 112),
                        (129, 128), (130, None)):
             for memb in (False, True):
@@ -1599,7 +1608,7 @@ def test_packed_k_class_views(n, memo, oracle, ab):
                 ref = ix.membership(qs, qe, k, n) if memb else ix.conservation(qs, qe, k, n)
                 assert ix.info()["last_rows_read"] == r1 - r0
                 ix.debug_set_tuning(0, 0, 0, 0, 0)
-                for _ in range(6):                                  # (a view is built by the fifth query of its class)
+                for _ in range(2):
                     got = ix.membership(qs, qe, k, n) if memb else ix.conservation(qs, qe, k, n)
                     assert np.array_equal(got, ref), (k, memb)
                 read = ix.info()["last_rows_read"]
@@ -1700,6 +1709,7 @@ def test_no_room_on_the_device_for_views_and_tile_tables(memo, oracle, ab):
         ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack=pack)
         s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, n)
         with ix:
+            ix.set_option(3, 0)                                # (every query tries to build its view, and finds no room)
             for k in (21, 31, 64):
                 want = oracle.conservation(s, e, o, 4, L - 3, k, n, literal=False)
                 for _ in range(7):
@@ -1715,7 +1725,9 @@ def test_no_room_on_the_device_for_views_and_tile_tables(memo, oracle, ab):
         ab.check(ab.lib().memo_debug_fail_side_allocations(0))
     ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack="dense")
     with ix:
-        for _ in range(7):
+        ix.set_option(3, 0)
+        ix.set_option(4, 5)
+        for _ in range(2):
             ix.conservation(4, L - 3, 21, n)
         inf = ix.info()
         assert inf["last_variant"] == 2 and abs(inf["last_rows_read"] / (r1 - r0) - 20 / 60) < 0.01      # (table + view of overlaps < 20)
@@ -1733,6 +1745,8 @@ def test_views_stay_within_their_budget(memo, oracle, ab):
     for pack, row_bytes in (("dense", 3.2), ("only", 4.0)):
         ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack=pack)
         with ix:
+            ix.set_option(3, 0)                     # MEMO_OPT_BUILD_COST_PCT 0: a class that is looked at builds its view
+            ix.set_option(4, 5)
             base = ix.info()["device_bytes"]
             rows_bytes = row_bytes * (r1 - r0)
             builds = []
@@ -1766,28 +1780,29 @@ def test_index_info_is_versioned(memo):
     ix, _ = synth.device_index(0, 50_000, 31, 10, 50_000, pack="only")
     with ix:
         full = ix.info()
-        assert full["struct_bytes"] == C.sizeof(_lib.IndexInfo) and full["version"] == 4 and full["rows"] > 0
-        for cut in (16, 24, 88, 136, C.sizeof(_lib.IndexInfo) - 8, C.sizeof(_lib.IndexInfo), C.sizeof(_lib.IndexInfo) + 64):
+        assert full["struct_bytes"] == C.sizeof(_lib.IndexInfo) and full["version"] == 5 and full["rows"] > 0
+        starts = sorted({getattr(_lib.IndexInfo, f).offset for f, _ in _lib.IndexInfo._fields_} | {C.sizeof(_lib.IndexInfo)})
+        for cut in (16, 20, 24, 30, 88, 136, 141, C.sizeof(_lib.IndexInfo) - 8, C.sizeof(_lib.IndexInfo), C.sizeof(_lib.IndexInfo) + 64):
             buf = (C.c_ubyte * (C.sizeof(_lib.IndexInfo) + 128))(*([0xA5] * (C.sizeof(_lib.IndexInfo) + 128)))
             C.cast(buf, C.POINTER(C.c_uint32))[0] = cut
-            _lib.check(_lib.lib().memo_index_get_info(ix._h, C.cast(buf, C.POINTER(_lib.IndexInfo))))
+            _lib.check(_lib.lib().memo_index_get_info_v5(ix._h, C.cast(buf, C.POINTER(_lib.IndexInfo))))
             wrote = C.cast(buf, C.POINTER(C.c_uint32))[0]
-            assert wrote == min(cut, C.sizeof(_lib.IndexInfo))
+            assert wrote == max(s for s in starts if s <= cut)                    # (a size inside a field: down to the field's start)
             assert all(b == 0xA5 for b in bytes(buf)[wrote:]), cut          # the guard bytes behind the caller's struct
             got = _lib.IndexInfo.from_buffer_copy(bytes(buf)[:wrote] + bytes(C.sizeof(_lib.IndexInfo) - wrote))
-            assert got.version == 4 and got.rows == full["rows"]
+            assert got.version == 5 and got.rows == full["rows"]
             if cut >= 136:
                 assert got.last_rows_read == full["last_rows_read"] and got.max_annot == full["max_annot"]
         for bad in (0, 8, 15):
             inf = _lib.IndexInfo()
             inf.struct_bytes = bad
-            assert _lib.lib().memo_index_get_info(ix._h, C.byref(inf)) == _lib.MEMO_EINVAL
+            assert _lib.lib().memo_index_get_info_v5(ix._h, C.byref(inf)) == _lib.MEMO_EINVAL
             assert b"struct_bytes" in _lib.lib().memo_last_error()
 
 
 def test_prepare_builds_views_and_tables_now(memo, oracle):
     """memo_index_prepare: the k-class view, the tile table and (builder-made indexes) the query order of the rows, built
-    before the first query instead of inside the fifth; idempotent; nothing is launched into the caller's buffer"""
+    before the first query instead of by the query that finds them worth their pass; idempotent; nothing is launched into the caller's buffer"""
     from memo_amd import synth
     n, L = 100, 2_000_000
     num, den = synth.rows_per_position(n)
@@ -1795,6 +1810,7 @@ def test_prepare_builds_views_and_tables_now(memo, oracle):
         ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack=pack)
         s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, n)
         with ix:
+            ix.set_option(4, 5)
             before = ix.info()
             taken = ix.prepare(31, n)
             inf = ix.info()
@@ -1827,11 +1843,70 @@ def test_prepare_builds_views_and_tables_now(memo, oracle):
         ix.prepare(101, n)
         assert ix.info()["row_order"] == 2
         assert np.array_equal(ix.conservation(0, L, 101, n), oracle.conservation(s, e, o, 0, L, 101, n, literal=False))
-    with memo.DeviceIndex.from_host_packed(s, e, o) as ix:
+    with memo.DeviceIndex.from_host_packed(s, e, o) as ix:   # ... or until the queries have lost to the start order what the pass costs
         want = oracle.conservation(s, e, o, 0, L, 101, n, literal=False)
-        for i in range(6):
+        for i in range(6):                                     # (six queries of 2 * 10^6 positions have not: 1.7 us against 340)
             assert np.array_equal(ix.conservation(0, L, 101, n), want)
-            assert ix.info()["row_order"] == (0 if i < 4 else 2), i
+            assert ix.info()["row_order"] == 0, i
+        ix.set_option(3, 0)                                    # MEMO_OPT_BUILD_COST_PCT 0: now
+        assert np.array_equal(ix.conservation(0, L, 101, n), want) and ix.info()["row_order"] == 2
+        ix.check()
+        assert np.array_equal(ix.conservation(5, L - 9, 101, n), want[5:L - 9])
+
+
+def test_views_are_built_when_they_have_paid_for_themselves(memo, oracle):
+    """no fixed "fifth query".  Every query of a k class that runs without its view adds what the view would
+    have saved it (the rows of its window the view leaves out x what a sweep pays per row); the view is built by the query that finds
+    the sum has reached the pass's estimated cost (ski rental: MEMO_OPT_BUILD_COST_PCT 100).  On a 10^7-position index of 5 * 10^7 rows
+    (k = 31: a view spares half of them, 12 us per whole-chromosome query, against ~0.4 ms for the pass): ten whole-chromosome queries
+    build nothing, two hundred build one view, ten thousand windows of 10^4 positions build nothing; memo_index_prepare builds at
+    once; the same for the views of the 4-byte words."""
+    import ctypes as C
+    from memo_amd import synth, _lib
+    n, L, k = 100, 10_000_000, 31
+    num, den = synth.rows_per_position(n)
+    d = C.c_void_p()
+    _lib.check(_lib.lib().memo_dev_malloc(0, L, C.byref(d)))
+    try:
+        for pack in ("dense", "only"):
+            sr0, sr1 = synth.shard_rows(2_000_000, 2_300_000, k, num, den, L)
+            s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
+            want = oracle.conservation(s, e, o, 2_000_000, 2_300_000, k, n, literal=False).astype(np.uint8)
+
+            def queries(ix, count, qs, qe):
+                for _ in range(count):
+                    ix.conservation_u8_dev(qs, qe, k, n, d.value)
+                ix.check()
+
+            ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack=pack)
+            with ix:
+                queries(ix, 10, 0, L)
+                inf = ix.info()
+                assert inf["view_builds"] == 0 and inf["last_rows_read"] == r1 - r0, (pack, inf)
+                queries(ix, 190, 0, L)
+                inf = ix.info()
+                assert inf["view_builds"] == 1 and inf["views_resident"] == 1 and inf["last_rows_read"] < 0.55 * (r1 - r0), (pack, inf)
+                assert np.array_equal(ix.conservation(2_000_000, 2_300_000, k, n, dtype=np.uint8), want)
+            ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack=pack)
+            with ix:
+                rng = np.random.default_rng(5)
+                for a in rng.integers(0, L - 10_000, 10_000):
+                    ix.conservation_u8_dev(int(a), int(a) + 10_000, k, n, d.value)
+                ix.check()
+                assert ix.info()["view_builds"] == 0, pack
+                assert ix.prepare(k, n) > 0 and ix.info()["view_builds"] == 1           # asked for: now
+                assert np.array_equal(ix.conservation(2_000_000, 2_300_000, k, n, dtype=np.uint8), want)
+                assert ix.info()["last_rows_read"] < 0.55 * (r1 - r0)
+            ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack=pack)
+            with ix:                                                                  # a lazier and an eager host
+                ix.set_option(3, 1000)                                                # MEMO_OPT_BUILD_COST_PCT
+                queries(ix, 200, 0, L)
+                assert ix.info()["view_builds"] == 0, pack
+                ix.set_option(3, 0)
+                queries(ix, 1, 0, L)
+                assert ix.info()["view_builds"] == 1, pack
+    finally:
+        _lib.lib().memo_dev_free(0, d)
 
 
 def test_cycling_through_k_classes_does_not_thrash(memo, oracle):
@@ -1847,6 +1922,7 @@ def test_cycling_through_k_classes_does_not_thrash(memo, oracle):
     want = {k: oracle.conservation(s, e, o, 0, L, k, n, literal=False) for k in ks}
     with ix:
         ix.set_option(2, 800)                               # MEMO_OPT_VIEW_BUDGET_PCT: room for all eight
+        ix.set_option(4, 5)
         for k in ks:
             ix.prepare(k, n)
         warm = ix.info()
@@ -1861,6 +1937,7 @@ def test_cycling_through_k_classes_does_not_thrash(memo, oracle):
         assert inf["device_bytes"] == warm["device_bytes"]
     ix, _ = synth.device_index(0, L, 64, n, L, pack="dense")
     with ix:                                                # the default budget (200 %) holds about five of these classes
+        ix.set_option(3, 0)                                 # (a class that is looked at builds: the back-off alone keeps the peace)
         for rnd in range(12):
             for k in ks:
                 for _ in range(2):
@@ -1886,6 +1963,7 @@ def test_row_order_inside_buckets_never_changes_a_result(memo, oracle, ab):
         e = s + ov
         o = rng.integers(1, n_docs, m).astype(np.int64)
         with memo.DeviceIndex.from_host(s, e, o) as ix:
+            ix.set_option(3, 0)
             ix.debug_row_order(1)
             ix.pack(keep_wide=False)
             assert ix.info()["row_order"] == 0
@@ -1914,7 +1992,7 @@ def test_row_order_inside_buckets_never_changes_a_result(memo, oracle, ab):
                 ix.debug_row_order(order)                                       # idempotent
                 assert np.array_equal(_export(ix)[0], again)
                 for k in (3, 21, 31, 64, 101, 200, 256):
-                    for rep in range(6 if k in (21, 101) else 1):               # (the fifth query of a class builds its view)
+                    for rep in range(2 if k in (21, 101) else 1):               # (MEMO_OPT_BUILD_COST_PCT 0: the first query of a class builds its view)
                         qs, qe = 16, length + 40
                         got = ix.conservation(qs, qe, k, n_docs)
                     want = results.setdefault((k, "c"), oracle.conservation(*oracle.filter_rows(s, e, o, qs, qe, k), qs, qe, k, n_docs,
@@ -1947,6 +2025,7 @@ def test_places_inside_a_dense_group_never_change_a_result(memo, oracle, ab):
             with memo.DeviceIndex.from_host(s, e, o) as ix:
                 ix.pack(keep_wide=False)
                 ix.pack_dense(keep_packed=False)
+                ix.set_option(4, 5)                                              # (five rows per group; six: test_six_row_views)
                 for k in (2, 3, 8, 9, 16, 17, 21, 30, 31, 32, 33):
                     ix.prepare(k, n_docs)
                     for qs, qe in ((0, length + 50), (30_001, 50_017), (69_990, 72_100)):
@@ -1963,6 +2042,101 @@ def test_places_inside_a_dense_group_never_change_a_result(memo, oracle, ab):
                 ix.check()
     finally:
         ab.check(ab.lib().memo_debug_view_colouring(1))
+
+
+def test_fused_view_builder_writes_round_4s_bytes(memo, oracle, ab):
+    """memo_view.hip (round 5): a dense k-class view is built by count -> scan -> ONE fused pass (compaction, the places of the rows
+    inside their groups, packing) instead of round 4's five kernels.  Same decisions, so the same BYTES: views of five rows per group
+    (placed and not) and of six, dense rows with the never-writing rows left out (dense_compact), eight- and nine-bit annots, on a
+    ragged index with empty stretches, buckets above the placing limits (96 / 128 rows) and one bucket whose kept rows do not fit the
+    fused pass's LDS stage (it streams through in pieces).  memo_debug_view_builder(1) = round 4's builder (A/B library)."""
+    rng = np.random.default_rng(67)
+    length = 90_000
+    for n_docs, m in ((120, 300_000), (500, 260_000)):
+        s = rng.integers(1, length, m)
+        s[:500] = rng.integers(30_016, 30_048, 500)          # > 128 rows of a view in one bucket
+        s[500:700] = rng.integers(50_000, 50_032, 200)
+        s[700:20_700] = rng.integers(60_000, 60_032, 20_000)  # more kept rows in one bucket than the fused pass stages (5120): pieces
+        s[20_700:20_705] = 60_040                            # (five rows right behind it)
+        s[(s > 70_000) & (s < 72_000)] = 69_999              # an empty stretch
+        s = np.sort(s).astype(np.int64)
+        ov = rng.integers(0, 64, m)
+        ov[::7] = rng.integers(63, 90, len(ov[::7]))         # a seventh of the rows never writes at k <= 64: they leave the dense rows
+        e = s + ov
+        o = rng.integers(1, n_docs, m).astype(np.int64)
+        got = {}
+        try:
+            for builder in (1, 0):
+                ab.check(ab.lib().memo_debug_view_builder(builder))
+                for colour in (1, 0):
+                    ab.check(ab.lib().memo_debug_view_colouring(colour))
+                    for six in ((0, 1) if n_docs <= 255 else (0,)):
+                        ab.check(ab.lib().memo_debug_six_views(six))
+                        with memo.DeviceIndex.from_host(s, e, o) as ix:
+                            ix.pack(keep_wide=False)
+                            ix.pack_dense(keep_packed=False)
+                            inf = ix.info()
+                            assert inf["dense_row_count"] < m                   # (dense_compact ran: through the same builder)
+                            dense = _export_dense(ix)
+                            for k in (3, 9, 17, 21, 31, 32, 33):
+                                ix.prepare(k, n_docs)
+                                view = ix.export_view(k, 6 if six and k <= 32 else 5)
+                                assert view is not None, (builder, colour, six, k)
+                                key = (colour, six, k)
+                                if builder == 1:
+                                    got[key] = (dense, view)
+                                else:
+                                    d0, v0 = got[key]
+                                    assert np.array_equal(dense[0], d0[0]) and np.array_equal(dense[1], d0[1]), ("dense rows", n_docs, key)
+                                    assert view[2:] == v0[2:], (n_docs, key, view[2:], v0[2:])
+                                    assert np.array_equal(view[1], v0[1]), ("table", n_docs, key)
+                                    rpg = 6 if six and k <= 32 else 5
+                                    if colour == 0:                             # rows in the order they come: the same bytes
+                                        same = view[0] == v0[0]
+                                        assert same.all(), ("groups", n_docs, key, int(np.argmin(same)) // 4, len(same) // 4)
+                                    else:                                       # placed: every bucket holds the same rows (round 5 places them
+                                        mine, theirs = _view_rows(view, rpg), _view_rows(v0, rpg)      # without round 4's sort: other places)
+                                        tab = view[1]
+                                        assert len(mine) == len(theirs)
+                                        bucket_of = np.searchsorted(tab[1:], np.arange(len(mine)), side="right")
+                                        a = mine[np.lexsort((mine, bucket_of))]
+                                        b = theirs[np.lexsort((theirs, bucket_of))]
+                                        assert np.array_equal(a, b), ("rows of the buckets", n_docs, key)
+                                want = oracle.conservation(*oracle.filter_rows(s, e, o, 5, length + 50, k), 5, length + 50, k, n_docs, literal=False)
+                                assert np.array_equal(ix.conservation(5, length + 50, k, n_docs), want), (builder, colour, six, k)
+                            ix.check()
+        finally:
+            ab.check(ab.lib().memo_debug_view_builder(0))
+            ab.check(ab.lib().memo_debug_view_colouring(1))
+            ab.check(ab.lib().memo_debug_six_views(-1))
+
+
+def _view_rows(view, rpg):
+    """the rows of an exported view as one integer per row (slot), in slot order: five-row groups: (B | annot << 16) of rows
+    [0, rows); six-row groups: (lo | annot << 10 | bucket << 18) of every slot (the places a bucket leaves empty hold copies)"""
+    g = view[0].reshape(-1, 4).astype(np.uint64)
+    if rpg == 5:
+        hi = (g[:, 3] >> 16) & 0x1F
+        out = np.empty((len(g), 5), np.uint64)
+        for j in range(4):
+            out[:, j] = (g[:, j] & 0xFFFF) | (((g[:, j] >> 24) | (((hi >> j) & 1) << 8)) << 16)
+        out[:, 4] = ((g[:, 0] >> 16) & 0xFF) | (((g[:, 1] >> 16) & 0xFF) << 8) | ((((g[:, 2] >> 16) & 0xFF) | (((hi >> 4) & 1) << 8)) << 16)
+        return out.reshape(-1)[:view[2]]
+    lo = [g[:, 0] & 0x3FF, g[:, 1] & 0x3FF, g[:, 2] & 0x3FF, g[:, 3] & 0x3FF, (g[:, 0] >> 10) & 0x3FF, (g[:, 3] >> 10) & 0x3FF]
+    an = [g[:, 0] >> 24, g[:, 1] >> 24, g[:, 2] >> 24, g[:, 3] >> 24, (g[:, 1] >> 10) & 0xFF, (g[:, 2] >> 10) & 0xFF]
+    bucket = (g[:, 2] >> 18) & 31
+    return np.stack([lo[i] | (an[i] << 10) | (bucket << 18) for i in range(6)], axis=1).reshape(-1)
+
+
+def _export_dense(ix):
+    """(groups, bucket table) of the dense rows of an index"""
+    from memo_amd import _lib
+    inf = ix.info()
+    groups = np.empty(4 * ((inf["dense_row_count"] + 4) // 5), np.uint32)
+    boff = np.empty(inf["buckets"], np.int64)
+    longs = np.empty(3 * inf["long_rows"], np.int64)
+    _lib.check(_lib.lib().memo_index_export_dense(ix._h, groups.ctypes.data, boff.ctypes.data, longs.ctypes.data if longs.size else None))
+    return groups, boff
 
 
 def test_dense_rows_of_256_to_511_genomes(memo, oracle, ab):
@@ -1983,10 +2157,11 @@ def test_dense_rows_of_256_to_511_genomes(memo, oracle, ab):
                 assert ix.info()["packed_format"] == (12 if top_annot > 255 else 4)
                 ix.pack_dense(keep_packed=keep_packed)
                 assert ix.info()["dense_rows"] == 1
+                ix.set_option(3, 0)
                 for k in (2, 3, 9, 21, 31, 32, 33, 48, 64):
                     if k in (21, 33):
                         ix.prepare(k, n_docs)
-                    for rep in range(6 if k == 9 else 1):                       # (the fifth query of a class builds its view)
+                    for rep in range(2 if k == 9 else 1):                       # (MEMO_OPT_BUILD_COST_PCT 0: the first query of a class builds its view)
                         got = ix.conservation(0, length + 60, k, n_docs)
                     inf = ix.info()
                     assert (inf["last_sweep"], inf["last_variant"]) == (5, 2), (n_docs, k, inf["last_sweep"], inf["last_variant"])
@@ -2056,7 +2231,7 @@ def test_six_row_views_experiment(memo, oracle, ab):
                             assert np.array_equal(got, want[key].astype(dt)), (six, key, dt)
                 ix.check()
     finally:
-        ab.check(ab.lib().memo_debug_six_views(0))
+        ab.check(ab.lib().memo_debug_six_views(-1))
 
 
 def test_level_arrays_follow_the_overlap_lengths(memo, oracle, ab):

@@ -70,12 +70,12 @@ def test_index_info_layout_matches_the_header(memo, tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     lines = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
     size, version = (int(x) for x in lines[0].split())
-    assert size == C.sizeof(_lib.IndexInfo) and version == 4
+    assert size == C.sizeof(_lib.IndexInfo) and version == 5
     for ln in lines[1:]:
         if ln:
             n, off = ln.split()
             assert getattr(_lib.IndexInfo, n).offset == int(off), n
-    assert _lib.lib().memo_index_get_info(None, None) == _lib.MEMO_EINVAL
+    assert _lib.lib().memo_index_get_info_v5(None, None) == _lib.MEMO_EINVAL
 
 
 def test_no_gpu_fails_loudly(memo):
