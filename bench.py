@@ -312,40 +312,46 @@ def main():
     others = (world == 1 and not args.force_dist and not args.headline_only)
     formats = [args.rows] + ([f for f in ("wide", "packed", "dense") if f != args.rows and
                               (f != "dense" or can_dense) and (f == "wide" or k - 1 <= 255)] if others else [])
-    for f in formats:
-        if host_rows is not None:
-            ixf = memo_amd.DeviceIndex.from_host(*host_rows, device=local)
-            r0, r1 = int(np.searchsorted(host_rows[0], qs, side="right")), int(np.searchsorted(host_rows[0], qe + k, side="left"))
-        else:
-            ixf, (r0, r1) = synth.device_index(qs, qe, k, num_docs, pivot, device=local)
-        nrows = r1 - r0
-        if f != "wide":
-            ixf.pack(keep_wide=True)            # allocates the packed rows
-            ixf.pack(keep_wide=True)            # the timed pass: same buffers
-            info = ixf.info()
-            packed_fmt = info["packed_format"]
-            pk_bytes = 6 if packed_fmt == 6 else 4
-            pack_bytes = (24 + pk_bytes) * nrows + 8 * nrows        # census reads the annot column once more
-            pack_pass = {"what": "memo_index_pack: int64 columns -> packed rows, once per index, not part of a query "
-                                 "(annot_census_kernel reads 8 B/row; pack_rows_kernel reads 24 B and writes "
-                                 "%d B per row, format %d)" % (pk_bytes, packed_fmt),
-                         "ms": info["pack_ms"], "rows": nrows, "bytes": pack_bytes,
-                         "GBs": pack_bytes / (info["pack_ms"] * 1e-3) / 1e9 if info["pack_ms"] > 0 else None,
-                         "timed_with": "HIP event pair inside memo_index_pack (memo_index_info.pack_ms), second call "
-                                       "on reused buffers"}
-            ixf.pack(keep_wide=False)           # drop the int64 columns
-        if f == "dense":
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            null_stream = torch.cuda.default_stream()           # memo_index_pack_dense works on the NULL stream
-            e0.record(null_stream)
-            ixf.pack_dense(keep_packed=False)
-            e1.record(null_stream)
-            torch.cuda.synchronize()
-            dms = e0.elapsed_time(e1)
-            dense_pass = {"what": "memo_index_pack_dense: 4-byte rows -> dense rows, five per 16 bytes (reads 4 B, writes "
-                                  "3.2 B per row; includes the hipMalloc of the dense rows), once per index",
-                          "ms": dms, "rows": nrows, "bytes": 7.2 * nrows, "GBs": 7.2 * nrows / (dms * 1e-3) / 1e9}
-        indexes[f] = ixf
+    one_device = os.environ.get("MEMO_BENCH_ONE_DEVICE") == "1" and world > 1
+    for turn in range(world if one_device else 1):       # (test transport: the ranks share one GPU and build one after the other)
+      if one_device:
+          dist.barrier()
+      if one_device and turn != rank:
+          continue
+      for f in formats:
+          if host_rows is not None:
+              ixf = memo_amd.DeviceIndex.from_host(*host_rows, device=local)
+              r0, r1 = int(np.searchsorted(host_rows[0], qs, side="right")), int(np.searchsorted(host_rows[0], qe + k, side="left"))
+          else:
+              ixf, (r0, r1) = synth.device_index(qs, qe, k, num_docs, pivot, device=local)
+          nrows = r1 - r0
+          if f != "wide":
+              ixf.pack(keep_wide=True)            # allocates the packed rows
+              ixf.pack(keep_wide=True)            # the timed pass: same buffers
+              info = ixf.info()
+              packed_fmt = info["packed_format"]
+              pk_bytes = 6 if packed_fmt == 6 else 4
+              pack_bytes = (24 + pk_bytes) * nrows + 8 * nrows        # census reads the annot column once more
+              pack_pass = {"what": "memo_index_pack: int64 columns -> packed rows, once per index, not part of a query "
+                                   "(annot_census_kernel reads 8 B/row; pack_rows_kernel reads 24 B and writes "
+                                   "%d B per row, format %d)" % (pk_bytes, packed_fmt),
+                           "ms": info["pack_ms"], "rows": nrows, "bytes": pack_bytes,
+                           "GBs": pack_bytes / (info["pack_ms"] * 1e-3) / 1e9 if info["pack_ms"] > 0 else None,
+                           "timed_with": "HIP event pair inside memo_index_pack (memo_index_info.pack_ms), second call "
+                                         "on reused buffers"}
+              ixf.pack(keep_wide=False)           # drop the int64 columns
+          if f == "dense":
+              e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+              null_stream = torch.cuda.default_stream()           # memo_index_pack_dense works on the NULL stream
+              e0.record(null_stream)
+              ixf.pack_dense(keep_packed=False)
+              e1.record(null_stream)
+              torch.cuda.synchronize()
+              dms = e0.elapsed_time(e1)
+              dense_pass = {"what": "memo_index_pack_dense: 4-byte rows -> dense rows, five per 16 bytes (reads 4 B, writes "
+                                    "3.2 B per row; includes the hipMalloc of the dense rows), once per index",
+                            "ms": dms, "rows": nrows, "bytes": 7.2 * nrows, "GBs": 7.2 * nrows / (dms * 1e-3) / 1e9}
+          indexes[f] = ixf
     rows = r1 - r0
     rows_read = {f: rows for f in indexes}
     ix = indexes[args.rows]
@@ -544,7 +550,14 @@ def main():
                 probe.data_ptr(), L, trial_r, scratch.data_ptr(), local, stream.cuda_stream)))
             tp = timed(lambda: _lib.check(runs_pack_fn(
                 outs[0].data_ptr(), L, trial_r, probe.data_ptr(), local, stream.cuda_stream)))
-            usable["runs"] = (lib.memo_transport_runs_bytes(L, runs_cap), t, tp)
+            # ... and the world - 1 slices of a step by ONE launch (memo_transport_runs_unpack_many_dev: what finish() does)
+            t_all = 0.0
+            if world > 1:
+                many_w = (C.c_void_p * (world - 1))(*([probe.data_ptr()] * (world - 1)))
+                many_o = (C.c_void_p * (world - 1))(*([scratch.data_ptr()] * (world - 1)))      # (timing only: one target)
+                t_all = timed(lambda: _lib.check(lib.memo_transport_runs_unpack_many_dev(many_w, many_o, world - 1, L, trial_r, vbytes, local,
+                                                                                          stream.cuda_stream)))
+            usable["runs"] = (lib.memo_transport_runs_bytes(L, runs_cap), t, tp, t_all)
         del probe, scratch
         best, model = shard.pick_coding(world, t_sweep, usable, link=link)
         w_best = 1.0
@@ -572,6 +585,7 @@ def main():
                   "modelled_step_ms": shard.modelled_step(world, t_sweep, *usable[coding], link=link,
                                                           root_weight=root_weight) * 1e3,
                   "candidates": {c: {"wire_bytes": int(usable[c][0]), "decode_ms_per_slice": usable[c][1] * 1e3, "encode_ms": usable[c][2] * 1e3,
+                                     "decode_ms_all_slices_one_launch": usable[c][3] * 1e3 if len(usable[c]) > 3 else None,
                                      "modelled_step_ms": model[c] * 1e3} for c in names}}
     nibble = coding != "plain"              # (name kept: "the slices travel coded")
     # rank 0 sweeps the first root_weight of its window (a multiple of 8 positions); everybody else all of it
@@ -650,8 +664,15 @@ def main():
             for g in range(1, world):
                 roots[b][g].copy_(host_side[b][g])
         if nibble and rank == 0:
-            for g in range(1 if skip_own else 0, world):
-                unpack(roots[b][g], decoded[b][g])
+            first = 1 if skip_own else 0
+            if coding == "runs" and world - first > 0:      # every slice of the step by one launch
+                cnt = world - first
+                ws = (C.c_void_p * cnt)(*[roots[b][g].data_ptr() for g in range(first, world)])
+                os_ = (C.c_void_p * cnt)(*[decoded[b][g].data_ptr() for g in range(first, world)])
+                _lib.check(lib.memo_transport_runs_unpack_many_dev(ws, os_, cnt, L, b_cap, vbytes, local, stream.cuda_stream))
+            else:
+                for g in range(first, world):
+                    unpack(roots[b][g], decoded[b][g])
 
     def step(i):
         b = i % nbuf
@@ -736,6 +757,8 @@ def main():
         if all_rows and all_rows > 0:
             indexes[which].set_option(1, 0)         # MEMO_OPT_VIEWS = 0: the views go, every sweep reads all the rows
         elif all_rows == -5:
+            indexes[which].set_option(1, 0)         # (one view resident at a time, as in the headline's own leg)
+            indexes[which].set_option(1, 1)
             indexes[which].set_option(4, 5)
             indexes[which].prepare(k, num_docs, membership)
             ob = fmt_bytes[which]
@@ -754,6 +777,8 @@ def main():
                 indexes[which].set_option(1, 1)
                 indexes[which].prepare(k, num_docs, membership)     # (the headline's view again)
             elif all_rows == -5:
+                indexes[which].set_option(1, 0)
+                indexes[which].set_option(1, 1)
                 indexes[which].set_option(4, 0)
                 indexes[which].prepare(k, num_docs, membership)
         if all_rows and all_rows < 0:

@@ -55,6 +55,12 @@ int memo_transport_runs_stats(const void *d_wire, int32_t device, void *stream, 
  * A config-5 slice (500 genomes, 2^25 positions, k = 31) is 67 MB as plain uint16 and ~9 MB coded. */
 int memo_transport_runs16_pack_dev(const uint16_t *d_vec, int64_t n, uint32_t b_capacity, void *d_wire, int32_t device,
                                    void *stream);
+/* The slices of one gather step -- count wires of the same length n and capacity, as rank 0 receives them from its peers --
+ * decoded by ONE launch into count result vectors (value_bytes 1: uint8 as memo_transport_runs_unpack_dev, 2: uint16 as
+ * ..._runs16_...): a slice is too short to fill the device, and count launches one after the other cost count launch-and-drain
+ * times on the rank every peer waits for.  d_wires / d_vecs: HOST arrays of count device pointers. */
+int memo_transport_runs_unpack_many_dev(const void *const *d_wires, void *const *d_vecs, int32_t count, int64_t n, uint32_t b_capacity,
+                                        int32_t value_bytes, int32_t device, void *stream);
 int memo_transport_runs16_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint16_t *d_vec, int32_t device,
                                      void *stream);
 

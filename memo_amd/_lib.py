@@ -113,6 +113,7 @@ SYMBOLS = {
     "memo_transport_runs_stats": (C.c_int, [_P, _I32, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "memo_transport_runs16_pack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
     "memo_transport_runs16_unpack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
+    "memo_transport_runs_unpack_many_dev": (C.c_int, [_P, _P, _I32, _I64, C.c_uint32, _I32, _I32, _P]),
     "memo_transport_bytes": (_SZ, [_I64, C.c_uint32]),
     "memo_transport_pack_dev": (C.c_int, [_P, _I64, C.c_uint32, _P, _I32, _P]),
     "memo_transport_unpack_dev": (C.c_int, [_P, _I64, _P, _I32, _P]),

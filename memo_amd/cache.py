@@ -4,7 +4,7 @@
 window of a 10^8-row index, profiles/r01_cli_timing_16decoders.txt); the sweep is 2 % of it.  The Parquet
 file stays the source of truth.  Beside it, `<index>.parquet.memo/<record>.v3.pk` keeps, per record
 (chromosome), exactly what the GPU wants: the packed rows (4 B per row; + 2 B when an annot exceeds 4095),
-the dense rows (3.2 B per row, when every annot fits 8 bits: the benchmarked kernel's format),
+the dense rows (3.2 B per row, when every annot fits 9 bits: the benchmarked kernel's format),
 the start-bucket table and the few rows with end < start -- as produced by the library itself
 (memo_builder_* + memo_index_export_packed).  A repeat query maps the file, cuts the window's rows out with
 two lookups in the bucket table and uploads them through the pinned ring (memo_index_import_packed): no
@@ -21,8 +21,9 @@ cache) so that later queries neither rebuild nor respawn.
 
 v3 (round 4): beside the dense rows the file holds the k-class VIEW of them for the `-k` the cache was built for (the rows
 whose overlap is below the class's cap: all a conservation query with k - 1 <= cap can be touched by -- what a resident index
-builds by its class's fifth query, memo_index_info_t.last_rows_read) when that spares a fifth of the dense rows: a hit with
-such a k uploads and sweeps fewer rows (a cached `memo query` spends half of its wall clock on slice + upload).
+builds once its class's queries have made it worth the pass, memo_index_info_t.last_rows_read) when that spares a fifth of the
+dense rows: a hit with such a k uploads and sweeps fewer rows (a cached `memo query` spends half of its wall clock on slice +
+upload).  Round 5: the view is the one the device builds (memo_index_export_view), not a host-side rebuild.
 """
 import ctypes as C
 import json
@@ -101,40 +102,6 @@ def header_ok(head, file_bytes):
         return False
 
 
-def dense_view(p3, boff3, rows3, cap):
-    """the rows of exported dense groups (memo_index_export_dense; layout: memo_amd/csrc/memo_sweep.h, PackedRows3) whose 6-bit
-    overlap is below `cap`, as dense groups of their own with their own bucket table: (groups uint32[4 g], table int64, rows) --
-    what dense_filter builds on the device for a resident index.  None when that would spare less than a fifth of the rows."""
-    g = p3.reshape(-1, 4)
-    n = 5 * len(g)
-    B = np.empty(n, np.uint32)
-    A = np.empty(n, np.uint32)
-    hi = (g[:, 3] >> 16) & 0x1F              # X_3: the ninth annot bit of rows 0 .. 4 (indexes of 256 .. 511 genomes)
-    for j in range(4):                       # dword j = B_j | X_j << 16 | A_j << 24
-        B[j::5] = g[:, j] & 0xFFFF
-        A[j::5] = (g[:, j] >> 24) | (((hi >> j) & 1) << 8)
-    B[4::5] = ((g[:, 0] >> 16) & 0xFF) | (((g[:, 1] >> 16) & 0xFF) << 8)      # X_0 = B_4 & 255, X_1 = B_4 >> 8
-    A[4::5] = ((g[:, 2] >> 16) & 0xFF) | (((hi >> 4) & 1) << 8)               # X_2 = A_4
-    B, A = B[:rows3], A[:rows3]
-    keep = (B & 63) < cap
-    rows_v = int(keep.sum())
-    if rows_v * 5 > rows3 * 4:
-        return None
-    before = np.concatenate([np.zeros(1, np.int64), np.cumsum(keep, dtype=np.int64)])
-    table = before[boff3]                                                     # (entries are row numbers in [0, rows3])
-    pad = (-rows_v) % 5
-    Bv = np.concatenate([B[keep], np.full(pad, 63, np.uint32)])               # (rows behind the last one are never read by number)
-    Av = np.concatenate([A[keep], np.zeros(pad, np.uint32)])
-    out = np.empty((len(Bv) // 5, 4), np.uint32)
-    b4, a4 = Bv[4::5], Av[4::5]
-    hi = sum(((Av[j::5] >> 8) & 1) << j for j in range(5)).astype(np.uint32)
-    out[:, 0] = Bv[0::5] | ((b4 & 255) << 16) | ((Av[0::5] & 255) << 24)
-    out[:, 1] = Bv[1::5] | ((b4 >> 8) << 16) | ((Av[1::5] & 255) << 24)
-    out[:, 2] = Bv[2::5] | ((a4 & 255) << 16) | ((Av[2::5] & 255) << 24)
-    out[:, 3] = Bv[3::5] | (hi << 16) | ((Av[3::5] & 255) << 24)
-    return out.reshape(-1), table, rows_v
-
-
 def view_cap(k):
     """the cap of the k class of the dense rows (classes of two: overlaps below 2, 4 ... 32), or None when k has no class"""
     km1 = int(k) - 1
@@ -166,9 +133,15 @@ def write(in_file, record, ix, k=None):
     view, pv, boffv = None, np.empty(0, np.uint32), np.empty(0, np.int64)
     cap = view_cap(k) if k is not None else None
     if cap and rows3:
-        made = dense_view(p3, boff3, rows3, cap)
-        if made is not None:
-            pv, boffv, rows_v = made
+        # the k class's view as the DEVICE builds it (memo_index_prepare + memo_index_export_view: a few ms, and the rows' places
+        # inside their groups chosen against LDS bank conflicts) -- rounds 3-4 rebuilt it here with whole-chromosome NumPy
+        # temporaries, 30-40 bytes of host memory per row.  Groups of five rows: what memo_index_import_dense takes.
+        ix.set_option(4, 5)                           # MEMO_OPT_VIEW_ROWS
+        ix.prepare(k, int(min(max(inf["max_annot"] + 1, 2), 511)))
+        made = ix.export_view(k, 5)
+        ix.set_option(4, 0)
+        if made is not None and made[3] == cap:
+            pv, boffv, rows_v = made[0], made[1], made[2]
             view = {"cap": cap, "rows": rows_v}
     off_pk = HEADER_BYTES
     off_pa = _align(off_pk + pk.nbytes)

@@ -363,14 +363,14 @@ __global__ __launch_bounds__(256) void runs_pack_kernel(const V *in, int64_t n, 
     }
 }
 
+// one block of 32768 positions of one slice (shared by the kernel of one slice and the kernel of a whole gather step's slices)
 template <typename V>
-__global__ __launch_bounds__(256) void runs_unpack_kernel(const uint16_t *A, const uint8_t *B, const uint2 *table,
-                                                          unsigned int b_cap, int64_t n, V *out) {
+__device__ __forceinline__ void runs_unpack_block(const uint16_t *A, const uint8_t *B, const uint2 *table, unsigned int b_cap, int64_t n,
+                                                  V *out, int64_t block) {
     constexpr int VB = (int)sizeof(V), NW = 4 * VB;
     __shared__ __attribute__((aligned(16))) uint8_t vals[kRunsStaged];
     __shared__ int wave_sum[kRounds][4];
     const int tid = threadIdx.x, wv = tid >> 6;
-    const int64_t block = blockIdx.x;
     const uint2 ent = table[block];
     const unsigned int bytes = (ent.y * (unsigned int)VB + 3u) & ~3u;
     if ((uint64_t)ent.x + bytes > b_cap) return;  // this block did not fit on the sender's side (stats say so)
@@ -422,6 +422,31 @@ __global__ __launch_bounds__(256) void runs_unpack_kernel(const uint16_t *A, con
                 if (p0 + i < n) out[p0 + i] = VB == 1 ? (V)(q[i >> 2] >> (8 * (i & 3))) : (V)(q[i >> 1] >> (16 * (i & 1)));
         }
     }
+}
+
+template <typename V>
+__global__ __launch_bounds__(256) void runs_unpack_kernel(const uint16_t *A, const uint8_t *B, const uint2 *table,
+                                                          unsigned int b_cap, int64_t n, V *out) {
+    runs_unpack_block<V>(A, B, table, b_cap, n, out, (int64_t)blockIdx.x);
+}
+
+// the slices rank 0 received in one gather step, decoded by ONE launch: a slice of 2^25 positions is 1024 workgroups -- four
+// per CU, one short wave of them -- so seven launches one after the other cost seven launch-and-drain times (7 x 21-35 us on
+// BASELINE config 5, more than the 0.18 ms sweep of k = 21 beside them: profiles/r04_scaling_model_c5.txt); together they
+// fill the device once
+constexpr int kManySlices = 16;
+struct RunsMany {
+    const char *wire[kManySlices];
+    void *out[kManySlices];
+};
+
+template <typename V>
+__global__ __launch_bounds__(256) void runs_unpack_many_kernel(const RunsMany m, int64_t blocks, size_t t_off, size_t a_off, size_t b_off,
+                                                               unsigned int b_cap, int64_t n) {
+    const int64_t slice = (int64_t)blockIdx.x / blocks, block = (int64_t)blockIdx.x % blocks;
+    const char *w = m.wire[slice];
+    runs_unpack_block<V>(reinterpret_cast<const uint16_t *>(w + a_off), reinterpret_cast<const uint8_t *>(w + b_off),
+                         reinterpret_cast<const uint2 *>(w + t_off), b_cap, n, static_cast<V *>(m.out[slice]), block);
 }
 
 struct RunsLayout {
@@ -620,6 +645,37 @@ int memo_transport_runs16_pack_dev(const uint16_t *d_vec, int64_t n, uint32_t b_
 int memo_transport_runs16_unpack_dev(const void *d_wire, int64_t n, uint32_t b_capacity, uint16_t *d_vec, int32_t device,
                                      void *stream) {
     return runs_unpack<uint16_t>(d_wire, n, b_capacity, d_vec, device, stream);
+}
+
+// count slices of the same length and capacity (what one gather step brings to rank 0) -> count result vectors, one launch
+// (value_bytes 1: uint8 results, 2: uint16).  d_wires / d_vecs: HOST arrays of device pointers.
+int memo_transport_runs_unpack_many_dev(const void *const *d_wires, void *const *d_vecs, int32_t count, int64_t n, uint32_t b_capacity,
+                                        int32_t value_bytes, int32_t device, void *stream) {
+    if (count < 0 || (count > 0 && (!d_wires || !d_vecs)) || (value_bytes != 1 && value_bytes != 2))
+        return fail(MEMO_EINVAL, "bad transport arguments");
+    for (int32_t i = 0; i < count; ++i)
+        if (int rc = runs_check_args(d_vecs[i], d_wires[i], n, b_capacity, value_bytes)) return rc;
+    DeviceGuard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const RunsLayout l = runs_layout(n, b_capacity);
+    if (!l.blocks) return MEMO_OK;
+    for (int32_t at = 0; at < count; at += kManySlices) {
+        const int32_t now = count - at < kManySlices ? count - at : kManySlices;
+        if (l.blocks * now >= ((int64_t)1 << 31)) return fail(MEMO_EINVAL, "slices too long for one launch");
+        RunsMany m;
+        for (int32_t i = 0; i < kManySlices; ++i) {
+            m.wire[i] = static_cast<const char *>(d_wires[at + (i < now ? i : 0)]);
+            m.out[i] = d_vecs[at + (i < now ? i : 0)];
+        }
+        if (value_bytes == 1)
+            hipLaunchKernelGGL(runs_unpack_many_kernel<uint8_t>, dim3((unsigned)(l.blocks * now)), dim3(256), 0, st, m, l.blocks, l.t_off,
+                               l.a_off, l.b_off, b_capacity, n);
+        else
+            hipLaunchKernelGGL(runs_unpack_many_kernel<uint16_t>, dim3((unsigned)(l.blocks * now)), dim3(256), 0, st, m, l.blocks, l.t_off,
+                               l.a_off, l.b_off, b_capacity, n);
+        HIP_TRY(hipGetLastError());
+    }
+    return MEMO_OK;
 }
 
 // what the sender needed (host values; synchronises `stream`): B bytes taken against the B region's capacity.

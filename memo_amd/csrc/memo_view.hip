@@ -296,24 +296,28 @@ struct ViewLds {
     uint8_t *bm2;
 };
 
-// source rows [r_lo, r_hi) -> their kept rows, in source order, at stage[at ...]; returns how many
+// source rows [r_lo, r_hi) -> their kept rows, in source order, at stage[at ...]; returns how many.
+// U 16-byte loads per lane in flight, and the next U requested before these are used (the wave has the registers: its
+// occupancy is set by its LDS, so nothing else hides HBM's latency).
 __device__ __forceinline__ uint32_t view_load_compact(const ViewArgs &a, const ViewLds &L, uint64_t r_lo, uint64_t r_hi, uint32_t at,
                                                       int lane) {
     const uint64_t g_lo = r_lo / 5, g_hi = (r_hi + 4) / 5;
+    constexpr int U = 8;
     uint32_t n = at;
-    constexpr int U = 8;  // 16-byte loads in flight per lane (the wave has the registers: its occupancy is set by its LDS)
-    for (uint64_t g0 = g_lo; g0 < g_hi; g0 += 64 * U) {
-        uint4 V[U];
+    uint4 V[U], W[U];
+    auto request = [&](uint4 (&R)[U], uint64_t g0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint64_t g = g0 + (uint64_t)(64 * u + lane);
-            V[u] = g < g_hi ? a.src[g] : make_uint4(63u, 63u, 63u, 63u);
+            R[u] = g < g_hi ? a.src[g] : make_uint4(63u, 63u, 63u, 63u);
         }
+    };
+    auto compact = [&](const uint4 (&R)[U], uint64_t g0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint64_t g = g0 + (uint64_t)(64 * u + lane);
             if (g0 + (uint64_t)(64 * u) >= g_hi) break;  // (wave-uniform)
-            uint32_t m = g < g_hi ? group_keep(V[u], g, a.rows, a.cap) : 0u;
+            uint32_t m = g < g_hi ? group_keep(R[u], g, a.rows, a.cap) : 0u;
             const uint64_t r = 5 * g;  // rows of the group outside [r_lo, r_hi): the first and the last group of the range
             if (r < r_lo) m &= ~((1u << (uint32_t)(r_lo - r)) - 1u);
             if (r + 5 > r_hi) m &= r >= r_hi ? 0u : (1u << (uint32_t)(r_hi - r)) - 1u;
@@ -322,17 +326,25 @@ __device__ __forceinline__ uint32_t view_load_compact(const ViewArgs &a, const V
             uint32_t idx = n + lanes_below(b0) + lanes_below(b1) + lanes_below(b2) + lanes_below(b3) + lanes_below(b4);
             // (no branches: a row that goes is stored to a slot nobody reads -- plain stores of many lanes to one address cost one)
             constexpr uint32_t kNowhere = kViewCap + 7;
-            L.stage[(m & 1u) ? idx : kNowhere] = group_row<0>(V[u]);
+            L.stage[(m & 1u) ? idx : kNowhere] = group_row<0>(R[u]);
             idx += m & 1u;
-            L.stage[(m & 2u) ? idx : kNowhere] = group_row<1>(V[u]);
+            L.stage[(m & 2u) ? idx : kNowhere] = group_row<1>(R[u]);
             idx += (m >> 1) & 1u;
-            L.stage[(m & 4u) ? idx : kNowhere] = group_row<2>(V[u]);
+            L.stage[(m & 4u) ? idx : kNowhere] = group_row<2>(R[u]);
             idx += (m >> 2) & 1u;
-            L.stage[(m & 8u) ? idx : kNowhere] = group_row<3>(V[u]);
+            L.stage[(m & 8u) ? idx : kNowhere] = group_row<3>(R[u]);
             idx += (m >> 3) & 1u;
-            L.stage[(m & 16u) ? idx : kNowhere] = group_row<4>(V[u]);
+            L.stage[(m & 16u) ? idx : kNowhere] = group_row<4>(R[u]);
             n += (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3) + __popcll(b4));
         }
+    };
+    request(V, g_lo);
+    for (uint64_t g0 = g_lo; g0 < g_hi; g0 += 2 * 64 * U) {
+        if (g0 + 64 * U < g_hi) request(W, g0 + 64 * U);
+        compact(V, g0);
+        if (g0 + 64 * U >= g_hi) break;
+        if (g0 + 2 * 64 * U < g_hi) request(V, g0 + 2 * 64 * U);
+        compact(W, g0 + 64 * U);
     }
     return n - at;
 }

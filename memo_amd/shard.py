@@ -69,18 +69,21 @@ def sharded_query(sweep, qs, qe, k, rank, world, dist, alloc, dst=0, root_weight
 XGMI_LINK_BYTES_PER_S = 75e9   # one direction of one xGMI link (7 links x ~153 GB/s per GPU, both directions summed)
 
 
-def modelled_step(world, t_sweep, wire_bytes, t_decode, t_encode, link=XGMI_LINK_BYTES_PER_S, root_weight=1.0):
+def modelled_step(world, t_sweep, wire_bytes, t_decode, t_encode, t_decode_all=None, link=XGMI_LINK_BYTES_PER_S, root_weight=1.0):
     """seconds per step when every peer's slice goes to rank 0 coded: the slowest of a peer (sweep +
     encode), rank 0 (its own sweep of `root_weight` of a share + decoding the world - 1 slices it received;
     its own slice never travels) and a peer's link to rank 0 (each peer has its own; gather i overlaps
-    sweep i + 1)."""
+    sweep i + 1).  t_decode: one slice by a launch of its own; t_decode_all: the world - 1 slices of a step by ONE
+    launch (memo_transport_runs_unpack_many_dev), where the coding has that form."""
     if world == 1:
         return t_sweep
-    return max(t_sweep + t_encode, root_weight * t_sweep + (world - 1) * t_decode, wire_bytes / link)
+    decode = t_decode_all if t_decode_all is not None else (world - 1) * t_decode
+    return max(t_sweep + t_encode, root_weight * t_sweep + decode, wire_bytes / link)
 
 
 def pick_coding(world, t_sweep, usable, link=XGMI_LINK_BYTES_PER_S):
-    """usable: coding name -> (wire bytes, decode seconds per slice, encode seconds).  Returns the name
+    """usable: coding name -> (wire bytes, decode seconds per slice, encode seconds[, seconds to decode the world - 1 slices of a
+    step in one launch]).  Returns the name
     with the shortest modelled step (ties: alphabetical, so that every rank would agree) and the model."""
     model = {c: modelled_step(world, t_sweep, *usable[c], link=link) for c in usable}
     return min(sorted(model), key=model.get), model

@@ -1658,28 +1658,32 @@ def test_queries_of_one_index_on_several_streams(memo, oracle):
 @pytest.mark.parametrize("n_ranks,workload,extra", [(2, "c3", []), (3, "c2", []), (2, "c2", ["--plain-gather"]),
                                                      (2, "c4", []), (2, "c3", ["--root-weight", "0.3"]),
                                                      (2, "c5", []), (2, "c5", ["--k", "21"]), (2, "c5", ["--plain-gather"]),
-                                                     (2, "c5", ["--k", "101", "--coding", "runs"])])
+                                                     (2, "c5", ["--k", "101", "--coding", "runs"]),
+                                                     (8, "c5", ["--k", "21"]), (8, "c3", [])])
 def test_bench_two_ranks_on_one_gpu(n_ranks, workload, extra):
     """`python bench.py --gpus N` as the driver spells it, with N > 1 RANKS for the first time on this pool's one-GPU boxes:
     RCCL refuses two ranks on a device, so the ranks share GPU 0 (MEMO_BENCH_ONE_DEVICE=1) and gloo carries the bytes through
     host memory (MEMO_BENCH_BACKEND=gloo; bench.py marks the line "test_transport").  Everything else is the N > 1 path as
     an 8-GPU node runs it: self-launch through torch.distributed.run, link probe, coding choice from the ranks' statistics,
     root weight, double-buffered send / receive per step, decode on rank 0, the gathered slice of the last rank against the
-    oracle, every slice complete, one JSON line."""
+    oracle, every slice complete, one JSON line.  Round 5: the same with EIGHT ranks -- what the first contact with an 8-GPU node runs:
+    seven receives and ONE decode launch for seven slices per step (memo_transport_runs_unpack_many_dev), a root weight chosen for
+    seven peers; eight config-5 shards on the dense rows share the one GPU (they build their indexes one after the other)."""
     import json
     import subprocess
     import sys
+    steps, warm = ("2", "1") if n_ranks > 3 else ("4", "2")
     env = dict(os.environ, MEMO_BENCH_ONE_DEVICE="1", MEMO_BENCH_BACKEND="gloo", MEMO_BENCH_ASSUME_DEVICES=str(n_ranks))
     for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(v, None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n_ranks), "--steps", "4", "--warmup", "2",
-                        "--workload", workload] + extra, capture_output=True, text=True, env=env, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n_ranks), "--steps", steps, "--warmup", warm,
+                        "--workload", workload] + extra, capture_output=True, text=True, env=env, timeout=1800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == n_ranks and j["steps"] == 4 and j["scaling"] == "weak" and "test_transport" in j
+    assert j["n_gpus"] == n_ranks and j["steps"] == int(steps) and j["scaling"] == "weak" and "test_transport" in j
     assert j["ranks_seen"]["world_size"] == n_ranks and len(j["ranks_seen"]["ranks"]) == n_ranks
     assert j["gather_parity_sample"]["equal_to_oracle"] is True and j["gather_parity_sample"]["rank"] == n_ranks - 1
     assert j["gather_parity_sample"].get("every_slice_complete", True) is True
@@ -1694,6 +1698,11 @@ def test_bench_two_ranks_on_one_gpu(n_ranks, workload, extra):
             assert set(cands) == {"plain", "runs"} and cands["runs"]["wire_bytes"] < 0.3 * cands["plain"]["wire_bytes"]
             if "--coding" in extra:
                 assert j["config"]["gather_coding_choice"]["picked"] == "runs" and "2 byte(s) per change" in j["config"]["gather_payload"]
+    if n_ranks == 8:          # all seven peers' slices were received and decoded, and the choice was made for seven peers
+        choice = j["config"]["gather_coding_choice"]
+        assert choice["candidates"]["runs"]["decode_ms_all_slices_one_launch"] is not None
+        assert choice["picked"] == "runs" or workload == "c3", choice["picked"]
+        assert 0 < choice["root_weight"] <= 1 and len({r["rank"] for r in j["ranks_seen"]["ranks"]}) == 8
 
 
 def test_no_room_on_the_device_for_views_and_tile_tables(memo, oracle, ab):
@@ -2373,6 +2382,39 @@ def test_transport_runs_coding_round_trip(memo, oracle):
     assert size < 0.26 * length, size                                             # < 2.1 bits per position on the wire
     with pytest.raises(memo.MemoError):
         _lib.check(L.memo_transport_runs_pack_dev(1, 100, 6, 16, 0, None))       # capacity not a multiple of 4
+
+
+def test_transport_runs_many_slices_one_launch(memo):
+    """memo_transport_runs_unpack_many_dev: the slices of one gather step (as rank 0 receives them from its peers: same length,
+    same capacity) decoded by ONE launch -- 1, 7 and 19 slices (more than one launch's 16), uint8 and uint16 values, lengths on
+    and off the coding's 32768-position blocks; equal to decoding every slice by itself"""
+    import ctypes as C
+    import torch
+    from memo_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(29)
+    for vb, pack_fn, dt in ((1, L.memo_transport_runs_pack_dev, np.uint8), (2, L.memo_transport_runs16_pack_dev, np.uint16)):
+        for n in (1, 4097, 32768, 100_001, 1_000_003):
+            for count in (1, 7, 19):
+                b_cap = (n * vb + 4 * (n // 32768 + 1) + 3) & ~3
+                vals = [np.repeat(rng.integers(1, 60000 if vb == 2 else 250, n // 5 + 1), rng.integers(1, 10, n // 5 + 1))[:n] for _ in range(count)]
+                vals = [np.resize(v, n).astype(dt) for v in vals]
+                srcs = [torch.from_numpy(v.view(np.int16 if vb == 2 else np.uint8)).cuda() for v in vals]
+                wires = [torch.zeros(L.memo_transport_runs_bytes(n, b_cap), dtype=torch.uint8, device="cuda") for _ in range(count)]
+                outs = [torch.full((n + 16,), 7, dtype=torch.int16 if vb == 2 else torch.uint8, device="cuda") for _ in range(count)]
+                for s_, w_ in zip(srcs, wires):
+                    _lib.check(pack_fn(s_.data_ptr(), n, b_cap, w_.data_ptr(), 0, None))
+                ws = (C.c_void_p * count)(*[w_.data_ptr() for w_ in wires])
+                os_ = (C.c_void_p * count)(*[o_.data_ptr() for o_ in outs])
+                _lib.check(L.memo_transport_runs_unpack_many_dev(ws, os_, count, n, b_cap, vb, 0, None))
+                torch.cuda.synchronize()
+                for i in range(count):
+                    got = outs[i][:n].cpu().numpy().view(dt)
+                    assert np.array_equal(got, vals[i]), (vb, n, count, i)
+                    assert int(outs[i][n]) == 7                                      # nothing written behind a slice
+    assert L.memo_transport_runs_unpack_many_dev(None, None, 0, 100, 400, 1, 0, None) == 0
+    assert L.memo_transport_runs_unpack_many_dev(None, None, 2, 100, 400, 1, 0, None) == _lib.MEMO_EINVAL
+    assert L.memo_transport_runs_unpack_many_dev(None, None, 0, 100, 400, 3, 0, None) == _lib.MEMO_EINVAL
 
 
 def test_transport_runs16_coding_round_trip(memo, oracle):

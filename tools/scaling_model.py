@@ -22,6 +22,8 @@ ap.add_argument("--link-GBs", type=float, default=75.0, help="one direction of o
 ap.add_argument("--nibble", default="53101352,0.031,0.108", help="wire bytes, decode ms per slice, encode ms")
 ap.add_argument("--dense", default="41250080,0.058,0.153")
 ap.add_argument("--runs", default="23046320,0.036,0.064")
+ap.add_argument("--runs-many", default="", help="ms to decode 1, 3 and 7 slices of the runs coding with ONE launch (memo_transport_runs_unpack_many_dev), "
+                                                "comma-separated; empty: world - 1 launches of the single-slice decode")
 ap.add_argument("--value-bytes", type=int, default=1, help="bytes per result value as plain bytes (2: more than 255 genomes, config 5)")
 ap.add_argument("--only", default="", help="comma-separated codings to consider besides plain (config 5: runs)")
 a = ap.parse_args()
@@ -40,7 +42,8 @@ for world in (2, 4, 8):
     for w in shard.ROOT_WEIGHTS + (0.0,):
         for name, (wire, dec, enc) in codings.items():
             peer = sweep + enc
-            root = w * sweep + (world - 1) * dec
+            many = [float(x) * 1e-3 for x in a.runs_many.split(",")] if (a.runs_many and name == "runs") else None
+            root = w * sweep + (many[{2: 0, 4: 1, 8: 2}[world]] if many else (world - 1) * dec)
             wire_t = wire / link
             step = max(peer, root, wire_t)
             total = (world - 1 + w) * a.L / step
