@@ -899,8 +899,9 @@ def main():
             key = f"{args.workload}_{args.rows}" if host_rows is None else \
                 f"{os.path.basename(os.path.dirname(os.path.abspath(args.rows_file)))}_{'memb' if membership else 'cons'}_k{k}_{args.rows}"
             tj = json.load(open(prof)).get(key)
-            if tj and tj.get("result_bytes_per_position", b_out) == b_out and \
-                    abs(tj.get("algorithmic_bytes", b_alg) - b_alg) <= 0.01 * b_alg:   # same kernel instantiation, same rows read
+            if tj and tj.get("result_bytes_per_position") == b_out and tj.get("algorithmic_bytes") is not None and \
+                    abs(tj["algorithmic_bytes"] - b_alg) <= 0.01 * b_alg:   # same kernel instantiation, same rows read (an entry that
+                                                                            # does not say what it measured matches nothing)
                 res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
                 res["roofline"]["traffic_source"] = (
                     "profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
@@ -935,6 +936,37 @@ def main():
                             "view_amortised_after_queries whole-window queries of the class: until then this -- the same kernel on all the "
                             "rows of the same format, also what every query of an index that answers one gets: the one-shot forms, `memo "
                             "query`), then the same view with its rows placed (places_build_ms, places_amortised_after_queries)"}
+        if world == 1 and args.cpu_sample > 0 and others and "wide" in indexes and host_rows is None and not membership:
+            # THE REFERENCE'S SEAM (memo_query.py:103-105: memo_init + memo_query + the argmax of print_res): memo_conservation --
+            # three host int64 columns in, a host uint16 result out; what a maintainer who applies INTEGRATION.md section 2 gets.
+            # PCIe and the host's packing pass inclusive: never `value`.  The columns come back from the resident int64 index
+            # (12 GB for config 3); three calls, the first pays the pinned ring and the worker pool.
+            try:
+                ds, de, do = indexes["wide"].columns()
+                cols = [np.empty(rows, np.int64) for _ in range(3)]
+                for h_, d_ in zip(cols, (ds, de, do)):
+                    _lib.check(lib.memo_dev_download(local, h_.ctypes.data, d_, h_.nbytes, None))
+                ms_seam, seam = [], None
+                for _ in range(3):
+                    t_s = time.perf_counter()
+                    seam = memo_amd.conservation(cols[0], cols[1], cols[2], qs, qe, k, num_docs, device=local)
+                    ms_seam.append((time.perf_counter() - t_s) * 1e3)
+                got = out.cpu().numpy()
+                same = bool(np.array_equal(seam, got.view(np.uint8).astype(np.uint16) if narrow else got.view(np.uint16)))
+                from memo_amd.index import dense_rows_can_answer
+                dense_in = dense_rows_can_answer(rows, int(cols[0][0]), int(cols[0][-1]), 0, k, num_docs, False)
+                res["one_shot_seam"] = {
+                    "what": "memo_conservation (include/memo_amd.h): host int64 columns in, host uint16 result out -- the three calls "
+                            "memo_query.py:103-105 make; rows packed on the host into pinned memory, PCIe, sweep, result back; the "
+                            "index is built and destroyed inside the call",
+                    "ms": float(min(ms_seam[1:])), "ms_calls": [float(x) for x in ms_seam], "value": L / (min(ms_seam[1:]) * 1e-3),
+                    "unit": "query-positions/s", "rows": rows, "host_bytes_in": 24 * rows, "host_bytes_out": 2 * L,
+                    "way_in": ("host packer -> dense rows (3.2 B per row over PCIe)" if dense_in else "host packer -> 4-byte words"),
+                    "host_threads": int(os.environ.get("MEMO_HOST_THREADS", min(os.cpu_count() or 1, 32))),
+                    "host_cpus_visible": os.cpu_count(), "parity": same}
+                del cols, seam
+            except Exception as exc:                         # (the seam's line must not cost the run its headline)
+                res["one_shot_seam"] = {"error": repr(exc)}
         if world == 1 and args.cpu_sample > 0:
             def gpu_slice(S):
                 h = out[:S].cpu().numpy()

@@ -21,12 +21,11 @@ extern "C" {
  * row_source: 0 = the library's choice (conservation: the dense rows where they are resident and can answer,
  *   else the 4- / 6-byte rows, else the int64 columns), 1 = the int64 columns even when packed rows exist,
  *   2 = same as 0 (kept for older scripts), 3 = the 4- / 6-byte rows even where the dense rows could answer,
- *   4 = the dense rows swept by PERSISTENT workgroups with their rows streamed by LDS-DMA (memo_sweep_cons3p.hip)
- *   wherever the query fits that kernel, 5 = the dense rows with one workgroup per tile, 6 / 7 = persistent workgroups
- *   whose rows go into registers at the head of a tile / one tile ahead, 8 = the dense rows with one workgroup per
- *   tile that reads its row slice from the index's tile table (memo_sweep_cons3t.hip); 4 .. 7 read all the dense rows,
+ *   5 = the dense rows with one workgroup per tile, every wave working its tile out (round 2's kernel: what a negative window start
+ *   or a device without room for a tile table gets), 8 = the dense rows with one workgroup per tile that reads its row slice from the
+ *   index's tile table (memo_sweep_cons3t.hip); 5 reads all the dense rows,
  *   0 and 8 the k-class view of them where one pays (memo_index_info_t.last_rows_read), 9 = as 0 without views, 10 = as 5
- *   with views, 11 / 12 = as 6 / 7 with views, 13 = as 0 with the "this row writes" test kept in the row blocks even where the
+ *   with views, 13 = as 0 with the "this row writes" test kept in the row blocks even where the
  *   view holds exactly the rows that write (cap = k - 1; round 4);
  * scatter (conservation, packed rows): 1 = clip every interval to the tile, 2 = unclipped into doubling
  *   level arrays with a halo, 3 = unclipped into radix-4 level arrays, 4 = unclipped into mixed level arrays
@@ -44,19 +43,15 @@ int memo_debug_row_order(memo_index_t *ix, int32_t order);
  * bench.py times the same index with and without); 0 = back to the library's choice.  (The product switch is
  * memo_index_set_option(MEMO_OPT_VIEWS), which also drops the views.) */
 int memo_debug_no_views(memo_index_t *ix, int32_t on);
-/* this THREAD's later builds of a dense k-class view: 0 = the rows keep the order the filter leaves them in, 1 (the default) = the
- * place of a row inside its 16-byte group is chosen against LDS bank conflicts (memo_interleave.hip: colour_view_kernel), 2 = the
- * same with the groups ended at bucket boundaries (aligned_view_kernel<5>: places a bucket leaves empty hold a copy of one of its rows;
- * measured level with 1, kept for A/B).  Results never depend on it. */
+/* this THREAD's later builds of a dense k-class view: 0 = the rows keep the order they come in, whoever asks; 1 (the default) = the place
+ * of a row inside its 16-byte group may be chosen against LDS bank conflicts (memo_view.hip: view_place_bucket; MEMO_OPT_VIEW_PLACES of
+ * the index decides).  Results never depend on it. */
 int memo_debug_view_colouring(int32_t on);
 /* this THREAD's later conservation queries on dense rows: which kind of k-class view they build and read where views of SIX rows per
  * group apply (k - 1 <= 31, up to 255 genomes, buckets of 32 positions; memo_view.hip; info.last_variant 3): 1 = six wherever they apply,
  * 0 = five always, -1 (the default) = the library's choice (MEMO_OPT_VIEW_ROWS of the index, else six where the view holds enough rows
  * per bucket for the padding of every bucket to whole groups not to matter). */
 int memo_debug_six_views(int32_t on);
-/* this THREAD's later builds of a dense k-class view: 1 = round 4's builder (keep bits, scatter, places chosen by one lane per bucket,
- * packing: five kernels), 0 (the default) = count, scan and one fused pass (memo_view.hip).  The two write the same bytes. */
-int memo_debug_view_builder(int32_t legacy);
 /* this THREAD's later calls: every device allocation for a view or a tile table fails (the test of the no-memory path) */
 int memo_debug_fail_side_allocations(int32_t on);
 /* this thread's later memo_index_pack_dense / dense builders keep the rows that can never write at k <= 64 in the dense rows */

@@ -134,7 +134,6 @@ DEBUG_SYMBOLS = {
     "memo_debug_no_views": (C.c_int, [_P, _I32]),
     "memo_debug_view_colouring": (C.c_int, [_I32]),
     "memo_debug_six_views": (C.c_int, [_I32]),
-    "memo_debug_view_builder": (C.c_int, [_I32]),
     "memo_debug_fail_side_allocations": (C.c_int, [_I32]),
     "memo_debug_dense_keep_all": (C.c_int, [_I32]),
     "memo_debug_one_shot_way": (C.c_int, [_I32]),

@@ -69,9 +69,8 @@ struct memo_tuning {
     int force_wide = 0;  // 1 = read the int64 columns even when packed rows exist
     int scatter = 0;     // conservation, packed rows: 1 = clipped, 2 = unclipped + halo
     int persistent = 0;  // dense rows: 0 = the library's choice, 5 = the table-driven kernel (sweep_conservation_halo3t_kernel),
-                         //   1 = every wave works its tile out by itself (sweep_conservation_halo3_kernel),
-                         //   2 / 3 / 4 = persistent workgroups (sweep_conservation_halo3p_kernel) wherever the query fits: rows by
-                         //   LDS-DMA / into registers at the head of a tile / into registers one tile ahead
+                         //   1 = every wave works its tile out by itself (sweep_conservation_halo3_kernel)
+                         //   (the name is round 3's: 2 / 3 / 4 were persistent workgroups -- profiles/r03_persistent_sweep.txt: 17 - 50 % slower)
     int no_views = 0;    // dense rows: 1 = never read a k-class view (A/B)
     int no_all_write = 0;  // dense rows: 1 = the row blocks keep their "this row writes" test on a view of exactly the writing rows (A/B)
     int force_packed = 0;  // 1 = read the 4-byte rows even when the dense rows are resident and could answer (they are
@@ -190,7 +189,7 @@ struct memo_index {
     uint64_t retired_bytes = 0;
     int last_sweep = 0;          // level arrays of the last conservation sweep (memo_index_info_t.last_sweep)
     int last_arrays = 0;         // mixed level arrays (last_sweep 4): how many of them the sweep's level plan allocated
-    int last_variant = 0;        // ... 1 when it ran as persistent workgroups (memo_sweep_cons3p.hip), 2 table-driven (memo_sweep_cons3t.hip)
+    int last_variant = 0;        // ... 2 table-driven on five-row groups (memo_sweep_cons3t.hip), 3 on a view of six rows per group; 0 no table
     int has_wide = 1;          // the three int64 columns are still resident
     // rows with end < start (never written by the reference's index builder, but legal input to
     // memo_query.py): copied aside at finalize and applied by long_rows_kernel after each sweep
@@ -213,9 +212,6 @@ int dense_compact(memo_index *ix);     // memo_index.hip: leave the rows that ca
 int dense_rows_for(memo_index *ix, int km1, int64_t window, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows,
                    int *view_cap = nullptr, bool allow_six = false, int *rpg = nullptr);
 extern thread_local int g_six_views;  // (AB library, memo_debug_six_views: -1 the library's choice, 0 five rows per group always, 1 six wherever they apply)
-void aligned_group_counts(const int64_t *boff, uint64_t nb, uint32_t *count, int rpg, hipStream_t st);
-void aligned_view_fill(const uint32_t *words, const int64_t *boff, const uint32_t *glocal, const uint64_t *gblock, uint64_t nb, int64_t bbase,
-                   int km1, int f12, uint32_t *groups, int64_t *boff6, int rpg, int colour, hipStream_t st);
 constexpr int kNoRoom = 1;  // (internal) the device has no memory for a view / tile table: run without it
 constexpr size_t kMaxTileTables = 64;
 void retire(memo_index *ix, void *p, uint64_t bytes);  // memo_index.hip: out of service now, freed once the device has drained
@@ -234,9 +230,7 @@ void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables der
 // memo_interleave.hip: reorder the 4-byte rows inside every bucket (mode 0: start order, 1: chunks of four dealt round-robin
 // over the bucket's starts, 2: the same with the rows of a start ordered by overlap mod 32), in place, queued on st
 int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshift, int fmt, int mode, hipStream_t st);
-int colour_view_words(uint32_t *words, const int64_t *boff, uint64_t nb, int km1, int f12, hipStream_t st);  // (memo_interleave.hip)
-extern thread_local int g_view_builder;  // (AB library, memo_debug_view_builder: 1 = round 4's five-kernel view builder, kept one round for the bit-for-bit check)
-extern thread_local int g_view_colouring;  // 1: the dense rows' k-class views get their rows' places inside a group chosen against bank conflicts (memo_debug_view_colouring of the AB library turns it off)
+extern thread_local int g_view_colouring;  // 1: the dense rows' k-class views may get their rows' places inside a group chosen against bank conflicts (memo_debug_view_colouring of the AB library turns it off)
 constexpr int kRowOrderDefault = 2;  // interleave_words mode the product applies wherever 4-byte rows come into being
 int order_words_now(memo_index *ix, int mode);  // memo_index.hip: waits for the device, orders ix->pk in place, waits again
 inline int row_order_mode(const memo_index *ix) { return ix->tune.row_order ? ix->tune.row_order - 1 : kRowOrderDefault; }

@@ -37,11 +37,11 @@ int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32
     if (waves != 0 && waves != 1 && waves != 4 && waves != 8) return fail(MEMO_EINVAL, "waves must be 0, 1, 4 or 8");
     if (membership_algo != 0 && (membership_algo < 2 || membership_algo > 4))
         return fail(MEMO_EINVAL, "membership_algo must be 0 (choose), 2 (doubling), 3 (runs) or 4 (planes)");
-    if (row_source < 0 || row_source > 13)
+    if (row_source < 0 || row_source > 13 || row_source == 4 || row_source == 6 || row_source == 7 || row_source == 11 || row_source == 12)
         return fail(MEMO_EINVAL, "row_source must be 0 (library's choice: dense rows where they are resident and can answer, else "
-                                 "the 4- / 6-byte rows, else the int64 columns), 1 (int64 columns), 2 (same as 0) or 3 (4- / 6-byte "
-                                 "rows even where the dense rows could answer), 4 (dense rows swept by persistent workgroups with LDS-DMA where the "
-                                 "query fits), 5 (dense rows, one workgroup per tile) or 6 .. 13 (include/memo_amd_debug.h)");
+                                 "the 4- / 6-byte rows, else the int64 columns), 1 (int64 columns), 2 (same as 0), 3 (4- / 6-byte "
+                                 "rows even where the dense rows could answer), 5 (dense rows, every wave works its tile out), 8, 9, 10 or 13 "
+                                 "(include/memo_amd_debug.h; 4, 6, 7, 11, 12 were round 3's persistent sweeps: profiles/r03_persistent_sweep.txt)");
     if (scatter < 0 || scatter > 5)
         return fail(MEMO_EINVAL, "scatter must be 0 (choose), 1 (clipped), 2 (unclipped, doubling levels), 3 (unclipped, radix-4 levels) "
                                  "4 (unclipped, mixed levels, every array) or 5 (mixed levels, the arrays of the library's level plan)");
@@ -50,8 +50,8 @@ int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32
     ix->tune.memb_algo = membership_algo;
     ix->tune.force_wide = row_source == 1;
     ix->tune.force_packed = row_source == 3;
-    ix->tune.persistent = row_source == 4 ? 2 : row_source == 5 || row_source == 10 ? 1 : row_source == 6 || row_source == 11 ? 3 : row_source == 7 || row_source == 12 ? 4 : row_source == 8 ? 5 : 0;
-    ix->tune.no_views = row_source == 9 || row_source == 5 || (row_source >= 4 && row_source <= 7);
+    ix->tune.persistent = row_source == 5 || row_source == 10 ? 1 : row_source == 8 ? 5 : 0;
+    ix->tune.no_views = row_source == 9 || row_source == 5;
     ix->tune.no_all_write = row_source == 13;
     ix->tune.scatter = scatter;
     return MEMO_OK;
@@ -73,12 +73,7 @@ int memo_debug_no_views(memo_index_t *ix, int32_t on) {
 }
 
 int memo_debug_view_colouring(int32_t on) {  // (views already built keep the order they have)
-    g_view_colouring = on == 2 ? 2 : (on ? 1 : 0);  // (2: rows placed AND groups ended at bucket boundaries: an experiment that bought nothing)
-    return MEMO_OK;
-}
-
-int memo_debug_view_builder(int32_t legacy) {
-    g_view_builder = legacy ? 1 : 0;
+    g_view_colouring = on ? 1 : 0;
     return MEMO_OK;
 }
 

@@ -290,298 +290,57 @@ __device__ __forceinline__ void block_bucket(uint32_t *__restrict__ words, int64
 // chunks of four dealt over the 32 classes of annot mod 32, the rows of a class by their end (then annot, start): a membership
 // sweep's ds_or goes to plane row `annot` (odd pitch: 32 consecutive residues are 32 banks) at the word of the run's first
 // bit, end - (k - 1), so the 32 lanes of a half-wave -- 32 residues, ends of one quantile of the bucket -- hit 32 banks
-__global__ __launch_bounds__(256) void interleave_buckets_kernel(uint32_t *__restrict__ words, const int64_t *__restrict__ boff,
-                                                                 int64_t nbuckets, int bshift, int fmt12, int mode) {
-    __shared__ uint32_t key[kMaxBucketRows];
-    __shared__ uint32_t first[4][256], cnt[4][256];  // (block path: first[0] / cnt[0]; wave path: 32 entries of each wave's)
+//
+// Two kernels share a launch's buckets, four at a time ("a turn"): the turns whose four buckets are small (<= 256 rows each,
+// buckets of 32 positions: every index of up to ~8 rows per position) go to interleave_small_kernel -- a bucket per WAVE, 3.3 KiB
+// of LDS per wave, so that a CU holds 32 waves of them -- and all the others to interleave_large_kernel, a bucket per workgroup
+// with 32 KiB of keys.  (Round 4 had one kernel with the large one's LDS: 12 waves per CU; the pass waits on LDS round trips
+// and dependent steps, and BASELINE config 3's 3.1 * 10^6 buckets took 6.1 ms.)  Each kernel skips the other's turns.
+__device__ __forceinline__ bool small_turn(const int64_t (&r)[5], int bshift) {
+    int64_t longest = 0;
+    for (int j = 0; j < 4; ++j) longest = r[j + 1] - r[j] > longest ? r[j + 1] - r[j] : longest;
+    return bshift == 5 && longest <= kWaveRows;
+}
+
+__global__ __launch_bounds__(256) void interleave_small_kernel(uint32_t *__restrict__ words, const int64_t *__restrict__ boff,
+                                                               int64_t nbuckets, int bshift, int fmt12, int mode) {
+    __shared__ uint32_t key[4][kWaveRows];
+    __shared__ uint32_t first[4][32], cnt[4][32];
     __shared__ uint32_t table[4][kWaveQ * 32];
-    __shared__ uint32_t shared_high;
     KeyCodec C;
     C.fmt12 = fmt12;
     C.mode = mode;
     C.bshift = bshift;
     C.cshift = mode == 3 ? 26 : 20;
     const int wave = threadIdx.x >> 6;
-    // four buckets per workgroup and turn: one per wave when all four are small, else one after the other by everybody
     for (int64_t b0 = 4 * (int64_t)blockIdx.x; b0 < nbuckets; b0 += 4 * (int64_t)gridDim.x) {
         int64_t r[5];
         for (int j = 0; j < 5; ++j) r[j] = boff[b0 + j < nbuckets ? b0 + j : nbuckets];
-        int64_t longest = 0;
-        for (int j = 0; j < 4; ++j) longest = r[j + 1] - r[j] > longest ? r[j + 1] - r[j] : longest;
-        if (bshift == 5 && longest <= kWaveRows) {
-            const int64_t R = r[wave + 1] - r[wave];
-            if (R >= 2) wave_bucket(words, r[wave], (int)R, C, key + 256 * wave, first[wave], cnt[wave], table[wave]);
-        } else {
-            for (int j = 0; j < 4; ++j) {
-                const int64_t R = r[j + 1] - r[j];
-                if (R >= 2 && R <= kMaxBucketRows) block_bucket(words, r[j], (int)R, C, key, first[0], cnt[0], &shared_high);
-            }
-        }
-        __syncthreads();  // (a turn that took the wave path may be followed by one that takes the block path)
+        if (!small_turn(r, bshift)) continue;  // (workgroup-uniform; the waves never meet at a barrier here)
+        const int64_t R = r[wave + 1] - r[wave];
+        if (R >= 2) wave_bucket(words, r[wave], (int)R, C, key[wave], first[wave], cnt[wave], table[wave]);
     }
 }
 
-
-// ---- the dense rows' k-class views: which of a group's five places a row takes --------------------------------------
-// The dense-row sweep (memo_sweep_dense.h: group_rows) gives a lane one 16-byte GROUP of five rows, and a wave's i-th row
-// instruction visits place i of 64 consecutive groups: the 32 rows of a half-wave are the rows 5 g + i of 32 consecutive
-// groups.  A row's two ds_min go to cell A = start - (k - 1) + overlap (first block) and cell B = start - 2^level (second
-// block) of its level's array (arrays are a multiple of 32 cells apart), and a half-wave's 32 atomics cost max(2, lanes on
-// the fullest of the 32 banks) cycles (profiles/r04_lds_atomics.txt).  What the k = 31 filter leaves of an interleaved
-// bucket costs 4.3 + 3.4 cycles per row instruction and half-wave by that model (both blocks near random), 2 + 2 being
-// the floor.  The order built here, per bucket of a view (one LANE per bucket: ~80 rows of BASELINE config 3):
-//   * the rows are taken in the order of A mod 32 (a counting sort) and given one of five COLOURS -- the place i = row
-//     number mod 5 -- greedily: the colour that has no row of the same A mod 32 yet, nor of the same B mod 32 (weights:
-//     a second row on a bank is free, a third is not), and room left (a colour has as many rows as the bucket has row
-//     numbers = i mod 5);
-//   * a colour's rows are laid down in the order they were taken: A mod 32 rises along the groups of a bucket, so that the
-//     pieces of two or three buckets that make up a half-wave's 32 groups (whatever group the tile began at) hold
-//     complementary ranges of A.
-// Model: 2.9 + 2.6 cycles (tools/view_order_model.py).  The levels are those of k - 1 = the class's cap: the odd k of the
-// class sees a few rows one level off (nothing but B's bank changes).  Buckets of more than 128 rows stay as they are.
-constexpr int kColourRows = 128;
-
-__global__ __launch_bounds__(64) void colour_view_kernel(uint32_t *__restrict__ words, const int64_t *__restrict__ boff, int64_t nbuckets,
-                                                         int km1, int f12) {
-    __shared__ uint32_t stage[kColourRows][64];
-    __shared__ uint8_t order[kColourRows][64];
-    __shared__ uint8_t cnt[32][64];
-    const int lane = threadIdx.x;
-    for (int64_t b0 = 64 * (int64_t)blockIdx.x; b0 < nbuckets; b0 += 64 * (int64_t)gridDim.x) {
-        const int64_t b = b0 + lane;
-        int64_t r0 = 0;
-        int R = 0;
-        if (b < nbuckets) {
-            r0 = boff[b];
-            const int64_t n = boff[b + 1] - r0;
-            R = n >= 6 && n <= kColourRows ? (int)n : 0;
-        }
-        for (int a = 0; a < 32; ++a) cnt[a][lane] = 0;
-        // (start mod 1024, overlap) of a word: format 4 (start | overlap << 16 | annot << 24) or, f12, format 12 (overlap | start << 8 | annot << 20)
-        auto start_of = [&](uint32_t w) { return (f12 ? w >> 8 : w) & 1023u; };
-        auto ov_of = [&](uint32_t w) { return (f12 ? w : w >> 16) & 63u; };
-        auto res_a = [&](uint32_t w) { return (start_of(w) + ov_of(w) - (uint32_t)km1) & 31u; };
-        for (int i = 0; i < R; ++i) {
-            const uint32_t w = words[r0 + i];
-            stage[i][lane] = w;
-            ++cnt[res_a(w)][lane];
-        }
-        {  // counts -> first places
-            int run = 0;
-            for (int a = 0; a < 32; ++a) {
-                const int c = cnt[a][lane];
-                cnt[a][lane] = (uint8_t)run;
-                run += c;
-            }
-        }
-        for (int i = 0; i < R; ++i) {
-            const uint32_t a = res_a(stage[i][lane]);
-            order[cnt[a][lane]++][lane] = (uint8_t)i;
-        }
-        // colours: place p = (row number) mod 5
-        uint32_t usedA[5], usedA2[5], usedB[5], usedB2[5];
-        int load[5], room[5];
-        int64_t at[5];
-        const int r0m = (int)(r0 % 5);
-#pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            usedA[c] = usedA2[c] = usedB[c] = usedB2[c] = 0u;
-            load[c] = 0;
-            const int skip = (c - r0m + 5) % 5;  // the bucket's first row number that is c mod 5: r0 + skip
-            at[c] = r0 + skip;
-            room[c] = R > skip ? (R - skip + 4) / 5 : 0;
-        }
-        for (int j = 0; j < R; ++j) {
-            const uint32_t w = stage[order[j][lane]][lane];
-            const uint32_t ov = ov_of(w), s = start_of(w);
-            const int n = km1 - (int)ov;  // (>= 1: the view holds the rows whose overlap is below the cap)
-            const uint32_t A = 1u << ((s + ov - (uint32_t)km1) & 31u);
-            const uint32_t B = 1u << ((s - (1u << (31 - __clz(n > 0 ? n : 1)))) & 31u);
-            int best = 0;
-            uint32_t bestp = 0xFFFFFFFFu;
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                uint32_t p = (usedA[c] & A ? 4u : 0u) + (usedA2[c] & A ? 16u : 0u) + (usedB[c] & B ? 5u : 0u) + (usedB2[c] & B ? 16u : 0u);
-                p = (p << 8) + (uint32_t)load[c];
-                if (load[c] >= room[c]) p = 0xFFFFFFFEu;
-                if (p < bestp) {
-                    bestp = p;
-                    best = c;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                if (c == best) {
-                    usedA2[c] |= usedA[c] & A;
-                    usedB2[c] |= usedB[c] & B;
-                    usedA[c] |= A;
-                    usedB[c] |= B;
-                    words[at[c] + 5 * (int64_t)load[c]] = w;
-                    ++load[c];
-                }
-            }
+__global__ __launch_bounds__(256) void interleave_large_kernel(uint32_t *__restrict__ words, const int64_t *__restrict__ boff,
+                                                               int64_t nbuckets, int bshift, int fmt12, int mode) {
+    __shared__ uint32_t key[kMaxBucketRows];
+    __shared__ uint32_t first[256], cnt[256];
+    __shared__ uint32_t shared_high;
+    KeyCodec C;
+    C.fmt12 = fmt12;
+    C.mode = mode;
+    C.bshift = bshift;
+    C.cshift = mode == 3 ? 26 : 20;
+    for (int64_t b0 = 4 * (int64_t)blockIdx.x; b0 < nbuckets; b0 += 4 * (int64_t)gridDim.x) {
+        int64_t r[5];
+        for (int j = 0; j < 5; ++j) r[j] = boff[b0 + j < nbuckets ? b0 + j : nbuckets];
+        if (small_turn(r, bshift)) continue;
+        for (int j = 0; j < 4; ++j) {
+            const int64_t R = r[j + 1] - r[j];
+            if (R >= 2 && R <= kMaxBucketRows) block_bucket(words, r[j], (int)R, C, key, first, cnt, &shared_high);
         }
     }
-}
-
-
-// ---- six rows per 16 bytes: a k-class view whose groups carry their bucket (round 4, A/B: memo_debug_six_views) ------------------
-// A view row needs 5 + 5 + 8 bits -- start inside its 32-position bucket, overlap (below the cap: <= 31), annot -- once its group
-// says which bucket it is in and groups end at bucket boundaries: 2.67 B per row instead of 3.2.  Layout of a group (dword j = row j's
-// ten bits | 14 bits of rows 4 / 5 and the bucket | row j's annot on top, so that rows 0 .. 3 are their dword as the ds_min operand):
-//   dword 0 = lo_0 | lo_4 << 10 | a_0 << 24      dword 1 = lo_1 | a_4 << 10 | a_1 << 24
-//   dword 2 = lo_2 | a_5 << 10 | bucket mod 32 << 18 | a_2 << 24      dword 3 = lo_3 | lo_5 << 10 | a_3 << 24
-//   lo = start mod 32 | overlap << 5.   Places a bucket leaves empty hold a row of annot 255 (it writes; no result can see it).
-// The places are coloured as in colour_view_kernel, with six colours.  One lane per bucket; buckets of fewer than 6 or more than
-// kSixRows rows keep their order.  Needs buckets of 32 positions and annots of eight bits.
-constexpr int kSixRows = 96;
-
-struct SixRow {
-    uint32_t lo, a;
-};
-__device__ __forceinline__ SixRow six_of(uint32_t w, int f12) {
-    const uint32_t start = (f12 ? w >> 8 : w) & 31u, ov = (f12 ? w : w >> 16) & 63u, annot = f12 ? (w >> 20) & 0xFFu : w >> 24;
-    SixRow r;
-    r.lo = start | ((ov > 31u ? 31u : ov) << 5);
-    r.a = annot;
-    return r;
-}
-__device__ __forceinline__ uint4 six_group(const SixRow (&r)[6], uint32_t bucket5) {
-    return make_uint4(r[0].lo | (r[4].lo << 10) | (r[0].a << 24), r[1].lo | (r[4].a << 10) | (r[1].a << 24),
-                      r[2].lo | (r[5].a << 10) | (bucket5 << 18) | (r[2].a << 24), r[3].lo | (r[5].lo << 10) | (r[3].a << 24));
-}
-
-// the same six words as a group of FIVE rows (PackedRows3: memo_index.hip, pack3_rows_kernel) -- r[5] unused
-__device__ __forceinline__ uint4 five_group(const uint32_t (&w)[6], int f12) {
-    uint32_t B[5], A[5], hi = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const uint32_t x = w[i];
-        const uint32_t len = f12 ? x & 0xFFu : (x >> 16) & 0xFFu, start = f12 ? x >> 8 : x, annot = f12 ? (x >> 20) & 0x1FFu : x >> 24;
-        B[i] = ((start & 1023u) << 6) | (len > 63u ? 63u : len);
-        A[i] = annot & 0xFFu;
-        hi |= (annot >> 8) << i;
-    }
-    return make_uint4(B[0] | ((B[4] & 0xFFu) << 16) | (A[0] << 24), B[1] | ((B[4] >> 8) << 16) | (A[1] << 24),
-                      B[2] | (A[4] << 16) | (A[2] << 24), B[3] | (hi << 16) | (A[3] << 24));
-}
-
-// P = 6: the six-row groups above.  P = 5 (A/B, memo_debug_view_colouring 2; measured level with the product's back-to-back views): the
-// five-row groups of PackedRows3, ending at bucket boundaries like the six-row ones.  A place a bucket leaves empty holds a COPY of one of the bucket's rows: min and
-// and are idempotent, every kernel that reads the view may sweep it.
-template <int P>
-__global__ __launch_bounds__(64) void aligned_view_kernel(const uint32_t *__restrict__ words, const int64_t *__restrict__ boff,
-                                                      const uint32_t *__restrict__ glocal, const uint64_t *__restrict__ gblock,
-                                                      int64_t nbuckets, int64_t bbase, int km1, int f12, uint4 *__restrict__ groups,
-                                                      int64_t *__restrict__ boff6, int colour) {
-    __shared__ uint32_t stage[kSixRows][64];
-    __shared__ uint32_t placed[kSixRows + 6][64];
-    __shared__ uint8_t order[kSixRows][64];
-    __shared__ uint8_t cnt[32][64];
-    const int lane = threadIdx.x;
-    for (int64_t b0 = 64 * (int64_t)blockIdx.x; b0 < nbuckets; b0 += 64 * (int64_t)gridDim.x) {
-        const int64_t b = b0 + lane;
-        if (b >= nbuckets) continue;  // (no barrier below: every lane works on its own columns)
-        const int64_t r0 = boff[b], n64 = boff[b + 1] - r0;
-        const uint64_t g0 = gblock[b >> 10] + glocal[b];
-        boff6[b] = (int64_t)(P * g0);
-        if (b == nbuckets - 1) boff6[nbuckets] = (int64_t)(P * (g0 + (uint64_t)((n64 + P - 1) / P)));
-        if (n64 <= 0) continue;
-        const uint32_t bucket5 = (uint32_t)((b + bbase) & 31);
-        const int64_t ng = (n64 + P - 1) / P;
-        const uint32_t pad = words[r0 + n64 - 1];  // (a place the bucket leaves empty: a copy of its last row)
-        auto emit = [&](uint64_t g, const uint32_t (&w)[6]) {
-            if constexpr (P == 6) {
-                SixRow r[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) r[c] = six_of(w[c], f12);
-                groups[g] = six_group(r, bucket5);
-            } else {
-                groups[g] = five_group(w, f12);
-            }
-        };
-        if (n64 < 6 || n64 > kSixRows || !colour) {  // as they come
-            for (int64_t j = 0; j < ng; ++j) {
-                uint32_t w[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) w[c] = c < P && P * j + c < n64 ? words[r0 + P * j + c] : pad;
-                emit(g0 + (uint64_t)j, w);
-            }
-            continue;
-        }
-        const int R = (int)n64, NG = (int)ng;
-        auto start_of = [&](uint32_t w) { return (f12 ? w >> 8 : w) & 1023u; };
-        auto ov_of = [&](uint32_t w) { return (f12 ? w : w >> 16) & 63u; };
-        auto res_a = [&](uint32_t w) { return (start_of(w) + ov_of(w) - (uint32_t)km1) & 31u; };
-        for (int a = 0; a < 32; ++a) cnt[a][lane] = 0;
-        for (int i = 0; i < R; ++i) {
-            const uint32_t w = words[r0 + i];
-            stage[i][lane] = w;
-            ++cnt[res_a(w)][lane];
-        }
-        {
-            int run = 0;
-            for (int a = 0; a < 32; ++a) {
-                const int c = cnt[a][lane];
-                cnt[a][lane] = (uint8_t)run;
-                run += c;
-            }
-        }
-        for (int i = 0; i < R; ++i) {
-            const uint32_t a = res_a(stage[i][lane]);
-            order[cnt[a][lane]++][lane] = (uint8_t)i;
-        }
-        for (int i = 0; i < P * NG; ++i) placed[i][lane] = pad;
-        uint32_t usedA[P], usedA2[P], usedB[P], usedB2[P];
-        int load[P];
-#pragma unroll
-        for (int c = 0; c < P; ++c) {
-            usedA[c] = usedA2[c] = usedB[c] = usedB2[c] = 0u;
-            load[c] = 0;
-        }
-        for (int j = 0; j < R; ++j) {
-            const uint32_t w = stage[order[j][lane]][lane];
-            const uint32_t ov = ov_of(w), s = start_of(w);
-            const int n = km1 - (int)ov;
-            const uint32_t A = 1u << ((s + ov - (uint32_t)km1) & 31u);
-            const uint32_t B = 1u << ((s - (1u << (31 - __clz(n > 0 ? n : 1)))) & 31u);
-            int best = 0;
-            uint32_t bestp = 0xFFFFFFFFu;
-#pragma unroll
-            for (int c = 0; c < P; ++c) {
-                uint32_t p = (usedA[c] & A ? 4u : 0u) + (usedA2[c] & A ? 16u : 0u) + (usedB[c] & B ? 5u : 0u) + (usedB2[c] & B ? 16u : 0u);
-                p = (p << 8) + (uint32_t)load[c];
-                if (load[c] >= NG) p = 0xFFFFFFFEu;  // (a colour holds one row of every group)
-                if (p < bestp) {
-                    bestp = p;
-                    best = c;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < P; ++c) {
-                if (c == best) {
-                    usedA2[c] |= usedA[c] & A;
-                    usedB2[c] |= usedB[c] & B;
-                    usedA[c] |= A;
-                    usedB[c] |= B;
-                    placed[P * load[c] + c][lane] = w;
-                    ++load[c];
-                }
-            }
-        }
-        for (int j = 0; j < NG; ++j) {
-            uint32_t w[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) w[c] = c < P ? placed[P * j + c][lane] : pad;
-            emit(g0 + (uint64_t)j, w);
-        }
-    }
-}
-
-// groups of six per bucket: count[b] = ceil(rows of bucket b / 6) (what the two-level scan of memo_index.hip takes)
-__global__ void group_counts_kernel(const int64_t *__restrict__ boff, int64_t nbuckets, uint32_t *__restrict__ count, int rpg) {
-    const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (b < nbuckets) count[b] = (uint32_t)((boff[b + 1] - boff[b] + rpg - 1) / rpg);
 }
 
 }  // namespace
@@ -592,41 +351,13 @@ int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshi
     if (mode == 3 && bshift != 5) mode = 2;  // (the membership order's key is laid out for 32 starts per bucket)
     const int64_t nbuckets = (int64_t)nb - 1;
     const int64_t turns = (nbuckets + 3) / 4;
-    const unsigned grid = (unsigned)(turns < 256 * 32 ? turns : 256 * 32);
-    hipLaunchKernelGGL(interleave_buckets_kernel, dim3(grid), dim3(256), 0, st, words, boff, nbuckets, bshift, fmt == 12 ? 1 : 0,
-                       mode);
+    const unsigned grid = (unsigned)(turns < 256 * 64 ? turns : 256 * 64);
+    if (bshift == 5)
+        hipLaunchKernelGGL(interleave_small_kernel, dim3(grid), dim3(256), 0, st, words, boff, nbuckets, bshift, fmt == 12 ? 1 : 0, mode);
+    hipLaunchKernelGGL(interleave_large_kernel, dim3(grid < 256 * 16 ? grid : 256 * 16), dim3(256), 0, st, words, boff, nbuckets, bshift,
+                       fmt == 12 ? 1 : 0, mode);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
-}
-
-// words: a dense view's rows as format-4 words (start mod 1024 | overlap << 16 | annot << 24; f12: format-12 words) in bucket order,
-// boff: the view's bucket table (nb entries, the last pinned to the row count); km1 = the view's cap.  In place; queued on st.
-int colour_view_words(uint32_t *words, const int64_t *boff, uint64_t nb, int km1, int f12, hipStream_t st) {
-    if (!words || !boff || nb < 2 || km1 < 1 || km1 > 63) return MEMO_OK;
-    const int64_t nbuckets = (int64_t)nb - 1;
-    const int64_t turns = (nbuckets + 63) / 64;
-    const unsigned grid = (unsigned)(turns < 256 * 64 ? turns : 256 * 64);
-    hipLaunchKernelGGL(colour_view_kernel, dim3(grid), dim3(64), 0, st, words, boff, nbuckets, km1, f12);
-    HIP_TRY(hipGetLastError());
-    return MEMO_OK;
-}
-
-// the two halves of a six-row view's build around memo_index.hip's scan: the groups every bucket needs, then the groups themselves
-void aligned_group_counts(const int64_t *boff, uint64_t nb, uint32_t *count, int rpg, hipStream_t st) {
-    const int64_t nbuckets = (int64_t)nb - 1;
-    hipLaunchKernelGGL(group_counts_kernel, dim3((unsigned)((nbuckets + 255) / 256)), dim3(256), 0, st, boff, nbuckets, count, rpg);
-}
-void aligned_view_fill(const uint32_t *words, const int64_t *boff, const uint32_t *glocal, const uint64_t *gblock, uint64_t nb, int64_t bbase,
-                   int km1, int f12, uint32_t *groups, int64_t *boff6, int rpg, int colour, hipStream_t st) {
-    const int64_t nbuckets = (int64_t)nb - 1;
-    const int64_t turns = (nbuckets + 63) / 64;
-    const unsigned grid = (unsigned)(turns < 256 * 64 ? turns : 256 * 64);
-    if (rpg == 6)
-        hipLaunchKernelGGL(aligned_view_kernel<6>, dim3(grid), dim3(64), 0, st, words, boff, glocal, gblock, nbuckets, bbase, km1, f12,
-                           reinterpret_cast<uint4 *>(groups), boff6, colour);
-    else
-        hipLaunchKernelGGL(aligned_view_kernel<5>, dim3(grid), dim3(64), 0, st, words, boff, glocal, gblock, nbuckets, bbase, km1, f12,
-                           reinterpret_cast<uint4 *>(groups), boff6, colour);
 }
 
 }  // namespace memo

@@ -22,7 +22,6 @@ struct SweepArgs {
     int64_t tile0;          // pivot position of tile 0 (multiple of the tile width, <= qs)
     int64_t ntiles;
     int64_t tiles_per_xcd;  // ceil(ntiles / 8)
-    int64_t tiles_per_wg;   // persistent sweeps (memo_sweep_cons3p.hip): tiles per workgroup; tiles_per_xcd = runs per XCD group
     int x_lo_first, x_hi_last;  //   ... and the window's edges inside its first / last tile
     int64_t tile_abs0;      // table-driven dense sweep (memo_sweep_cons3t.hip): tile 0's number in pivot coordinates (tile0 / w),
     const void *ttab;       //   the tile table (32 bytes per tile) and its length
@@ -571,13 +570,9 @@ using SweepKernel = void (*)(const SweepArgs);
 
 inline int floor_log2(uint32_t v) { return 31 - __builtin_clz(v); }
 int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t lds, hipStream_t st);
-// memo_sweep_cons3p.hip (linked into libmemo_amd_ab.so only: an experiment that lost, kept for A/B): the persistent
-// dense-row sweep registers itself here; 1 = this query does not fit it (take the tile-per-workgroup kernel)
 // memo_sweep_cons3t.hip: the table-driven dense-row sweep; 1 = this query does not fit it
 int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStream_t st, bool annot9 = false, bool all_write = false,
                   bool six = false);
-using PersistentLaunch = int (*)(SweepArgs &A, int tw, int elem_bytes, int device, int mode, hipStream_t st);
-extern PersistentLaunch g_persistent_launch;
 int pick_rows(const memo_index *ix, int32_t k, int &fmt);
 int check_query_args(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int32_t num_docs,
                      const void *d_out);

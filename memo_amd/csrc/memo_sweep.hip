@@ -71,7 +71,6 @@ thread_local bool g_prepare_only = false;
 thread_local bool g_side_alloc_fails = false;
 thread_local int g_view_colouring = 1;
 thread_local int g_six_views = -1;
-PersistentLaunch g_persistent_launch = nullptr;  // set by memo_sweep_cons3p.o where it is linked in (the AB library)
 
 int pick_rows(const memo_index *ix, int32_t k, int &fmt) {
     fmt = 0;

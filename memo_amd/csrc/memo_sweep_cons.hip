@@ -1420,17 +1420,6 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                 A.p3 = vp3;
                 A.boff = vboff;
                 ix->last_rows_read = vrows;
-                if (attempt == 0 && top8 && g_persistent_launch && tune.persistent >= 2 && tune.persistent <= 4 && !g_prepare_only) {
-                    // persistent workgroups (memo_sweep_cons3p.hip, AB library only: 17 - 50 % slower than a workgroup per tile,
-                    // profiles/r03_persistent_sweep.txt); 1 = this query does not fit it
-                    const int prc = g_persistent_launch(A, tw, (int)sizeof(OutT), ix->device, tune.persistent - 2, st);
-                    if (prc < 0) return prc;
-                    if (prc == MEMO_OK) {
-                        ix->last_sweep = 5;
-                        ix->last_variant = 1;
-                        return long_rows_conservation<OutT>(ix, qs, qe, k, A.ncols, d_out, st);
-                    }
-                }
                 if (table) {
                     // the tile's row slice from a table built once per (index, k): memo_sweep_cons3t.hip; 1 = does not fit
                     const int trc = launch_halo3t(ix, A, tw, (int)sizeof(OutT), st, top9, view_cap == k - 1 && !tune.no_all_write, rpg == 6);

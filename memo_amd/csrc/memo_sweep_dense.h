@@ -1,7 +1,6 @@
-// memo_sweep_dense.h -- device pieces shared by the sweeps that read the dense rows with a lean, unrolled tile body
-// (memo_sweep_cons3t.hip: the product's table-driven kernel; memo_sweep_cons3p.hip: the persistent experiment of the
-// AB library): level clear / read in inline asm, the branch-free row block (plain and masked by row number), a group's
-// five rows, the register fold + store.
+// memo_sweep_dense.h -- device pieces of the sweep that reads the dense rows with a lean, unrolled tile body
+// (memo_sweep_cons3t.hip: the table-driven kernel): level clear / read in inline asm, the branch-free row block (plain and
+// masked by row number), a group's five rows -- or six, for views whose groups carry their bucket --, the register fold + store.
 #ifndef MEMO_SWEEP_DENSE_H
 #define MEMO_SWEEP_DENSE_H
 

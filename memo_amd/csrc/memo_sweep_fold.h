@@ -1,4 +1,4 @@
-// memo_sweep_fold.h -- the register fold step shared by the conservation sweeps (memo_sweep_cons.hip, memo_sweep_cons3p.hip)
+// memo_sweep_fold.h -- the register fold step shared by the conservation sweeps (memo_sweep_cons.hip, memo_sweep_cons3t.hip)
 #ifndef MEMO_SWEEP_FOLD_H
 #define MEMO_SWEEP_FOLD_H
 

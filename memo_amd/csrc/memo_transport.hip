@@ -242,7 +242,7 @@ __global__ void dense_exceptions_kernel(const unsigned long long *exc, const uns
 // thread and round; ranks inside the block from the wave prefix and the (round, wave) sums.
 // head: [0] B bytes taken, [1] B capacity
 // ------------------------------------------------------------------------------------------
-constexpr int kRunsStaged = 8192;  // bytes of a block's values staged in LDS (config 3: ~3300 per block); more: straight to / from HBM
+XX
 
 // V = uint8_t (results of at most 255 genomes) or uint16_t (BASELINE config 5: 500 genomes -- round 4: a config-5 slice
 // travelled as 67 MB of plain bytes, 0.9 ms of link against sweeps of 0.2-0.6 ms).  Same streams; B holds sizeof(V)

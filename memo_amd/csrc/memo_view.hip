@@ -13,37 +13,6 @@ using namespace memo;
 
 namespace {
 
-// ---- dense_compact: the rows whose length field is saturated (they can never write at k <= 64) leave the dense rows ----
-// field and annot of dense row r (PackedRows3, memo_sweep.h)
-__device__ __forceinline__ void dense_row(const uint4 *p3, uint64_t r, uint32_t &B, uint32_t &A) {
-    const uint4 g = p3[r / 5];
-    switch ((int)(r % 5)) {
-        case 0: B = g.x & 0xFFFFu; A = g.x >> 24; break;
-        case 1: B = g.y & 0xFFFFu; A = g.y >> 24; break;
-        case 2: B = g.z & 0xFFFFu; A = g.z >> 24; break;
-        case 3: B = g.w & 0xFFFFu; A = g.w >> 24; break;
-        default: B = ((g.x >> 16) & 0xFFu) | (((g.y >> 16) & 0xFFu) << 8); A = (g.z >> 16) & 0xFFu; break;
-    }
-    A |= ((g.w >> (16 + (int)(r % 5))) & 1u) << 8;  // (the ninth annot bit: indexes of 256 .. 511 genomes)
-}
-
-// keep[r / 32] bit r % 32 = row r stays; count[r / 32] = how many of the 32
-// (grid-stride over whole waves: a launch cannot have 2^32 work-items, and an index can have more rows than that)
-__global__ __launch_bounds__(256) void dense_keep_kernel(const uint4 *p3, uint64_t rows, uint32_t cap, uint32_t *keep, uint32_t *count) {
-    const uint64_t top = (rows + 255) & ~(uint64_t)255;
-    for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < top; r += (uint64_t)gridDim.x * 256) {
-        uint32_t B = 63, A = 0;
-        if (r < rows) dense_row(p3, r, B, A);
-        const unsigned long long m = __ballot(r < rows && (B & 63u) < cap);
-        const int lane = threadIdx.x & 63;
-        if ((lane & 31) == 0 && (r >> 5) < ((rows + 31) >> 5)) {
-            const uint32_t half = (uint32_t)(m >> (lane & 32));
-            keep[r >> 5] = half;
-            count[r >> 5] = (uint32_t)__popc(half);
-        }
-    }
-}
-
 // two-level exclusive scan of count[] (n entries): local[i] = prefix inside i's block of 1024, blocksum[b] = the block's total
 __global__ __launch_bounds__(256) void scan_local_kernel(const uint32_t *count, uint64_t n, uint32_t *local, uint64_t *blocksum) {
     __shared__ uint32_t part[256];
@@ -99,18 +68,6 @@ __device__ __forceinline__ uint64_t kept_before(uint64_t r, const uint32_t *keep
     return blockpre[w >> 10] + local[w] + (uint32_t)__popc(keep[w] & ((1u << (r & 31)) - 1u));
 }
 
-// the rows that stay, as format-4 words (start mod 2^10 | length << 16 | annot << 24; f12: as format-12 words, length | start
-// mod 2^10 << 8 | annot << 20 -- nine annot bits) at their new numbers: what pack3_rows_kernel takes
-__global__ __launch_bounds__(256) void dense_scatter_kernel(const uint4 *p3, uint64_t rows, const uint32_t *keep, const uint32_t *local,
-                                                            const uint64_t *blockpre, uint32_t *words, int f12) {
-    for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * 256) {
-        if (!((keep[r >> 5] >> (r & 31)) & 1u)) continue;
-        uint32_t B, A;
-        dense_row(p3, r, B, A);
-        words[kept_before(r, keep, local, blockpre)] = f12 ? (B & 63u) | ((B >> 6) << 8) | (A << 20) : (B >> 6) | ((B & 63u) << 16) | (A << 24);
-    }
-}
-
 // boff3[b] = rows that stay among the first boff[b] rows; the last entry is pinned to the total
 __global__ void dense_table_kernel(const int64_t *boff, uint64_t nb, uint64_t rows, uint64_t total, const uint32_t *keep,
                                    const uint32_t *local, const uint64_t *blockpre, int64_t *boff3) {
@@ -141,28 +98,6 @@ __global__ __launch_bounds__(256) void packed_scatter_kernel(const uint32_t *pk,
     for (uint64_t r = blockIdx.x * (uint64_t)256 + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * 256)
         if ((keep[r >> 5] >> (r & 31)) & 1u) out[kept_before(r, keep, local, blockpre)] = pk[r];
 }
-
-// memo_index_pack_dense: 4-byte words -> dense rows, five per 16-byte group (layout: PackedRows3, memo_sweep.h).
-// f12: the words are format 12 (overlap | start << 8 | annot << 20) with annots of up to NINE bits: the ninth bit of row i's
-// annot goes to bit 16 + i of the group's last dword (the byte no row used while annots had eight)
-__global__ void legacy_pack3_rows_kernel(const uint32_t *pk, uint64_t padded, uint64_t groups, uint4 *p3, int f12) {
-    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < groups;
-         g += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t B[5], A[5], hi = 0;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const uint32_t x = 5 * g + i < padded ? pk[5 * g + i] : 0u;
-            const uint32_t len = f12 ? x & 0xFFu : (x >> 16) & 0xFFu, start = f12 ? x >> 8 : x, annot = f12 ? (x >> 20) & 0x1FFu : x >> 24;
-            B[i] = ((start & 1023u) << 6) | (len > 63u ? 63u : len);  // (start & 1023) << 6 | min(length, 63)
-            A[i] = annot & 0xFFu;
-            hi |= (annot >> 8) << i;
-        }
-        p3[g] = make_uint4(B[0] | ((B[4] & 0xFFu) << 16) | (A[0] << 24), B[1] | ((B[4] >> 8) << 16) | (A[1] << 24),
-                           B[2] | (A[4] << 16) | (A[2] << 24), B[3] | (hi << 16) | (A[3] << 24));
-    }
-}
-
-
 
 // ======================================================================================================================
 // Dense k-class views, round 5: count -> scan -> ONE fused pass.
@@ -653,8 +588,6 @@ hipError_t side_alloc(void **p, size_t bytes) {
     return err;
 }
 
-thread_local int g_view_builder = 0;  // (AB library, memo_debug_view_builder: 1 = round 4's five kernels, for the bit-for-bit check)
-
 // The dense rows of `src` (groups, bucket table of nb entries, row count) whose overlap is below `cap`, as a view of their own
 // -- groups of rpg = 5 rows back to back with the kept-rows table, or of rpg = 6 rows that carry their bucket, with a table in
 // units of (padded) rows -- or nothing (*out_p3 stays NULL) when fewer than min_tenths tenths of the rows would go.
@@ -756,13 +689,11 @@ static int dense_view_build(int device, const uint32_t *src_p3, const int64_t *s
     return rc;
 }
 
-static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_boff, uint64_t rows, uint64_t nb, int cap,
-                        int min_tenths, hipStream_t st, uint32_t **out_p3, int64_t **out_boff, uint64_t *out_rows,
-                        uint64_t *out_padded, int len_shift = -1, int colour_km1 = 0, int f12 = 0, int aligned_rpg = 0, int64_t bbase = 0) {
-    if (len_shift < 0 && !g_view_builder && aligned_rpg != 5)  // the dense rows: count, scan, one fused pass
-        return dense_view_build(device, src_p3, src_boff, rows, nb, cap, min_tenths, st, aligned_rpg == 6 ? 6 : 5,
-                                g_view_colouring ? colour_km1 : 0, out_p3, out_boff, out_rows, out_padded);
-    *out_p3 = nullptr;
+// The same for the 4-byte WORDS (formats 4 / 12: the overlap byte sits at bit len_shift): the words whose overlap is below cap, in
+// the order they come, with the kept-rows table -- keep bits, scan, scatter (the order inside the view's buckets is the caller's).
+static int packed_filter(int device, const uint32_t *src, const int64_t *src_boff, uint64_t rows, uint64_t nb, int cap, int min_tenths,
+                         hipStream_t st, int len_shift, uint32_t **out_pk, int64_t **out_boff, uint64_t *out_rows, uint64_t *out_padded) {
+    *out_pk = nullptr;
     *out_boff = nullptr;
     if (!rows || rows >= ((uint64_t)1 << 38)) return MEMO_OK;
     DeviceGuard guard(device);
@@ -770,114 +701,47 @@ static int dense_filter(int device, const uint32_t *src_p3, const int64_t *src_b
     const unsigned row_grid = (unsigned)((rows + 255) / 256 < ((uint64_t)1 << 20) ? (rows + 255) / 256 : (uint64_t)1 << 20);
     uint32_t *keep = nullptr, *local = nullptr, *words = nullptr;
     uint64_t *blockpre = nullptr;
-    uint4 *p3n = nullptr;
-    int64_t *boff3 = nullptr;
+    int64_t *boffv = nullptr;
     int rc = MEMO_OK;
     do {
         hipError_t err = side_alloc((void **)&keep, n32 * 4 + 4);
         if (err == hipSuccess) err = side_alloc((void **)&local, n32 * 4);
         if (err == hipSuccess) err = side_alloc((void **)&blockpre, (nblk + 1) * 8);
         if (err == hipErrorOutOfMemory) { rc = kNoRoom; break; }
-        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
-        const uint4 *p3 = reinterpret_cast<const uint4 *>(src_p3);
-        if (len_shift >= 0)
-            hipLaunchKernelGGL(packed_keep_kernel, dim3(row_grid), dim3(256), 0, st, src_p3, rows, len_shift, (uint32_t)cap,
-                               keep, local);
-        else
-            hipLaunchKernelGGL(dense_keep_kernel, dim3(row_grid), dim3(256), 0, st, p3, rows, (uint32_t)cap, keep, local);
+        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "packed view: %s", hipGetErrorString(err)); break; }
+        hipLaunchKernelGGL(packed_keep_kernel, dim3(row_grid), dim3(256), 0, st, src, rows, len_shift, (uint32_t)cap, keep, local);
         hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblk), dim3(256), 0, st, local, n32, local, blockpre);
         hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, blockpre, nblk);
         uint64_t total = 0;
         err = hipGetLastError();
         if (err == hipSuccess) err = hipMemcpyAsync(&total, blockpre + nblk, 8, hipMemcpyDeviceToHost, st);
         if (err == hipSuccess) err = hipStreamSynchronize(st);
-        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
+        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "packed view: %s", hipGetErrorString(err)); break; }
         if (total + rows / 10 * (uint64_t)min_tenths > rows) break;  // too few would go
-        uint64_t padded3 = ((total + 15) & ~(uint64_t)15) + kPadRows;
-        const uint64_t groups = dense_groups_for(padded3);
-        err = side_alloc((void **)&words, padded3 * 4);
-        if (err == hipSuccess) err = hipMemsetAsync(words, 0, padded3 * 4, st);
-        if (err == hipSuccess && len_shift < 0) err = side_alloc((void **)&p3n, groups * 16);
-        if (err == hipSuccess) err = side_alloc((void **)&boff3, nb * 8);
+        const uint64_t padded = ((total + 15) & ~(uint64_t)15) + kPadRows;
+        err = side_alloc((void **)&words, padded * 4);
+        if (err == hipSuccess) err = side_alloc((void **)&boffv, nb * 8);
         if (err == hipErrorOutOfMemory) { rc = kNoRoom; break; }
-        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
-        if (len_shift >= 0) {
-            hipLaunchKernelGGL(packed_scatter_kernel, dim3(row_grid), dim3(256), 0, st, src_p3, rows, keep, local, blockpre,
-                               words);
-        } else {
-            hipLaunchKernelGGL(dense_scatter_kernel, dim3(row_grid), dim3(256), 0, st, p3, rows, keep, local, blockpre, words, f12);
-        }
+        if (err == hipSuccess) err = hipMemsetAsync(words + total, 0, (padded - total) * 4, st);
+        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "packed view: %s", hipGetErrorString(err)); break; }
+        hipLaunchKernelGGL(packed_scatter_kernel, dim3(row_grid), dim3(256), 0, st, src, rows, keep, local, blockpre, words);
         hipLaunchKernelGGL(dense_table_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, src_boff, nb, rows, total, keep, local,
-                           blockpre, boff3);
-        if (len_shift < 0 && aligned_rpg) {
-            // a k-class view whose groups (five rows, or -- A/B -- six that carry their bucket) end at bucket boundaries, the place of a
-            // row inside its group chosen against LDS bank conflicts (memo_interleave.hip: aligned_view_kernel): groups per bucket ->
-            // their prefix sums (the scan above, on nb - 1 counts) -> the groups and their table
-            const uint64_t nbk = nb - 1, nblk6 = (nbk + 1023) >> 10;
-            uint32_t *gcount = nullptr;
-            uint64_t *gblock = nullptr;
-            hipError_t e6 = side_alloc((void **)&gcount, nbk * 4 + 4);
-            if (e6 == hipSuccess) e6 = side_alloc((void **)&gblock, (nblk6 + 1) * 8);
-            uint64_t total6 = 0;
-            if (e6 == hipSuccess) {
-                aligned_group_counts(boff3, nb, gcount, aligned_rpg, st);
-                hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblk6), dim3(256), 0, st, gcount, nbk, gcount, gblock);
-                hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, gblock, nblk6);
-                e6 = hipGetLastError();
-                if (e6 == hipSuccess) e6 = hipMemcpyAsync(&total6, gblock + nblk6, 8, hipMemcpyDeviceToHost, st);
-                if (e6 == hipSuccess) e6 = hipStreamSynchronize(st);
-            }
-            uint4 *g6 = nullptr;
-            int64_t *boff6 = nullptr;
-            if (e6 == hipSuccess) e6 = side_alloc((void **)&g6, (total6 + 64) * 16);
-            if (e6 == hipSuccess) e6 = side_alloc((void **)&boff6, nb * 8);
-            if (e6 == hipSuccess) e6 = hipMemsetAsync(g6, 0, (total6 + 64) * 16, st);
-            if (e6 == hipSuccess) {
-                aligned_view_fill(words, boff3, gcount, gblock, nb, bbase, colour_km1, f12, reinterpret_cast<uint32_t *>(g6), boff6, aligned_rpg,
-                              g_view_colouring, st);
-                e6 = hipGetLastError();
-                if (e6 == hipSuccess) e6 = hipStreamSynchronize(st);
-            }
-            (void)hipFree(gcount);
-            (void)hipFree(gblock);
-            if (e6 == hipSuccess) {
-                (void)hipFree(p3n);
-                (void)hipFree(boff3);
-                p3n = g6;
-                boff3 = boff6;
-                padded3 = (uint64_t)aligned_rpg * total6;
-            } else {
-                (void)hipFree(g6);
-                (void)hipFree(boff6);
-            }
-            if (e6 == hipErrorOutOfMemory) { rc = kNoRoom; break; }
-            if (e6 != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter (six): %s", hipGetErrorString(e6)); break; }
-        } else if (len_shift < 0) {
-            // (a k-class view: which of its group's five places a row takes is chosen against LDS bank conflicts, memo_interleave.hip)
-            if (colour_km1 > 0 && g_view_colouring) (void)colour_view_words(words, boff3, nb, colour_km1, f12, st);
-            hipLaunchKernelGGL(legacy_pack3_rows_kernel, dim3(4096), dim3(256), 0, st, words, padded3, groups, p3n, f12);
-        }
+                           blockpre, boffv);
         err = hipGetLastError();
         if (err == hipSuccess) err = hipStreamSynchronize(st);
-        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense_filter: %s", hipGetErrorString(err)); break; }
-        if (len_shift >= 0) {
-            *out_p3 = words;  // (the compacted words are the result)
-            words = nullptr;
-        } else {
-            *out_p3 = reinterpret_cast<uint32_t *>(p3n);
-        }
-        *out_boff = boff3;
+        if (err != hipSuccess) { rc = fail(MEMO_EHIP, "packed view: %s", hipGetErrorString(err)); break; }
+        *out_pk = words;
+        *out_boff = boffv;
         *out_rows = total;
-        *out_padded = padded3;
-        p3n = nullptr;
-        boff3 = nullptr;
+        *out_padded = padded;
+        words = nullptr;
+        boffv = nullptr;
     } while (0);
     (void)hipFree(keep);
     (void)hipFree(local);
     (void)hipFree(blockpre);
     (void)hipFree(words);
-    (void)hipFree(p3n);
-    (void)hipFree(boff3);
+    (void)hipFree(boffv);
     return rc;
 }
 
@@ -888,8 +752,7 @@ int dense_compact(memo_index *ix) {
     uint32_t *p3n = nullptr;
     int64_t *boff3 = nullptr;
     uint64_t total = 0, padded3 = 0;
-    int rc = dense_filter(ix->device, ix->p3, ix->boff, ix->rows, ix->nb, 63, 1, nullptr, &p3n, &boff3, &total, &padded3, -1, 0,
-                          ix->max_annot > 255 ? 1 : 0);
+    int rc = dense_view_build(ix->device, ix->p3, ix->boff, ix->rows, ix->nb, 63, 1, nullptr, 5, 0, &p3n, &boff3, &total, &padded3);
     if (rc == kNoRoom) rc = MEMO_OK;  // (no room for a second copy: every row stays)
     if (rc || !p3n) return rc;
     DeviceGuard guard(ix->device);
@@ -1208,8 +1071,8 @@ int packed_rows_for(memo_index *ix, int km1, int64_t window, bool membership, hi
     if (v.state == 0) {
         DeviceGuard guard(ix->device);
         const int rc = build_timed(ix, v, st, [&]() {
-            int r = dense_filter(ix->device, ix->pk, ix->boff, ix->rows, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded,
-                                 ix->packed_fmt == 12 ? 0 : 16);
+            int r = packed_filter(ix->device, ix->pk, ix->boff, ix->rows, ix->nb, cap, 2, st, ix->packed_fmt == 12 ? 0 : 16, &v.p3, &v.boff,
+                                  &v.rows, &v.padded);
             // (what the filter leaves of an interleaved bucket is no longer dealt evenly: the view's buckets are ordered again)
             if (!r && v.p3 && ix->row_order) r = interleave_words(v.p3, v.boff, ix->nb, ix->bshift, ix->packed_fmt, ix->row_order, st);
             return r;
@@ -1277,14 +1140,13 @@ int dense_rows_for(memo_index *ix, int km1, int64_t window, hipStream_t st, uint
     const int64_t *src_boff = *boff;
     const uint64_t nsrc = *rows;
     const uint64_t base_bytes = dense_groups_for(ix->boff3 ? ix->padded3 : ix->padded) * 16;
-    // rpg: 6, or 5 (A/B, memo_debug_view_colouring 2 + round 4's builder: five-row groups ended at bucket boundaries)
-    const int rpg_arg = six ? 6 : (ix->bshift == 5 && g_view_colouring == 2 ? 5 : 0);
+    const int rpg_arg = six ? 6 : 5;
     if (v.state == 0) {
         DeviceGuard guard(ix->device);
-        const bool place = can_place && (g_prepare_only || g_view_builder);  // (asked for: everything at once; a query: first the view)
+        const bool place = can_place && g_prepare_only;  // (asked for: everything at once; a query: first the view)
         const int rc = build_timed(ix, v, st, [&]() {
-            return dense_filter(ix->device, src_p3, src_boff, nsrc, ix->nb, cap, 2, st, &v.p3, &v.boff, &v.rows, &v.padded, -1, place ? cap : 0,
-                                ix->max_annot > 255 ? 1 : 0, rpg_arg, ix->bbase);
+            return dense_view_build(ix->device, src_p3, src_boff, nsrc, ix->nb, cap, 2, st, rpg_arg, place ? cap : 0, &v.p3, &v.boff, &v.rows,
+                                    &v.padded);
         });
         if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)
         v.cap = cap;
@@ -1309,8 +1171,7 @@ int dense_rows_for(memo_index *ix, int km1, int64_t window, hipStream_t st, uint
         DeviceGuard guard(ix->device);
         memo_index::DenseView nv;
         const int rc = build_timed(ix, nv, st, [&]() {
-            return dense_filter(ix->device, src_p3, src_boff, nsrc, ix->nb, cap, 0, st, &nv.p3, &nv.boff, &nv.rows, &nv.padded, -1, cap,
-                                ix->max_annot > 255 ? 1 : 0, rpg_arg, ix->bbase);
+            return dense_view_build(ix->device, src_p3, src_boff, nsrc, ix->nb, cap, 0, st, rpg_arg, cap, &nv.p3, &nv.boff, &nv.rows, &nv.padded);
         });
         if (rc && rc != kNoRoom) return rc;
         if (rc == kNoRoom || !nv.p3) {  // (no room for the second copy: the view stays as it is; look again much later)

@@ -78,7 +78,7 @@ while time.time() < t_end:
                 ix.pack_dense(keep_packed=True)
         if rng.random() < 0.5:                                     # the order of the 4-byte rows inside their buckets (memo_interleave.hip):
             ix.debug_row_order(int(rng.integers(1, 5)))            #   start order, the two dealt orders, the membership order
-        _lib.lib().memo_debug_view_colouring(int(rng.choice([0, 1, 1, 1, 2])))   # the places of a dense view's rows inside their groups (2: groups ended at bucket boundaries)
+        _lib.lib().memo_debug_view_colouring(int(rng.choice([0, 1, 1])))   # the places of a dense view's rows inside their groups
         _lib.lib().memo_debug_six_views(int(rng.choice([-1, -1, 0, 1])))             # the six-row views experiment (memo_interleave.hip: aligned_view_kernel<6>)
         k_pet = int(rng.choice([5, 9, 17, 31, 33, 101]))          # (asked often enough for its class's view to be built)
         if rng.random() < 0.3:                                     # memo_index_prepare: the view / tile table / row order before the first query
@@ -97,7 +97,7 @@ while time.time() < t_end:
                 qs &= ~3                                                      # (windows on the 4-position raster: aligned result stores)
             qe = int(rng.integers(qs, length + 200))
             tune = (int(rng.choice([0, 256, 512, 1024, 2048, 4096, 1472, 1728])), int(rng.choice([0, 1, 4, 8])),
-                    int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13])), int(rng.integers(0, 6)))
+                    int(rng.choice([0, 2, 3, 4])), int(rng.choice([0, 0, 0, 1, 2, 3, 5, 8, 9, 10, 13])), int(rng.integers(0, 6)))
             if dense_only and tune[3] in (1, 3):
                 tune = tune[:3] + (0,) + tune[4:]                             # (no int64 columns / 4-byte rows to force)
             ix.debug_set_tuning(*tune)

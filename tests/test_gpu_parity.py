@@ -1525,7 +1525,7 @@ def test_config5_shard_dense_rows(memo, oracle):
 def test_dense_row_sweep_variants(memo, oracle, ab):
     """The dense rows are swept by sweep_conservation_halo3t_kernel (the tile's row slice from the index's tile table;
     memo_sweep_cons3t.hip) wherever the query fits it; the round-2 kernel (every wave works its tile out) answers the
-    rest, and the AB library also carries the persistent experiments (LDS-DMA / register staging).  Every variant, every
+    rest.  Both, every
     k <= 64 that changes the number of level arrays, windows on and off the 4-position raster, both result types:
     bit-equal to each other and to the oracle; the table is rebuilt when the dense rows change; five values of k make the
     four-table cache evict."""
@@ -1540,16 +1540,13 @@ def test_dense_row_sweep_variants(memo, oracle, ab):
                     ix.debug_set_tuning(0, 0, 0, 5, 0)
                     ref = ix.conservation(qs, qe, k, n, dtype=dt)
                     assert ix.info()["last_sweep"] == 5 and ix.info()["last_variant"] == 0
-                    for src, variant in ((8, 2), (0, 2), (4, 1), (6, 1), (7, 1)):
+                    for src, variant in ((8, 2), (0, 2)):
                         ix.debug_set_tuning(0, 0, 0, src, 0)
                         got = ix.conservation(qs, qe, k, n, dtype=dt)
                         assert np.array_equal(got, ref), (src, k, qs, qe, dt)
                         inf = ix.info()
                         assert inf["last_sweep"] == 5
-                        if variant == 2:      # (the persistent kernels decline short windows; the table kernel takes every window --
-                            assert inf["last_variant"] == 2, (src, k, qs, qe, inf)    # off the 4-position raster too, since late round 4)
-                        else:
-                            assert inf["last_variant"] in (0, 1)
+                        assert inf["last_variant"] == variant, (src, k, qs, qe, inf)  # (the table kernel takes every window, off the 4-position raster too)
             a, b = 3_000_000, 3_300_000
             sr0, sr1 = synth.shard_rows(a, b, k, num, den, L)
             s, e, o = oracle.synth_rows(sr0, sr1 - sr0, num, den, n)
@@ -2053,12 +2050,93 @@ def test_places_inside_a_dense_group_never_change_a_result(memo, oracle, ab):
         ab.check(ab.lib().memo_debug_view_colouring(1))
 
 
-def test_fused_view_builder_writes_round_4s_bytes(memo, oracle, ab):
+def _dense_rows_fields(groups, rows):
+    """(B, A) of the first `rows` rows of dense five-row groups (memo_amd/csrc/memo_sweep.h: PackedRows3)"""
+    g = groups.reshape(-1, 4).astype(np.uint64)
+    hi = (g[:, 3] >> 16) & 0x1F
+    B = np.empty((len(g), 5), np.uint64)
+    A = np.empty((len(g), 5), np.uint64)
+    for j in range(4):
+        B[:, j] = g[:, j] & 0xFFFF
+        A[:, j] = (g[:, j] >> 24) | (((hi >> j) & 1) << 8)
+    B[:, 4] = ((g[:, 0] >> 16) & 0xFF) | (((g[:, 1] >> 16) & 0xFF) << 8)
+    A[:, 4] = ((g[:, 2] >> 16) & 0xFF) | (((hi >> 4) & 1) << 8)
+    return B.reshape(-1)[:rows], A.reshape(-1)[:rows]
+
+
+def _view_twin(dense, rows3, cap, rpg):
+    """what a k-class view of exported dense rows has to be when its rows keep the order they come in -- NumPy; (groups, table,
+    rows): five rows per group back to back with the kept-rows table, or six per group, every bucket padded to whole groups with
+    copies of its last row, the table in units of places"""
+    groups, table = dense
+    B, A = _dense_rows_fields(groups, rows3)
+    keep = (B & 63) < cap
+    before = np.concatenate([np.zeros(1, np.int64), np.cumsum(keep, dtype=np.int64)])
+    tab = before[table]
+    Bv, Av = B[keep], A[keep]
+    rows_v = len(Bv)
+    if rpg == 6:
+        n = np.diff(tab)
+        ng = (n + 5) // 6
+        tab6 = 6 * np.concatenate([np.zeros(1, np.int64), np.cumsum(ng)])
+        slot_row = np.empty(tab6[-1], np.int64)
+        for b in np.nonzero(n)[0]:
+            q = np.arange(6 * ng[b])
+            slot_row[tab6[b]:tab6[b + 1]] = tab[b] + np.minimum(q, n[b] - 1)
+        Bs, As = Bv[slot_row], Av[slot_row]
+        lo = ((Bs >> 6) & 31) | (np.minimum(Bs & 63, 31) << 5)
+        bucket = (Bs >> 11) & 31
+        lo, an, bucket = lo.reshape(-1, 6), (As & 0xFF).reshape(-1, 6), bucket.reshape(-1, 6)
+        out = np.empty((len(lo), 4), np.uint64)
+        out[:, 0] = lo[:, 0] | (lo[:, 4] << 10) | (an[:, 0] << 24)
+        out[:, 1] = lo[:, 1] | (an[:, 4] << 10) | (an[:, 1] << 24)
+        out[:, 2] = lo[:, 2] | (an[:, 5] << 10) | (bucket[:, 0] << 18) | (an[:, 2] << 24)
+        out[:, 3] = lo[:, 3] | (lo[:, 5] << 10) | (an[:, 3] << 24)
+        return out.astype(np.uint32).reshape(-1), tab6, rows_v
+    pad = (-rows_v) % 5
+    Bp = np.concatenate([Bv, np.zeros(pad, np.uint64)]).reshape(-1, 5)
+    Ap = np.concatenate([Av, np.zeros(pad, np.uint64)]).reshape(-1, 5)
+    hi = sum(((Ap[:, j] >> 8) & 1) << j for j in range(5))
+    out = np.empty((len(Bp), 4), np.uint64)
+    out[:, 0] = Bp[:, 0] | ((Bp[:, 4] & 255) << 16) | ((Ap[:, 0] & 255) << 24)
+    out[:, 1] = Bp[:, 1] | ((Bp[:, 4] >> 8) << 16) | ((Ap[:, 1] & 255) << 24)
+    out[:, 2] = Bp[:, 2] | ((Ap[:, 4] & 255) << 16) | ((Ap[:, 2] & 255) << 24)
+    out[:, 3] = Bp[:, 3] | (hi << 16) | ((Ap[:, 3] & 255) << 24)
+    return out.astype(np.uint32).reshape(-1), tab, rows_v
+
+
+def _lds_cycles(rows_w, km1, rpg):
+    """tools/view_order_model.py's cost of a view's rows (one integer per place, _view_rows): LDS cycles per row instruction and
+    half-wave -- 32 consecutive groups, place i -- for the first and the second block of a row's interval"""
+    w = rows_w[:len(rows_w) // (32 * rpg) * (32 * rpg)]
+    if rpg == 5:
+        s, ov = (w >> 6) & 1023, w & 63
+    else:
+        s, ov = (w & 31) | (((w >> 18) & 31) << 5), (w >> 5) & 31
+    n = np.maximum(km1 - ov.astype(np.int64), 1)
+    lev = np.floor(np.log2(n)).astype(np.int64)
+    cells = [lev * 1024 + ((s.astype(np.int64) - n) & 1023), lev * 1024 + ((s.astype(np.int64) - (1 << lev)) & 1023)]
+    total = 0.0
+    for cell in cells:
+        c = cell.reshape(-1, 32, rpg).transpose(0, 2, 1).reshape(-1, 32)      # one row per (half-wave, place)
+        worst = np.zeros(len(c), np.int64)
+        for b in range(32):
+            on = (c & 31) == b
+            srt = np.sort(np.where(on, c, -1), axis=1)
+            same = (srt[:, 1:] == srt[:, :-1]) & (srt[:, 1:] >= 0)
+            worst = np.maximum(worst, on.sum(1) + same.sum(1))               # a lane per different address, two per repeated one (- 1)
+        total += np.maximum(worst, 2).mean()
+    return total
+
+
+def test_dense_views_as_the_fused_pass_builds_them(memo, oracle, ab):
     """memo_view.hip (round 5): a dense k-class view is built by count -> scan -> ONE fused pass (compaction, the places of the rows
-    inside their groups, packing) instead of round 4's five kernels.  Same decisions, so the same BYTES: views of five rows per group
-    (placed and not) and of six, dense rows with the never-writing rows left out (dense_compact), eight- and nine-bit annots, on a
-    ragged index with empty stretches, buckets above the placing limits (96 / 128 rows) and one bucket whose kept rows do not fit the
-    fused pass's LDS stage (it streams through in pieces).  memo_debug_view_builder(1) = round 4's builder (A/B library)."""
+    inside their groups, packing) instead of round 4's five kernels.  (1) Rows in the order they come: the exported bytes equal a NumPy
+    twin's -- views of five rows per group and of six, the dense rows with the never-writing rows left out (dense_compact: the same pass),
+    eight- and nine-bit annots, on a ragged index with empty stretches, buckets above the placing limits (96 / 128 rows) and one bucket
+    whose kept rows do not fit the pass's LDS stage (it streams through in pieces).  (2) Rows placed: every bucket holds the same rows
+    as before, and by the LDS cycle model the places are worth having (on an index of BASELINE's shape: a fifth fewer cycles).  (3) The
+    sweep on every one of them equals the oracle."""
     rng = np.random.default_rng(67)
     length = 90_000
     for n_docs, m in ((120, 300_000), (500, 260_000)):
@@ -2073,51 +2151,64 @@ def test_fused_view_builder_writes_round_4s_bytes(memo, oracle, ab):
         ov[::7] = rng.integers(63, 90, len(ov[::7]))         # a seventh of the rows never writes at k <= 64: they leave the dense rows
         e = s + ov
         o = rng.integers(1, n_docs, m).astype(np.int64)
-        got = {}
         try:
-            for builder in (1, 0):
-                ab.check(ab.lib().memo_debug_view_builder(builder))
-                for colour in (1, 0):
+            for six in ((0, 1) if n_docs <= 255 else (0,)):
+                ab.check(ab.lib().memo_debug_six_views(six))
+                plain = {}
+                for colour in (0, 1):
                     ab.check(ab.lib().memo_debug_view_colouring(colour))
-                    for six in ((0, 1) if n_docs <= 255 else (0,)):
-                        ab.check(ab.lib().memo_debug_six_views(six))
-                        with memo.DeviceIndex.from_host(s, e, o) as ix:
-                            ix.pack(keep_wide=False)
-                            ix.pack_dense(keep_packed=False)
-                            inf = ix.info()
-                            assert inf["dense_row_count"] < m                   # (dense_compact ran: through the same builder)
-                            dense = _export_dense(ix)
-                            for k in (3, 9, 17, 21, 31, 32, 33):
-                                ix.prepare(k, n_docs)
-                                view = ix.export_view(k, 6 if six and k <= 32 else 5)
-                                assert view is not None, (builder, colour, six, k)
-                                key = (colour, six, k)
-                                if builder == 1:
-                                    got[key] = (dense, view)
-                                else:
-                                    d0, v0 = got[key]
-                                    assert np.array_equal(dense[0], d0[0]) and np.array_equal(dense[1], d0[1]), ("dense rows", n_docs, key)
-                                    assert view[2:] == v0[2:], (n_docs, key, view[2:], v0[2:])
-                                    assert np.array_equal(view[1], v0[1]), ("table", n_docs, key)
-                                    rpg = 6 if six and k <= 32 else 5
-                                    if colour == 0:                             # rows in the order they come: the same bytes
-                                        same = view[0] == v0[0]
-                                        assert same.all(), ("groups", n_docs, key, int(np.argmin(same)) // 4, len(same) // 4)
-                                    else:                                       # placed: every bucket holds the same rows (round 5 places them
-                                        mine, theirs = _view_rows(view, rpg), _view_rows(v0, rpg)      # without round 4's sort: other places)
-                                        tab = view[1]
-                                        assert len(mine) == len(theirs)
-                                        bucket_of = np.searchsorted(tab[1:], np.arange(len(mine)), side="right")
-                                        a = mine[np.lexsort((mine, bucket_of))]
-                                        b = theirs[np.lexsort((theirs, bucket_of))]
-                                        assert np.array_equal(a, b), ("rows of the buckets", n_docs, key)
-                                want = oracle.conservation(*oracle.filter_rows(s, e, o, 5, length + 50, k), 5, length + 50, k, n_docs, literal=False)
-                                assert np.array_equal(ix.conservation(5, length + 50, k, n_docs), want), (builder, colour, six, k)
-                            ix.check()
+                    with memo.DeviceIndex.from_host(s, e, o) as ix:
+                        ix.pack(keep_wide=True)
+                        pk = _export(ix)[0]
+                        ix.pack(keep_wide=False)
+                        ix.pack_dense(keep_packed=False)
+                        inf = ix.info()
+                        rows3 = inf["dense_row_count"]
+                        assert rows3 < m                                      # (dense_compact ran: through the same pass)
+                        dense = _export_dense(ix)
+                        if colour == 0 and not six:                           # the dense rows themselves: the packed rows that can write at k <= 64
+                            f12 = inf["packed_format"] == 12
+                            st_, ov_, an_ = ((pk >> 8) & 0xFFF, pk & 0xFF, pk >> 20) if f12 else (pk & 0xFFFF, (pk >> 16) & 0xFF, pk >> 24)
+                            stay = ov_ < 63
+                            B, A = _dense_rows_fields(dense[0], rows3)
+                            assert np.array_equal(B, (((st_[stay] & 1023) << 6) | ov_[stay]).astype(np.uint64)) and np.array_equal(A, an_[stay].astype(np.uint64))
+                        for k in (3, 9, 17, 21, 31, 32, 33):
+                            rpg = 6 if six and k <= 32 else 5
+                            ix.prepare(k, n_docs)
+                            view = ix.export_view(k, rpg)
+                            assert view is not None, (colour, six, k)
+                            twin = _view_twin(dense, rows3, view[3], rpg)
+                            assert view[2] == twin[2] and np.array_equal(view[1], twin[1]), ("table", n_docs, colour, six, k)
+                            if colour == 0:
+                                same = view[0] == twin[0]
+                                assert same.all(), ("groups", n_docs, six, k, int(np.argmin(same)) // 4, len(same) // 4)
+                                plain[k] = view
+                            else:
+                                mine, theirs = _view_rows(view, rpg), _view_rows(plain[k], rpg)
+                                assert len(mine) == len(theirs)
+                                bucket_of = np.searchsorted(view[1][1:], np.arange(len(mine)), side="right")
+                                assert np.array_equal(mine[np.lexsort((mine, bucket_of))], theirs[np.lexsort((theirs, bucket_of))]), (n_docs, six, k)
+                            want = oracle.conservation(*oracle.filter_rows(s, e, o, 5, length + 50, k), 5, length + 50, k, n_docs, literal=False)
+                            assert np.array_equal(ix.conservation(5, length + 50, k, n_docs), want), (colour, six, k)
+                            assert ix.info()["last_view_placed"] == colour and ix.info()["last_view_rows_per_group"] == rpg
+                        ix.check()
         finally:
-            ab.check(ab.lib().memo_debug_view_builder(0))
             ab.check(ab.lib().memo_debug_view_colouring(1))
             ab.check(ab.lib().memo_debug_six_views(-1))
+    # what the places are worth, by the cycle model, on BASELINE's shape (5 rows per position, overlaps uniform in 0 .. 59), k = 31
+    from memo_amd import synth
+    for rpg in (5, 6):
+        cyc = {}
+        for placed in (0, 1):
+            ix, _ = synth.device_index(0, 600_000, 64, 100, 600_000, pack="dense")
+            with ix:
+                ix.set_option(4, rpg)
+                ix.set_option(5, placed)
+                ix.prepare(31, 100)
+                view = ix.export_view(31, rpg)
+                assert ix.info()["view_placings"] == placed
+                cyc[placed] = _lds_cycles(_view_rows(view, rpg), 30, rpg)
+        assert cyc[1] < 0.85 * cyc[0], (rpg, cyc)
 
 
 def _view_rows(view, rpg):

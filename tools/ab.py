@@ -39,7 +39,6 @@ def main():
                     help="an index from a file (.npz with start, end, annot, num_docs, length: tools/realistic_index.py) instead of the "
                          "synthetic generator; the window is [0, length)")
     ap.add_argument("--membership", action="store_true", help="with --rows-file: membership queries")
-    ap.add_argument("--aligned-views", action="store_true", help="dense views whose five-row groups end at bucket boundaries (memo_debug_view_colouring 2)")
     ap.add_argument("--six", action="store_true", help="dense k-class views as groups of six rows (memo_debug_six_views 1)")
     ap.add_argument("--no-colour", action="store_true", help="dense k-class views keep the order the filter leaves (memo_debug_view_colouring 0)")
     ap.add_argument("variants", nargs="+")
@@ -53,8 +52,6 @@ def main():
         _lib.lib().memo_debug_view_colouring(0)
     if a.six:
         _lib.lib().memo_debug_six_views(1)
-    if a.aligned_views:
-        _lib.lib().memo_debug_view_colouring(2)
     if a.rows_file:
         import memo_amd
         z = np.load(a.rows_file)
@@ -86,17 +83,35 @@ def main():
         else:
             ix.conservation_dev(a.qs, L, a.k, num_docs, out, st.cuda_stream)
 
+    # Every variant's RESULT against the first variant's before a time is printed (round 4: the first ds_write_addtid_b32 clear
+    # was wrong AND faster, and this harness, which timed without checking, said "faster").  A checksum per launch:
+    # the sum of the result's 64-bit words, on the device, one number back.
+    def checksum():
+        flat = out.reshape(-1).view(torch.uint8)
+        n8 = flat.numel() // 8 * 8
+        return int(flat[:n8].view(torch.int64).sum().item()) ^ (int(flat[n8:].to(torch.int64).sum().item()) << 1)
+
+    sums = {}
     for r in range(a.rounds + 1):
         for v in variants:
             ix.debug_set_tuning(*(list(v) + [0] * 5)[:5])
+            if r < 2:
+                out.zero_()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             launch()
             e1.record(st)
             torch.cuda.synchronize()
+            if r < 2:                               # (the warm-up round and the first timed one)
+                sums.setdefault(v, set()).add(checksum())
             if r:                                   # round 0 = warm-up
                 times[v].append(e0.elapsed_time(e1))
     ix.check()
+    want = sums[variants[0]]
+    for v in variants:
+        if sums[v] != want or len(sums[v]) != 1:
+            raise SystemExit(f"ab.py: variant {v} gives another result than variant {variants[0]} (checksums {sorted(sums[v])} against "
+                             f"{sorted(want)}): no time is printed for a kernel that is wrong")
     for v in variants:
         src = v[3] if len(v) > 3 else 0
         brow = 24 if (not a.pack or src == 1) else (3.2 if ix.info()["dense_rows"] and (src == 2 or a.pack == "dense") and a.k <= 64 and not membership

@@ -58,8 +58,14 @@ def main():
     allw = json.load(open(path)) if os.path.exists(path) else {}
     out["round"] = tag
     out["result_bytes_per_position"] = int(os.environ.get("RESULT_BYTES", "1"))   # bench default: uint8 results
-    if os.environ.get("ALG_BYTES"):
-        out["algorithmic_bytes"] = float(os.environ["ALG_BYTES"])                # what bench.py prices this launch at
+    # what bench.py prices this launch at: WITHOUT it an entry would match any run of the same workload name (round 4: the
+    # k = 31 packed view's counters ended up under an all-rows k = 101 line) -- no entry is written without it
+    if not os.environ.get("ALG_BYTES"):
+        sys.exit("pmc_summary.py: set ALG_BYTES to roofline.algorithmic_bytes of the bench line printed inside the counter pass")
+    out["algorithmic_bytes"] = float(os.environ["ALG_BYTES"])
+    if out["hbm_bytes_per_launch"] < 0.98 * out["algorithmic_bytes"]:
+        sys.exit("pmc_summary.py: %.4g B measured under %.4g B algorithmic: these counters are not of that launch"
+                 % (out["hbm_bytes_per_launch"], out["algorithmic_bytes"]))
     allw[wl] = out
     json.dump(allw, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
