@@ -242,7 +242,9 @@ __global__ void dense_exceptions_kernel(const unsigned long long *exc, const uns
 // thread and round; ranks inside the block from the wave prefix and the (round, wave) sums.
 // head: [0] B bytes taken, [1] B capacity
 // ------------------------------------------------------------------------------------------
-XX
+constexpr int kRunsStaged = 24576;  // bytes of a block's values staged in LDS (config 3: ~3300 per block; config 5 at k = 21, two bytes per
+                                    // change: ~11 000 -- past round 4's 8192 every value was a dependent load from HBM, and that slice's
+                                    // decode took 33 us against 22 for k = 31: profiles/r05_transport.txt); more: straight to / from HBM
 
 // V = uint8_t (results of at most 255 genomes) or uint16_t (BASELINE config 5: 500 genomes -- round 4: a config-5 slice
 // travelled as 67 MB of plain bytes, 0.9 ms of link against sweeps of 0.2-0.6 ms).  Same streams; B holds sizeof(V)
