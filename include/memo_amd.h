@@ -37,8 +37,10 @@
  * *_dev forms enqueue on the caller's stream and return; one thread may put queries of one index on several streams:
  * whatever a query builds for later ones (views, tile tables) is complete on the device before the call returns, and
  * nothing a queued sweep reads is freed before the device has drained: what a query takes out of service (a view past the
- * budget) waits on the index's retire list for the next memo_query_check -- queries themselves do not wait for the device
- * (except the one that BUILDS a view: it waits for its own stream; memo_index_prepare moves that out of the query path).
+ * budget) waits on the index's retire list for the next memo_query_check -- queries themselves never wait for the DEVICE; the
+ * query that builds something (a view, the placed copy of a view, the query order of rows that came in start order: each
+ * built beside what is in use, never over it) waits for ITS stream once; memo_index_prepare moves all of that out of the query
+ * path.
  */
 #ifndef MEMO_AMD_H
 #define MEMO_AMD_H
@@ -186,6 +188,8 @@ int memo_index_get_info_v5(const memo_index_t *ix, memo_index_info_t *info);  /*
  *                             percent of that row source's own bytes; past it the least recently used view is dropped (its
  *                             class is then rebuilt only after four times as many queries as the last time).  Default 200:
  *                             a long-lived index that holds both row sources can grow to three times their bytes.  0 .. 1600.
+ *                             (Tile tables are not under this budget: up to 64 of them per index, 32 B per tile of the chromosome
+ *                             each -- 3.4 MB for 10^8 positions -- least recently used out first.)
  *   MEMO_OPT_BUILD_COST_PCT   when a query builds a view (or brings rows that came in start order into the query order): every query
  *                             of a k class that runs without its view adds what the view would have saved it (the rows of its window
  *                             the view leaves out x what a sweep pays per row); the view is built by the query that finds the sum has
@@ -208,7 +212,8 @@ int memo_index_get_info_v5(const memo_index_t *ix, memo_index_info_t *info);  /*
 #define MEMO_OPT_VIEW_PLACES 5
 int memo_index_set_option(memo_index_t *ix, int32_t option, int64_t value);
 /* Build NOW what queries of one kind would otherwise build on the way: the k-class view of the rows such a query reads (else
- * built inside the class's fifth query, on the caller's stream, with a wait for it) and the tile table of the table-driven
+ * built by the query that finds it has become worth its pass -- MEMO_OPT_BUILD_COST_PCT -- on the caller's stream, with a wait
+ * for it; the places of its rows by a later one: MEMO_OPT_VIEW_PLACES) and the tile table of the table-driven
  * sweep (else built by the first query that needs it).  The stand-in for what memo_init does per query (memo_query.py:45-49:
  * recentre, shadow-cast, drop the rows that cannot write) done once for every later query of this k class.  window_hint: the
  * length of the windows to come (0 = the whole chromosome; it decides tile shapes only).  Blocking; returns the device bytes

@@ -220,6 +220,10 @@ int builder_why(const memo_builder_t *b);  // memo_hostpack.hip: which rows a bu
 extern thread_local bool g_dense_keep_all;  // (AB library, memo_debug_dense_keep_all: dense_compact keeps every row)
 extern thread_local int g_one_shot_way;     // (AB library, memo_debug_one_shot_way: 1 = int64 columns, 2 = 4-byte words)
 extern thread_local bool g_prepare_only;  // memo_index_prepare: the query path builds what it would build and launches nothing
+// ... and hands this as the result pointer: a launch site that missed g_prepare_only refuses it instead of writing to it (launch_tiles,
+// launch_halo3t, the fill and long-row launches: memo_sweep.hip: refuse_plan_pointer)
+static void *const kNeverWritten = reinterpret_cast<void *>(uintptr_t(4096));
+int refuse_plan_pointer(const void *d_out);
 extern thread_local bool g_side_alloc_fails;  // (AB library, memo_debug_fail_side_allocations: every side_alloc fails -- the test of kNoRoom)
 hipError_t side_alloc(void **p, size_t bytes);
 void drop_dense_views(memo_index *ix);

@@ -232,7 +232,7 @@ int memo_builder_finish(memo_builder_t *b, memo_index_t **out) {
         ix->pk = b->d_pk;
     b->d_pk = nullptr;  // the index owns them now
     ix->packed_fmt = b->dense ? 4 : b->fmt;  // (dense rows: what an index looks like after memo_index_pack_dense(ix, 0))
-    ix->order_pending = b->dense ? 0 : 1;    // (start order now; the query order by the fifth query: memo_common.h)
+    ix->order_pending = b->dense ? 0 : 1;    // (start order now; the query order once the queries have lost to it what the pass costs: memo_view.hip, keep_row_order)
     ix->finalized = 1;
     b->failed = MEMO_EINVAL;  // a builder finishes once
     if (b->dense) {  // rows that can never write at k <= 64 leave the dense rows when they are many (memo_common.h: boff3)
@@ -375,7 +375,7 @@ static int import_rows(uint64_t rows, int32_t device, int32_t bucket_shift, int6
         return rc;
     }
     ix->packed_fmt = pa ? 6 : (max_annot > 255 ? 12 : 4);  // the rule both packers follow: by the largest annot
-    ix->order_pending = (dense || pa) ? 0 : 1;  // (whatever order the file holds; the query order by the fifth query: idempotent)
+    ix->order_pending = (dense || pa) ? 0 : 1;  // (whatever order the file holds; the query order when it has become worth its pass: idempotent)
     ix->finalized = 1;
     if ((rc = memo_len_census(ix))) {
         memo_index_destroy(ix);

@@ -5,6 +5,7 @@
 // (:28-36, :45): three int64 columns, kept in HBM so that many windows reuse one upload.
 #include <chrono>
 #include <cstdarg>
+#include <exception>
 #include <cstddef>
 #include <new>
 
@@ -893,12 +894,21 @@ int memo_index_prepare(memo_index_t *ix, int32_t k, int32_t num_docs, int32_t me
     // the window the queries to come are like: it starts on every kernel's tile grid, and nothing is ever written to d_out
     const int64_t top = ix->max_s < 0 ? 0 : ix->max_s;
     const int64_t len = window_hint > 0 ? window_hint : (top + 1 > 4096 ? top + 1 : 4096);
-    void *const never_written = reinterpret_cast<void *>(uintptr_t(4096));
-    g_prepare_only = true;
-    const int rc = membership ? memo_query_membership_dev(ix, 0, len, k, num_docs, static_cast<uint32_t *>(never_written), stream)
-                   : num_docs <= 255 ? memo_query_conservation_u8_dev(ix, 0, len, k, num_docs, static_cast<uint8_t *>(never_written), stream)
-                                     : memo_query_conservation_dev(ix, 0, len, k, num_docs, static_cast<uint16_t *>(never_written), stream);
-    g_prepare_only = false;
+    void *const never_written = kNeverWritten;
+    int rc;
+    {
+        struct PlanOnly {  // (the query path plans and builds, and launches nothing: reset on every way out of this scope)
+            PlanOnly() { g_prepare_only = true; }
+            ~PlanOnly() { g_prepare_only = false; }
+        } plan_only;
+        try {
+            rc = membership ? memo_query_membership_dev(ix, 0, len, k, num_docs, static_cast<uint32_t *>(never_written), stream)
+                 : num_docs <= 255 ? memo_query_conservation_u8_dev(ix, 0, len, k, num_docs, static_cast<uint8_t *>(never_written), stream)
+                                   : memo_query_conservation_dev(ix, 0, len, k, num_docs, static_cast<uint16_t *>(never_written), stream);
+        } catch (const std::exception &ex) {  // (the query path's std::vector / std::map may throw: no exception crosses the C ABI)
+            rc = fail(MEMO_EHIP, "memo_index_prepare: %s", ex.what());
+        }
+    }
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());  // (views and tables are complete; and what the builds took out of service can go)
     flush_retired(ix);

@@ -59,6 +59,7 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
     if (A.tiles_per_xcd * 8 * threads >= ((int64_t)1 << 32))
         return fail(MEMO_EINVAL, "window too long for one launch at tile width %d", w);
     if (g_prepare_only) return MEMO_OK;  // memo_index_prepare: everything a query builds on the way exists now; nothing is launched
+    if (int rc = refuse_plan_pointer(A.out)) return rc;
     hipLaunchKernelGGL(kernel, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(threads), lds, st, A);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
@@ -68,6 +69,9 @@ int launch_tiles(SweepKernel kernel, SweepArgs &A, int w, int threads, size_t ld
 // fmt: 0 = int64 columns, 4 / 6 = packed words (+ 16-bit order column), 3 = only the dense rows are left
 // (memo_index_pack_dense dropped the words): k - 1 <= 63, and only kernels that read PackedRows3
 thread_local bool g_prepare_only = false;
+int refuse_plan_pointer(const void *d_out) {  // (a launch must never see memo_index_prepare's stand-in for a result)
+    return d_out == kNeverWritten ? fail(MEMO_EHIP, "internal: a sweep was about to be launched into memo_index_prepare's placeholder result") : MEMO_OK;
+}
 thread_local bool g_side_alloc_fails = false;
 thread_local int g_view_colouring = 1;
 thread_local int g_six_views = -1;

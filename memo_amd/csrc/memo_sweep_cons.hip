@@ -1144,6 +1144,7 @@ template <typename OutT>
 static int long_rows_conservation(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int ncols,
                                   OutT *d_out, hipStream_t st) {
     if (!ix->n_long || g_prepare_only) return MEMO_OK;
+    if (int prc = refuse_plan_pointer(d_out)) return prc;
     const int64_t fqs = ix->whole_set ? ix->whole_qs : qs, fqe = ix->whole_set ? ix->whole_qe : qe;
     hipLaunchKernelGGL((long_rows_conservation_kernel<OutT>), dim3((unsigned)ix->n_long), dim3(256), 0, st,
                        ix->ls, ix->le, ix->lo, qs, qe, k - 1, ncols, d_out, ix->d_status, fqs, fqe);
@@ -1242,6 +1243,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (k <= 1 || ix->rows == 0) {
         if (g_prepare_only) return MEMO_OK;
+        if ((rc = refuse_plan_pointer(d_out))) return rc;
         hipLaunchKernelGGL((fill_conservation_kernel<OutT>), dim3(2048), dim3(256), 0, st, d_out,
                            qe - qs, (OutT)num_docs);
         HIP_TRY(hipGetLastError());

@@ -59,7 +59,8 @@ __global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase
 // T = 256: four waves per tile (eight tiles = 32 waves per CU), the only form instantiated (T = 128 lost: see the launcher)
 // A9: an index of 256 .. 511 genomes -- the order in the top NINE bits of a level cell (memo_sweep_dense.h: MEMO_ROW9_AT), uint16 results
 // AW: the row source is a k-class view whose cap is this k - 1 -- every row of it writes, the row blocks carry no test (memo_sweep_dense.h)
-// SIX: the row source is a view in groups of six rows that carry their bucket (memo_interleave.hip: six_view_kernel; A/B)
+// SIX: the row source is a k-class view in groups of six rows that carry their bucket (memo_view.hip: view_build_kernel<6>; the
+// library's choice of view where it applies: -2.3 % at k = 31 against five-row views, profiles/r05_view_pass.txt)
 template <int NLEV, typename OutT, int T, bool A9 = false, bool AW = false, bool SIX = false>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 : 4, 8)))
 void sweep_conservation_halo3t_kernel(const SweepArgs A) {
@@ -317,6 +318,7 @@ int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStrea
                                : (all_write ? kernel_six<uint16_t, true>(A.nlev) : kernel_six<uint16_t, false>(A.nlev));
     if (!kern) return 1;
     if (g_prepare_only) return MEMO_OK;  // memo_index_prepare: the table is built, nothing is launched
+    if (int prc = refuse_plan_pointer(A.out)) return prc;
     hipLaunchKernelGGL(kern, dim3((unsigned)(A.tiles_per_xcd * 8)), dim3(256), (size_t)A.nlev * 4096, st, A);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;

@@ -238,7 +238,7 @@ __device__ __forceinline__ void group_rows(const uint4 &V, const RowConst &C, ui
     }
 }
 
-// ---- groups of SIX rows that carry their bucket (memo_interleave.hip: six_view_kernel; A/B, round 4) -----------------------------
+// ---- groups of SIX rows that carry their bucket (memo_view.hip: view_build_kernel<6>, pack_six) ---------------------------------
 // A row's ten bits (start mod 32 | overlap << 5) are the low bits of LO, its ds_min operand D has its annot on top; BIAS = the level
 // arrays' bias + 4 * the cell of the group's bucket.  operands: %0-%3 temporaries; %4-%9 LO of rows 0 .. 5; %10-%15 their D;
 // %16 BIAS; %17 km1 (SGPR), %18 ls4 (SGPR), %19 top_bit; masked form: %20 the lane's group number, %21 groups left (SGPR)

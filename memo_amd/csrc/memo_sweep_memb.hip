@@ -425,6 +425,7 @@ SweepKernel memb_runs_kernel(int w, int waves) {
 static int long_rows_membership(const memo_index *ix, int64_t qs, int64_t qe, int32_t k, int ncols, int nw,
                                 uint32_t *d_out, hipStream_t st) {
     if (!ix->n_long || g_prepare_only) return MEMO_OK;
+    if (int prc = refuse_plan_pointer(d_out)) return prc;
     hipLaunchKernelGGL(long_rows_membership_kernel, dim3((unsigned)ix->n_long), dim3(256), 0, st, ix->ls,
                        ix->le, ix->lo, qs, qe, k - 1, ncols, nw, d_out, ix->d_status,
                        ix->whole_set ? ix->whole_qs : qs, ix->whole_set ? ix->whole_qe : qe);
@@ -444,6 +445,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     const int nw = (num_docs + 31) / 32;
     if (k <= 1 || ix->rows == 0) {
         if (g_prepare_only) return MEMO_OK;
+        if ((rc = refuse_plan_pointer(d_out))) return rc;
         hipLaunchKernelGGL(fill_membership_kernel, dim3(2048), dim3(256), 0, st, d_out,
                            (qe - qs) * nw, nw, num_docs);
         HIP_TRY(hipGetLastError());

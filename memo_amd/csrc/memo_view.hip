@@ -110,9 +110,9 @@ __global__ __launch_bounds__(256) void packed_scatter_kernel(const uint32_t *pk,
 //   2. the two-level scan of those counts; view_table_kernel: the view's bucket table (kept rows before every bucket);
 //   3. view_build_kernel<P>: one WAVE per run of up to 64 buckets: streams the run's source groups with coalesced 16-byte
 //      loads (the source is read twice in all, nothing else), compacts the kept rows into LDS in source order (ballot +
-//      mbcnt: deterministic), then lane j takes bucket j of the run: counting sort by the bank of a row's first block, the
-//      greedy choice of one of P places per row -- the same decisions as round 4's colour_view_kernel (identical bytes), taken
-//      with colour MASKS per bank instead of bank masks per colour (a third of the instructions) -- and the wave packs the
+//      mbcnt: deterministic), then lane j takes bucket j of the run: the
+//      choice of one of P places per row (view_place_bucket: round 4's greedy rule, taken with colour MASKS per bank instead of
+//      bank masks per colour and without its sort) -- when places were asked for -- and the wave packs the
 //      groups and writes them with coalesced 16-byte stores.  P = 5: PackedRows3 groups, the view's rows back to back (a
 //      group may straddle two buckets: the two edge groups of a run are written with atomicOr into zeroed groups); P = 6:
 //      groups of six rows that carry their bucket and end at bucket boundaries (2.67 B per row; memo_sweep_dense.h:
@@ -347,7 +347,7 @@ __device__ __forceinline__ uint32_t view_emit(const ViewArgs &a, const ViewLds &
 // P = 5: slot q of the bucket is the view's row vb + q, its place in its group (vb + q) mod 5; P = 6: 6 * ng slots, place q mod 6.
 // The lanes of a wave run this together, a bucket each.
 //
-// The places (round 4: colour_view_kernel; the cost model: profiles/r04_lds_atomics.txt, tools/view_order_model.py).  The sweep gives
+// The places (round 4's one-lane-per-bucket kernel, NOTEBOOK.md; the cost model: profiles/r04_lds_atomics.txt, tools/view_order_model.py).  The sweep gives
 // a lane one group, and a wave's i-th row instruction visits place i of 64 consecutive groups: a half-wave's 32 atomics of one
 // instruction are place i of 32 groups.  A row's two ds_min go to cell A = start - (k - 1) + overlap (first block) and B = start -
 // 2^level (second block); the 32 atomics cost max(2, lanes on the fullest bank) cycles.  So the rows of a bucket are split into P
@@ -460,7 +460,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         const uint64_t v_run0 = (uint64_t)__shfl((long long)vb, 0, 64);
         // P = 5: slot 0 of the output staging is the view's row pbase (a multiple of 5); rows before pfrom are not this run's
         uint64_t pbase = v_run0 / 5 * 5, pfrom = v_run0;
-        uint32_t carried = 0;  // P = 5: rows of the last, partial group so far (staged at stage[kViewCap ...])
+        // P = 5: slots of the last, partial group so far: rows carried from the piece before (staged at stage[kViewCap ...]) -- and, at
+        // the head of a run, the rows of that group that belong to the run before (never read: view_emit masks them by `from`)
+        uint32_t carried = P == 5 ? (uint32_t)(pfrom - pbase) : 0u;
         if (lane < 8) L.inv[lane] = (uint16_t)(kViewCap + lane);  // (slots of the first group that are not this run's: never used, but read)
         __syncthreads();
         int s = 0;
@@ -859,7 +861,7 @@ static void keep_views_in_budget(memo_index *ix, const memo_index::DenseView *fr
 
 // ---- when is a pass over the rows worth it? ---------------------------------------------------------------------------------
 // memo_query.py:45-49 drops the rows that cannot write at the query's k in every query; a view drops them once -- at the price
-// of a pass over the rows.  Rounds 3-4 paid that price inside the FIFTH query of a class, whatever the queries were: on BASELINE
+// of a pass over the rows.  Rounds 3-4 paid that price inside the fifth query of a class, whatever the queries were: on BASELINE
 // config 3 a view paid for itself after 65 whole-chromosome queries, so queries 5 .. 69 of a class were a net loss, and a host
 // that sweeps 1-Mbp windows paid 8 ms for a view that saves it a microsecond per query.  Now every query of a
 // class that runs without its view adds what the view would have saved it -- the rows of its window the view leaves out x

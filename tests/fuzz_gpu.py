@@ -79,7 +79,7 @@ while time.time() < t_end:
         if rng.random() < 0.5:                                     # the order of the 4-byte rows inside their buckets (memo_interleave.hip):
             ix.debug_row_order(int(rng.integers(1, 5)))            #   start order, the two dealt orders, the membership order
         _lib.lib().memo_debug_view_colouring(int(rng.choice([0, 1, 1])))   # the places of a dense view's rows inside their groups
-        _lib.lib().memo_debug_six_views(int(rng.choice([-1, -1, 0, 1])))             # the six-row views experiment (memo_interleave.hip: aligned_view_kernel<6>)
+        _lib.lib().memo_debug_six_views(int(rng.choice([-1, -1, 0, 1])))             # which kind of dense view: the library's choice, five rows per group, six (memo_view.hip)
         k_pet = int(rng.choice([5, 9, 17, 31, 33, 101]))          # (asked often enough for its class's view to be built)
         if rng.random() < 0.3:                                     # memo_index_prepare: the view / tile table / row order before the first query
             try:

@@ -449,7 +449,7 @@ def test_builder_equals_int64_upload(n_rows, n_docs, pieces, memo, oracle):
                 ref.pack(keep_wide=True)
                 assert ref.info()["buckets"] == inf["buckets"]
                 # the host packer's words, 16-bit annots and bucket table are the device's, bit for bit -- once the builder's
-                # rows are in the query order too (memo_index_pack on a packed index; else: by the fifth query that reads them)
+                # rows are in the query order too (memo_index_pack on a packed index; else: once the queries that read them have made the pass worth it)
                 assert inf["row_order"] == 0
                 ix.pack(keep_wide=False)
                 assert ix.info()["row_order"] == ref.info()["row_order"] == (0 if _fmt(n_docs) == 6 else 2)
@@ -634,6 +634,7 @@ def test_builder_switches_to_12_bit_annots_late(memo, oracle):
         with b.finish() as ix:
             assert ix.info()["packed_format"] == 12
             _check_windows(ix, s, e, o, n_docs, rng, oracle, length, ks=(31, 101), windows=3)
+            ix.pack()                                               # (a packed index: its rows into the query order now)
             with memo.DeviceIndex.from_host(s, e, o) as ref:        # the device's format-12 words are the same words
                 ref.pack()
                 assert all(np.array_equal(x, y) for x, y in zip(_export(ix), _export(ref)))
@@ -1587,7 +1588,7 @@ def test_dense_row_sweep_variants(memo, oracle, ab):
 @pytest.mark.parametrize("n", [100, 500])
 def test_packed_k_class_views(n, memo, oracle, ab):
     """The 4-byte words have k-class views too (packed_rows_for: the rows whose overlap is below the class's cap -- 2 ... 32 by 2, ... 64 by 8, ... 128 by 16 --, built by
-    the class's fifth query when that spares a fifth of the rows): what membership queries, k > 64 and indexes of more than 255
+    the query that finds it worth its pass, when that spares a fifth of the rows): what membership queries, k > 64 and indexes of more than 255
     genomes read (format 4 at 100 genomes, format 12 at 500).  Same results as on all the rows (row_source 9), conservation and
     membership, every kernel family; info.last_rows_read says what was read."""
     from memo_amd import synth
@@ -1624,7 +1625,7 @@ def test_packed_k_class_views(n, memo, oracle, ab):
 
 def test_queries_of_one_index_on_several_streams(memo, oracle):
     """include/memo_amd.h, "Threads and streams": one thread may enqueue queries of one index on several streams.  What a
-    query builds for later ones -- a tile table per (rows, tile width, k), a k-class view by the class's fifth query -- is
+    query builds for later ones -- a tile table per (rows, tile width, k), a k-class view once it has become worth its pass -- is
     built on the stream of the query that needed it and read by the next query on ANOTHER stream, so it has to be complete
     when the call returns; an evicted tile table (more than four (k, view) pairs) must outlive the sweeps queued on it.
     Thirty-six queries, six k, three streams, nothing synchronised until the end: every result equals the oracle's."""
@@ -1842,7 +1843,7 @@ def test_prepare_builds_views_and_tables_now(memo, oracle):
             assert inf["views_resident"] == 0 and inf["device_bytes"] <= before["device_bytes"] + (1 << 20)
             assert np.array_equal(ix.conservation(0, L, 31, n, dtype=np.uint8), got) and ix.info()["last_rows_read"] == r1 - r0
             ix.set_option(1, 1)
-    # an index that came in through the builder: start order until the fifth query -- or prepare
+    # an index that came in through the builder: start order until prepare
     s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, n)
     with memo.DeviceIndex.from_host_packed(s, e, o) as ix:
         assert ix.info()["row_order"] == 0
@@ -2011,7 +2012,7 @@ def test_row_order_inside_buckets_never_changes_a_result(memo, oracle, ab):
 
 
 def test_places_inside_a_dense_group_never_change_a_result(memo, oracle, ab):
-    """memo_interleave.hip, colour_view_kernel: the rows of a dense k-class view get their place inside their 16-byte group (and
+    """memo_view.hip, view_place_bucket: the rows of a dense k-class view get their place inside their 16-byte group (and
     their group inside the bucket) chosen against LDS bank conflicts.  Views built with and without it, on a ragged index
     with empty stretches, a few buckets above the kernel's 128-row limit and windows that begin inside a bucket: the same rows
     read, results equal to the oracle and to each other, every k of every class of two."""
@@ -2195,6 +2196,31 @@ def test_dense_views_as_the_fused_pass_builds_them(memo, oracle, ab):
         finally:
             ab.check(ab.lib().memo_debug_view_colouring(1))
             ab.check(ab.lib().memo_debug_six_views(-1))
+    # every bucket too long for the stage, runs of four buckets that begin inside a group (the fuzzer's find: 256-position buckets
+    # of ~9000 rows): the dense rows and two views against the twin
+    m, length, n_docs = 115_870, 3000, 33
+    s = np.sort(rng.integers(60, 2900, m)).astype(np.int64)
+    ov = rng.integers(0, 72, m)
+    e = s + ov
+    o = rng.integers(1, n_docs, m).astype(np.int64)
+    with memo.DeviceIndex.from_host(s, e, o, bucket_shift=8) as ix:
+        ix.pack(keep_wide=True)
+        pk = _export(ix)[0]
+        ix.pack_dense(keep_packed=False)
+        inf = ix.info()
+        assert inf["bucket_shift"] == 8 and inf["dense_row_count"] < m
+        dense = _export_dense(ix)
+        B, A = _dense_rows_fields(dense[0], inf["dense_row_count"])
+        stay = ((pk >> 16) & 0xFF) < 63
+        assert np.array_equal(B, ((((pk & 0xFFFF)[stay] & 1023) << 6) | ((pk >> 16) & 0xFF)[stay]).astype(np.uint64))
+        assert np.array_equal(A, (pk >> 24)[stay].astype(np.uint64))
+        for k in (5, 21):
+            ix.prepare(k, n_docs)
+            view = ix.export_view(k, 5)
+            twin = _view_twin(dense, inf["dense_row_count"], view[3], 5)
+            assert view[2] == twin[2] and np.array_equal(view[1], twin[1]) and np.array_equal(view[0], twin[0]), k
+            want = oracle.conservation(*oracle.filter_rows(s, e, o, 1984, 2655, k), 1984, 2655, k, n_docs, literal=False)
+            assert np.array_equal(ix.conservation(1984, 2655, k, n_docs), want), k
     # what the places are worth, by the cycle model, on BASELINE's shape (5 rows per position, overlaps uniform in 0 .. 59), k = 31
     from memo_amd import synth
     for rpg in (5, 6):
@@ -2300,7 +2326,7 @@ def test_dense_rows_of_256_to_511_genomes(memo, oracle, ab):
 
 def test_six_row_views_experiment(memo, oracle, ab):
     """memo_debug_six_views (A/B library only; round-4 experiment, off in the product): the dense k-class views as groups of SIX rows that
-    carry their bucket (memo_interleave.hip: six_view_kernel; 2.67 B per row) on the table-driven kernel's form for them
+    carry their bucket (memo_view.hip: view_build_kernel<6>; 2.67 B per row) on the table-driven kernel's form for them
     (info.last_variant 3).  Ragged index with an empty stretch and a bucket above the builder's 96-row limit, every k class it takes
     (k - 1 <= 31), windows that begin inside a bucket, both result types: equal to the oracle and to the five-row views."""
     rng = np.random.default_rng(61)

@@ -27,7 +27,7 @@ def counter_rows(d, counter):
 
 def mean(rows, key):
     """the MEDIAN over the kernel's launches (the first launches of a run may be another workload of the same kernel: the
-    dense-row sweep reads all the dense rows until the k-class view is built by the fifth query)"""
+    dense-row sweep reads all the dense rows until the k-class view is built)"""
     v = sorted(float(r["Counter_Value"]) for r in rows if key in r["Kernel_Name"])
     return (v[len(v) // 2], len(v)) if v else (None, 0)
 

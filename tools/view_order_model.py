@@ -4,7 +4,8 @@ profiles/r04_lds_atomics.txt (a half-wave's 32 ds_min take max(2, lanes on the f
 2k - 1).  Rows of BASELINE config 3 (five per position, overlap uniform in [0, 60)), k = 31: the view keeps overlap < 30.
 
   current      the 4-byte rows' interleaved order (memo_interleave.hip, mode 2), filtered
-  coloured     memo_interleave.hip: colour_view_kernel (rows taken by A mod 32, one of five places chosen greedily, laid down in that order)
+  coloured     round 4's colour_view_kernel (rows taken by A mod 32, one of five places chosen greedily, laid down in that order);
+               round 5 (memo_view.hip: view_place_bucket) takes the rows in the order they come: 5.76 against 5.53 by this model
 
 Anywhere (numpy only).  Prints cycles per row instruction and half-wave: first block, second block; at four alignments of the tile's
 first group.
