@@ -331,10 +331,11 @@ def main():
               info = ixf.info()
               packed_fmt = info["packed_format"]
               pk_bytes = 6 if packed_fmt == 6 else 4
-              pack_bytes = (24 + pk_bytes) * nrows + 8 * nrows        # census reads the annot column once more
+              pack_bytes = (24 + pk_bytes) * nrows + 2 * pk_bytes * nrows        # + the order inside the buckets: the words read and written again
               pack_pass = {"what": "memo_index_pack: int64 columns -> packed rows, once per index, not part of a query "
-                                   "(annot_census_kernel reads 8 B/row; pack_rows_kernel reads 24 B and writes "
-                                   "%d B per row, format %d)" % (pk_bytes, packed_fmt),
+                                   "(the layout guessed from a sample of the annot column; pack_rows_kernel reads 24 B, writes "
+                                   "%d B per row (format %d) and takes the exact annot census on the way; then the rows' order inside "
+                                   "their buckets, in place: interleave_small_kernel)" % (pk_bytes, packed_fmt),
                            "ms": info["pack_ms"], "rows": nrows, "bytes": pack_bytes,
                            "GBs": pack_bytes / (info["pack_ms"] * 1e-3) / 1e9 if info["pack_ms"] > 0 else None,
                            "timed_with": "HIP event pair inside memo_index_pack (memo_index_info.pack_ms), second call "

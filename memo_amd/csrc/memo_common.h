@@ -233,7 +233,7 @@ inline uint64_t dense_groups_for(uint64_t padded) { return (padded + 4) / 5 + 64
 void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables derive from the dense rows and the bucket table
 // memo_interleave.hip: reorder the 4-byte rows inside every bucket (mode 0: start order, 1: chunks of four dealt round-robin
 // over the bucket's starts, 2: the same with the rows of a start ordered by overlap mod 32), in place, queued on st
-int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshift, int fmt, int mode, hipStream_t st);
+int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshift, int fmt, int mode, hipStream_t st, uint64_t *scratch);  // scratch: ix->d_scratch
 extern thread_local int g_view_colouring;  // 1: the dense rows' k-class views may get their rows' places inside a group chosen against bank conflicts (memo_debug_view_colouring of the AB library turns it off)
 constexpr int kRowOrderDefault = 2;  // interleave_words mode the product applies wherever 4-byte rows come into being
 int order_words_now(memo_index *ix, int mode);  // memo_index.hip: waits for the device, orders ix->pk in place, waits again

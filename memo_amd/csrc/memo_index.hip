@@ -90,10 +90,12 @@ __global__ void collect_long_rows_kernel(const int64_t *s, const int64_t *e, con
 }
 
 // memo_index_pack: annot range census, then one word (+ optional 16-bit annot) per row
-__global__ void annot_census_kernel(const int64_t *o, uint64_t rows, uint64_t *scratch) {
+// (step > 1: a SAMPLE, every step-th row -- memo_index_pack guesses the word layout from it and packs at once; the packing kernel
+// takes the exact census on the way: reading the annot column twice was 0.85 ms of config 3's packing pass)
+__global__ void annot_census_kernel(const int64_t *o, uint64_t rows, uint64_t *scratch, uint64_t step) {
     uint64_t outside = 0, over8 = 0, top = 0;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < rows;
-         i += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t i = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) * step; i < rows;
+         i += (uint64_t)gridDim.x * blockDim.x * step) {
         const int64_t v = o[i];
         if (v < 0 || v > 65535) ++outside;
         else if ((uint64_t)v > top) top = (uint64_t)v;
@@ -106,8 +108,10 @@ __global__ void annot_census_kernel(const int64_t *o, uint64_t rows, uint64_t *s
 
 // fmt: 4 = start16 | len8 << 16 | annot8 << 24;  12 = len8 | start12 << 8 | annot12 << 20;  6 = the first word with
 // annot 0 + a 16-bit annot column  (PackedRows, memo_sweep.h)
+// ... and, with `census`, what annot_census_kernel counts, of every row: scratch[3] annots outside [0, 65535], [5] the largest
 __global__ void pack_rows_kernel(const int64_t *s, const int64_t *e, const int64_t *o, uint64_t rows,
-                                 uint64_t padded, uint32_t *pk, uint16_t *pa, int fmt) {
+                                 uint64_t padded, uint32_t *pk, uint16_t *pa, int fmt, uint64_t *census) {
+    uint64_t outside = 0, top = 0;
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < padded;
          i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t w = 0, a = 0;
@@ -115,11 +119,25 @@ __global__ void pack_rows_kernel(const int64_t *s, const int64_t *e, const int64
             const int64_t len = e[i] - s[i];
             // end < start (handled by long_rows_kernel) packs as "never writes", like len >= 255
             const uint32_t l8 = (uint32_t)(len > 255 || len < 0 ? 255 : len);
-            a = (uint32_t)o[i];
+            const int64_t v = o[i];
+            if (v < 0 || v > 65535) ++outside;
+            else if ((uint64_t)v > top) top = (uint64_t)v;
+            a = (uint32_t)v;
             w = fmt == 12 ? l8 | (((uint32_t)s[i] & 0xFFFu) << 8) | (a << 20) : ((uint32_t)s[i] & 0xFFFFu) | (l8 << 16);
         }
         if (fmt == 6) pa[i] = (uint16_t)a; else if (fmt == 4) w |= a << 24;
         pk[i] = w;
+    }
+    if (census) {  // one pair of atomics per wave
+        for (int off = 32; off; off >>= 1) {
+            const uint64_t t = (uint64_t)__shfl_xor((long long)top, off, 64);
+            top = t > top ? t : top;
+            outside += (uint64_t)__shfl_xor((long long)outside, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (outside) atomicAdd((unsigned long long *)&census[3], (unsigned long long)outside);
+            if (top) atomicMax((unsigned long long *)&census[5], (unsigned long long)top);
+        }
     }
 }
 
@@ -671,36 +689,53 @@ int memo_index_pack(memo_index_t *ix, int32_t keep_wide) {
     drop_dense(ix);  // derived from the words that are about to be rewritten
     drop_packed_views(ix);
     const bool had = ix->pk && ix->packed_rows == ix->padded;
-    const bool had_pa = had && ix->pa;
     if (!had) drop_packed(ix);
     ix->packed_fmt = 0;
     if (!ix->pk) HIP_TRY(hipMalloc(&ix->pk, ix->padded * sizeof(uint32_t)));
     ix->packed_rows = ix->padded;
     uint64_t h[8] = {0};
     HIP_TRY(hipEventRecord(ev0, st));
+    // The layout follows from the largest annot: guessed from a sample of the annot column (every 256th row), packed at once with
+    // the exact census taken on the way, packed again only when a row the sample missed needs a wider layout.
+    auto layout_of = [](uint64_t top) { return top <= 255 ? 4 : (top <= 4095 ? 12 : 6); };
+    int fmt = 4;
     if (ix->rows) {
         HIP_TRY(hipMemsetAsync(ix->d_scratch, 0, 64, st));
-        const unsigned grid = (unsigned)(ix->rows / 256 + 1 < 4096 ? ix->rows / 256 + 1 : 4096);
-        hipLaunchKernelGGL(annot_census_kernel, dim3(grid), dim3(256), 0, st, ix->o, ix->rows, ix->d_scratch);
+        const uint64_t step = ix->rows > (1u << 20) ? 256 : 1, samples = ix->rows / step + 1;
+        const unsigned grid = (unsigned)(samples / 256 + 1 < 4096 ? samples / 256 + 1 : 4096);
+        hipLaunchKernelGGL(annot_census_kernel, dim3(grid), dim3(256), 0, st, ix->o, ix->rows, ix->d_scratch, step);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(h, ix->d_scratch, 64, hipMemcpyDeviceToHost));
         if (h[3])
-            return fail(MEMO_EINVAL, "%llu rows have an annot outside [0, 65535]: cannot be packed",
-                        (unsigned long long)h[3]);
+            return fail(MEMO_EINVAL, "rows have an annot outside [0, 65535]: cannot be packed");
+        fmt = layout_of(h[5]);
+        for (int pass = 0; pass < 2; ++pass) {
+            if (fmt == 6 && !ix->pa) HIP_TRY(hipMalloc(&ix->pa, ix->padded * sizeof(uint16_t)));
+            HIP_TRY(hipMemsetAsync(ix->d_scratch, 0, 64, st));
+            hipLaunchKernelGGL(pack_rows_kernel, dim3(4096), dim3(256), 0, st, ix->s, ix->e, ix->o, ix->rows, ix->padded, ix->pk,
+                               fmt == 6 ? ix->pa : nullptr, fmt, pass == 0 ? ix->d_scratch : nullptr);
+            HIP_TRY(hipGetLastError());
+            if (pass) break;
+            HIP_TRY(hipMemcpyAsync(h, ix->d_scratch, 64, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (h[3])
+                return fail(MEMO_EINVAL, "%llu rows have an annot outside [0, 65535]: cannot be packed", (unsigned long long)h[3]);
+            if (layout_of(h[5]) == fmt) break;
+            fmt = layout_of(h[5]);  // (a row the sample missed: once more, in the layout it needs)
+        }
+    } else {
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(64), dim3(256), 0, st, ix->s, ix->e, ix->o, ix->rows, ix->padded, ix->pk, nullptr, fmt,
+                           nullptr);
+        HIP_TRY(hipGetLastError());
     }
-    const int fmt = h[5] <= 255 ? 4 : (h[5] <= 4095 ? 12 : 6);  // by the largest annot
     ix->max_annot = h[5];
-    if (fmt == 6 && !ix->pa) HIP_TRY(hipMalloc(&ix->pa, ix->padded * sizeof(uint16_t)));
-    if (fmt != 6 && had_pa) {
+    if (fmt != 6 && ix->pa) {
         (void)hipFree(ix->pa);
         ix->pa = nullptr;
     }
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(4096), dim3(256), 0, st, ix->s, ix->e, ix->o, ix->rows,
-                       ix->padded, ix->pk, fmt == 6 ? ix->pa : nullptr, fmt);
-    HIP_TRY(hipGetLastError());
     ix->row_order = 0;
     if (const int mode = row_order_mode(ix); mode && (fmt == 4 || fmt == 12) && ix->rows) {  // the order inside a bucket (memo_interleave.hip)
-        if (int rc = interleave_words(ix->pk, ix->boff, ix->nb, ix->bshift, fmt, mode, st)) return rc;
+        if (int rc = interleave_words(ix->pk, ix->boff, ix->nb, ix->bshift, fmt, mode, st, ix->d_scratch)) return rc;
         ix->row_order = mode;
     }
     HIP_TRY(hipEventRecord(ev1, st));

@@ -203,6 +203,90 @@ __device__ __forceinline__ void wave_bucket(uint32_t *__restrict__ words, int64_
     wave_sync();  // (key / first / cnt / table are reused by this wave's next bucket)
 }
 
+// ---- two buckets per wave, a LANE per start (rows that arrive in start order, at most eight per start) -------------
+// What the pass costs is instructions (wave_bucket: ~500 per bucket of 160 rows, most of them in loops whose lanes are a
+// third idle).  Where the rows of a bucket come grouped by start and no start has more than eight -- BASELINE config 3: five
+// each -- lane s owns start s: its (up to eight) keys in registers, ordered by a sorting network, its two chunks of four
+// placed by two 32-lane prefix sums, written as 16-byte pieces that follow one another along the lanes (coalesced).
+// ~130 instructions per bucket.  Anything else -- a start with more rows, rows out of start order, the membership order
+// (its classes are not starts) -- returns false and takes wave_bucket.
+__device__ __forceinline__ void sort8(uint32_t (&k)[8]) {  // (Batcher's odd-even merge sort: 19 compare-exchanges)
+    auto cx = [&](int a, int b) {
+        const uint32_t lo = k[a] < k[b] ? k[a] : k[b], hi = k[a] < k[b] ? k[b] : k[a];
+        k[a] = lo;
+        k[b] = hi;
+    };
+    cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7);
+    cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7);
+    cx(1, 2); cx(5, 6);
+    cx(0, 4); cx(1, 5); cx(2, 6); cx(3, 7);
+    cx(2, 4); cx(3, 5);
+    cx(1, 2); cx(3, 4); cx(5, 6);
+}
+
+// buckets b and b + 1: rows [r0, r1) and [r1, r2); key[] holds 512 words, cnt / first 64 each.  Returns false (nothing
+// written) when the pair does not qualify.
+__device__ __forceinline__ bool lane_pair(uint32_t *__restrict__ words, int64_t r0, int64_t r1, int64_t r2, const KeyCodec &C, uint32_t *key,
+                                          uint32_t *first, uint32_t *cnt, uint32_t *high2) {
+    const int lane = threadIdx.x & 63;
+    const int R = (int)(r2 - r0), RA = (int)(r1 - r0);
+    cnt[lane] = 0;
+    first[lane] = 0xFFFFFFFFu;
+    wave_sync();
+    bool ok = true;
+    for (int e = lane; e < ((R + 63) & ~63); e += 64) {
+        uint32_t k = 0xFFFFFFFFu, prev = 0;
+        if (e < R) {
+            const uint32_t w = words[r0 + e];
+            k = C.key(w);
+            if (e == 0) high2[0] = C.high_of(w);
+            if (e == RA) high2[1] = C.high_of(w);
+            key[e] = k;
+            const uint32_t cls = (k >> 20) + (e >= RA ? 32u : 0u);
+            atomicAdd(&cnt[cls], 1u);
+            atomicMin(&first[cls], (uint32_t)e);
+        }
+        // start order inside a bucket: a row's start is not below the one before it (same bucket)
+        prev = (uint32_t)__shfl_up((int)k, 1, 64);
+        if (e < R && (e & 63) && e != RA && (prev >> 20) > (k >> 20)) ok = false;
+    }
+    wave_sync();
+    // (the rows at the seams of the 64-row rounds: checked through LDS)
+    for (int e = 64 + lane * 64; e < R; e += 64 * 64)
+        if (e != RA && (key[e - 1] >> 20) > (key[e] >> 20)) ok = false;
+    const uint32_t c = cnt[lane], f = first[lane];
+    // grouped by start: the rows of a class are consecutive -- first + count covers them iff no other class lies between, which
+    // start order guarantees; eight at most
+    if (c > 8) ok = false;
+    if (__ballot(!ok)) return false;
+    uint32_t k[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = (uint32_t)i < c ? key[f + i] : 0xFFFFFFFFu;
+    sort8(k);
+    // chunks: pass 0 holds the first four rows of every start, pass 1 the rest; inside a pass, start order
+    const uint32_t v0 = c < 4 ? c : 4, v1 = c > 4 ? c - 4 : 0;
+    uint32_t s0 = v0, s1 = v1;
+    for (int off = 1; off < 32; off <<= 1) {
+        const uint32_t t0 = (uint32_t)__shfl_up((int)s0, off, 32), t1 = (uint32_t)__shfl_up((int)s1, off, 32);
+        if ((lane & 31) >= off) {
+            s0 += t0;
+            s1 += t1;
+        }
+    }
+    const uint32_t all0 = (uint32_t)__shfl((int)s0, 31, 32);  // rows of the bucket in pass 0
+    const int64_t base = lane < 32 ? r0 : r1;
+    const uint32_t high = high2[lane >> 5];
+    uint32_t *d0 = words + base + (s0 - v0), *d1 = words + base + all0 + (s1 - v1);
+    wave_sync();  // (every key is in registers: the rows may be overwritten)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if ((uint32_t)i < v0) d0[i] = C.word(k[i], high);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if ((uint32_t)i < v1) d1[i] = C.word(k[4 + i], high);
+    return true;
+}
+
 // ---- a whole workgroup, one bucket of up to kMaxBucketRows rows, any bucket width ---------------------------------
 __device__ __forceinline__ void block_bucket(uint32_t *__restrict__ words, int64_t r0, int R, const KeyCodec &C, uint32_t *key,
                                              uint32_t *first /*[256]*/, uint32_t *cnt /*[256]*/, uint32_t *shared_high) {
@@ -291,39 +375,49 @@ __device__ __forceinline__ void block_bucket(uint32_t *__restrict__ words, int64
 // sweep's ds_or goes to plane row `annot` (odd pitch: 32 consecutive residues are 32 banks) at the word of the run's first
 // bit, end - (k - 1), so the 32 lanes of a half-wave -- 32 residues, ends of one quantile of the bucket -- hit 32 banks
 //
-// Two kernels share a launch's buckets, four at a time ("a turn"): the turns whose four buckets are small (<= 256 rows each,
-// buckets of 32 positions: every index of up to ~8 rows per position) go to interleave_small_kernel -- a bucket per WAVE, 3.3 KiB
-// of LDS per wave, so that a CU holds 32 waves of them -- and all the others to interleave_large_kernel, a bucket per workgroup
+// Two kernels share a launch's buckets, eight at a time ("a turn"): the turns whose eight buckets are small (<= 256 rows each,
+// buckets of 32 positions: every index of up to ~8 rows per position) go to interleave_small_kernel -- two buckets per WAVE (a lane per start where no start has more than eight
+// rows: lane_pair; else a bucket at a time: wave_bucket), 4.6 KiB of LDS per wave, so that a CU holds 32 waves of them -- and all the others to interleave_large_kernel, a bucket per workgroup
 // with 32 KiB of keys.  (Round 4 had one kernel with the large one's LDS: 12 waves per CU; the pass waits on LDS round trips
 // and dependent steps, and BASELINE config 3's 3.1 * 10^6 buckets took 6.1 ms.)  Each kernel skips the other's turns.
-__device__ __forceinline__ bool small_turn(const int64_t (&r)[5], int bshift) {
+constexpr int kTurn = 8;  // buckets a workgroup takes at a time: two per wave
+
+__device__ __forceinline__ bool small_turn(const int64_t (&r)[kTurn + 1], int bshift) {
     int64_t longest = 0;
-    for (int j = 0; j < 4; ++j) longest = r[j + 1] - r[j] > longest ? r[j + 1] - r[j] : longest;
+    for (int j = 0; j < kTurn; ++j) longest = r[j + 1] - r[j] > longest ? r[j + 1] - r[j] : longest;
     return bshift == 5 && longest <= kWaveRows;
 }
 
 __global__ __launch_bounds__(256) void interleave_small_kernel(uint32_t *__restrict__ words, const int64_t *__restrict__ boff,
-                                                               int64_t nbuckets, int bshift, int fmt12, int mode) {
-    __shared__ uint32_t key[4][kWaveRows];
-    __shared__ uint32_t first[4][32], cnt[4][32];
+                                                               int64_t nbuckets, int bshift, int fmt12, int mode, unsigned int *left_over) {
+    __shared__ uint32_t key[4][2 * kWaveRows];
+    __shared__ uint32_t first[4][64], cnt[4][64];
     __shared__ uint32_t table[4][kWaveQ * 32];
+    __shared__ uint32_t high2[4][2];
     KeyCodec C;
     C.fmt12 = fmt12;
     C.mode = mode;
     C.bshift = bshift;
     C.cshift = mode == 3 ? 26 : 20;
     const int wave = threadIdx.x >> 6;
-    for (int64_t b0 = 4 * (int64_t)blockIdx.x; b0 < nbuckets; b0 += 4 * (int64_t)gridDim.x) {
-        int64_t r[5];
-        for (int j = 0; j < 5; ++j) r[j] = boff[b0 + j < nbuckets ? b0 + j : nbuckets];
-        if (!small_turn(r, bshift)) continue;  // (workgroup-uniform; the waves never meet at a barrier here)
-        const int64_t R = r[wave + 1] - r[wave];
-        if (R >= 2) wave_bucket(words, r[wave], (int)R, C, key[wave], first[wave], cnt[wave], table[wave]);
+    for (int64_t b0 = kTurn * (int64_t)blockIdx.x; b0 < nbuckets; b0 += kTurn * (int64_t)gridDim.x) {
+        int64_t r[kTurn + 1];
+        for (int j = 0; j <= kTurn; ++j) r[j] = boff[b0 + j < nbuckets ? b0 + j : nbuckets];
+        if (!small_turn(r, bshift)) {  // (workgroup-uniform; the waves never meet at a barrier here)
+            if (threadIdx.x == 0 && *left_over == 0) atomicOr(left_over, 1u);  // (interleave_large_kernel has something to do)
+            continue;
+        }
+        const int64_t ra = r[2 * wave], rb = r[2 * wave + 1], rc = r[2 * wave + 2];
+        if (rc - ra < 2) continue;
+        if ((mode == 1 || mode == 2) && lane_pair(words, ra, rb, rc, C, key[wave], first[wave], cnt[wave], high2[wave])) continue;
+        if (rb - ra >= 2) wave_bucket(words, ra, (int)(rb - ra), C, key[wave], first[wave], cnt[wave], table[wave]);
+        if (rc - rb >= 2) wave_bucket(words, rb, (int)(rc - rb), C, key[wave], first[wave], cnt[wave], table[wave]);
     }
 }
 
 __global__ __launch_bounds__(256) void interleave_large_kernel(uint32_t *__restrict__ words, const int64_t *__restrict__ boff,
-                                                               int64_t nbuckets, int bshift, int fmt12, int mode) {
+                                                               int64_t nbuckets, int bshift, int fmt12, int mode, const unsigned int *left_over) {
+    if (left_over && *left_over == 0) return;  // (every turn was a small one: 0.47 ms of skipping for config 3's 3.9 * 10^5 turns otherwise)
     __shared__ uint32_t key[kMaxBucketRows];
     __shared__ uint32_t first[256], cnt[256];
     __shared__ uint32_t shared_high;
@@ -332,11 +426,11 @@ __global__ __launch_bounds__(256) void interleave_large_kernel(uint32_t *__restr
     C.mode = mode;
     C.bshift = bshift;
     C.cshift = mode == 3 ? 26 : 20;
-    for (int64_t b0 = 4 * (int64_t)blockIdx.x; b0 < nbuckets; b0 += 4 * (int64_t)gridDim.x) {
-        int64_t r[5];
-        for (int j = 0; j < 5; ++j) r[j] = boff[b0 + j < nbuckets ? b0 + j : nbuckets];
+    for (int64_t b0 = kTurn * (int64_t)blockIdx.x; b0 < nbuckets; b0 += kTurn * (int64_t)gridDim.x) {
+        int64_t r[kTurn + 1];
+        for (int j = 0; j <= kTurn; ++j) r[j] = boff[b0 + j < nbuckets ? b0 + j : nbuckets];
         if (small_turn(r, bshift)) continue;
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < kTurn; ++j) {
             const int64_t R = r[j + 1] - r[j];
             if (R >= 2 && R <= kMaxBucketRows) block_bucket(words, r[j], (int)R, C, key, first, cnt, &shared_high);
         }
@@ -346,16 +440,20 @@ __global__ __launch_bounds__(256) void interleave_large_kernel(uint32_t *__restr
 }  // namespace
 
 // words: rows of formats 4 / 12, boff: their bucket table (nb entries, the last pinned to the row count).  Queued on st.
-int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshift, int fmt, int mode, hipStream_t st) {
+int interleave_words(uint32_t *words, const int64_t *boff, uint64_t nb, int bshift, int fmt, int mode, hipStream_t st, uint64_t *scratch) {
     if (!words || !boff || nb < 2 || (fmt != 4 && fmt != 12) || bshift < 1 || bshift > 8) return MEMO_OK;
     if (mode == 3 && bshift != 5) mode = 2;  // (the membership order's key is laid out for 32 starts per bucket)
     const int64_t nbuckets = (int64_t)nb - 1;
-    const int64_t turns = (nbuckets + 3) / 4;
+    const int64_t turns = (nbuckets + kTurn - 1) / kTurn;
     const unsigned grid = (unsigned)(turns < 256 * 64 ? turns : 256 * 64);
-    if (bshift == 5)
-        hipLaunchKernelGGL(interleave_small_kernel, dim3(grid), dim3(256), 0, st, words, boff, nbuckets, bshift, fmt == 12 ? 1 : 0, mode);
+    unsigned int *left_over = scratch && bshift == 5 ? reinterpret_cast<unsigned int *>(scratch + 7) : nullptr;  // (the index's scratch words)
+    if (bshift == 5) {
+        if (left_over) HIP_TRY(hipMemsetAsync(left_over, 0, 4, st));
+        if (!left_over) return fail(MEMO_EINVAL, "interleave_words needs the index's scratch words");
+        hipLaunchKernelGGL(interleave_small_kernel, dim3(grid), dim3(256), 0, st, words, boff, nbuckets, bshift, fmt == 12 ? 1 : 0, mode, left_over);
+    }
     hipLaunchKernelGGL(interleave_large_kernel, dim3(grid < 256 * 16 ? grid : 256 * 16), dim3(256), 0, st, words, boff, nbuckets, bshift,
-                       fmt == 12 ? 1 : 0, mode);
+                       fmt == 12 ? 1 : 0, mode, (const unsigned int *)left_over);
     HIP_TRY(hipGetLastError());
     return MEMO_OK;
 }

@@ -98,7 +98,11 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
                 V[j] = make_uint4(0x0000003Fu, 0x0000003Fu, 0x0000003Fu, 0x0000003Fu);  // (rows that cannot write)
                 continue;
             }
-            V[j] = src0[pg < g.ng ? pg + (uint32_t)lane : 0u];
+            // (a piece that straddles the slice's end: its lanes past the last group read THAT group again -- a line the wave fetches
+            // anyway -- instead of up to 63 groups behind the slice: half a KiB per tile on average, 25 % of a k = 9 view's tile, 12 % at
+            // k = 17, 6 % at k = 31 by TCP_TCC_READ_REQ, profiles/r05_six_rows.txt; the rows' numbers, not their bytes, mask them)
+            const uint32_t at = pg + (uint32_t)lane;
+            V[j] = src0[pg < g.ng ? (at < g.ng ? at : g.ng - 1u) : 0u];
         }
     };
     issue(0);

@@ -932,7 +932,7 @@ int order_words_now(memo_index *ix, int mode) {
     DeviceGuard guard(ix->device);
     HIP_TRY(hipDeviceSynchronize());
     drop_packed_views(ix);  // (views are subsets in the old order)
-    if (int rc = interleave_words(ix->pk, ix->boff, ix->nb, ix->bshift, ix->packed_fmt, mode, nullptr)) return rc;
+    if (int rc = interleave_words(ix->pk, ix->boff, ix->nb, ix->bshift, ix->packed_fmt, mode, nullptr, ix->d_scratch)) return rc;
     HIP_TRY(hipDeviceSynchronize());
     ix->row_order = mode;
     return MEMO_OK;
@@ -960,7 +960,7 @@ static int order_words_on(memo_index *ix, int mode, hipStream_t st) {
     if (err == hipSuccess) err = hipEventRecord(e0, st);
     if (err == hipSuccess) err = hipMemcpyAsync(copy, ix->pk, bytes, hipMemcpyDeviceToDevice, st);
     int rc = MEMO_OK;
-    if (err == hipSuccess) rc = interleave_words(copy, ix->boff, ix->nb, ix->bshift, ix->packed_fmt, mode, st);
+    if (err == hipSuccess) rc = interleave_words(copy, ix->boff, ix->nb, ix->bshift, ix->packed_fmt, mode, st, ix->d_scratch);
     if (err == hipSuccess && !rc) err = hipEventRecord(e1, st);
     if (err == hipSuccess && !rc) err = hipEventSynchronize(e1);
     float ms = 0.f;
@@ -1076,7 +1076,7 @@ int packed_rows_for(memo_index *ix, int km1, int64_t window, bool membership, hi
             int r = packed_filter(ix->device, ix->pk, ix->boff, ix->rows, ix->nb, cap, 2, st, ix->packed_fmt == 12 ? 0 : 16, &v.p3, &v.boff,
                                   &v.rows, &v.padded);
             // (what the filter leaves of an interleaved bucket is no longer dealt evenly: the view's buckets are ordered again)
-            if (!r && v.p3 && ix->row_order) r = interleave_words(v.p3, v.boff, ix->nb, ix->bshift, ix->packed_fmt, ix->row_order, st);
+            if (!r && v.p3 && ix->row_order) r = interleave_words(v.p3, v.boff, ix->nb, ix->bshift, ix->packed_fmt, ix->row_order, st, ix->d_scratch);
             return r;
         });
         if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)

@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"])
     ap.add_argument("--ks", default="17,21,31")
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--builders", default="1,0")
+    ap.add_argument("--builders", default="0", help="(round 4's builder, 1, is gone: its timings are in profiles/r05_view_pass.txt)")
     ap.add_argument("--colour", type=int, default=1, help="0: the rows of a view keep the order they come in (memo_debug_view_colouring)")
     a = ap.parse_args()
     import torch  # noqa: F401  (load order: INTEGRATION.md section 5)
@@ -29,7 +29,6 @@ def main():
     with ix:
         for rep in range(a.reps):
             for builder in [int(x) for x in a.builders.split(",")]:
-                lib.memo_debug_view_builder(builder)
                 for six in ((0, 1) if num_docs <= 255 else (0,)):
                     lib.memo_debug_six_views(six)
                     for k in [int(x) for x in a.ks.split(",")]:
@@ -40,7 +39,6 @@ def main():
                         print(json.dumps({"workload": a.workload, "builder": "round 4" if builder else "fused", "placed": bool(a.colour), "rows_per_group": 6 if six else 5,
                                           "k": k, "view_ms": round(inf["last_view_ms"], 3), "rows_in": r1 - r0, "bytes_taken": taken,
                                           "views": inf["views_resident"]}), flush=True)
-        lib.memo_debug_view_builder(0)
         lib.memo_debug_six_views(0)
 
 

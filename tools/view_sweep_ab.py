@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Round 5: the conservation sweep on a dense k-class view as each builder leaves it -- round 4's five kernels (places chosen after a
-sort by the first block's bank) against the fused pass (places chosen in the order the rows come), five and six rows per group, rows
-placed and not.  One index per variant, `--launches` launches back to back, median of the last two thirds; variants alternate
-`--reps` times.  GPU box; A/B library."""
+"""Round 5: the conservation sweep on a dense k-class view as memo_view.hip builds it: five and six rows per group, rows placed and
+not.  (With round 4's builder still in the tree -- places chosen after a sort by the first block's bank -- its views measured 0.6 %
+faster at k = 31 than the fused pass's placed ones, level at k = 21: profiles/r05_view_pass.txt.)  One index per variant,
+`--launches` launches back to back, median of the last two thirds; variants alternate `--reps` times.  GPU box; A/B library."""
 import argparse
 import json
 import os
@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--ks", default="31")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--launches", type=int, default=900)
-    ap.add_argument("--variants", default="1:5:1,0:5:1,0:5:0,0:6:1,0:6:0", help="builder:rows_per_group:placed, ...")
+    ap.add_argument("--variants", default="0:5:1,0:5:0,0:6:1,0:6:0", help="0:rows_per_group:placed, ...")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -32,7 +32,6 @@ def main():
         for rep in range(a.reps):
             for var in a.variants.split(","):
                 builder, rpg, placed = (int(x) for x in var.split(":"))
-                lib.memo_debug_view_builder(builder)
                 lib.memo_debug_view_colouring(placed)
                 lib.memo_debug_six_views(1 if rpg == 6 else 0)
                 for k in [int(x) for x in a.ks.split(",")]:
@@ -47,11 +46,10 @@ def main():
                     torch.cuda.synchronize()
                     ms = np.array([e0.elapsed_time(e1) for e0, e1 in ev[a.launches // 3:]])
                     inf = ix.info()
-                    print(json.dumps({"builder": "round 4" if builder else "fused", "rows_per_group": rpg, "placed": bool(placed), "k": k,
+                    print(json.dumps({"rows_per_group": rpg, "placed": bool(placed), "k": k,
                                       "ms_median": round(float(np.median(ms)), 4), "ms_min": round(float(ms.min()), 4),
                                       "rows_read": inf["last_rows_read"], "variant": inf["last_variant"], "view_ms": round(inf["last_view_ms"], 3)}),
                           flush=True)
-        lib.memo_debug_view_builder(0)
         lib.memo_debug_view_colouring(1)
         lib.memo_debug_six_views(-1)
 
