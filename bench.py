@@ -899,7 +899,8 @@ def main():
         if os.path.exists(prof):
             key = f"{args.workload}_{args.rows}" if host_rows is None else \
                 f"{os.path.basename(os.path.dirname(os.path.abspath(args.rows_file)))}_{'memb' if membership else 'cons'}_k{k}_{args.rows}"
-            tj = json.load(open(prof)).get(key)
+            allt = json.load(open(prof))
+            tj = allt.get(f"{key}_k{k}") or allt.get(key)            # (entries of a k other than the workload's default carry it in their key)
             if tj and tj.get("result_bytes_per_position") == b_out and tj.get("algorithmic_bytes") is not None and \
                     abs(tj["algorithmic_bytes"] - b_alg) <= 0.01 * b_alg:   # same kernel instantiation, same rows read (an entry that
                                                                             # does not say what it measured matches nothing)

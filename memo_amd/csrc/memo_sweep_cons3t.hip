@@ -98,11 +98,16 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
                 V[j] = make_uint4(0x0000003Fu, 0x0000003Fu, 0x0000003Fu, 0x0000003Fu);  // (rows that cannot write)
                 continue;
             }
-            // (a piece that straddles the slice's end: its lanes past the last group read THAT group again -- a line the wave fetches
-            // anyway -- instead of up to 63 groups behind the slice: half a KiB per tile on average, 25 % of a k = 9 view's tile, 12 % at
-            // k = 17, 6 % at k = 31 by TCP_TCC_READ_REQ, profiles/r05_six_rows.txt; the rows' numbers, not their bytes, mask them)
+            // (a piece that straddles the slice's end reads up to 63 groups BEHIND the slice -- half a KiB per tile on average: TCP_TCC_READ_REQ
+            // is 24 % above a k = 17 view's bytes, profiles/r05_six_rows.txt.  Those are the next tile's first lines, which that tile --
+            // same XCD, running beside this one -- fetches anyway: clamping the lanes to the slice's last group measured 0.5-1.5 % SLOWER,
+            // same box, alternating builds; -DMEMO_SLICE_CLAMP keeps the experiment.)
             const uint32_t at = pg + (uint32_t)lane;
+#ifdef MEMO_SLICE_CLAMP
             V[j] = src0[pg < g.ng ? (at < g.ng ? at : g.ng - 1u) : 0u];
+#else
+            V[j] = src0[pg < g.ng ? at : 0u];
+#endif
         }
     };
     issue(0);
