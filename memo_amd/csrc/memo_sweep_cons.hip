@@ -598,6 +598,16 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
             // skipping them beats issuing them with no lane -- 0.395 against 0.415 ms (profiles/r02_mixed_levels.txt)
             uint32_t tmp, a1, a2, s4, q, dd;
             MEMO_EXEC_ALL_ONES(A.status);
+            // diagnostic builds (tools/build_variant.sh): what do the lanes of one instruction on ONE cell cost -- rows of a start
+            // and a level share their second block's cell?  32: the second ds_min goes to the first block's cell (as many instructions,
+            // no two lanes on one address but for equal rows); 64: no second ds_min.  Wrong results either way.
+#if MEMO_ABLATE & 32
+#define MEMO_R4_SECOND "ds_min_u32 %1, %11\n\t"
+#elif MEMO_ABLATE & 64
+#define MEMO_R4_SECOND
+#else
+#define MEMO_R4_SECOND "ds_min_u32 %2, %11\n\t"
+#endif
 #define MEMO_R4_BLOCK(LEN_SEL, REL_START)                                                                         \
             asm volatile(                                                                                          \
                 "v_mov_b32 %4, 0\n\t"                 /* q = 0 where the row does not write */                     \
@@ -613,7 +623,7 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
                 "v_lshrrev_b32 %3, %4, %12\n\t"      /* 4 S (bytes) */                                            \
                 "v_sub_u32 %2, %2, %3\n\t"           /* a2: cell start - S */                                     \
                 "ds_min_u32 %1, %11\n\t"                                                                          \
-                "ds_min_u32 %2, %11\n\t"                                                                          \
+                MEMO_R4_SECOND                                                                                     \
                 "v_sub_u32 %4, 29, %4\n\t"           /* 2 i */                                                    \
                 "v_lshrrev_b32 %4, %4, %0\n\t"       /* q */                                                      \
                 "s_mov_b64 exec, -1"                                                                               \
@@ -625,6 +635,7 @@ void sweep_conservation_r4_kernel(const SweepArgs A) {
             else
                 MEMO_R4_BLOCK("BYTE_0", "v_sub_u32 %5, %6, %8\n\tv_bfe_u32 %5, %5, 8, 12\n\t");
 #undef MEMO_R4_BLOCK
+#undef MEMO_R4_SECOND
             if (q >= 2) {
                 const uint32_t data = TOP ? w : col;
                 uint32_t a3, a4;

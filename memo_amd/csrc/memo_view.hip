@@ -119,11 +119,14 @@ __global__ __launch_bounds__(256) void packed_scatter_kernel(const uint32_t *pk,
 //      group_rows6), places a bucket leaves empty hold a copy of its last row (min is idempotent).
 // A bucket whose kept rows do not fit the LDS stage streams through it in pieces, in source order.
 // ======================================================================================================================
-constexpr int kViewCap = 5120;              // kept rows a piece stages (+ 8 carried)
-constexpr int kViewSlots = kViewCap + 6 * 64 + 16;
+// kept rows a piece stages (+ 8 carried): with places, the rows of 64 buckets of BASELINE's shape (a lane each: 39 KiB of LDS, four
+// waves per CU -- the greedy loop is what the pass costs, and it wants every lane busy); without, a third of that (13 KiB, twelve
+// waves per CU: the pass is a stream, and waves in flight are what hide HBM's latency)
+constexpr int kViewCapPlaced = 5120, kViewCapPlain = 2048;
+constexpr int kViewSlack = 6 * 64 + 16;     // slots beyond the rows: six-row views pad every bucket to whole groups
 constexpr int kViewRun = 64;                // buckets per run: a lane each
 constexpr int kColourMax5 = 128, kColourMax6 = 96;  // buckets of more rows keep the order they come in (as in round 4)
-constexpr size_t kViewLds = (size_t)(kViewCap + 8) * 4 + (size_t)kViewSlots * 2 + 4 * 32 * 64;
+inline size_t view_lds_bytes(int cap, bool place) { return (size_t)(cap + 8) * 4 + (size_t)(cap + kViewSlack) * 2 + (place ? 4 * 32 * 64 : 0); }
 
 // row i of group V as W = B | annot << 16   (B = (start mod 2^10) << 6 | min(overlap, 63): 16 bits; annot: 9 bits)
 template <int I>
@@ -215,6 +218,7 @@ struct ViewArgs {
     uint32_t cap;            // a row stays when its overlap is below cap
     int km1;                 // the k - 1 whose level arrays the places are chosen for (the class's cap); 0: rows keep their order
     int run_buckets;         // buckets per run (<= kViewRun)
+    int stage_rows;          // kept rows the LDS stage holds (kViewCapPlaced / kViewCapPlain)
 };
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long ballot) {
@@ -223,8 +227,9 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long ballot) {
 
 // one wave's LDS (dynamic): the kept rows of a piece in source order, slot -> row, colour masks per bank
 struct ViewLds {
-    uint32_t *stage;  // [kViewCap + 8]: W of the kept rows; the last 8: rows carried from the piece before
-    uint16_t *inv;    // [kViewSlots]: which staged row a slot of the output holds
+    uint32_t cap;     // rows the stage holds (ViewArgs::stage_rows)
+    uint32_t *stage;  // [cap + 8]: W of the kept rows; the last 8: rows carried from the piece before (and the slot nobody reads)
+    uint16_t *inv;    // [cap + kViewSlack]: which staged row a slot of the output holds
     uint8_t *am1;     // [32][64]: colours that hold a row whose FIRST block falls on bank a (a column per lane: its bucket's)
     uint8_t *am2;     // ... two rows or more
     uint8_t *bm1;     // the same for the second block
@@ -260,7 +265,7 @@ __device__ __forceinline__ uint32_t view_load_compact(const ViewArgs &a, const V
                                      b4 = __ballot(m & 16u);
             uint32_t idx = n + lanes_below(b0) + lanes_below(b1) + lanes_below(b2) + lanes_below(b3) + lanes_below(b4);
             // (no branches: a row that goes is stored to a slot nobody reads -- plain stores of many lanes to one address cost one)
-            constexpr uint32_t kNowhere = kViewCap + 7;
+            const uint32_t kNowhere = L.cap + 7u;
             L.stage[(m & 1u) ? idx : kNowhere] = group_row<0>(R[u]);
             idx += m & 1u;
             L.stage[(m & 2u) ? idx : kNowhere] = group_row<1>(R[u]);
@@ -436,8 +441,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     extern __shared__ __attribute__((aligned(16))) uint32_t view_lds[];
     ViewLds L;
     L.stage = view_lds;
-    L.inv = reinterpret_cast<uint16_t *>(L.stage + kViewCap + 8);
-    L.am1 = reinterpret_cast<uint8_t *>(L.inv + kViewSlots);
+    L.cap = (uint32_t)a.stage_rows;
+    L.inv = reinterpret_cast<uint16_t *>(L.stage + L.cap + 8);
+    L.am1 = reinterpret_cast<uint8_t *>(L.inv + L.cap + kViewSlack);  // (the four mask arrays exist only when places are chosen: a.km1 > 0)
     L.am2 = L.am1 + 32 * 64;
     L.bm1 = L.am2 + 32 * 64;
     L.bm2 = L.bm1 + 32 * 64;
@@ -460,15 +466,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         const uint64_t v_run0 = (uint64_t)__shfl((long long)vb, 0, 64);
         // P = 5: slot 0 of the output staging is the view's row pbase (a multiple of 5); rows before pfrom are not this run's
         uint64_t pbase = v_run0 / 5 * 5, pfrom = v_run0;
-        // P = 5: slots of the last, partial group so far: rows carried from the piece before (staged at stage[kViewCap ...]) -- and, at
+        // P = 5: slots of the last, partial group so far: rows carried from the piece before (staged at stage[cap ...]) -- and, at
         // the head of a run, the rows of that group that belong to the run before (never read: view_emit masks them by `from`)
         uint32_t carried = P == 5 ? (uint32_t)(pfrom - pbase) : 0u;
-        if (lane < 8) L.inv[lane] = (uint16_t)(kViewCap + lane);  // (slots of the first group that are not this run's: never used, but read)
+        if (lane < 8) L.inv[lane] = (uint16_t)(L.cap + lane);  // (slots of the first group that are not this run's: never used, but read)
         __syncthreads();
         int s = 0;
         while (s < nbk) {
             const uint64_t v0 = (uint64_t)__shfl((long long)vb, s, 64);
-            const unsigned long long fits = __ballot(lane >= s && lane < nbk && ve - v0 <= (uint64_t)kViewCap);
+            const unsigned long long fits = __ballot(lane >= s && lane < nbk && ve - v0 <= (uint64_t)L.cap);
             const int e = s + (int)__popcll(fits);  // (ve rises with the lane: the buckets that fit are s .. e - 1)
             if (e > s) {
                 // ---- buckets s .. e - 1 whole: load, place, emit ----
@@ -487,7 +493,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                 } else {
                     bslot = (uint32_t)(vb - pbase);
                 }
-                for (int i = lane; i < 4 * 32 * 64 / 4; i += 64) reinterpret_cast<uint32_t *>(L.am1)[i] = 0;  // (no colour holds a row yet)
+                if (a.km1 > 0)
+                    for (int i = lane; i < 4 * 32 * 64 / 4; i += 64) reinterpret_cast<uint32_t *>(L.am1)[i] = 0;  // (no colour holds a row yet)
                 __syncthreads();
                 view_place_bucket<P>(a, L, off, n, bslot, (uint32_t)(vb % 5), lane);
                 __syncthreads();
@@ -506,8 +513,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                     if (!last && (uint32_t)lane < left) w = L.stage[L.inv[5 * whole + lane]];
                     __syncthreads();
                     if (!last && (uint32_t)lane < left) {
-                        L.stage[kViewCap + lane] = w;
-                        L.inv[lane] = (uint16_t)(kViewCap + lane);
+                        L.stage[L.cap + lane] = w;
+                        L.inv[lane] = (uint16_t)(L.cap + lane);
                     }
                     pbase += 5ull * whole;
                     if (pfrom < pbase) pfrom = pbase;
@@ -526,8 +533,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                 carried = 0;
             }
             uint64_t done = v0;  // kept rows of the bucket emitted or carried so far
-            for (uint64_t r = r_lo; r < r_hi; r += (uint64_t)kViewCap / 5 * 5) {
-                const uint64_t r_end = r + (uint64_t)kViewCap / 5 * 5 < r_hi ? r + (uint64_t)kViewCap / 5 * 5 : r_hi;
+            const uint64_t piece = (uint64_t)L.cap / 5 * 5;  // source rows per piece
+            for (uint64_t r = r_lo; r < r_hi; r += piece) {
+                const uint64_t r_end = r + piece < r_hi ? r + piece : r_hi;
                 const uint32_t got = view_load_compact(a, L, r, r_end, 0, lane);
                 __syncthreads();
                 for (uint32_t q = (uint32_t)lane; q < got; q += 64) L.inv[carried + q] = (uint16_t)q;
@@ -558,8 +566,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                 if ((uint32_t)lane < left) w = L.stage[L.inv[P * whole + lane]];
                 __syncthreads();
                 if ((uint32_t)lane < left) {
-                    L.stage[kViewCap + lane] = w;
-                    L.inv[lane] = (uint16_t)(kViewCap + lane);
+                    L.stage[L.cap + lane] = w;
+                    L.inv[lane] = (uint16_t)(L.cap + lane);
                 }
                 carried = left;
                 __syncthreads();
@@ -663,17 +671,19 @@ static int dense_view_build(int device, const uint32_t *src_p3, const int64_t *s
         a.km1 = colour_km1;
         // buckets per run: as many as (nearly always) fit the stage whole, so that a run is one piece and every lane has a bucket
         const double per_bucket = (double)total / (double)nbk;
-        int rb = per_bucket > 1.0 ? (int)(0.85 * kViewCap / per_bucket) : kViewRun;
+        a.stage_rows = colour_km1 > 0 ? kViewCapPlaced : kViewCapPlain;
+        int rb = per_bucket > 1.0 ? (int)(0.85 * a.stage_rows / per_bucket) : kViewRun;
         a.run_buckets = rb > kViewRun ? kViewRun : (rb < 4 ? 4 : rb);
+        const size_t lds_bytes = view_lds_bytes(a.stage_rows, colour_km1 > 0);
         const int64_t nruns = ((int64_t)nbk + a.run_buckets - 1) / a.run_buckets;
         if (rpg == 5)
             hipLaunchKernelGGL(view_zero_edges_kernel, dim3((unsigned)((nruns + 1 + 255) / 256)), dim3(256), 0, st, boffv, (int64_t)nbk,
                                a.run_buckets, outg);
-        const unsigned grid = (unsigned)(nruns < 256 * 5 * 4 ? nruns : 256 * 5 * 4);
+        const unsigned grid = (unsigned)(nruns < 256 * 16 * 4 ? nruns : 256 * 16 * 4);
         if (rpg == 6)
-            hipLaunchKernelGGL(view_build_kernel<6>, dim3(grid), dim3(64), kViewLds, st, a);
+            hipLaunchKernelGGL(view_build_kernel<6>, dim3(grid), dim3(64), lds_bytes, st, a);
         else
-            hipLaunchKernelGGL(view_build_kernel<5>, dim3(grid), dim3(64), kViewLds, st, a);
+            hipLaunchKernelGGL(view_build_kernel<5>, dim3(grid), dim3(64), lds_bytes, st, a);
         err = hipGetLastError();
         if (err == hipSuccess) err = hipStreamSynchronize(st);
         if (err != hipSuccess) { rc = fail(MEMO_EHIP, "dense view: %s", hipGetErrorString(err)); break; }
