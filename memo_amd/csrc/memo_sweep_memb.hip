@@ -103,14 +103,27 @@ __global__ __launch_bounds__(T) void sweep_membership_kernel(const SweepArgs A) 
 // ------------------------------------------------------------------------------------------
 template <int J>
 __device__ __forceinline__ void transpose32_stage(uint32_t (&m)[32]) {
-    constexpr uint32_t mask = J == 16 ? 0x0000FFFFu : J == 8 ? 0x00FF00FFu : J == 4 ? 0x0F0F0F0Fu
-                              : J == 2 ? 0x33333333u : 0x55555555u;
+    // swap the high J-bit halves of m[k] with the low halves of m[k + J].  Whole bytes move with one v_perm_b32 per word (two
+    // instructions a pair); below a byte a shift and a bit-field insert per word (four a pair) -- 256 vector instructions per
+    // 32 x 32 block where the xor-swap (shift, xor-and, shift, xor, xor) takes 400: the planes kernels are bound by vector issue
+    // on sparse indexes (profiles/r05_sq_counters_realistic.txt)
+    constexpr uint32_t mask = J == 4 ? 0x0F0F0F0Fu : J == 2 ? 0x33333333u : 0x55555555u;
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
-        if ((k & J) == 0) {  // swap the high J-bit halves of m[k] with the low halves of m[k + J]
-            const uint32_t tt = ((m[k] >> J) ^ m[k + J]) & mask;
-            m[k] ^= tt << J;
-            m[k + J] ^= tt;
+        if ((k & J) == 0) {
+            const uint32_t a = m[k], b = m[k + J];
+            if (J == 16) {
+                m[k] = __builtin_amdgcn_perm(b, a, 0x05040100u);      // a.lo16 | b.lo16 << 16
+                m[k + J] = __builtin_amdgcn_perm(b, a, 0x07060302u);  // a.hi16 | b.hi16 << 16
+            } else if (J == 8) {
+                m[k] = __builtin_amdgcn_perm(b, a, 0x06020400u);      // bytes a0 b0 a2 b2
+                m[k + J] = __builtin_amdgcn_perm(b, a, 0x07030501u);  // bytes a1 b1 a3 b3
+            } else {
+                // (x & mask) | (y & ~mask) as ONE v_bfi_b32 (the compiler's rendering of the C expression took an extra and)
+                const uint32_t bs = b << J, as = a >> J;
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(m[k]) : "s"(mask), "v"(a), "v"(bs));
+                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(m[k + J]) : "s"(mask), "v"(as), "v"(b));
+            }
         }
     }
 }
@@ -180,6 +193,58 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
     }
 }
 
+
+// One row of a planes kernel: the run of n = k - 1 - overlap bits that ends at bit d of plane row `col`.
+//   SHORT (k - 1 <= 31): the run fits two words.  No test, no branch: a row that cannot write has n = 0, an empty run, and its
+//   two ds_or add nothing (its cell is inside the plane row like any other: d is).  By hand, 9 - 10 vector instructions after the
+//   row's three fields and no scalar ones (the compiler's branchy form: 17 and 8; its branch-free one 21): saturating subtracts
+//   for n and for the bits that spill into the second word, v_bfm_b32 for both masks.
+//   Otherwise (up to 255 bits): first word, whole words, last word.  The whole words are plain stores: all-ones or-ed into a
+//   word is all-ones stored (whatever another lane's ds_or does before or after), and a store returns nothing -- the
+//   compiler's rendering of atomicOr(p, ~0u) was ds_wrxchg_rtn_b32 with an s_waitcnt lgkmcnt(0) per word, and, the returned
+//   register being reused, one more wait in EVERY row, the short path's too (round 5; it had gone unnoticed since round 2).
+//   base: the planes' LDS byte address in a VGPR; p4, s4: 4 * PITCH, 4 * SKEW; SK: SKEW != 0 (4, 8 or 16 result words).
+template <bool SHORT, bool SK>
+__device__ __forceinline__ void planes_put(uint32_t *lds, uint32_t base, int km1, uint32_t p4, uint32_t s4, uint32_t len, uint32_t d,
+                                           uint32_t col) {
+    if constexpr (SHORT) {
+        uint32_t n, first, t, wq, addr, lo;
+        if constexpr (SK) {
+            const uint32_t colhi = col >> 5;
+            asm volatile("v_mad_u32_u24 %0, %1, %2, %3\n\t"
+                         "v_mad_u32_u24 %0, %4, %5, %0"
+                         : "=&v"(t) : "v"(col), "s"(p4), "v"(base), "v"(colhi), "s"(s4));
+        } else {
+            asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(col), "s"(p4), "v"(base));
+        }
+        asm volatile(
+            "v_sub_u32_e64 %0, %6, %7 clamp\n\t"   // n = max(k - 1 - overlap, 0)
+            "v_sub_u32 %1, %8, %0\n\t"             // first bit of the run
+            "v_lshrrev_b32 %2, 5, %1\n\t"          // its word
+            "v_lshl_add_u32 %3, %2, 2, %5\n\t"     // its address
+            "v_bfm_b32 %4, %0, %1\n\t"             // ((1 << n) - 1) << (first & 31)
+            "v_lshl_add_u32 %2, %2, 5, 32\n\t"     // first bit of the next word
+            "v_sub_u32_e64 %2, %8, %2 clamp\n\t"   // bits of the run in it
+            "v_bfm_b32 %2, %2, 0\n\t"
+            "ds_or_b32 %3, %4\n\t"
+            "ds_or_b32 %3, %2 offset:4"
+            : "=&v"(n), "=&v"(first), "=&v"(wq), "=&v"(addr), "=&v"(lo)
+            : "v"(t), "s"(km1), "v"(len), "v"(d)
+            : "memory");
+    } else {
+        const int n = km1 - (int)len;
+        if (n > 0) {
+            uint32_t *row = lds + (__umul24(col, p4 >> 2) + (SK ? __umul24(col >> 5, s4 >> 2) : 0u));
+            const uint32_t first = d - (uint32_t)n, last = d - 1u;
+            uint32_t *cell = row + (first >> 5);
+            const int more = (int)(last >> 5) - (int)(first >> 5);
+            const uint32_t head = 0xFFFFFFFFu << (first & 31u), tail = 0xFFFFFFFFu >> (31u - (last & 31u));
+            atomicOr(cell, more ? head : head & tail);
+            for (int i = 1; i < more; ++i) __hip_atomic_store(cell + i, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (more) atomicOr(cell + more, tail);
+        }
+    }
+}
 
 // The second half of both planes kernels: the planes are complete (all scatters issued); transpose every 32 x 32 block
 // in registers, stage the tile position-major in LDS over the planes, copy it out in whole 16-byte pieces.
@@ -253,7 +318,7 @@ __device__ __forceinline__ void planes_transpose_store(const SweepArgs &A, const
 //   nw words of padding per position word: both chosen so that the lanes of a wave (nw groups x
 //   64/nw position words) fall on 64 different banks.
 // ------------------------------------------------------------------------------------------
-template <typename Rows, int U, int T>
+template <typename Rows, int U, int T, bool SHORT, bool SK>
 __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
@@ -274,26 +339,9 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
     const int km1 = A.km1;
     const int HLW = A.nlev;  // words of halo left of the tile: ceil((k - 1) / 32)
     const uint32_t keym = pin_vgpr((int)Rows::tile_key(t.a - 32 * HLW));  // bit 32 * HLW of a plane row = tile slot 0
-    auto scatter = [&](uint32_t w, uint32_t col) {
-        const int n = km1 - Rows::len(w);  // bits of the run [end - (k-1), start)
-        if (n > 0) {
-            const uint32_t d = Rows::rel_start(w, keym);  // start - a + 32 * HLW
-            const uint32_t first = d - (uint32_t)n;
-            uint32_t *cell = lds + (__umul24(col, (uint32_t)PITCH) + __umul24(col >> 5, (uint32_t)SKEW) + (first >> 5));
-            if (km1 <= 31) {  // (uniform) the run fits two words: no branches
-                const uint64_t run = (uint64_t)((1u << n) - 1u) << (first & 31u);
-                atomicOr(cell, (uint32_t)run);
-                atomicOr(cell + 1, (uint32_t)(run >> 32));
-            } else {  // up to 255 bits: first word, whole words, last word
-                const uint32_t last = d - 1u;
-                const int more = (int)(last >> 5) - (int)(first >> 5);
-                const uint32_t head = 0xFFFFFFFFu << (first & 31u), tail = 0xFFFFFFFFu >> (31u - (last & 31u));
-                atomicOr(cell, more ? head : head & tail);
-                for (int i = 1; i < more; ++i) atomicOr(cell + i, 0xFFFFFFFFu);
-                if (more) atomicOr(cell + more, tail);
-            }
-        }
-    };
+    const uint32_t base = pin_vgpr((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds);
+    const uint32_t p4 = 4u * (uint32_t)PITCH, s4 = 4u * (uint32_t)SKEW;
+    auto scatter = [&](uint32_t w, uint32_t col) { planes_put<SHORT, SK>(lds, base, km1, p4, s4, (uint32_t)Rows::len(w), Rows::rel_start(w, keym), col); };
     Rows::template consume<T, U>(A, t, 0, V, N, scatter);
     for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
         Rows::template issue<T, U>(A, t, b, V, N);
@@ -306,7 +354,7 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
 // genomes).  A row's field after the 16-bit subtract of the tile's key is (start - a + 32 HLW) << 6 | overlap, so the
 // plane row's bit numbers have to stay below 2^10: the launcher sizes the tile for that (W + k - 1 + bucket + 32 HLW <=
 // 1024).
-template <int U, int T>
+template <int U, int T, bool SHORT, bool SK>
 __global__ __launch_bounds__(T) void sweep_membership_planes3_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     using Rows = PackedRows3;
@@ -326,26 +374,10 @@ __global__ __launch_bounds__(T) void sweep_membership_planes3_kernel(const Sweep
     const int km1 = A.km1;
     const int HLW = A.nlev;  // words of halo left of the tile: ceil((k - 1) / 32)
     const uint32_t key6 = pin_vgpr((int)((((uint32_t)(t.a - 32 * HLW)) & 1023u) << 6));  // bit 32 * HLW of a plane row = tile slot 0
-    auto put = [&](uint32_t r, uint32_t col) {  // r = (start - a + 32 HLW) << 6 | overlap
-        const int n = km1 - (int)(r & 63u);     // bits of the run [end - (k-1), start)
-        if (n > 0) {
-            const uint32_t d = r >> 6;
-            const uint32_t first = d - (uint32_t)n;
-            uint32_t *cell = lds + (__umul24(col, (uint32_t)PITCH) + __umul24(col >> 5, (uint32_t)SKEW) + (first >> 5));
-            if (km1 <= 31) {  // (uniform) the run fits two words: no branches
-                const uint64_t run = (uint64_t)((1u << n) - 1u) << (first & 31u);
-                atomicOr(cell, (uint32_t)run);
-                atomicOr(cell + 1, (uint32_t)(run >> 32));
-            } else {  // up to 63 bits: first word, a whole word, last word
-                const uint32_t last = d - 1u;
-                const int more = (int)(last >> 5) - (int)(first >> 5);
-                const uint32_t head = 0xFFFFFFFFu << (first & 31u), tail = 0xFFFFFFFFu >> (31u - (last & 31u));
-                atomicOr(cell, more ? head : head & tail);
-                for (int i = 1; i < more; ++i) atomicOr(cell + i, 0xFFFFFFFFu);
-                if (more) atomicOr(cell + more, tail);
-            }
-        }
-    };
+    // r = (start - a + 32 HLW) << 6 | overlap
+    const uint32_t base = pin_vgpr((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds);
+    const uint32_t p4 = 4u * (uint32_t)PITCH, s4 = 4u * (uint32_t)SKEW;
+    auto put = [&](uint32_t r, uint32_t col) { planes_put<SHORT, SK>(lds, base, km1, p4, s4, r & 63u, r >> 6, col); };
     auto g = [&](uint32_t b, uint32_t data) {  // 16-bit subtract on the low half; the result's high half is zero
         uint32_t r;
         asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(b), "v"(key6));
@@ -357,6 +389,18 @@ __global__ __launch_bounds__(T) void sweep_membership_planes3_kernel(const Sweep
         Rows::template consume<T, U>(A, t, b, V, g);
     }
     planes_transpose_store<T>(A, t, lds);
+}
+
+template <typename Rows, int T>
+SweepKernel planes_kernel_t(bool two_words, bool skewed) {
+    if (two_words)
+        return skewed ? (SweepKernel)sweep_membership_planes_kernel<Rows, 6, T, true, true> : (SweepKernel)sweep_membership_planes_kernel<Rows, 6, T, true, false>;
+    return skewed ? (SweepKernel)sweep_membership_planes_kernel<Rows, 6, T, false, true> : (SweepKernel)sweep_membership_planes_kernel<Rows, 6, T, false, false>;
+}
+
+template <typename Rows>
+SweepKernel planes_kernel(int T, bool two_words, bool skewed) {
+    return T == 64 ? planes_kernel_t<Rows, 64>(two_words, skewed) : planes_kernel_t<Rows, 256>(two_words, skewed);
 }
 
 __global__ void fill_membership_kernel(uint32_t *out, int64_t n, int nw, int ncols) {
@@ -513,7 +557,10 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.out_words = nw;
             const size_t planes = ((size_t)32 * nw * A.ls + (size_t)nw * skew + 8) * 4;
             const size_t staged = ((size_t)pw * (32 * nw + nw) + 4) * 4;
-            SweepKernel kern = (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256>;
+            SweepKernel kern = k - 1 <= 31 ? (skew ? (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, true, true>
+                                                   : (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, true, false>)
+                                           : (skew ? (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, false, true>
+                                                   : (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, false, false>);
             if ((rc = launch_tiles(kern, A, tw, 256, planes > staged ? planes : staged, st))) return rc;
             ix->last_sweep = 6;
             return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
@@ -544,7 +591,11 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // 16 result words; otherwise whatever else was chosen
     if ((algo == 4 || (tune.memb_algo == 0 && algo == 3)) && fmt && !checked && nw <= 16) {
         const int bw = 1 << ix->bshift, T = waves == 1 ? 64 : 256;
-        int tw = w ? w : 1024;
+        // ~16 KiB of planes per tile whatever the number of result words: 1024 positions at four words (config 4), 2048 at two,
+        // 4096 at one -- on the sequence-built index (50 genomes: two words) 2048 against 1024 positions: 0.267 against 0.297 ms at
+        // k = 31, 0.44 against 0.47 at k = 101; 4096 is slower again, as 2048 is at four words (profiles/r05_large_k.txt)
+        int tw = w ? w : (nw <= 2 ? 4096 / nw : 1024);
+        if (fmt == 12 && tw > 2048) tw = 2048;       // (12-bit start field)
         if (tw > 32 * (T / nw)) tw = 32 * (T / nw);  // one 32 x 32 block per lane
         tw = tw / bw * bw;
         if (tw >= bw && tw >= 32) {
@@ -561,12 +612,10 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.magic = (uint32_t)((((uint64_t)1 << 32) + 32 * nw - 1) / (32 * nw));
             const size_t planes = ((size_t)32 * nw * A.ls + (size_t)nw * skew + 8) * 4;
             const size_t staged = ((size_t)pw * (32 * nw + nw) + 4) * 4;
-            SweepKernel kern = fmt == 4 ? (T == 64 ? (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false>, 6, 64>
-                                                   : (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false>, 6, 256>)
-                               : fmt == 12 ? (T == 64 ? (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false, true>, 6, 64>
-                                                      : (SweepKernel)sweep_membership_planes_kernel<PackedRows<false, false, true>, 6, 256>)
-                                        : (T == 64 ? (SweepKernel)sweep_membership_planes_kernel<PackedRows<true, false>, 6, 64>
-                                                   : (SweepKernel)sweep_membership_planes_kernel<PackedRows<true, false>, 6, 256>);
+            const bool two_words = k - 1 <= 31;  // (the run of a row fits two plane words: the branch-free row block)
+            SweepKernel kern = fmt == 4    ? planes_kernel<PackedRows<false, false>>(T, two_words, skew != 0)
+                               : fmt == 12 ? planes_kernel<PackedRows<false, false, true>>(T, two_words, skew != 0)
+                                           : planes_kernel<PackedRows<true, false>>(T, two_words, skew != 0);
             if ((rc = use_words())) return rc;
             if ((rc = launch_tiles(kern, A, tw, T, planes > staged ? planes : staged, st))) return rc;
             return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
