@@ -112,6 +112,13 @@ __device__ __forceinline__ void transpose32_stage(uint32_t (&m)[32]) {
     for (int k = 0; k < 32; ++k) {
         if ((k & J) == 0) {
             const uint32_t a = m[k], b = m[k + J];
+#ifdef MEMO_PLANES_XOR_TRANSPOSE  // (A/B: rounds 1-4's xor-swap)
+            constexpr uint32_t mk = J == 16 ? 0x0000FFFFu : J == 8 ? 0x00FF00FFu : mask;
+            const uint32_t tt = ((a >> J) ^ b) & mk;
+            m[k] = a ^ (tt << J);
+            m[k + J] = b ^ tt;
+            continue;
+#endif
             if (J == 16) {
                 m[k] = __builtin_amdgcn_perm(b, a, 0x05040100u);      // a.lo16 | b.lo16 << 16
                 m[k + J] = __builtin_amdgcn_perm(b, a, 0x07060302u);  // a.hi16 | b.hi16 << 16
@@ -205,10 +212,24 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 //   register being reused, one more wait in EVERY row, the short path's too (round 5; it had gone unnoticed since round 2).
 //   base: the planes' LDS byte address in a VGPR; p4, s4: 4 * PITCH, 4 * SKEW; SK: SKEW != 0 (4, 8 or 16 result words).
 template <bool SHORT, bool SK>
-__device__ __forceinline__ void planes_put(uint32_t *lds, uint32_t base, int km1, uint32_t p4, uint32_t s4, uint32_t len, uint32_t d,
-                                           uint32_t col) {
+__device__ __forceinline__ void planes_put(uint32_t *lds, int *status, uint32_t base, int km1, uint32_t p4, uint32_t s4, uint32_t len,
+                                           uint32_t d, uint32_t col) {
+#ifdef MEMO_PLANES_BRANCHY_ROW  // (A/B: rounds 2-4's row, a test and a 64-bit shift)
+    if constexpr (SHORT) {
+        const int n = km1 - (int)len;
+        if (n > 0) {
+            const uint32_t first = d - (uint32_t)n;
+            uint32_t *cell = lds + (__umul24(col, p4 >> 2) + __umul24(col >> 5, s4 >> 2) + (first >> 5));
+            const uint64_t run = (uint64_t)((1u << n) - 1u) << (first & 31u);
+            atomicOr(cell, (uint32_t)run);
+            atomicOr(cell + 1, (uint32_t)(run >> 32));
+        }
+        return;
+    }
+#endif
     if constexpr (SHORT) {
         uint32_t n, first, t, wq, addr, lo;
+        MEMO_EXEC_ALL_ONES(status);  // (the row loops are wave-uniform: every lane of the wave is here)
         if constexpr (SK) {
             const uint32_t colhi = col >> 5;
             asm volatile("v_mad_u32_u24 %0, %1, %2, %3\n\t"
@@ -218,7 +239,12 @@ __device__ __forceinline__ void planes_put(uint32_t *lds, uint32_t base, int km1
             asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(col), "s"(p4), "v"(base));
         }
         asm volatile(
+#ifdef MEMO_PLANES_NO_CMPX  // (A/B: rows that cannot write -- the dead rows of a load that straddles an end of the slice too -- or nothing in)
             "v_sub_u32_e64 %0, %6, %7 clamp\n\t"   // n = max(k - 1 - overlap, 0)
+#else
+            "v_sub_u32 %0, %6, %7\n\t"             // n = k - 1 - overlap
+            "v_cmpx_lt_i32 vcc, 0, %0\n\t"         // the rest on the lanes whose row writes
+#endif
             "v_sub_u32 %1, %8, %0\n\t"             // first bit of the run
             "v_lshrrev_b32 %2, 5, %1\n\t"          // its word
             "v_lshl_add_u32 %3, %2, 2, %5\n\t"     // its address
@@ -227,10 +253,16 @@ __device__ __forceinline__ void planes_put(uint32_t *lds, uint32_t base, int km1
             "v_sub_u32_e64 %2, %8, %2 clamp\n\t"   // bits of the run in it
             "v_bfm_b32 %2, %2, 0\n\t"
             "ds_or_b32 %3, %4\n\t"
+#if !defined(MEMO_PLANES_NO_CMPX) && !defined(MEMO_PLANES_ALWAYS_SECOND)
+            "v_cmpx_ne_u32 vcc, 0, %2\n\t"         // (a run inside one word -- about half of them at k = 31 -- has no second ds_or)
+#endif
             "ds_or_b32 %3, %2 offset:4"
+#ifndef MEMO_PLANES_NO_CMPX
+            "\n\ts_mov_b64 exec, -1"
+#endif
             : "=&v"(n), "=&v"(first), "=&v"(wq), "=&v"(addr), "=&v"(lo)
             : "v"(t), "s"(km1), "v"(len), "v"(d)
-            : "memory");
+            : "memory", "vcc");
     } else {
         const int n = km1 - (int)len;
         if (n > 0) {
@@ -341,7 +373,7 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
     const uint32_t keym = pin_vgpr((int)Rows::tile_key(t.a - 32 * HLW));  // bit 32 * HLW of a plane row = tile slot 0
     const uint32_t base = pin_vgpr((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds);
     const uint32_t p4 = 4u * (uint32_t)PITCH, s4 = 4u * (uint32_t)SKEW;
-    auto scatter = [&](uint32_t w, uint32_t col) { planes_put<SHORT, SK>(lds, base, km1, p4, s4, (uint32_t)Rows::len(w), Rows::rel_start(w, keym), col); };
+    auto scatter = [&](uint32_t w, uint32_t col) { planes_put<SHORT, SK>(lds, A.status, base, km1, p4, s4, (uint32_t)Rows::len(w), Rows::rel_start(w, keym), col); };
     Rows::template consume<T, U>(A, t, 0, V, N, scatter);
     for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
         Rows::template issue<T, U>(A, t, b, V, N);
@@ -377,7 +409,7 @@ __global__ __launch_bounds__(T) void sweep_membership_planes3_kernel(const Sweep
     // r = (start - a + 32 HLW) << 6 | overlap
     const uint32_t base = pin_vgpr((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds);
     const uint32_t p4 = 4u * (uint32_t)PITCH, s4 = 4u * (uint32_t)SKEW;
-    auto put = [&](uint32_t r, uint32_t col) { planes_put<SHORT, SK>(lds, base, km1, p4, s4, r & 63u, r >> 6, col); };
+    auto put = [&](uint32_t r, uint32_t col) { planes_put<SHORT, SK>(lds, A.status, base, km1, p4, s4, r & 63u, r >> 6, col); };
     auto g = [&](uint32_t b, uint32_t data) {  // 16-bit subtract on the low half; the result's high half is zero
         uint32_t r;
         asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(b), "v"(key6));
@@ -591,10 +623,11 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     // 16 result words; otherwise whatever else was chosen
     if ((algo == 4 || (tune.memb_algo == 0 && algo == 3)) && fmt && !checked && nw <= 16) {
         const int bw = 1 << ix->bshift, T = waves == 1 ? 64 : 256;
-        // ~16 KiB of planes per tile whatever the number of result words: 1024 positions at four words (config 4), 2048 at two,
-        // 4096 at one -- on the sequence-built index (50 genomes: two words) 2048 against 1024 positions: 0.267 against 0.297 ms at
-        // k = 31, 0.44 against 0.47 at k = 101; 4096 is slower again, as 2048 is at four words (profiles/r05_large_k.txt)
-        int tw = w ? w : (nw <= 2 ? 4096 / nw : 1024);
+        // ~16 KiB of planes per tile whatever the number of result words (128 of the 256 lanes transpose a block each): 1024
+        // positions at four words (config 4), 2048 at two, 4096 at one, 512 at eight -- on the sequence-built index (50 genomes: two
+        // words) 2048 against 1024 positions: 0.267 against 0.297 ms at k = 31; 4096 is slower again, as 2048 and 512 are at four
+        // words; 250 genomes: 512 against 1024: 1.39 against 1.59 ms (profiles/r05_large_k.txt)
+        int tw = w ? w : (4096 / nw < 256 ? 256 : 4096 / nw);
         if (fmt == 12 && tw > 2048) tw = 2048;       // (12-bit start field)
         if (tw > 32 * (T / nw)) tw = 32 * (T / nw);  // one 32 x 32 block per lane
         tw = tw / bw * bw;

@@ -514,7 +514,7 @@ def _device_disassembly(obj, tmp_path):
     return subprocess.run([objdump, "-d", str(tmp_path / dev[0])], capture_output=True, text=True, check=True).stdout
 
 
-@pytest.mark.parametrize("obj", ["memo_sweep_cons.o", "memo_sweep_cons3t.o"])
+@pytest.mark.parametrize("obj", ["memo_sweep_cons.o", "memo_sweep_cons3t.o", "memo_sweep_memb.o"])
 def test_row_blocks_run_with_every_lane_enabled(memo, tmp_path, obj):
     """The branch-free row blocks narrow EXEC themselves (v_cmpx) and restore it with `s_mov_b64 exec, -1` -- which is
     only right when every lane was enabled on entry, something the compiler is never told (round-2 VERDICT, weak 6).

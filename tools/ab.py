@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--membership", action="store_true", help="with --rows-file: membership queries")
     ap.add_argument("--six", action="store_true", help="dense k-class views as groups of six rows (memo_debug_six_views 1)")
     ap.add_argument("--no-colour", action="store_true", help="dense k-class views keep the order the filter leaves (memo_debug_view_colouring 0)")
+    ap.add_argument("--prepare", action="store_true", help="memo_index_prepare first: the k-class view and the order of the rows are there "
+                                                           "before the first timed launch (otherwise the library's rule may build them mid-run)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     num_docs, L, membership = WORKLOADS[a.workload]
@@ -69,6 +71,8 @@ def main():
         ix.debug_row_order(a.row_order)
     if a.pack == "both":
         ix.pack_dense(keep_packed=True)
+    if a.prepare:
+        ix.prepare(a.k, num_docs, membership=membership)
     W = (num_docs + 31) // 32
     out = torch.empty((L, W) if membership else (L,), dtype=torch.int32 if membership else torch.int16, device="cuda")
     st = torch.cuda.current_stream()
