@@ -627,7 +627,7 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
         // positions at four words (config 4), 2048 at two, 4096 at one, 512 at eight -- on the sequence-built index (50 genomes: two
         // words) 2048 against 1024 positions: 0.267 against 0.297 ms at k = 31; 4096 is slower again, as 2048 and 512 are at four
         // words; 250 genomes: 512 against 1024: 1.39 against 1.59 ms (profiles/r05_large_k.txt)
-        int tw = w ? w : (4096 / nw < 256 ? 256 : 4096 / nw);
+        int tw = w ? w : (4096 / nw < 256 ? 256 : 4096 / nw / 32 * 32);  // (whole 32-position words)
         if (fmt == 12 && tw > 2048) tw = 2048;       // (12-bit start field)
         if (tw > 32 * (T / nw)) tw = 32 * (T / nw);  // one 32 x 32 block per lane
         tw = tw / bw * bw;
