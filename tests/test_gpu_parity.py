@@ -1032,6 +1032,37 @@ def test_num_docs_word_boundaries(memo, oracle):
         assert np.array_equal(memo.conservation(s, e, o, 100, 2900, 31, n_docs), want), n_docs
 
 
+@pytest.mark.parametrize("n_docs", [20, 50, 100, 250, 257, 500])
+def test_membership_planes_by_result_words(n_docs, memo, oracle):
+    """the planes kernels at the tile width the launcher derives from the number of result words (4096 / words positions, whole
+    32-position words, whole buckets: 1, 2, 4, 8, 9 and 16 words here), both instantiations -- runs of two words at most (k - 1 <= 31: the
+    hand-written row block, a second word only where the run reaches it) and longer ones (whole words as plain stores) -- on the
+    4-byte rows and on the dense rows, bucket widths 1, 2 and 32; windows that start and end inside a tile
+    (reference: src/memo_query.py:50-51, :60-62)"""
+    rng = np.random.default_rng(500 + n_docs)
+    length = 40_000
+    s, e, o = _random_index(rng, 150_000, length, n_docs, 120)
+    for bucket_shift in (0, 1, 5):
+        for dense in (False, True):
+            if dense and n_docs > 255:
+                continue
+            with memo.DeviceIndex.from_host(s, e, o, bucket_shift=bucket_shift) as ix:
+                ix.pack()
+                if dense:
+                    ix.pack_dense(keep_packed=False)
+                    assert ix.info()["dense_rows"] == 1
+                for k in (2, 8, 31, 32, 33, 64, 101, 200):
+                    if dense and k > 64:
+                        continue
+                    qs = int(rng.integers(0, length // 3))
+                    qe = int(rng.integers(qs + 1, min(qs + 9000, length + 50)))
+                    rows = oracle.filter_rows(s, e, o, qs, qe, k)
+                    want = oracle.membership(*rows, qs, qe, k, n_docs, literal=False)
+                    assert np.array_equal(ix.membership(qs, qe, k, n_docs), want), (bucket_shift, dense, k, qs, qe)
+                    assert ix.info()["last_sweep"] == (6 if dense else 7), (dense, k, ix.info()["last_sweep"])
+                ix.check()
+
+
 def test_membership_many_genomes_is_sliced(memo, oracle):
     """num_docs in the thousands: the genome words do not fit one LDS tile and are swept in slices"""
     rng = np.random.default_rng(12)
