@@ -171,7 +171,8 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
         const uint32_t first = 0xFFFFFFFFu << (c & 31), last = 0xFFFFFFFFu >> (31 - ((h - 1) & 31));
         atomicOr(row + w0, w0 == w1 ? first & last : first);  // one instruction for both shapes
         if (w1 > w0) {
-            for (int w = w0 + 1; w < w1; ++w) atomicOr(row + w, 0xFFFFFFFFu);
+            // (whole words: plain stores -- atomicOr(p, ~0u) compiles to ds_wrxchg_rtn_b32 and a wait for its result: planes_put)
+            for (int w = w0 + 1; w < w1; ++w) __hip_atomic_store(row + w, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             atomicOr(row + w1, last);
         }
     });
