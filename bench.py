@@ -312,6 +312,8 @@ def main():
     others = (world == 1 and not args.force_dist and not args.headline_only)
     formats = [args.rows] + ([f for f in ("wide", "packed", "dense") if f != args.rows and
                               (f != "dense" or can_dense) and (f == "wide" or k - 1 <= 255)] if others else [])
+    if args.calibrate and "wide" not in formats:
+        formats.append("wide")              # (the PMC calibration kernel streams the int64 columns: 16 known bytes per row)
     one_device = os.environ.get("MEMO_BENCH_ONE_DEVICE") == "1" and world > 1
     for turn in range(world if one_device else 1):       # (test transport: the ranks share one GPU and build one after the other)
       if one_device:
