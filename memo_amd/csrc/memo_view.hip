@@ -1002,17 +1002,25 @@ static int order_words_on(memo_index *ix, int mode, hipStream_t st) {
 // order; what that costs a sweep depends on how many rows share a start (a half-wave's atomics on one cell: profiles/
 // r04_row_order.txt -- 1.5 % of a sweep at 5 rows per start, 7 % at 25, 20 % at 25 and k = 101), and the ordering pass costs
 // a dozen sweeps or more: the queries so far must have lost that much (order_due), or memo_index_prepare asks for it.
-// (A membership order -- rows dealt over annot mod 32, interleave mode 3 -- was built and measured: config 4 at k = 101 0.870 ->
-// 0.863 ms, k = 31 0.528 -> 0.524: the planes kernel is not bound by its atomics' bank conflicts; profiles/r04_membership.txt.
-// One order serves both kinds of query; mode 3 stays reachable through memo_debug_row_order of the A/B library.)
-static int keep_row_order(memo_index *ix, int64_t window, int km1, hipStream_t st) {
+// WHICH order follows from the kind of query that has paid for the pass: conservation deals a bucket's rows over its starts
+// (interleave mode 2), membership over annot mod 32 (mode 3: the lanes of a half-wave on different genomes' plane rows).  Round 4
+// had measured the two level on config 4 -- under a planes kernel whose every row waited for the LDS (memo_sweep_memb.hip:
+// planes_put); since round 5 it does not, and on the sequence-built index the membership order is 6-7 % ahead at k = 31 and 101
+// (config 4: level; profiles/r05_large_k.txt).  Rows that are in the OTHER kind's order (memo_index_pack orders for conservation:
+// it cannot know) are re-ordered by the same rule with that gain, each time four times later: kinds that alternate settle.
+constexpr double kMembershipOrderGain = 0.06;
+static int keep_row_order(memo_index *ix, int64_t window, int km1, bool membership, hipStream_t st) {
     if (!ix->pk || (ix->packed_fmt != 4 && ix->packed_fmt != 12)) return MEMO_OK;
-    const int want = row_order_mode(ix);
-    if (want == ix->row_order || !ix->order_pending) return MEMO_OK;
+    int want = ix->tune.row_order ? ix->tune.row_order - 1 : (membership ? 3 : kRowOrderDefault);
+    if (want == 3 && ix->bshift != 5) want = 2;  // (as order_words_on maps it)
+    if (want == ix->row_order) return MEMO_OK;
+    const bool pending = ix->order_pending != 0;  // the rows are in start order
+    if (!pending && (ix->tune.row_order || ix->row_order == 0)) return MEMO_OK;  // (an order asked for by name, or none wanted: stays)
     if (!g_prepare_only) {
         const double span = (double)ix->max_s - (double)ix->min_s + 1.0, per_start = (double)ix->rows / (span > 1 ? span : 1);
         double gain = 0.003 * per_start * (km1 >= 64 ? 3.0 : 1.0);
         gain = gain > 0.2 ? 0.2 : gain;
+        if (!pending && membership) gain = kMembershipOrderGain;
         ix->order_lost_ns += rows_in_window(ix, (double)ix->rows, window, km1) * 1.3 * kSweepNsPerRow * gain;
         const double per_row = ix->order_ns_per_row > 0 ? ix->order_ns_per_row : kOrderNsPerRow;
         const double cost = ((double)ix->rows * per_row + kPassFixedNs) * (double)ix->order_backoff * (double)ix->build_cost_pct / 100.0;
@@ -1023,6 +1031,10 @@ static int keep_row_order(memo_index *ix, int64_t window, int km1, hipStream_t s
         ix->order_lost_ns = 0;
         if (ix->order_backoff < (1 << 16)) ix->order_backoff *= 4;
         return MEMO_OK;
+    }
+    if (!rc) {
+        ix->order_lost_ns = 0;
+        if (!pending && ix->order_backoff < (1 << 16)) ix->order_backoff *= 4;  // (a change of kinds: the next one has to be worth more)
     }
     return rc;
 }
@@ -1068,8 +1080,7 @@ static int build_timed(memo_index *ix, memo_index::DenseView &v, hipStream_t st,
 // genomes read): the rows whose overlap is below the class's cap (2, 4 ... 32, 40 ... 64, 80 ... 128), with their own bucket table, built
 // when it has become worth it (view_due) and spares a fifth of the rows.  BASELINE config 5 at k = 101 sweeps ... its 8.4 * 10^8 rows that way.
 int packed_rows_for(memo_index *ix, int km1, int64_t window, bool membership, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows) {
-    (void)membership;
-    if (int rc = keep_row_order(ix, window, km1, st)) return rc;
+    if (int rc = keep_row_order(ix, window, km1, membership, st)) return rc;
     *pk = ix->pk;
     *boff = ix->boff;
     *rows = ix->rows;

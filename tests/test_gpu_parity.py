@@ -1890,6 +1890,28 @@ def test_prepare_builds_views_and_tables_now(memo, oracle):
         assert np.array_equal(ix.conservation(0, L, 101, n), want) and ix.info()["row_order"] == 2
         ix.check()
         assert np.array_equal(ix.conservation(5, L - 9, 101, n), want[5:L - 9])
+    # WHICH order follows from the kind of query that pays for the pass: membership deals a bucket's rows over annot mod 32
+    # (interleave mode 3), conservation over the bucket's starts (mode 2); rows in the other kind's order are re-ordered by the same rule
+    with memo.DeviceIndex.from_host_packed(s, e, o) as ix:
+        wantm = oracle.membership(s, e, o, 1000, 300_000, 31, n, literal=False)
+        ix.prepare(31, n, membership=True)
+        assert ix.info()["row_order"] == 3
+        assert np.array_equal(ix.membership(1000, 300_000, 31, n), wantm)
+        assert np.array_equal(ix.conservation(0, L, 101, n), want) and ix.info()["row_order"] == 3      # one query has not paid for a pass
+        ix.set_option(3, 0)                                                                              # ... now it has
+        assert np.array_equal(ix.conservation(0, L, 101, n), want) and ix.info()["row_order"] == 2
+        assert np.array_equal(ix.membership(1000, 300_000, 31, n), wantm) and ix.info()["row_order"] == 3
+        ix.check()
+    with memo.DeviceIndex.from_host(s, e, o) as ix:
+        ix.pack()
+        assert ix.info()["row_order"] == 2                      # (memo_index_pack cannot know: the conservation order)
+        for _ in range(3):
+            assert np.array_equal(ix.membership(1000, 300_000, 31, n), wantm)
+        assert ix.info()["row_order"] == 2                      # (three queries of 3 * 10^5 positions have not paid for the pass)
+        ix.prepare(31, n, membership=True)
+        assert ix.info()["row_order"] == 3
+        assert np.array_equal(ix.membership(1000, 300_000, 31, n), wantm)
+        ix.check()
 
 
 def test_views_are_built_when_they_have_paid_for_themselves(memo, oracle):
