@@ -190,7 +190,8 @@ int memo_index_get_info_v5(const memo_index_t *ix, memo_index_info_t *info);  /*
  *                             a long-lived index that holds both row sources can grow to three times their bytes.  0 .. 1600.
  *                             (Tile tables are not under this budget: up to 64 of them per index, 32 B per tile of the chromosome
  *                             each -- 3.4 MB for 10^8 positions -- least recently used out first.)
- *   MEMO_OPT_BUILD_COST_PCT   when a query builds a view (or brings rows that came in start order into the query order): every query
+ *   MEMO_OPT_BUILD_COST_PCT   when a query builds a view (or brings the 4-byte rows into the order its KIND of query reads fastest -- rows that
+ *                             came in start order, or rows ordered for conservation under membership queries and the reverse): every query
  *                             of a k class that runs without its view adds what the view would have saved it (the rows of its window
  *                             the view leaves out x what a sweep pays per row); the view is built by the query that finds the sum has
  *                             reached this many percent of what the pass is estimated to cost (calibrated, then measured by the

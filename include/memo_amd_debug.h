@@ -34,9 +34,9 @@ extern "C" {
  *   the index is inside the result matrix, else 1. */
 int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32_t membership_algo,
                           int32_t row_source, int32_t scatter);
-/* Order of the 4-byte rows inside a start bucket (memo_amd/csrc/memo_interleave.hip): 0 = the library's choice (3), 1 = start order (as the packers write them), 2 = chunks of four rows dealt round-robin
+/* Order of the 4-byte rows inside a start bucket (memo_amd/csrc/memo_interleave.hip): 0 = the library's choice (3 for conservation, 4 for membership: whichever kind of query pays for the pass), 1 = start order (as the packers write them), 2 = chunks of four rows dealt round-robin
  * over the bucket's starts, 3 = the same with the rows of a start ordered by overlap mod 32, 4 = chunks dealt over annot mod 32,
- * the rows of a class by their end (an order made for the membership planes; measured: 1 % -- profiles/r04_membership.txt).  Applied at once to resident 4-byte rows (their k-class views are dropped) and by every
+ * the rows of a class by their end (the order made for the membership planes: 6-7 % on a sequence-built index, level on config 4 -- profiles/r05_large_k.txt).  Applied at once to resident 4-byte rows (their k-class views are dropped) and by every
  * later memo_index_pack of this index.  Results never depend on it. */
 int memo_debug_row_order(memo_index_t *ix, int32_t order);
 /* 1 = this index's sweeps read all the rows of their format even where a k-class view is resident (views already built stay:
