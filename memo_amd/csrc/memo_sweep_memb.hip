@@ -112,13 +112,6 @@ __device__ __forceinline__ void transpose32_stage(uint32_t (&m)[32]) {
     for (int k = 0; k < 32; ++k) {
         if ((k & J) == 0) {
             const uint32_t a = m[k], b = m[k + J];
-#ifdef MEMO_PLANES_XOR_TRANSPOSE  // (A/B: rounds 1-4's xor-swap)
-            constexpr uint32_t mk = J == 16 ? 0x0000FFFFu : J == 8 ? 0x00FF00FFu : mask;
-            const uint32_t tt = ((a >> J) ^ b) & mk;
-            m[k] = a ^ (tt << J);
-            m[k + J] = b ^ tt;
-            continue;
-#endif
             if (J == 16) {
                 m[k] = __builtin_amdgcn_perm(b, a, 0x05040100u);      // a.lo16 | b.lo16 << 16
                 m[k + J] = __builtin_amdgcn_perm(b, a, 0x07060302u);  // a.hi16 | b.hi16 << 16
@@ -215,19 +208,6 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 template <bool SHORT, bool SK>
 __device__ __forceinline__ void planes_put(uint32_t *lds, int *status, uint32_t base, int km1, uint32_t p4, uint32_t s4, uint32_t len,
                                            uint32_t d, uint32_t col) {
-#ifdef MEMO_PLANES_BRANCHY_ROW  // (A/B: rounds 2-4's row, a test and a 64-bit shift)
-    if constexpr (SHORT) {
-        const int n = km1 - (int)len;
-        if (n > 0) {
-            const uint32_t first = d - (uint32_t)n;
-            uint32_t *cell = lds + (__umul24(col, p4 >> 2) + __umul24(col >> 5, s4 >> 2) + (first >> 5));
-            const uint64_t run = (uint64_t)((1u << n) - 1u) << (first & 31u);
-            atomicOr(cell, (uint32_t)run);
-            atomicOr(cell + 1, (uint32_t)(run >> 32));
-        }
-        return;
-    }
-#endif
     if constexpr (SHORT) {
         uint32_t n, first, t, wq, addr, lo;
         MEMO_EXEC_ALL_ONES(status);  // (the row loops are wave-uniform: every lane of the wave is here)
@@ -240,12 +220,9 @@ __device__ __forceinline__ void planes_put(uint32_t *lds, int *status, uint32_t 
             asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(col), "s"(p4), "v"(base));
         }
         asm volatile(
-#ifdef MEMO_PLANES_NO_CMPX  // (A/B: rows that cannot write -- the dead rows of a load that straddles an end of the slice too -- or nothing in)
-            "v_sub_u32_e64 %0, %6, %7 clamp\n\t"   // n = max(k - 1 - overlap, 0)
-#else
             "v_sub_u32 %0, %6, %7\n\t"             // n = k - 1 - overlap
-            "v_cmpx_lt_i32 vcc, 0, %0\n\t"         // the rest on the lanes whose row writes
-#endif
+            "v_cmpx_lt_i32 vcc, 0, %0\n\t"         // the rest on the lanes whose row writes (the dead rows of a load that straddles
+                                                   // an end of the slice too: two atomics that add nothing cost what any two cost)
             "v_sub_u32 %1, %8, %0\n\t"             // first bit of the run
             "v_lshrrev_b32 %2, 5, %1\n\t"          // its word
             "v_lshl_add_u32 %3, %2, 2, %5\n\t"     // its address
@@ -254,13 +231,9 @@ __device__ __forceinline__ void planes_put(uint32_t *lds, int *status, uint32_t 
             "v_sub_u32_e64 %2, %8, %2 clamp\n\t"   // bits of the run in it
             "v_bfm_b32 %2, %2, 0\n\t"
             "ds_or_b32 %3, %4\n\t"
-#if !defined(MEMO_PLANES_NO_CMPX) && !defined(MEMO_PLANES_ALWAYS_SECOND)
             "v_cmpx_ne_u32 vcc, 0, %2\n\t"         // (a run inside one word -- about half of them at k = 31 -- has no second ds_or)
-#endif
-            "ds_or_b32 %3, %2 offset:4"
-#ifndef MEMO_PLANES_NO_CMPX
-            "\n\ts_mov_b64 exec, -1"
-#endif
+            "ds_or_b32 %3, %2 offset:4\n\t"
+            "s_mov_b64 exec, -1"
             : "=&v"(n), "=&v"(first), "=&v"(wq), "=&v"(addr), "=&v"(lo)
             : "v"(t), "s"(km1), "v"(len), "v"(d)
             : "memory", "vcc");
