@@ -918,8 +918,10 @@ static bool view_due(memo_index *ix, memo_index::DenseView &v, int kind, double 
 static void view_built(memo_index *ix, float build_ms, int kind, double src_rows) {  // what the pass cost, for the next estimate
     constexpr double kConst[3] = {kDenseViewNsPerRow, kPackedViewNsPerRow, kPlacedViewNsPerRow};
     const double ns = (double)build_ms * 1e6 - kPassFixedNs;
-    const double floor = 0.25 * kConst[kind];
-    if (src_rows > 0) ix->view_ns_per_row[kind] = ns / src_rows > floor ? ns / src_rows : floor;
+    // within a factor of four of the calibrated constant: the pass is timed with its allocations, and a hipMalloc that stalls (350 ms
+    // for 0.85 GB seen on one box: gpurun r5valid) must not make every later view of the index look two hundred times as dear
+    const double floor = 0.25 * kConst[kind], ceil = 4.0 * kConst[kind];
+    if (src_rows > 0) ix->view_ns_per_row[kind] = ns / src_rows > floor ? (ns / src_rows < ceil ? ns / src_rows : ceil) : floor;
 }
 
 // A dense view that exists with its rows in the order they came: is it time to build it again with their places chosen
@@ -994,7 +996,8 @@ static int order_words_on(memo_index *ix, int mode, hipStream_t st) {
     ix->row_order = mode;
     ix->order_pending = 0;
     const double ns = (double)ms * 1e6 - kPassFixedNs;
-    ix->order_ns_per_row = ns / (double)ix->rows > 0.25 * kOrderNsPerRow ? ns / (double)ix->rows : 0.25 * kOrderNsPerRow;
+    const double per = ns / (double)ix->rows;  // (within a factor of four of the constant, like view_built)
+    ix->order_ns_per_row = per > 0.25 * kOrderNsPerRow ? (per < 4.0 * kOrderNsPerRow ? per : 4.0 * kOrderNsPerRow) : 0.25 * kOrderNsPerRow;
     return MEMO_OK;
 }
 
