@@ -1566,6 +1566,8 @@ def test_dense_row_sweep_variants(memo, oracle, ab):
     ix, (r0, r1) = synth.device_index(0, L, 64, n, L, pack="dense")
     num, den = synth.rows_per_position(n)
     with ix:
+        ix.set_option(3, 100000)  # MEMO_OPT_BUILD_COST_PCT: no view in this part (sixty queries of k = 31's class are about what one costs;
+                                  # a view of six rows would answer as variant 3)
         for k in (2, 3, 4, 5, 8, 9, 16, 17, 21, 31, 32, 33, 48, 64, 31):
             for qs, qe in ((0, L), (4, L - 3), (1_000_000, 5_000_001), (2_345_676, 2_345_680 + 1_500_000), (777, 5_555_555)):
                 for dt in (np.uint8, np.uint16):
