@@ -195,30 +195,31 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 }
 
 
-// One row of a planes kernel: the run of n = k - 1 - overlap bits that ends at bit d of plane row `col`.
-//   SHORT (k - 1 <= 31): the run fits two words.  No test, no branch: a row that cannot write has n = 0, an empty run, and its
-//   two ds_or add nothing (its cell is inside the plane row like any other: d is).  By hand, 9 - 10 vector instructions after the
-//   row's three fields and no scalar ones (the compiler's branchy form: 17 and 8; its branch-free one 21): saturating subtracts
-//   for n and for the bits that spill into the second word, v_bfm_b32 for both masks.
-//   Otherwise (up to 255 bits): first word, whole words, last word.  The whole words are plain stores: all-ones or-ed into a
-//   word is all-ones stored (whatever another lane's ds_or does before or after), and a store returns nothing -- the
-//   compiler's rendering of atomicOr(p, ~0u) was ds_wrxchg_rtn_b32 with an s_waitcnt lgkmcnt(0) per word, and, the returned
-//   register being reused, one more wait in EVERY row, the short path's too (round 5; it had gone unnoticed since round 2).
+// One row of a planes kernel: the run of n = k - 1 - overlap bits that ends at bit d of plane row `col`; hand-written blocks,
+// EXEC narrowed by v_cmpx and restored at the end (every lane of the wave is active in the row loops).
+//   MW = 0 (k - 1 <= 31): the run fits two words.  12 vector instructions with the row's three fields and no scalar ones (the
+//   compiler's branchy form: 17 and 8): v_bfm_b32 for both masks, a saturating subtract for the bits that spill into the second
+//   word; a row that cannot write issues nothing (a zero or-ed into LDS costs what any atomic costs: the first version, without
+//   the test, was 8 - 13 % slower through the dead rows of the loads that straddle a slice's end alone), a run inside one word
+//   no second ds_or.
+//   MW = 2, 3, 4, 8: longer runs, see the block.
 //   base: the planes' LDS byte address in a VGPR; p4, s4: 4 * PITCH, 4 * SKEW; SK: SKEW != 0 (4, 8 or 16 result words).
-template <bool SHORT, bool SK>
+template <int MW, bool SK>
 __device__ __forceinline__ void planes_put(uint32_t *lds, int *status, uint32_t base, int km1, uint32_t p4, uint32_t s4, uint32_t len,
                                            uint32_t d, uint32_t col) {
-    if constexpr (SHORT) {
-        uint32_t n, first, t, wq, addr, lo;
-        MEMO_EXEC_ALL_ONES(status);  // (the row loops are wave-uniform: every lane of the wave is here)
-        if constexpr (SK) {
-            const uint32_t colhi = col >> 5;
-            asm volatile("v_mad_u32_u24 %0, %1, %2, %3\n\t"
-                         "v_mad_u32_u24 %0, %4, %5, %0"
-                         : "=&v"(t) : "v"(col), "s"(p4), "v"(base), "v"(colhi), "s"(s4));
-        } else {
-            asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(col), "s"(p4), "v"(base));
-        }
+    (void)lds;
+    uint32_t t;
+    MEMO_EXEC_ALL_ONES(status);  // (the row loops are wave-uniform: every lane of the wave is here)
+    if constexpr (SK) {
+        const uint32_t colhi = col >> 5;
+        asm volatile("v_mad_u32_u24 %0, %1, %2, %3\n\t"
+                     "v_mad_u32_u24 %0, %4, %5, %0"
+                     : "=&v"(t) : "v"(col), "s"(p4), "v"(base), "v"(colhi), "s"(s4));
+    } else {
+        asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(col), "s"(p4), "v"(base));
+    }
+    if constexpr (MW == 0) {
+        uint32_t n, first, wq, addr, lo;
         asm volatile(
             "v_sub_u32 %0, %6, %7\n\t"             // n = k - 1 - overlap
             "v_cmpx_lt_i32 vcc, 0, %0\n\t"         // the rest on the lanes whose row writes (the dead rows of a load that straddles
@@ -238,17 +239,47 @@ __device__ __forceinline__ void planes_put(uint32_t *lds, int *status, uint32_t 
             : "v"(t), "s"(km1), "v"(len), "v"(d)
             : "memory", "vcc");
     } else {
-        const int n = km1 - (int)len;
-        if (n > 0) {
-            uint32_t *row = lds + (__umul24(col, p4 >> 2) + (SK ? __umul24(col >> 5, s4 >> 2) : 0u));
-            const uint32_t first = d - (uint32_t)n, last = d - 1u;
-            uint32_t *cell = row + (first >> 5);
-            const int more = (int)(last >> 5) - (int)(first >> 5);
-            const uint32_t head = 0xFFFFFFFFu << (first & 31u), tail = 0xFFFFFFFFu >> (31u - (last & 31u));
-            atomicOr(cell, more ? head : head & tail);
-            for (int i = 1; i < more; ++i) __hip_atomic_store(cell + i, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (more) atomicOr(cell + more, tail);
-        }
+        // Runs of up to MW + 1 words (MW = the most words a run can reach past its first: (k - 1 + 30) / 32, rounded up to 2, 3, 4
+        // or 8): the first word (with the last one's mask where the run ends in it), the last word on the lanes whose run has
+        // one, then whole words -- plain stores: all-ones or-ed into a word is all-ones stored, whatever another lane's ds_or does
+        // before or after, and a store returns nothing (the compiler's rendering of atomicOr(p, ~0u) was ds_wrxchg_rtn_b32 with an
+        // s_waitcnt lgkmcnt(0) per word and, the returned register being reused, one more wait in EVERY row, the short path's too:
+        // unnoticed from round 2 to round 5) -- behind v_cmpx tests that only ever narrow EXEC: no loop, no branch.  One block.
+        uint32_t n, first, last, w0, w1, more, head, tail, ones, a0;
+#define MEMO_PLANES_WORD(I) "v_cmpx_lt_u32 vcc, " #I ", %5\n\tds_write_b32 %9, %8 offset:" #I "*4\n\t"
+#define MEMO_PLANES_LONG(WORDS)                                                                                                     \
+        asm volatile(                                                                                                               \
+            "v_sub_u32 %0, %11, %12\n\t"           /* n = k - 1 - overlap */                                                       \
+            "v_cmpx_lt_i32 vcc, 0, %0\n\t"         /* the lanes whose row writes */                                                \
+            "v_sub_u32 %1, %13, %0\n\t"            /* first bit of the run */                                                      \
+            "v_add_u32 %2, -1, %13\n\t"            /* last bit */                                                                  \
+            "v_lshrrev_b32 %3, 5, %1\n\t"          /* their words */                                                               \
+            "v_lshrrev_b32 %4, 5, %2\n\t"                                                                                          \
+            "v_sub_u32 %5, %4, %3\n\t"             /* words past the first */                                                      \
+            "v_lshlrev_b32_e64 %6, %1, -1\n\t"     /* -1 << (first & 31) */                                                        \
+            "v_not_b32 %2, %2\n\t"                                                                                                 \
+            "v_lshrrev_b32_e64 %7, %2, -1\n\t"     /* -1 >> (31 - (last & 31)) */                                                  \
+            "v_cmp_eq_u32 vcc, 0, %5\n\t"                                                                                          \
+            "v_cndmask_b32 %8, -1, %7, vcc\n\t"    /* the run ends in its first word: the last word's mask there; else all ones */ \
+            "v_and_b32 %6, %6, %8\n\t"                                                                                             \
+            "v_lshl_add_u32 %9, %3, 2, %10\n\t"    /* address of the first word */                                                 \
+            "ds_or_b32 %9, %6\n\t"                                                                                                 \
+            "v_cmpx_lt_u32 vcc, 0, %5\n\t"         /* runs of more than one word: the last one (%8 is all ones on these lanes) */  \
+            "v_lshl_add_u32 %3, %4, 2, %10\n\t"                                                                                    \
+            "ds_or_b32 %3, %7\n\t"                                                                                                 \
+            WORDS                                  /* whole words: tests that only ever narrow EXEC */                             \
+            "s_mov_b64 exec, -1"                                                                                                   \
+            : "=&v"(n), "=&v"(first), "=&v"(last), "=&v"(w0), "=&v"(w1), "=&v"(more), "=&v"(head), "=&v"(tail), "=&v"(ones), "=&v"(a0) \
+            : "v"(t), "s"(km1), "v"(len), "v"(d)                                                                                   \
+            : "memory", "vcc")
+        if constexpr (MW <= 2) MEMO_PLANES_LONG(MEMO_PLANES_WORD(1));
+        else if constexpr (MW == 3) MEMO_PLANES_LONG(MEMO_PLANES_WORD(1) MEMO_PLANES_WORD(2));
+        else if constexpr (MW == 4) MEMO_PLANES_LONG(MEMO_PLANES_WORD(1) MEMO_PLANES_WORD(2) MEMO_PLANES_WORD(3));
+        else
+            MEMO_PLANES_LONG(MEMO_PLANES_WORD(1) MEMO_PLANES_WORD(2) MEMO_PLANES_WORD(3) MEMO_PLANES_WORD(4) MEMO_PLANES_WORD(5)
+                             MEMO_PLANES_WORD(6) MEMO_PLANES_WORD(7));
+#undef MEMO_PLANES_LONG
+#undef MEMO_PLANES_WORD
     }
 }
 
@@ -324,7 +355,7 @@ __device__ __forceinline__ void planes_transpose_store(const SweepArgs &A, const
 //   nw words of padding per position word: both chosen so that the lanes of a wave (nw groups x
 //   64/nw position words) fall on 64 different banks.
 // ------------------------------------------------------------------------------------------
-template <typename Rows, int U, int T, bool SHORT, bool SK>
+template <typename Rows, int U, int T, int MW, bool SK>
 __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
@@ -347,7 +378,7 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
     const uint32_t keym = pin_vgpr((int)Rows::tile_key(t.a - 32 * HLW));  // bit 32 * HLW of a plane row = tile slot 0
     const uint32_t base = pin_vgpr((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds);
     const uint32_t p4 = 4u * (uint32_t)PITCH, s4 = 4u * (uint32_t)SKEW;
-    auto scatter = [&](uint32_t w, uint32_t col) { planes_put<SHORT, SK>(lds, A.status, base, km1, p4, s4, (uint32_t)Rows::len(w), Rows::rel_start(w, keym), col); };
+    auto scatter = [&](uint32_t w, uint32_t col) { planes_put<MW, SK>(lds, A.status, base, km1, p4, s4, (uint32_t)Rows::len(w), Rows::rel_start(w, keym), col); };
     Rows::template consume<T, U>(A, t, 0, V, N, scatter);
     for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
         Rows::template issue<T, U>(A, t, b, V, N);
@@ -360,7 +391,7 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
 // genomes).  A row's field after the 16-bit subtract of the tile's key is (start - a + 32 HLW) << 6 | overlap, so the
 // plane row's bit numbers have to stay below 2^10: the launcher sizes the tile for that (W + k - 1 + bucket + 32 HLW <=
 // 1024).
-template <int U, int T, bool SHORT, bool SK>
+template <int U, int T, int MW, bool SK>
 __global__ __launch_bounds__(T) void sweep_membership_planes3_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     using Rows = PackedRows3;
@@ -383,7 +414,7 @@ __global__ __launch_bounds__(T) void sweep_membership_planes3_kernel(const Sweep
     // r = (start - a + 32 HLW) << 6 | overlap
     const uint32_t base = pin_vgpr((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds);
     const uint32_t p4 = 4u * (uint32_t)PITCH, s4 = 4u * (uint32_t)SKEW;
-    auto put = [&](uint32_t r, uint32_t col) { planes_put<SHORT, SK>(lds, A.status, base, km1, p4, s4, r & 63u, r >> 6, col); };
+    auto put = [&](uint32_t r, uint32_t col) { planes_put<MW, SK>(lds, A.status, base, km1, p4, s4, r & 63u, r >> 6, col); };
     auto g = [&](uint32_t b, uint32_t data) {  // 16-bit subtract on the low half; the result's high half is zero
         uint32_t r;
         asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(b), "v"(key6));
@@ -397,16 +428,23 @@ __global__ __launch_bounds__(T) void sweep_membership_planes3_kernel(const Sweep
     planes_transpose_store<T>(A, t, lds);
 }
 
+template <typename Rows, int T, int MW>
+SweepKernel planes_kernel_m(bool skewed) {
+    return skewed ? (SweepKernel)sweep_membership_planes_kernel<Rows, 6, T, MW, true> : (SweepKernel)sweep_membership_planes_kernel<Rows, 6, T, MW, false>;
+}
+
 template <typename Rows, int T>
-SweepKernel planes_kernel_t(bool two_words, bool skewed) {
-    if (two_words)
-        return skewed ? (SweepKernel)sweep_membership_planes_kernel<Rows, 6, T, true, true> : (SweepKernel)sweep_membership_planes_kernel<Rows, 6, T, true, false>;
-    return skewed ? (SweepKernel)sweep_membership_planes_kernel<Rows, 6, T, false, true> : (SweepKernel)sweep_membership_planes_kernel<Rows, 6, T, false, false>;
+SweepKernel planes_kernel_t(int mw, bool skewed) {
+    return mw == 0   ? planes_kernel_m<Rows, T, 0>(skewed)
+           : mw == 2 ? planes_kernel_m<Rows, T, 2>(skewed)
+           : mw == 3 ? planes_kernel_m<Rows, T, 3>(skewed)
+           : mw == 4 ? planes_kernel_m<Rows, T, 4>(skewed)
+                     : planes_kernel_m<Rows, T, 8>(skewed);
 }
 
 template <typename Rows>
-SweepKernel planes_kernel(int T, bool two_words, bool skewed) {
-    return T == 64 ? planes_kernel_t<Rows, 64>(two_words, skewed) : planes_kernel_t<Rows, 256>(two_words, skewed);
+SweepKernel planes_kernel(int T, int mw, bool skewed) {
+    return T == 64 ? planes_kernel_t<Rows, 64>(mw, skewed) : planes_kernel_t<Rows, 256>(mw, skewed);
 }
 
 __global__ void fill_membership_kernel(uint32_t *out, int64_t n, int nw, int ncols) {
@@ -563,10 +601,11 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.out_words = nw;
             const size_t planes = ((size_t)32 * nw * A.ls + (size_t)nw * skew + 8) * 4;
             const size_t staged = ((size_t)pw * (32 * nw + nw) + 4) * 4;
-            SweepKernel kern = k - 1 <= 31 ? (skew ? (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, true, true>
-                                                   : (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, true, false>)
-                                           : (skew ? (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, false, true>
-                                                   : (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, false, false>);
+            // (k - 1 <= 63 here: a run reaches at most two words past its first)
+            SweepKernel kern = k - 1 <= 31 ? (skew ? (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, 0, true>
+                                                   : (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, 0, false>)
+                                           : (skew ? (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, 2, true>
+                                                   : (SweepKernel)sweep_membership_planes3_kernel<PackedRows3::kLoads, 256, 2, false>);
             if ((rc = launch_tiles(kern, A, tw, 256, planes > staged ? planes : staged, st))) return rc;
             ix->last_sweep = 6;
             return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
@@ -619,10 +658,11 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             A.magic = (uint32_t)((((uint64_t)1 << 32) + 32 * nw - 1) / (32 * nw));
             const size_t planes = ((size_t)32 * nw * A.ls + (size_t)nw * skew + 8) * 4;
             const size_t staged = ((size_t)pw * (32 * nw + nw) + 4) * 4;
-            const bool two_words = k - 1 <= 31;  // (the run of a row fits two plane words: the branch-free row block)
-            SweepKernel kern = fmt == 4    ? planes_kernel<PackedRows<false, false>>(T, two_words, skew != 0)
-                               : fmt == 12 ? planes_kernel<PackedRows<false, false, true>>(T, two_words, skew != 0)
-                                           : planes_kernel<PackedRows<true, false>>(T, two_words, skew != 0);
+            // the row block by the most words a run can reach past its first: 0 = the two-word block (k - 1 <= 31), else 2, 3, 4 or 8
+            const int reach = (k - 1 + 30) / 32, mw = k - 1 <= 31 ? 0 : (reach <= 2 ? 2 : reach <= 3 ? 3 : reach <= 4 ? 4 : 8);
+            SweepKernel kern = fmt == 4    ? planes_kernel<PackedRows<false, false>>(T, mw, skew != 0)
+                               : fmt == 12 ? planes_kernel<PackedRows<false, false, true>>(T, mw, skew != 0)
+                                           : planes_kernel<PackedRows<true, false>>(T, mw, skew != 0);
             if ((rc = use_words())) return rc;
             if ((rc = launch_tiles(kern, A, tw, T, planes > staged ? planes : staged, st))) return rc;
             return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
