@@ -205,9 +205,8 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 //   MW = 2, 3, 4, 8: longer runs, see the block.
 //   base: the planes' LDS byte address in a VGPR; p4, s4: 4 * PITCH, 4 * SKEW; SK: SKEW != 0 (4, 8 or 16 result words).
 template <int MW, bool SK>
-__device__ __forceinline__ void planes_put(uint32_t *lds, int *status, uint32_t base, int km1, uint32_t p4, uint32_t s4, uint32_t len,
-                                           uint32_t d, uint32_t col) {
-    (void)lds;
+__device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, uint32_t p4, uint32_t s4, uint32_t len, uint32_t d,
+                                           uint32_t col) {
     uint32_t t;
     MEMO_EXEC_ALL_ONES(status);  // (the row loops are wave-uniform: every lane of the wave is here)
     if constexpr (SK) {
@@ -343,9 +342,8 @@ __device__ __forceinline__ void planes_transpose_store(const SweepArgs &A, const
 //
 //   * a genome's plane row covers ceil((k-1)/32) words left of the tile and a few right of it, so that
 //     the run of any row of the slice (start - a <= W + k - 1 + bucket - 2, n = k - 1 - overlap bits
-//     ending at start) fits without clipping.  k <= 32: the run is (2^n - 1) << first bit as a 64-bit
-//     value, ds_or of its two halves into neighbouring words -- 18 VALU instructions per row instead
-//     of ~30 and no divergent branches; larger k: first word, whole words, last word;
+//     ending at start) fits without clipping.  The row itself is planes_put: MW = 0 (k <= 32) the run's two words, else
+//     first word, last word, whole words -- hand-written blocks, one instantiation per reach of a run;
 //   * lane (G, p) then reads the 32 plane rows of genome group G at position word p, transposes
 //     the 32 x 32 bits in registers and writes the 32 result words position-major into LDS, over
 //     the planes (all reads are behind a barrier by then);
@@ -378,7 +376,7 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
     const uint32_t keym = pin_vgpr((int)Rows::tile_key(t.a - 32 * HLW));  // bit 32 * HLW of a plane row = tile slot 0
     const uint32_t base = pin_vgpr((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds);
     const uint32_t p4 = 4u * (uint32_t)PITCH, s4 = 4u * (uint32_t)SKEW;
-    auto scatter = [&](uint32_t w, uint32_t col) { planes_put<MW, SK>(lds, A.status, base, km1, p4, s4, (uint32_t)Rows::len(w), Rows::rel_start(w, keym), col); };
+    auto scatter = [&](uint32_t w, uint32_t col) { planes_put<MW, SK>(A.status, base, km1, p4, s4, (uint32_t)Rows::len(w), Rows::rel_start(w, keym), col); };
     Rows::template consume<T, U>(A, t, 0, V, N, scatter);
     for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
         Rows::template issue<T, U>(A, t, b, V, N);
@@ -414,7 +412,7 @@ __global__ __launch_bounds__(T) void sweep_membership_planes3_kernel(const Sweep
     // r = (start - a + 32 HLW) << 6 | overlap
     const uint32_t base = pin_vgpr((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds);
     const uint32_t p4 = 4u * (uint32_t)PITCH, s4 = 4u * (uint32_t)SKEW;
-    auto put = [&](uint32_t r, uint32_t col) { planes_put<MW, SK>(lds, A.status, base, km1, p4, s4, r & 63u, r >> 6, col); };
+    auto put = [&](uint32_t r, uint32_t col) { planes_put<MW, SK>(A.status, base, km1, p4, s4, r & 63u, r >> 6, col); };
     auto g = [&](uint32_t b, uint32_t data) {  // 16-bit subtract on the low half; the result's high half is zero
         uint32_t r;
         asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(b), "v"(key6));
