@@ -134,6 +134,13 @@ typedef struct memo_index_info {
 const char *memo_last_error(void);
 int memo_device_count(void);
 const char *memo_version(void);
+/* Host threads the library runs flat out (the pool that narrows host rows for memo_conservation / memo_membership /
+ * memo_builder_* and stages transfers; the text emitters): the CPUs the process may run on, cut to its cgroup's CFS
+ * bandwidth quota -- a container granted 16 CPUs' worth of time per period on a 256-CPU host gets 16 threads, because
+ * threads beyond the quota only bring the period's freeze forward -- at most 32; MEMO_HOST_THREADS overrides.  The
+ * two inputs come back through the pointers (either may be NULL; quota 0 = none).  The reference's path is
+ * single-threaded (a bare @jit, memo_query.py:57): nothing to mirror, this is about being a good tenant. */
+int memo_host_threads(int32_t *cpus_allowed, double *cgroup_quota_cpus);
 
 /* ---- index lifecycle ---------------------------------------------------------------
  * Stands in for the arrays filter_pq returns (memo_query.py:28-36) and memo_init

@@ -57,6 +57,7 @@ SYMBOLS = {
     "memo_last_error": (C.c_char_p, []),
     "memo_device_count": (C.c_int, []),
     "memo_version": (C.c_char_p, []),
+    "memo_host_threads": (C.c_int, [C.POINTER(_I32), C.POINTER(C.c_double)]),
     "memo_index_create": (C.c_int, [_U64, _I32, C.POINTER(_P)]),
     "memo_index_upload": (C.c_int, [_P, _P, _P, _P, _U64]),
     "memo_index_upload_rows": (C.c_int, [_P, _U64, _P, _P, _P, _U64]),

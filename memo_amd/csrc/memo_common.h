@@ -26,6 +26,7 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // the worker threads' copy of piece i); work already queued on `producer` finishes first
 int download_pipelined(int device, void *host, const void *dev, size_t bytes, hipStream_t producer);
 int upload_pipelined(int device, void *dev, const void *host, size_t bytes);
+double pinned_alloc_ms_total();  // memo_hostcore.cpp: time this process has spent allocating pinned staging slots (MEMO_TIMING)
 
 struct DeviceGuard {  // the caller (e.g. torch) keeps its own notion of the current device
     int prev = -1;

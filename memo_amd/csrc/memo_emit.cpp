@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "memo_amd.h"
+#include "memo_cpus.h"
 #include "memo_amd_dap.h"
 
 // ---- print_res (memo_query.py:65-71) -----------------------------------------------------
@@ -18,8 +19,7 @@
 namespace {
 
 unsigned emit_threads(int64_t items, int64_t min_per_thread) {
-    unsigned hw = std::thread::hardware_concurrency();
-    if (hw == 0) hw = 1;
+    unsigned hw = (unsigned)memo::cpu_budget();  // allowed CPUs cut to the cgroup's CFS quota (memo_cpus.h)
     if (hw > 64) hw = 64;
     if (const char *v = getenv("MEMO_EMIT_THREADS")) {
         const int n = atoi(v);

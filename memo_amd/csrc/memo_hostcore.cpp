@@ -15,7 +15,10 @@
 // the 6-byte format for larger annots and handles every legal input).
 #include "memo_hostcore.h"
 
+#include "memo_cpus.h"
+
 #include <atomic>
+#include <chrono>
 #include <climits>
 #include <condition_variable>
 #include <cstdlib>
@@ -23,6 +26,13 @@
 #include <mutex>
 #include <new>
 #include <thread>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+#if defined(__linux__)
+#include <sys/mman.h>
+#endif
 
 namespace memo {
 
@@ -75,15 +85,24 @@ HostPool &HostPool::get() {
     return *p;
 }
 
-HostPool::HostPool() : impl_(new Impl()) {
-    unsigned hw = std::thread::hardware_concurrency();
-    if (hw == 0) hw = 1;
-    unsigned want = hw < 32 ? hw : 32;  // profiles/r02_oneshot_host_threads.txt: 32 threads pack fastest; 64 and up lose a third
+// How many threads: the CPUs this process may run on, cut to its cgroup's CFS quota (memo_cpus.h), at most 32 -- the
+// packer is bound by DRAM from ~16-24 threads on (tools/host_probe.cpp on the pool's 2 x EPYC 9575F: three int64 columns
+// stream at 300 GB/s with 8 threads, 470 with 32).  Round 2's finding "64 threads and up lose a third" was the quota: the
+// boxes grant 16 CPUs' worth of time per 100 ms, threads beyond that bring the period's freeze forward
+// (profiles/r06_oneshot.txt).
+int host_threads_default() {
+    int want = cpu_budget();
+    if (want > 32) want = 32;
     if (const char *v = getenv("MEMO_HOST_THREADS")) {
         const int n = atoi(v);
-        if (n > 0) want = (unsigned)n;
+        if (n > 0) want = n;
     }
-    for (unsigned i = 1; i < want; ++i) {
+    return want < 1 ? 1 : want;
+}
+
+HostPool::HostPool() : impl_(new Impl()) {
+    const int want = host_threads_default();
+    for (int i = 1; i < want; ++i) {
         impl_->workers.emplace_back([this] { impl_->loop(); });
         impl_->workers.back().detach();
     }
@@ -91,14 +110,12 @@ HostPool::HostPool() : impl_(new Impl()) {
 
 int HostPool::threads() const { return (int)impl_->workers.size() + 1; }
 
-void HostPool::run(int n, void (*f)(void *, int), void *ctx) {
-    if (n <= 0) return;
+// begin / help / end: the job's tasks are taken by the pool's threads from begin on; the caller may do something else
+// in between (the builder's push loop issues the copies), take tasks itself (help), and must call end.  One job at a
+// time: begin blocks while another thread's job runs.
+void HostPool::begin(int n, void (*f)(void *, int), void *ctx) {
     Impl &I = *impl_;
-    if (n == 1 || I.workers.empty()) {
-        for (int i = 0; i < n; ++i) f(ctx, i);
-        return;
-    }
-    std::lock_guard<std::mutex> serial(I.run_mutex);
+    I.run_mutex.lock();
     {
         std::lock_guard<std::mutex> lk(I.m);
         I.job = f;
@@ -109,10 +126,33 @@ void HostPool::run(int n, void (*f)(void *, int), void *ctx) {
         ++I.generation;
     }
     I.cv_work.notify_all();
-    I.work(f, ctx, n);
-    std::unique_lock<std::mutex> lk(I.m);
-    I.cv_done.wait(lk, [&] { return I.busy == 0; });
-    I.job = nullptr;
+}
+
+void HostPool::help() {
+    Impl &I = *impl_;
+    I.work(I.job, I.ctx, I.n);
+}
+
+void HostPool::end() {
+    Impl &I = *impl_;
+    {
+        std::unique_lock<std::mutex> lk(I.m);
+        I.cv_done.wait(lk, [&] { return I.busy == 0; });
+        I.job = nullptr;
+    }
+    I.run_mutex.unlock();
+}
+
+void HostPool::run(int n, void (*f)(void *, int), void *ctx) {
+    if (n <= 0) return;
+    Impl &I = *impl_;
+    if (n == 1 || I.workers.empty()) {
+        for (int i = 0; i < n; ++i) f(ctx, i);
+        return;
+    }
+    begin(n, f, ctx);
+    help();
+    end();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -121,10 +161,16 @@ void HostPool::run(int n, void (*f)(void *, int), void *ctx) {
 // used (hipHostMalloc of 24 MiB costs milliseconds: a call that moves one small piece pays for one slot, a call
 // that moves none -- a cache hit of `memo query` on a small window -- for nothing).
 // ------------------------------------------------------------------------------------------
+std::atomic<uint64_t> g_pinned_alloc_ns{0};  // time spent allocating pinned slots, process-wide (MEMO_TIMING reports it)
+double pinned_alloc_ms_total() { return (double)g_pinned_alloc_ns.load(std::memory_order_relaxed) * 1e-6; }
+
 int PinnedRing::buffer(int s, char **out) {
     if (!slot[s]) {
         void *p = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = hp::pinned_alloc(&p, kSlotBytes);
+        g_pinned_alloc_ns.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+                                    std::memory_order_relaxed);
         if (rc) return rc;
         if (!done[s] && (rc = hp::event_create(&done[s]))) {
             hp::pinned_free(p);
@@ -142,6 +188,17 @@ int PinnedRing::wait(int s) {
         if (rc) return rc;
         in_flight[s] = false;
     }
+    return MEMO_OK;
+}
+
+int PinnedRing::poll(int s, bool *idle) {
+    if (in_flight[s]) {
+        int done_now = 0;
+        int rc = hp::event_query(done[s], &done_now);
+        if (rc) return rc;
+        if (done_now) in_flight[s] = false;
+    }
+    *idle = !in_flight[s];
     return MEMO_OK;
 }
 
@@ -211,6 +268,19 @@ struct DeviceScope {  // the caller keeps its own notion of the current device
     }
 };
 
+// A result buffer the caller has just allocated (np.empty: untouched pages) is first written by the copy below: 200 MB
+// in 4 KiB pages are 49 000 page faults, more than half of the 7.5 ms the result of config 3 took to arrive.  The
+// whole 2 MiB pages inside it are offered to the kernel as huge pages (a hint, honoured where transparent huge
+// pages are set to madvise or always; contents and mapping are unchanged).
+void hint_huge_pages(void *p, size_t bytes) {
+#if defined(__linux__) && defined(MADV_HUGEPAGE)
+    const uintptr_t two = (uintptr_t)2 << 20, a = ((uintptr_t)p + two - 1) & ~(two - 1), e = ((uintptr_t)p + bytes) & ~(two - 1);
+    if (e > a) (void)madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);
+#else
+    (void)p, (void)bytes;
+#endif
+}
+
 void copy_tasks(HostPool &pool, char *dst, const char *src, size_t sz) {
     const int tasks = (int)((sz + ((size_t)1 << 20) - 1) >> 20);
     pool.run(tasks, [&](int t) {
@@ -233,6 +303,7 @@ int download_pipelined_core(int device, void *host, const void *dev, size_t byte
     PinnedRing *ring = nullptr;
     int rc = acquire_ring(device, &ring);
     if (rc) return rc;
+    hint_huge_pages(host, bytes);
     const size_t piece = PinnedRing::kSlotBytes;
     const size_t n = (bytes + piece - 1) / piece;
     HostPool &pool = HostPool::get();
@@ -295,9 +366,10 @@ int upload_pipelined_core(int device, void *dev, const void *host, size_t bytes)
 namespace {
 
 constexpr uint64_t kChunkRows = PinnedRing::kSlotBytes / 4;   // 4-byte words per pinned slot
-constexpr uint64_t kBlockRows = 1 << 14;                      // rows per worker task (256 tasks per pinned slot: an even share for 32 workers)
-constexpr uint64_t kBlockGroups = 3264;                       // dense: groups per worker task (16 320 rows = 51 pieces)
-constexpr uint64_t kChunkGroups = (uint64_t)1 << 20;          // dense: groups per pinned slot (16 MiB; one more may lead them)
+constexpr uint64_t kBlockRows = 1 << 14;                      // rows per worker task (384 tasks per pinned slot)
+constexpr uint64_t kBlockGroups = 3264;                       // dense: groups per worker task (16 320 rows = 51 pieces = 204 units of 80 rows)
+constexpr uint64_t kChunkGroups = 321 * kBlockGroups;         // dense: groups per pinned slot (16.0 MiB; one more may lead them)
+static_assert(kChunkRows % kBlockRows == 0 && kChunkGroups * 16 + 16 <= PinnedRing::kSlotBytes, "a slot holds whole tasks");
 
 struct PackArgs {
     const int64_t *start, *end, *annot;
@@ -332,8 +404,8 @@ struct RowScan {
         wide |= a12 > 255u;
         const int64_t bk = s >> A.shift;
         if (bk != pb) {  // first row of its bucket(s): boff[b] = lower_bound(start, b << shift)
-            if (bk > pb && !bad && bk < A.boff_size)
-                for (int64_t q = pb + 1; q <= bk; ++q) A.boff[q] = (int64_t)(A.global0 + i);
+            if (bk > pb && !bad && bk < A.boff_size)  // (q >= 0: the row before may belong to another task and be negative)
+                for (int64_t q = pb < -1 ? 0 : pb + 1; q <= bk; ++q) A.boff[q] = (int64_t)(A.global0 + i);
             pb = bk;
         }
         s_out = s;
@@ -434,7 +506,7 @@ template <int FMT>
 static ScanPieceFn scan_piece_for() {
 #if defined(__x86_64__)
     static const bool avx2 = [] {
-#ifdef MEMO_HOST_TEST_KNOBS  // (tests/test_host_sanitizers.py builds this file with it: both instances run under the sanitizers)
+#ifdef MEMO_HOST_TEST_KNOBS  // (tests/test_host_sanitizers.py builds this file with it: every instance runs under the sanitizers)
         if (const char *v = getenv("MEMO_HOST_SIMD")) {
             if (atoi(v) == 0) return false;
         }
@@ -481,7 +553,7 @@ static void scan_block(const PackArgs &A, uint64_t i0, uint64_t i1, int64_t prev
                     // (`bad` as RowScan has it at this row: set by any earlier piece, or by this one -- a piece that is
                     // bad anywhere fails the builder, what it wrote to the table is never read)
                     if (bk > pb && !bad && bk < A.boff_size)
-                        for (int64_t q = pb + 1; q <= bk; ++q) A.boff[q] = (int64_t)(A.global0 + i + (uint64_t)j);
+                        for (int64_t q = pb < -1 ? 0 : pb + 1; q <= bk; ++q) A.boff[q] = (int64_t)(A.global0 + i + (uint64_t)j);
                     pb = bk;
                 }
             }
@@ -493,17 +565,6 @@ static void scan_block(const PackArgs &A, uint64_t i0, uint64_t i1, int64_t prev
     res.bad = bad;
     res.wide_annot = f.annot_or > 255u ? 1 : 0;
     res.over511 = f.annot_or > 511u ? 1 : 0;
-}
-
-// rows [i0, i1) -> words (format 4 or 12), pk[i] for row i.  end < start (handled by long_rows_*_kernel) packs as
-// "never writes", like len >= 255.
-void pack_words(const PackArgs &A, uint64_t i0, uint64_t i1, int64_t prev_start, int64_t prev_bucket, uint32_t *pk,
-                int fmt, BlockResult &res) {
-    auto emit = [&](uint64_t at, int n, const uint32_t *W, const uint32_t *) { memcpy(pk + at, W, (size_t)n * 4); };
-    if (fmt == 12)
-        scan_block<12>(A, i0, i1, prev_start, prev_bucket, res, emit);
-    else
-        scan_block<4>(A, i0, i1, prev_start, prev_bucket, res, emit);
 }
 
 // the dense row: B = (start mod 2^10) << 6 | min(end - start, 63); end < start packs as "never writes" (k - 1 <= 63)
@@ -524,14 +585,296 @@ inline void dense_group(const uint32_t *B, const uint32_t *Aa, uint32_t *out) {
     out[3] = B[3] | (hi << 16) | ((Aa[3] & 0xFFu) << 24);
 }
 
+// ------------------------------------------------------------------------------------------
+// The hand-written packers (AVX-512 F / BW / DQ / VL / VBMI + BMI2: Zen 4 and later, Ice Lake and later).  The GPU boxes
+// of this pool grant the process 16 CPUs' worth of time per 100 ms (memo_cpus.h), so what the seam pays for a row is
+// CPU-seconds, and the compiler's rendering of scan_piece -- 64-bit unsigned minima and narrowing emulated in AVX2, the
+// groups assembled by scalar code -- costs ~3.6 ns per row there: 1.8 CPU-seconds for config 3's 5 * 10^8 rows, more
+// than a period's quota (profiles/r06_oneshot.txt).  Here 16 rows are one step: six loads, the checks as mask compares,
+// the fields narrowed by one two-source permute each and merged by ternary logic; 80 rows (five steps) become 16 groups
+// by four byte permutes (vpermi2b) and leave as four 64-byte stores -- non-temporal where the slot is aligned, the
+// pinned buffer is read by the DMA engine, not by a CPU.  The nine-bit annots' spare byte comes from the rows' mask bits
+// through pdep.  Same bits as scan_block + dense_group (tests/host_stub.cpp runs every instance against its
+// restatement; MEMO_HOST_SIMD chooses one in the sanitizer builds).  Blocks whose row count is not a multiple of 80 (16)
+// finish through scan_block.
+// ------------------------------------------------------------------------------------------
+#if defined(__x86_64__)
+#define MEMO_T512 __attribute__((target("avx512f,avx512bw,avx512dq,avx512vl,avx512vbmi,bmi2")))
+
+static int host_simd_level() {  // 0 plain, 1 AVX2 (compiler-vectorised scan_piece), 2 the AVX-512 packers
+    static const int level = [] {
+        int best = 0;
+        if (__builtin_cpu_supports("avx2")) best = 1;
+        if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") &&
+            __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512vbmi") && __builtin_cpu_supports("bmi2"))
+            best = 2;
+#ifdef MEMO_HOST_TEST_KNOBS  // (tests/test_host_sanitizers.py builds this file with it: every instance runs under the sanitizers)
+        if (const char *v = getenv("MEMO_HOST_SIMD")) {
+            const int want = atoi(v);
+            if (want >= 0 && want < best) best = want;
+        }
+#endif
+        return best;
+    }();
+    return level;
+}
+
+struct Fast512 {  // what a block's fast part leaves for its tail and its result
+    int64_t ps, pb;        // start and bucket of the last row done
+    unsigned uns = 0, neg = 0, coord = 0;
+    uint64_t annot_or = 0;
+    uint32_t top = 0;
+};
+
+// the rare rows of a 16-row step: first row of a bucket, end < start (as scan_block treats them)
+static inline void events16(const PackArgs &A, uint64_t row0, unsigned kb, unsigned kl, bool bad, int64_t &pb, BlockResult &res) {
+    unsigned m = kb | kl;
+    while (m) {
+        const int j = __builtin_ctz(m);
+        m &= m - 1;
+        const uint64_t i = row0 + (uint64_t)j;
+        const int64_t s = A.start[i];
+        if ((kl >> j) & 1u) {
+            res.long_rows.push_back(s);
+            res.long_rows.push_back(A.end[i]);
+            res.long_rows.push_back(A.annot[i]);
+        }
+        const int64_t bk = s >> A.shift;
+        if (bk != pb) {
+            if (bk > pb && !bad && bk < A.boff_size)
+                for (int64_t q = pb < -1 ? 0 : pb + 1; q <= bk; ++q) A.boff[q] = (int64_t)(A.global0 + i);
+            pb = bk;
+        }
+    }
+}
+
+struct Perm512 {  // byte permutes of the dense groups: output vector j (four groups) from row vectors j and j + 1
+    alignas(64) uint8_t idx[4][64];
+    alignas(64) uint8_t hidx[4][64];
+    Perm512() {
+        for (int j = 0; j < 4; ++j)
+            for (int t = 0; t < 4; ++t) {
+                const int r0 = 20 * j + 5 * t;  // first row of the group (row r, byte c sits at 4 r + c of the unit's 320 bytes)
+                auto at = [&](int r, int c) { return (uint8_t)(4 * r + c - 64 * j); };
+                uint8_t *o = idx[j] + 16 * t;
+                o[0] = at(r0, 0), o[1] = at(r0, 1), o[2] = at(r0 + 4, 0), o[3] = at(r0, 2);
+                o[4] = at(r0 + 1, 0), o[5] = at(r0 + 1, 1), o[6] = at(r0 + 4, 1), o[7] = at(r0 + 1, 2);
+                o[8] = at(r0 + 2, 0), o[9] = at(r0 + 2, 1), o[10] = at(r0 + 4, 2), o[11] = at(r0 + 2, 2);
+                o[12] = at(r0 + 3, 0), o[13] = at(r0 + 3, 1), o[14] = 0, o[15] = at(r0 + 3, 2);
+                for (int c = 0; c < 16; ++c) hidx[j][16 * t + c] = 0;
+                hidx[j][16 * t + 14] = (uint8_t)(4 * j + t);  // the group's spare byte: byte 4 j + t of the sixteen
+            }
+    }
+};
+
+// rows [i0, i0 + 80 units) -> 16 units groups at out; returns the state after the last row
+MEMO_T512 static void dense_units_512(const PackArgs &A, uint64_t i0, uint64_t units, int64_t prev_start, int64_t prev_bucket,
+                                      uint32_t *out, BlockResult &res, Fast512 &st) {
+    static const Perm512 P;
+    const __m512i idx0 = _mm512_load_si512(P.idx[0]), idx1 = _mm512_load_si512(P.idx[1]), idx2 = _mm512_load_si512(P.idx[2]),
+                  idx3 = _mm512_load_si512(P.idx[3]);
+    const __mmask64 keep = ~0x4000400040004000ull, spare = 0x4000400040004000ull;  // (bytes 14, 30, 46, 62: the spare bytes)
+    const __m512i lim = _mm512_set1_epi64(kHostCoordLimit), limm1 = _mm512_set1_epi64(kHostCoordLimit - 1),
+                  lim2 = _mm512_set1_epi64(2 * kHostCoordLimit - 2), c63 = _mm512_set1_epi64(63),
+                  thr = _mm512_set1_epi64((int64_t)1 << A.shift);
+    const __m512i even = _mm512_set_epi32(30, 28, 26, 24, 22, 20, 18, 16, 14, 12, 10, 8, 6, 4, 2, 0);
+    const __m512i cB = _mm512_set1_epi32(0xFFC0), cA = _mm512_set1_epi32(0xFF0000), c256 = _mm512_set1_epi32(256),
+                  c1FF = _mm512_set1_epi32(0x1FF);
+    const bool nt = ((uintptr_t)out & 63u) == 0;
+    __m512i sprev = _mm512_set1_epi64(prev_start), acc_a = _mm512_setzero_si512(), top = _mm512_setzero_si512();
+    unsigned uns = 0, neg = 0, coord = 0;
+    int64_t pb = prev_bucket;
+    const int64_t *S = A.start, *E = A.end, *An = A.annot;
+    for (uint64_t u = 0; u < units; ++u) {
+        __m512i R[5];
+        unsigned k9[5];
+        for (int v = 0; v < 5; ++v) {
+            const uint64_t i = i0 + 80 * u + 16 * (uint64_t)v;
+            const __m512i s0 = _mm512_loadu_si512(S + i), s1 = _mm512_loadu_si512(S + i + 8);
+            const __m512i e0 = _mm512_loadu_si512(E + i), e1 = _mm512_loadu_si512(E + i + 8);
+            const __m512i a0 = _mm512_loadu_si512(An + i), a1 = _mm512_loadu_si512(An + i + 8);
+            const __m512i p0 = _mm512_alignr_epi64(s0, sprev, 7), p1 = _mm512_alignr_epi64(s1, s0, 7);
+            sprev = s1;
+            uns |= (unsigned)_mm512_cmplt_epi64_mask(s0, p0) | (unsigned)_mm512_cmplt_epi64_mask(s1, p1);
+            const unsigned kb = (unsigned)_mm512_cmpge_epu64_mask(_mm512_xor_si512(s0, p0), thr) |
+                                ((unsigned)_mm512_cmpge_epu64_mask(_mm512_xor_si512(s1, p1), thr) << 8);
+            const unsigned kl = (unsigned)_mm512_cmplt_epi64_mask(e0, s0) | ((unsigned)_mm512_cmplt_epi64_mask(e1, s1) << 8);
+            neg |= (unsigned)_mm512_movepi64_mask(s0) | (unsigned)_mm512_movepi64_mask(s1);
+            coord |= (unsigned)_mm512_cmpge_epi64_mask(s0, lim) | (unsigned)_mm512_cmpge_epi64_mask(s1, lim) |
+                     (unsigned)_mm512_cmpgt_epu64_mask(_mm512_add_epi64(e0, limm1), lim2) |
+                     (unsigned)_mm512_cmpgt_epu64_mask(_mm512_add_epi64(e1, limm1), lim2);
+            acc_a = _mm512_ternarylogic_epi64(acc_a, a0, a1, 0xFE);
+            const __m512i l0 = _mm512_min_epu64(_mm512_sub_epi64(e0, s0), c63), l1 = _mm512_min_epu64(_mm512_sub_epi64(e1, s1), c63);
+            const __m512i s32 = _mm512_permutex2var_epi32(s0, even, s1), a32 = _mm512_permutex2var_epi32(a0, even, a1),
+                          l32 = _mm512_permutex2var_epi32(l0, even, l1);
+            const __m512i w = _mm512_ternarylogic_epi32(_mm512_slli_epi32(s32, 6), cB, l32, 0xEA);   // (s << 6 & 0xFFC0) | l
+            R[v] = _mm512_ternarylogic_epi32(_mm512_slli_epi32(a32, 16), cA, w, 0xEA);               // (a << 16 & 0xFF0000) | w
+            k9[v] = (unsigned)_mm512_test_epi32_mask(a32, c256);
+            top = _mm512_max_epu32(top, _mm512_and_si512(a32, c1FF));
+            if (kb | kl) events16(A, i, kb, kl, (uns | neg | coord) != 0, pb, res);
+        }
+        __m512i g0 = _mm512_maskz_permutex2var_epi8(keep, R[0], idx0, R[1]), g1 = _mm512_maskz_permutex2var_epi8(keep, R[1], idx1, R[2]),
+                g2 = _mm512_maskz_permutex2var_epi8(keep, R[2], idx2, R[3]), g3 = _mm512_maskz_permutex2var_epi8(keep, R[3], idx3, R[4]);
+        if (k9[0] | k9[1] | k9[2] | k9[3] | k9[4]) {  // ninth annot bits: bit r of the unit's 80-bit string belongs to row r
+            const uint64_t lo = (uint64_t)k9[0] | ((uint64_t)k9[1] << 16) | ((uint64_t)k9[2] << 32) | ((uint64_t)k9[3] << 48);
+            const uint64_t h0 = _pdep_u64(lo, 0x1F1F1F1F1F1F1F1Full);                                   // groups 0 .. 7: bits 0 .. 39
+            const uint64_t h1 = _pdep_u64((lo >> 40) | ((uint64_t)k9[4] << 24), 0x1F1F1F1F1F1F1F1Full);  // groups 8 .. 15: bits 40 .. 79
+            const __m512i H = _mm512_castsi128_si512(_mm_set_epi64x((long long)h1, (long long)h0));
+            g0 = _mm512_or_si512(g0, _mm512_maskz_permutexvar_epi8(spare, _mm512_load_si512(P.hidx[0]), H));
+            g1 = _mm512_or_si512(g1, _mm512_maskz_permutexvar_epi8(spare, _mm512_load_si512(P.hidx[1]), H));
+            g2 = _mm512_or_si512(g2, _mm512_maskz_permutexvar_epi8(spare, _mm512_load_si512(P.hidx[2]), H));
+            g3 = _mm512_or_si512(g3, _mm512_maskz_permutexvar_epi8(spare, _mm512_load_si512(P.hidx[3]), H));
+        }
+        uint32_t *o = out + 64 * u;
+        if (nt) {
+            _mm512_stream_si512((__m512i *)o, g0), _mm512_stream_si512((__m512i *)(o + 16), g1);
+            _mm512_stream_si512((__m512i *)(o + 32), g2), _mm512_stream_si512((__m512i *)(o + 48), g3);
+        } else {
+            _mm512_storeu_si512(o, g0), _mm512_storeu_si512(o + 16, g1), _mm512_storeu_si512(o + 32, g2), _mm512_storeu_si512(o + 48, g3);
+        }
+    }
+    if (nt) _mm_sfence();  // (the stores are weakly ordered: they are in memory before the task reports itself done)
+    st.ps = units ? S[i0 + 80 * units - 1] : prev_start;
+    st.pb = pb;
+    st.uns = uns, st.neg = neg, st.coord = coord;
+    st.annot_or = (uint64_t)_mm512_reduce_or_epi64(acc_a);
+    st.top = _mm512_reduce_max_epu32(top);
+}
+
+// rows [i0, i0 + 16 steps) -> one word each (format 4 or 12) at pk[i0 ...]
+template <int FMT>
+MEMO_T512 static void word_steps_512(const PackArgs &A, uint64_t i0, uint64_t steps, int64_t prev_start, int64_t prev_bucket,
+                                     uint32_t *pk, BlockResult &res, Fast512 &st) {
+    const __m512i lim = _mm512_set1_epi64(kHostCoordLimit), limm1 = _mm512_set1_epi64(kHostCoordLimit - 1),
+                  lim2 = _mm512_set1_epi64(2 * kHostCoordLimit - 2), c255 = _mm512_set1_epi64(255),
+                  thr = _mm512_set1_epi64((int64_t)1 << A.shift);
+    const __m512i even = _mm512_set_epi32(30, 28, 26, 24, 22, 20, 18, 16, 14, 12, 10, 8, 6, 4, 2, 0);
+    const __m512i cFFFF = _mm512_set1_epi32(0xFFFF), cFFF = _mm512_set1_epi32(0xFFF), cFFF00 = _mm512_set1_epi32(0xFFF00);
+    __m512i sprev = _mm512_set1_epi64(prev_start), acc_a = _mm512_setzero_si512(), top = _mm512_setzero_si512();
+    unsigned uns = 0, neg = 0, coord = 0;
+    int64_t pb = prev_bucket;
+    const int64_t *S = A.start, *E = A.end, *An = A.annot;
+    bool any_nt = false;
+    for (uint64_t v = 0; v < steps; ++v) {
+        const uint64_t i = i0 + 16 * v;
+        const __m512i s0 = _mm512_loadu_si512(S + i), s1 = _mm512_loadu_si512(S + i + 8);
+        const __m512i e0 = _mm512_loadu_si512(E + i), e1 = _mm512_loadu_si512(E + i + 8);
+        const __m512i a0 = _mm512_loadu_si512(An + i), a1 = _mm512_loadu_si512(An + i + 8);
+        const __m512i p0 = _mm512_alignr_epi64(s0, sprev, 7), p1 = _mm512_alignr_epi64(s1, s0, 7);
+        sprev = s1;
+        uns |= (unsigned)_mm512_cmplt_epi64_mask(s0, p0) | (unsigned)_mm512_cmplt_epi64_mask(s1, p1);
+        const unsigned kb = (unsigned)_mm512_cmpge_epu64_mask(_mm512_xor_si512(s0, p0), thr) |
+                            ((unsigned)_mm512_cmpge_epu64_mask(_mm512_xor_si512(s1, p1), thr) << 8);
+        const unsigned kl = (unsigned)_mm512_cmplt_epi64_mask(e0, s0) | ((unsigned)_mm512_cmplt_epi64_mask(e1, s1) << 8);
+        neg |= (unsigned)_mm512_movepi64_mask(s0) | (unsigned)_mm512_movepi64_mask(s1);
+        coord |= (unsigned)_mm512_cmpge_epi64_mask(s0, lim) | (unsigned)_mm512_cmpge_epi64_mask(s1, lim) |
+                 (unsigned)_mm512_cmpgt_epu64_mask(_mm512_add_epi64(e0, limm1), lim2) |
+                 (unsigned)_mm512_cmpgt_epu64_mask(_mm512_add_epi64(e1, limm1), lim2);
+        acc_a = _mm512_ternarylogic_epi64(acc_a, a0, a1, 0xFE);
+        const __m512i l0 = _mm512_min_epu64(_mm512_sub_epi64(e0, s0), c255), l1 = _mm512_min_epu64(_mm512_sub_epi64(e1, s1), c255);
+        const __m512i s32 = _mm512_permutex2var_epi32(s0, even, s1), l32 = _mm512_permutex2var_epi32(l0, even, l1);
+        const __m512i a12 = _mm512_and_si512(_mm512_permutex2var_epi32(a0, even, a1), cFFF);
+        __m512i w;
+        if (FMT == 12)  // len | (start mod 2^12) << 8 | annot << 20
+            w = _mm512_or_si512(_mm512_ternarylogic_epi32(_mm512_slli_epi32(s32, 8), cFFF00, l32, 0xEA), _mm512_slli_epi32(a12, 20));
+        else            // start mod 2^16 | len << 16 | annot << 24
+            w = _mm512_or_si512(_mm512_ternarylogic_epi32(s32, cFFFF, _mm512_slli_epi32(l32, 16), 0xEA), _mm512_slli_epi32(a12, 24));
+        top = _mm512_max_epu32(top, a12);
+        uint32_t *o = pk + i;
+        if (((uintptr_t)o & 63u) == 0) {
+            _mm512_stream_si512((__m512i *)o, w);
+            any_nt = true;
+        } else {
+            _mm512_storeu_si512(o, w);
+        }
+        if (kb | kl) events16(A, i, kb, kl, (uns | neg | coord) != 0, pb, res);
+    }
+    if (any_nt) _mm_sfence();
+    st.ps = steps ? S[i0 + 16 * steps - 1] : prev_start;
+    st.pb = pb;
+    st.uns = uns, st.neg = neg, st.coord = coord;
+    st.annot_or = (uint64_t)_mm512_reduce_or_epi64(acc_a);
+    st.top = _mm512_reduce_max_epu32(top);
+}
+
+// a block's result from its fast part (st) and the tail scan_block did (res already holds the tail's)
+static void fold_fast(const Fast512 &st, bool had_tail, BlockResult &res) {
+    int bad = (st.uns ? 1 : 0) | (st.neg ? 2 : 0) | (st.annot_or > 4095u ? 4 : 0) | (st.coord ? 8 : 0);
+    if (!had_tail) {
+        res.max_annot = 0;
+        res.bad = 0;
+        res.wide_annot = res.over511 = 0;
+    }
+    res.bad |= bad;
+    res.max_annot = st.top > res.max_annot ? st.top : res.max_annot;
+    res.wide_annot |= st.annot_or > 255u ? 1 : 0;
+    res.over511 |= st.annot_or > 511u ? 1 : 0;
+}
+#else
+static int host_simd_level() { return 0; }
+#endif
+
+// rows [i0, i1) -> words (format 4 or 12), pk[i] for row i.  end < start (handled by long_rows_*_kernel) packs as
+// "never writes", like len >= 255.
+void pack_words(const PackArgs &A, uint64_t i0, uint64_t i1, int64_t prev_start, int64_t prev_bucket, uint32_t *pk,
+                int fmt, BlockResult &res) {
+    auto emit = [&](uint64_t at, int n, const uint32_t *W, const uint32_t *) { memcpy(pk + at, W, (size_t)n * 4); };
+#if defined(__x86_64__)
+    if (host_simd_level() >= 2 && i1 - i0 >= 16) {
+        const uint64_t steps = (i1 - i0) / 16, mid = i0 + 16 * steps;
+        Fast512 st;
+        std::vector<int64_t> head_long;
+        if (fmt == 12)
+            word_steps_512<12>(A, i0, steps, prev_start, prev_bucket, pk, res, st);
+        else
+            word_steps_512<4>(A, i0, steps, prev_start, prev_bucket, pk, res, st);
+        if (mid < i1) {
+            head_long.swap(res.long_rows);  // (scan_block sets the other fields; the long rows of the fast part stay in front)
+            if (fmt == 12)
+                scan_block<12>(A, mid, i1, st.ps, st.pb, res, emit);
+            else
+                scan_block<4>(A, mid, i1, st.ps, st.pb, res, emit);
+            head_long.insert(head_long.end(), res.long_rows.begin(), res.long_rows.end());
+            res.long_rows.swap(head_long);
+        }
+        fold_fast(st, mid < i1, res);
+        return;
+    }
+#endif
+    if (fmt == 12)
+        scan_block<12>(A, i0, i1, prev_start, prev_bucket, res, emit);
+    else
+        scan_block<4>(A, i0, i1, prev_start, prev_bucket, res, emit);
+}
+
 // rows [i0, i0 + 5 * groups) -> groups at out (4 dwords each)
 void pack_dense(const PackArgs &A, uint64_t i0, uint64_t groups, int64_t prev_start, int64_t prev_bucket, uint32_t *out,
                 BlockResult &res) {
     static_assert(kPiece % 5 == 0, "a piece is whole groups");
-    scan_block<3>(A, i0, i0 + 5 * groups, prev_start, prev_bucket, res, [&](uint64_t at, int n, const uint32_t *W, const uint32_t *A8) {
-        uint32_t *o = out + 4 * ((at - i0) / 5);
-        for (int j = 0; j + 5 <= n; j += 5, o += 4) dense_group(W + j, A8 + j, o);
-    });
+    auto tail = [&](uint64_t r0, uint64_t g, int64_t ps, int64_t pb, uint32_t *o0) {
+        scan_block<3>(A, r0, r0 + 5 * g, ps, pb, res, [&](uint64_t at, int n, const uint32_t *W, const uint32_t *A8) {
+            uint32_t *o = o0 + 4 * ((at - r0) / 5);
+            for (int j = 0; j + 5 <= n; j += 5, o += 4) dense_group(W + j, A8 + j, o);
+        });
+    };
+#if defined(__x86_64__)
+    if (host_simd_level() >= 2 && groups >= 16) {
+        const uint64_t units = groups / 16, mid = i0 + 80 * units;
+        Fast512 st;
+        std::vector<int64_t> head_long;
+        dense_units_512(A, i0, units, prev_start, prev_bucket, out, res, st);
+        if (groups > 16 * units) {
+            head_long.swap(res.long_rows);
+            tail(mid, groups - 16 * units, st.ps, st.pb, out + 64 * units);
+            head_long.insert(head_long.end(), res.long_rows.begin(), res.long_rows.end());
+            res.long_rows.swap(head_long);
+        }
+        fold_fast(st, groups > 16 * units, res);
+        if (res.over511) res.bad |= 16;
+        return;
+    }
+#endif
+    tail(i0, groups, prev_start, prev_bucket, out);
     if (res.over511) res.bad |= 16;
 }
 
@@ -556,55 +899,186 @@ int merge_results(memo_builder *b, std::vector<BlockResult> &res) {
     return MEMO_OK;
 }
 
-int push_words(memo_builder *b, const PackArgs &A, uint64_t rows) {
-    HostPool &pool = HostPool::get();
-    PinnedRing *ring = b->ring;
-    const int64_t *start = A.start;
-    for (uint64_t c0 = 0; c0 < rows; c0 += kChunkRows) {
-        const uint64_t cn = rows - c0 < kChunkRows ? rows - c0 : kChunkRows;
-        const int s = ring->next;
-        ring->next = (s + 1) % PinnedRing::kSlots;
-        char *buf = nullptr;
-        int rc = ring->buffer(s, &buf);
-        if (!rc) rc = ring->wait(s);
-        if (rc) return builder_fail(b, rc, "pinned staging ring failed");
-        uint32_t *pk = reinterpret_cast<uint32_t *>(buf);
-        const int tasks = (int)((cn + kBlockRows - 1) / kBlockRows);
-        std::vector<BlockResult> res((size_t)tasks);
-        for (int pass = 0; pass < 2; ++pass) {  // a second pass only when this chunk is the first with an annot > 255
-            const int fmt = b->fmt;
-            pool.run(tasks, [&](int t) {
-                const uint64_t i0 = c0 + (uint64_t)t * kBlockRows;
-                const uint64_t i1 = i0 + kBlockRows < c0 + cn ? i0 + kBlockRows : c0 + cn;
-                const bool first = i0 == 0;
-                const int64_t prev_start = first ? (b->any ? b->last_start : INT64_MIN) : start[i0 - 1];
-                const int64_t prev_bucket = first ? b->last_bucket : (start[i0 - 1] >> b->bshift);
-                res[(size_t)t].long_rows.clear();
-                pack_words(A, i0, i1, prev_start, prev_bucket, pk - c0, fmt, res[(size_t)t]);
-            });
-            int bad = 0, wide = 0;
-            for (const BlockResult &r : res) {
-                bad |= r.bad;
-                wide |= r.wide_annot;
+// ------------------------------------------------------------------------------------------
+// One push as ONE job of the pool.  The rows are cut into chunks (what a pinned slot holds) of blocks (a worker's task).
+// Workers take blocks in order from one counter and pack them into the chunk's slot as soon as the slot is free; the
+// CALLER's thread issues the copies -- chunk c leaves the moment its last block reports itself done -- watches the copy
+// events without blocking, frees slots, and packs blocks itself whenever neither has anything for it.  No fork-join per
+// chunk (rounds 2-5: 67 of them per call on config 3, every one a wake-up of the pool and a wait for its slowest
+// thread), no HIP call off the caller's thread, and packing never waits for PCIe unless all four slots are full.
+//
+// pack(block, chunk, slot buffer, result): rows of the block -> the slot; blocks_of(chunk); issue(chunk, slot buffer).
+// ------------------------------------------------------------------------------------------
+struct PushPipe {
+    memo_builder *b;
+    PinnedRing *ring;
+    uint64_t nblocks = 0, per_chunk = 1, nchunks = 0;
+    int base_slot = 0;
+    std::atomic<uint64_t> next{0};
+    std::atomic<uint64_t> free_upto{0};  // chunks below this number may be packed: their slot is theirs
+    std::atomic<int> stop{0};            // a block refused its rows, or a HIP call failed: nobody takes another block
+    std::vector<std::atomic<uint32_t>> done;  // per chunk: blocks packed
+    std::vector<BlockResult> res;             // per block
+    char *buf[PinnedRing::kSlots] = {nullptr, nullptr, nullptr, nullptr};
+
+    PushPipe(memo_builder *b_, uint64_t nblocks_, uint64_t per_chunk_)
+        : b(b_), ring(b_->ring), nblocks(nblocks_), per_chunk(per_chunk_), nchunks((nblocks_ + per_chunk_ - 1) / per_chunk_),
+          base_slot(b_->ring->next), done((nblocks_ + per_chunk_ - 1) / per_chunk_), res(nblocks_) {
+        for (auto &d : done) d.store(0, std::memory_order_relaxed);
+    }
+    int slot_of(uint64_t chunk) const { return (int)((chunk + (uint64_t)base_slot) % PinnedRing::kSlots); }
+    uint64_t blocks_of(uint64_t chunk) const { return chunk + 1 < nchunks ? per_chunk : nblocks - chunk * per_chunk; }
+
+    template <typename Pack>
+    void pack_one(uint64_t blk, Pack &pack) {
+        const uint64_t c = blk / per_chunk;
+        pack(blk, c, buf[slot_of(c)], res[blk]);
+        if (res[blk].bad) stop.store(1, std::memory_order_relaxed);
+        done[c].fetch_add(1, std::memory_order_release);
+    }
+
+    template <typename Pack>
+    void worker(Pack &pack) {
+        for (;;) {
+            if (stop.load(std::memory_order_relaxed)) return;
+            const uint64_t blk = next.fetch_add(1, std::memory_order_relaxed);
+            if (blk >= nblocks) return;
+            const uint64_t c = blk / per_chunk;
+            for (unsigned spins = 0; free_upto.load(std::memory_order_acquire) <= c; ++spins) {  // the slot is still on its way out
+                if (stop.load(std::memory_order_relaxed)) {  // (a claimed block must still be counted: the issuer may wait for its chunk)
+                    done[c].fetch_add(1, std::memory_order_release);
+                    return;
+                }
+                if (spins < 256) {
+#if defined(__x86_64__)
+                    _mm_pause();
+#endif
+                } else {
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));  // (spinning spends the cgroup's CPU quota)
+                }
             }
-            if (bad) { b->why = bad; return builder_fail(b, MEMO_EUNPACKABLE, bad_message(bad)); }
-            if (wide && fmt == 4) {  // switch the index to 12-bit annots: rewrite what is on the device, redo this chunk
-                if ((rc = hp::stream_sync(ring->stream))) return builder_fail(b, rc, "copy stream failed");
-                if (b->rows + c0 && (rc = hp::widen_annots(b->d_pk, b->rows + c0, ring->stream)))
-                    return builder_fail(b, rc, "rewriting the rows with 12-bit annots failed");
-                b->fmt = 12;
+            if (stop.load(std::memory_order_relaxed)) {  // (the issuer gave up and let everybody through: the slot may not be ours)
+                done[c].fetch_add(1, std::memory_order_release);
+                return;
+            }
+            pack_one(blk, pack);
+        }
+    }
+
+    // the caller's loop; returns a HIP failure code or MEMO_OK (refused rows are in res[].bad)
+    template <typename Pack, typename Issue>
+    int drive(Pack &pack, Issue &issue) {
+        HostPool &pool = HostPool::get();
+        auto task = [&](int) { worker(pack); };
+        const bool threaded = nblocks > 2 && pool.threads() > 1;
+        if (threaded) pool.begin(pool.threads() - 1, [](void *c, int t) { (*static_cast<decltype(task) *>(c))(t); }, &task);
+        int rc = MEMO_OK;
+        uint64_t opened = 0, issued = 0, landed = 0;  // chunks whose slot is open / whose copy is queued / whose copy has finished
+        while (issued < nchunks && !rc) {
+            if (stop.load(std::memory_order_relaxed)) break;
+            bool progress = false;
+            while (opened < nchunks && opened < landed + PinnedRing::kSlots) {  // open the next slot
+                const int s = slot_of(opened);
+                if ((rc = ring->buffer(s, &buf[s]))) break;
+                if (opened < (uint64_t)PinnedRing::kSlots && (rc = ring->wait(s))) break;  // (an earlier push's copy)
+                free_upto.store(++opened, std::memory_order_release);
+                progress = true;
+            }
+            if (rc) break;
+            if (done[issued].load(std::memory_order_acquire) == blocks_of(issued)) {  // the next chunk is whole: send it
+                const int s = slot_of(issued);
+                if ((rc = issue(issued, buf[s])) || (rc = ring->mark(s))) break;
+                ++issued;
                 continue;
             }
-            break;
+            if (landed < issued) {  // has the oldest copy finished?
+                bool idle = false;
+                if ((rc = ring->poll(slot_of(landed), &idle))) break;
+                if (idle) {
+                    ++landed;
+                    continue;
+                }
+            }
+            // nothing to issue, nothing to free: pack a block (exactly the one looked at: a later one might wait for a slot only this thread opens)
+            uint64_t blk = next.load(std::memory_order_relaxed);
+            if (blk < nblocks && blk / per_chunk < opened) {
+                if (next.compare_exchange_strong(blk, blk + 1, std::memory_order_relaxed)) pack_one(blk, pack);
+                continue;
+            }
+            if (!progress) {
+#if defined(__x86_64__)
+                _mm_pause();
+#endif
+            }
         }
-        if ((rc = merge_results(b, res))) return rc;
-        if ((rc = hp::copy_h2d_async(b->d_pk + b->rows + c0, pk, cn * 4, ring->stream)) || (rc = ring->mark(s)))
-            return builder_fail(b, rc, "copy to the device failed");
+        if (rc || stop.load(std::memory_order_relaxed)) {
+            stop.store(1, std::memory_order_relaxed);
+            free_upto.store(nchunks, std::memory_order_release);  // (nobody waits for a slot any more; workers see `stop` first)
+        }
+        if (threaded) pool.end();
+        ring->next = slot_of(issued);
+        return rc;
+    }
+};
+
+int refuse(memo_builder *b, int bad) {
+    b->why = bad;
+    return builder_fail(b, MEMO_EUNPACKABLE, bad_message(bad));
+}
+
+// a sample of the annots decides the format the packing starts in (a wrong guess costs a restart of the push, below)
+bool sample_has_wide_annot(const int64_t *annot, uint64_t rows) {
+    const uint64_t step = rows / 2048 + 1;
+    for (uint64_t i = 0; i < rows; i += step)
+        if ((uint64_t)annot[i] > 255u) return true;
+    return (uint64_t)annot[rows - 1] > 255u;
+}
+
+int push_words(memo_builder *b, const PackArgs &A, uint64_t rows) {
+    const int64_t *start = A.start;
+    if (b->fmt == 4 && sample_has_wide_annot(A.annot, rows)) {  // switch before anything of this push is on its way
+        int rc = hp::stream_sync(b->ring->stream);
+        if (!rc && b->rows) rc = hp::widen_annots(b->d_pk, b->rows, b->ring->stream);
+        if (rc) return builder_fail(b, rc, "rewriting the rows with 12-bit annots failed");
+        b->fmt = 12;
+    }
+    for (int pass = 0; pass < 2; ++pass) {  // a second pass only when this push is the first with an annot > 255 and the sample missed it
+        const int fmt = b->fmt;
+        const uint64_t nblocks = (rows + kBlockRows - 1) / kBlockRows;
+        PushPipe pipe(b, nblocks, kChunkRows / kBlockRows);
+        auto pack = [&](uint64_t blk, uint64_t c, char *buf, BlockResult &r) {
+            const uint64_t i0 = blk * kBlockRows, i1 = i0 + kBlockRows < rows ? i0 + kBlockRows : rows;
+            const bool first = i0 == 0;
+            const int64_t prev_start = first ? (b->any ? b->last_start : INT64_MIN) : start[i0 - 1];
+            const int64_t prev_bucket = first ? b->last_bucket : (start[i0 - 1] >> b->bshift);
+            pack_words(A, i0, i1, prev_start, prev_bucket, reinterpret_cast<uint32_t *>(buf) - c * kChunkRows, fmt, r);
+            if (r.wide_annot && fmt == 4) pipe.stop.store(1, std::memory_order_relaxed);
+        };
+        auto issue = [&](uint64_t c, char *buf) {
+            const uint64_t c0 = c * kChunkRows, cn = rows - c0 < kChunkRows ? rows - c0 : kChunkRows;
+            return hp::copy_h2d_async(b->d_pk + b->rows + c0, buf, cn * 4, b->ring->stream);
+        };
+        int rc = pipe.drive(pack, issue);
+        if (rc) return builder_fail(b, rc, "copy to the device failed");
+        int bad = 0, wide = 0;
+        for (const BlockResult &r : pipe.res) {
+            bad |= r.bad;
+            wide |= r.wide_annot;
+        }
+        if (bad) return refuse(b, bad);
+        if (wide && fmt == 4) {  // switch the index to 12-bit annots: rewrite what is on the device, redo this push
+            if ((rc = hp::stream_sync(b->ring->stream))) return builder_fail(b, rc, "copy stream failed");
+            for (int s = 0; s < PinnedRing::kSlots; ++s) b->ring->in_flight[s] = false;
+            if (b->rows && (rc = hp::widen_annots(b->d_pk, b->rows, b->ring->stream)))
+                return builder_fail(b, rc, "rewriting the rows with 12-bit annots failed");
+            b->fmt = 12;
+            continue;
+        }
+        return merge_results(b, pipe.res);
     }
     return MEMO_OK;
 }
 
-// serial rows [i0, i1) of a push into the carried group (dense rows)
 int carry_rows(memo_builder *b, const PackArgs &A, uint64_t i0, uint64_t i1) {
     if (i0 >= i1) return MEMO_OK;
     const bool first = i0 == 0;
@@ -621,57 +1095,54 @@ int carry_rows(memo_builder *b, const PackArgs &A, uint64_t i0, uint64_t i1) {
     }
     scan.finish(res[0]);
     if (scan.top > 511u) res[0].bad |= 16;
-    if (res[0].bad) { b->why = res[0].bad; return builder_fail(b, MEMO_EUNPACKABLE, bad_message(res[0].bad)); }
+    if (res[0].bad) return refuse(b, res[0].bad);
     return merge_results(b, res);
 }
 
 int push_dense(memo_builder *b, const PackArgs &A, uint64_t rows) {
-    HostPool &pool = HostPool::get();
     PinnedRing *ring = b->ring;
     const int64_t *start = A.start;
     // rows that complete the group the last push left open
     const uint64_t head = b->carry_n ? ((uint64_t)(5 - b->carry_n) < rows ? (uint64_t)(5 - b->carry_n) : rows) : 0;
     int rc = carry_rows(b, A, 0, head);
     if (rc) return rc;
-    bool lead = b->carry_n == 5;  // a completed group waits to lead the next chunk
+    const bool lead = b->carry_n == 5;  // a completed group leads the first chunk
     const uint64_t groups = (rows - head) / 5, tail0 = head + 5 * groups;
-    for (uint64_t g0 = 0; g0 < groups || lead; g0 += kChunkGroups) {
-        const uint64_t gn = groups - g0 < kChunkGroups ? groups - g0 : kChunkGroups;
-        const int s = ring->next;
-        ring->next = (s + 1) % PinnedRing::kSlots;
-        char *buf = nullptr;
-        rc = ring->buffer(s, &buf);
-        if (!rc) rc = ring->wait(s);
-        if (rc) return builder_fail(b, rc, "pinned staging ring failed");
-        uint32_t *out = reinterpret_cast<uint32_t *>(buf);
-        uint64_t pos = 0;
-        if (lead) {
-            dense_group(b->carry_b, b->carry_a, out);
-            b->carry_n = 0;
-            lead = false;
-            pos = 1;
-        }
-        const int tasks = (int)((gn + kBlockGroups - 1) / kBlockGroups);
-        std::vector<BlockResult> res((size_t)tasks);
-        pool.run(tasks, [&](int t) {
-            const uint64_t ga = g0 + (uint64_t)t * kBlockGroups;
-            const uint64_t gb = ga + kBlockGroups < g0 + gn ? ga + kBlockGroups : g0 + gn;
+    if (groups || lead) {
+        if (b->groups_sent + groups + (lead ? 1 : 0) > b->d_groups) return builder_fail(b, MEMO_EINVAL, "more rows than the builder was made for");
+        const uint64_t nblocks = groups ? (groups + kBlockGroups - 1) / kBlockGroups : 1;  // (only the leading group: one empty block)
+        PushPipe pipe(b, nblocks, kChunkGroups / kBlockGroups);
+        const uint64_t pos = lead ? 1 : 0;  // the first chunk's groups sit one group into their slot
+        auto pack = [&](uint64_t blk, uint64_t c, char *buf, BlockResult &r) {
+            const uint64_t ga = blk * kBlockGroups, gb = ga + kBlockGroups < groups ? ga + kBlockGroups : groups;
+            if (ga >= gb) return;
             const uint64_t i0 = head + 5 * ga;
             const bool first = i0 == 0;
             const int64_t prev_start = first ? (b->any ? b->last_start : INT64_MIN) : start[i0 - 1];
             const int64_t prev_bucket = first ? b->last_bucket : (start[i0 - 1] >> b->bshift);
-            pack_dense(A, i0, gb - ga, prev_start, prev_bucket, out + 4 * (pos + ga - g0), res[(size_t)t]);
-        });
+            uint32_t *out = reinterpret_cast<uint32_t *>(buf) + 4 * ((c == 0 ? pos : 0) + ga - c * kChunkGroups);
+            pack_dense(A, i0, gb - ga, prev_start, prev_bucket, out, r);
+        };
+        uint64_t sent = b->groups_sent;
+        auto issue = [&](uint64_t c, char *buf) {
+            const uint64_t g0 = c * kChunkGroups, gn = groups - g0 < kChunkGroups ? groups - g0 : kChunkGroups;
+            uint64_t send = gn;
+            if (c == 0 && lead) {
+                dense_group(b->carry_b, b->carry_a, reinterpret_cast<uint32_t *>(buf));
+                b->carry_n = 0;
+                send += 1;
+            }
+            const int r = hp::copy_h2d_async(b->d_pk + 4 * sent, buf, send * 16, ring->stream);
+            sent += send;
+            return r;
+        };
+        rc = pipe.drive(pack, issue);
+        if (rc) return builder_fail(b, rc, "copy to the device failed");
         int bad = 0;
-        for (const BlockResult &r : res) bad |= r.bad;
-        if (bad) { b->why = bad; return builder_fail(b, MEMO_EUNPACKABLE, bad_message(bad)); }
-        if ((rc = merge_results(b, res))) return rc;
-        const uint64_t send = pos + gn;
-        if (b->groups_sent + send > b->d_groups) return builder_fail(b, MEMO_EINVAL, "more rows than the builder was made for");
-        if ((rc = hp::copy_h2d_async(b->d_pk + 4 * b->groups_sent, out, send * 16, ring->stream)) || (rc = ring->mark(s)))
-            return builder_fail(b, rc, "copy to the device failed");
-        b->groups_sent += send;
-        if (gn == 0) break;  // (only the leading group went)
+        for (const BlockResult &r : pipe.res) bad |= r.bad;
+        if (bad) return refuse(b, bad);
+        if ((rc = merge_results(b, pipe.res))) return rc;
+        b->groups_sent = sent;
     }
     return carry_rows(b, A, tail0, rows);  // the rows of the last, incomplete group wait for the next push
 }

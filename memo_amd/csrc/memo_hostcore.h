@@ -28,6 +28,7 @@ int event_create(void **event);
 void event_destroy(void *event);
 int event_record(void *event, void *stream);
 int event_sync(void *event);
+int event_query(void *event, int *done);               // *done = 1 when everything queued before the record has finished
 int copy_h2d_async(void *dev, const void *host, size_t bytes, void *stream);
 int copy_d2h_async(void *host, const void *dev, size_t bytes, void *stream);
 int copy_h2d(void *dev, const void *host, size_t bytes);       // blocking; pageable source allowed
@@ -40,6 +41,7 @@ constexpr int64_t kHostCoordLimit = (int64_t)1 << 61;
 constexpr uint64_t kMaxLongRows = (uint64_t)1 << 22;
 
 // ---- worker threads: one process-wide pool, created on FIRST USE by a call that needs it -----------------
+int host_threads_default();  // min(CPUs allowed, cgroup CFS quota, 32), or MEMO_HOST_THREADS (memo_cpus.h)
 class HostPool {
 public:
     static HostPool &get();
@@ -50,6 +52,11 @@ public:
     void run(int n, F &&f) {
         run(n, [](void *c, int t) { (*static_cast<F *>(c))(t); }, &f);
     }
+    // the same in three steps, for a caller with work of its own while the job runs (the builder's push loop issues the
+    // copies): begin wakes the pool on the n tasks, help makes the caller take tasks until none is left, end waits
+    void begin(int n, void (*f)(void *, int), void *ctx);
+    void help();
+    void end();
 
 private:
     HostPool();
@@ -59,22 +66,24 @@ private:
 
 // ---- pinned staging ring: slots allocated on first use, a copy stream, one event per slot ----------------
 struct PinnedRing {
-    static constexpr int kSlots = 3;
+    static constexpr int kSlots = 4;
     static constexpr size_t kSlotBytes = (size_t)24 << 20;
     int device = -1;
-    char *slot[kSlots] = {nullptr, nullptr, nullptr};
-    void *done[kSlots] = {nullptr, nullptr, nullptr};
-    bool in_flight[kSlots] = {false, false, false};
+    char *slot[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    void *done[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool in_flight[kSlots] = {false, false, false, false};
     void *stream = nullptr;
     int next = 0;
 
     int buffer(int s, char **out);  // the slot's pinned buffer, allocated now if this is its first use
     int wait(int s);                // the slot's last copy has left (or arrived in) the buffer
+    int poll(int s, bool *idle);    // the same without blocking: *idle = the slot can be written now
     int mark(int s);                // an asynchronous copy of the slot was just queued on `stream`
     int drain();
 };
 int acquire_ring(int device, PinnedRing **out);
 void release_ring(PinnedRing *r);
+double pinned_alloc_ms_total();  // time this process has spent allocating pinned slots (MEMO_TIMING)
 bool ring_cached(int device);  // an idle ring with at least one allocated slot exists for this device
 
 int download_pipelined_core(int device, void *host, const void *dev, size_t bytes);

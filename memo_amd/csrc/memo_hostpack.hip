@@ -6,6 +6,7 @@
 #include <new>
 
 #include "memo_common.h"
+#include "memo_cpus.h"
 #include "memo_hostcore.h"
 
 using namespace memo;
@@ -60,6 +61,11 @@ int event_record(void *event, void *stream) {
     return hip_rc(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)), "hipEventRecord");
 }
 int event_sync(void *event) { return hip_rc(hipEventSynchronize(static_cast<hipEvent_t>(event)), "hipEventSynchronize"); }
+int event_query(void *event, int *done) {
+    const hipError_t err = hipEventQuery(static_cast<hipEvent_t>(event));
+    *done = err == hipSuccess;
+    return err == hipSuccess || err == hipErrorNotReady ? MEMO_OK : hip_rc(err, "hipEventQuery");
+}
 int copy_h2d_async(void *dev, const void *host, size_t bytes, void *stream) {
     return hip_rc(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)), "hipMemcpyAsync H2D");
 }
@@ -93,6 +99,12 @@ int builder_why(const memo_builder_t *b) { return b ? b->why : 0; }
 }  // namespace memo
 
 extern "C" {
+
+int memo_host_threads(int32_t *cpus_allowed_out, double *cgroup_quota_cpus) {
+    if (cpus_allowed_out) *cpus_allowed_out = cpus_allowed();
+    if (cgroup_quota_cpus) *cgroup_quota_cpus = cgroup_cpu_quota();
+    return host_threads_default();
+}
 
 int memo_builder_create_rows(uint64_t max_rows, int32_t device, int32_t bucket_shift, int32_t row_format,
                              memo_builder_t **out) {

@@ -1003,6 +1003,8 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     const auto t0 = now();
+    const double pinned0 = pinned_alloc_ms_total();
+    double in_ms[3] = {0, 0, 0};  // the last builder's device allocation / packing + copies / finish (table, census, destroy)
     if (rows && k > 1 && k - 1 <= 255 && g_one_shot_way != 1) {
         // the dense rows first (3.2 B per row over PCIe and in HBM, sweep_conservation_halo3_kernel) when they can
         // answer THIS query -- judged from the first and last start before the rows are touched, and again from the
@@ -1011,11 +1013,15 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
                                memo_dense_rows_can_answer(rows, start[0], start[rows - 1], 0, k, num_docs, membership);
         for (int dense = try_dense ? 1 : 0; dense >= 0 && !ix; --dense) {
             memo_builder_t *b = nullptr;
+            const auto ta = now();
             if ((rc = memo_builder_create_rows(rows, device, 0, dense ? MEMO_ROWS_DENSE : MEMO_ROWS_PACKED, &b))) return rc;
+            const auto tb = now();
             rc = memo_builder_push(b, start, end, annot, rows);
+            const auto tc = now();
             if (!rc) rc = memo_builder_finish(b, &ix);
             const int why = builder_why(b);
             memo_builder_destroy(b);
+            in_ms[0] = ms(ta, tb), in_ms[1] = ms(tb, tc), in_ms[2] = ms(tc, now());
             if (rc == MEMO_EUNPACKABLE) {
                 rc = MEMO_OK;
                 ix = nullptr;
@@ -1064,10 +1070,10 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
     if (timing && !rc) {
         const auto t3 = now();
         fprintf(stderr,
-                "memo one-shot: %llu rows %s: rows in %.1f ms (%.1f GB/s of int64 columns), result alloc + sweep + check "
-                "%.1f ms, result out %.1f ms (%.1f GB/s), total %.1f ms\n",
+                "memo one-shot: %llu rows %s: rows in %.1f ms (%.1f GB/s of int64 columns; allocation %.1f, packing + copies %.1f "
+                "with %d host threads, finish %.1f; pinned slots allocated in this call %.1f), result alloc + sweep + check %.1f ms, result out %.1f ms (%.1f GB/s), total %.1f ms\n",
                 (unsigned long long)rows, ix->has_wide ? "as int64 columns" : (ix->packed_fmt == 6 ? "packed to 6 B" : ix->pk ? "packed to 4 B" : "packed to 3.2 B (dense rows)"),
-                ms(t0, t1), rows * 24.0 / 1e6 / (ms(t0, t1) + 1e-9), ms(t1, t2), ms(t2, t3),
+                ms(t0, t1), rows * 24.0 / 1e6 / (ms(t0, t1) + 1e-9), in_ms[0], in_ms[1], memo_host_threads(nullptr, nullptr), in_ms[2], pinned_alloc_ms_total() - pinned0, ms(t1, t2), ms(t2, t3),
                 bytes / 1e6 / (ms(t2, t3) + 1e-9), ms(t0, t3));
     }
     if (d_out) {

@@ -21,6 +21,7 @@ import os
 
 import numpy as np
 
+from . import _lib
 from ._lib import MemoUnpackable
 from .index import (DeviceIndex, IndexBuilder, dense_rows_can_answer, emit_conservation_buffer, emit_membership_buffer,
                     words)
@@ -114,7 +115,8 @@ def region_chunks(in_file, query_record, query_start, query_end):
     def chunks():
         # row groups decode in parallel (Arrow releases the GIL), a bounded window ahead of the
         # consumer, and are handed over in file order so that the rows stay start-sorted
-        depth = max(1, min(int(os.environ.get("MEMO_DECODE_THREADS", "16")), os.cpu_count() or 1))
+        # (as many decoders as the library would run host threads: the CPUs allowed, cut to the cgroup's CFS quota -- memo_host_threads)
+        depth = max(1, int(os.environ.get("MEMO_DECODE_THREADS") or _lib.lib().memo_host_threads(None, None)))
         with cf.ThreadPoolExecutor(max_workers=depth) as pool:
             window = [pool.submit(load, g) for g in groups[:depth]]
             for n in range(len(groups)):

@@ -137,6 +137,12 @@ int event_sync(void *event) {
     e->cv.wait(lk, [&] { return e->reached >= want; });
     return MEMO_OK;
 }
+int event_query(void *event, int *done) {
+    Event *e = static_cast<Event *>(event);
+    std::lock_guard<std::mutex> lk(e->m);
+    *done = e->reached >= e->recorded;
+    return MEMO_OK;
+}
 int copy_h2d_async(void *dev, const void *host, size_t bytes, void *stream) {
     S(stream)->push([=] { memcpy(dev, host, bytes); });
     return MEMO_OK;
@@ -274,6 +280,51 @@ int main() {
         std::thread t2([&] { run_builder(true, 612347 + 7 * round, 11 + round, -1, round == 2 ? 777 : 0); });
         t1.join();
         t2.join();
+    }
+    // one push of many chunks: more chunks than the ring has slots, so slots are reused while workers pack ahead
+    // (dense: 1 047 744 groups = 5.2 M rows per chunk; words: 6.3 M rows), then the same rows with a row out of order
+    // deep inside -- every worker has to stop, the caller has to come back
+    {
+        const uint64_t n = 27000007;
+        Rows r;
+        r.s.resize(n), r.e.resize(n), r.a.resize(n);
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        int64_t pos = 17;
+        for (uint64_t i = 0; i < n; ++i) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            pos += (int64_t)((x >> 33) % 3 == 0);
+            r.s[i] = pos;
+            r.e[i] = i % 100003 == 5 ? pos - 2 : pos + (int64_t)((x >> 40) % 90);
+            r.a[i] = 1 + (int64_t)((x >> 50) % 300);
+        }
+        for (int dense = 0; dense < 2; ++dense) {
+            memo_builder *b = new_builder(n, dense);
+            CHECK(builder_push_core(b, r.s.data(), r.e.data(), r.a.data(), 3) == MEMO_OK);   // (a ragged start: carried rows, a leading group)
+            CHECK(builder_push_core(b, r.s.data() + 3, r.e.data() + 3, r.a.data() + 3, n - 3) == MEMO_OK);
+            CHECK(builder_flush_core(b) == MEMO_OK);
+            CHECK(b->ring->drain() == MEMO_OK);
+            if (!dense) CHECK(b->fmt == 12);
+            verify(b, r, n);
+            free_builder(b);
+        }
+        r.s[n - 1000] = 3;
+        for (int dense = 0; dense < 2; ++dense) {
+            memo_builder *b = new_builder(n, dense);
+            CHECK(builder_push_core(b, r.s.data(), r.e.data(), r.a.data(), n) == MEMO_EUNPACKABLE && b->failed == MEMO_EUNPACKABLE && (b->why & 1));
+            free_builder(b);
+        }
+    }
+    // one annot > 255 that the sample of the annots misses: the push finds it while packing and starts over in format 12,
+    // the rows of the push before it are rewritten on the "device"
+    {
+        Rows r = make_rows(300000, 9, 200);
+        r.a[277777] = 300;
+        memo_builder *b = new_builder(300000, false);
+        CHECK(builder_push_core(b, r.s.data(), r.e.data(), r.a.data(), 100000) == MEMO_OK && b->fmt == 4);
+        CHECK(builder_push_core(b, r.s.data() + 100000, r.e.data() + 100000, r.a.data() + 100000, 200000) == MEMO_OK && b->fmt == 12);
+        CHECK(b->ring->drain() == MEMO_OK);
+        verify(b, r, 300000);
+        free_builder(b);
     }
     run_builder(true, 4, 5, -1, 0);      // less than one group
     run_builder(true, 5, 6, -1, 0);

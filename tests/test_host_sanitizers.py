@@ -83,7 +83,8 @@ def test_host_packer_under_sanitizers(tmp_path, sanitizer):
     """memo_amd/csrc/memo_hostcore.cpp -- worker pool, pinned ring, row packers (4-byte words and dense rows), the
     builder's push loop: the library's only multi-threaded host code -- with the device seam stubbed by
     tests/host_stub.cpp (memcpy on copier threads), under ASan + UBSan and under ThreadSanitizer: two builders on two
-    threads, ragged pieces, the late switch to 12-bit annots, refusals, the pipelined transfers."""
+    threads, ragged pieces, the late switch to 12-bit annots, refusals, the pipelined transfers, and one push of many chunks
+    (the push loop as ONE job of the pool: workers packing ahead into four slots, the caller issuing the copies)."""
     lib = subprocess.run(["gcc", "-print-file-name=lib%s.so" % ("tsan" if sanitizer == "thread" else "asan")],
                          capture_output=True, text=True).stdout.strip()
     if not (os.path.isabs(lib) and os.path.exists(lib)):
@@ -94,7 +95,7 @@ def test_host_packer_under_sanitizers(tmp_path, sanitizer):
                            os.path.join(ROOT, "tests", "host_stub.cpp"),
                            os.path.join(ROOT, "memo_amd", "csrc", "memo_hostcore.cpp"), "-o", exe])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="halt_on_error=1", MEMO_HOST_THREADS="6")
-    for simd in ("1", "0"):          # the packers' row pass: the AVX2 instance where the CPU has it, and the plain one
+    for simd in ("2", "1", "0"):     # the row pass: the hand-written AVX-512 packers, the compiler's AVX2 instance (where the CPU has them), the plain one
         r = subprocess.run([exe], capture_output=True, text=True, env=dict(env, MEMO_HOST_SIMD=simd), timeout=600)
         assert r.returncode == 0 and "hostcore ok" in r.stdout, (simd, (r.stdout + r.stderr)[-3000:])
         assert "WARNING: ThreadSanitizer" not in r.stderr and "runtime error" not in r.stderr, (simd, r.stderr[-3000:])

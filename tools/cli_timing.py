@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end `memo query` timing on a synthetic Parquet index (GPU box).
-  python tools/cli_timing.py --num-docs 100 --pivot 20000000 --out gpurun_out/cli"""
+  python tools/cli_timing.py --num-docs 100 --pivot 20000000 --out gpurun_out/cli
+  python tools/cli_timing.py --num-docs 100 --pivot 100000000 --memb-window 10000000     # BASELINE config 3 itself: 5e8 rows of Parquet"""
 import argparse
 import hashlib
 import os
@@ -16,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--num-docs", type=int, default=100)
 ap.add_argument("--pivot", type=int, default=20_000_000)
 ap.add_argument("--out", default="/tmp/cli_timing")
+ap.add_argument("--memb-window", type=int, default=2_000_000, help="positions of the membership query's window")
 a = ap.parse_args()
 os.makedirs(a.out, exist_ok=True)
 pq_path = os.path.join(a.out, f"synth_n{a.num_docs}_{a.pivot}.parquet")
@@ -33,7 +35,7 @@ for mode, what in (("0", "no cache (Parquet decode)"), ("sync", "cache miss + in
                    ("read", "cache hit, again")):
     print(f"-- MEMO_CACHE={mode}: {what}")
     for region, memb in ((f"chr1:0-{a.pivot}", False), (f"chr1:{a.pivot // 4}-{a.pivot // 2}", False),
-                         (f"chr1:0-{min(a.pivot, 2_000_000)}", True)):
+                         (f"chr1:0-{min(a.pivot, a.memb_window)}", True)):
         out = os.path.join(a.out, "out.txt")
         argv = [sys.executable, exe, "query", "-b", pq_path, "-n", str(a.num_docs), "-r", region, "-o", out] + (["-m"] if memb else [])
         t = time.time()
