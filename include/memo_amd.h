@@ -218,6 +218,7 @@ int memo_index_get_info_v5(const memo_index_t *ix, memo_index_info_t *info);  /*
 #define MEMO_OPT_BUILD_COST_PCT 3
 #define MEMO_OPT_VIEW_ROWS 4
 #define MEMO_OPT_VIEW_PLACES 5
+/* Returns the option's PREVIOUS value (>= 0) -- what a caller that changes an option for one pass puts back -- or a negative code. */
 int memo_index_set_option(memo_index_t *ix, int32_t option, int64_t value);
 /* Build NOW what queries of one kind would otherwise build on the way: the k-class view of the rows such a query reads (else
  * built by the query that finds it has become worth its pass -- MEMO_OPT_BUILD_COST_PCT -- on the caller's stream, with a wait

@@ -57,6 +57,18 @@ def _header_ok(head, file_bytes):       # (= memo_amd.cache.header_ok)
         return False
 
 
+def _lazy_buffer(nbytes):
+    """(mmap, address) of an anonymous mapping: pages appear when they are first written -- by the library's threads, not
+    by a zero-fill on this one (203 MB of text cost 0.2 s that way at BASELINE config 3: profiles/r06_cli_timing.txt) --
+    as huge pages where the kernel grants them"""
+    mm = mmap.mmap(-1, max(nbytes, 1))
+    try:
+        mm.madvise(mmap.MADV_HUGEPAGE)
+    except (AttributeError, OSError, ValueError):
+        pass
+    return mm, C.addressof(C.c_char.from_buffer(mm))
+
+
 def _open(in_file, record):
     """(header, writable-copy memory map, file size) of a valid cache file, else None"""
     path = _cache_path(in_file, record)
@@ -155,8 +167,8 @@ def try_query(in_file, region, k, num_docs, out_file, membership):
         t1 = time.perf_counter()
         L = max(qe - qs, 0)
         words = (num_docs + 31) // 32
-        host = (C.c_uint32 * (L * words))() if membership else (C.c_uint16 * L)()
-        nbytes = C.sizeof(host)
+        nbytes = 4 * L * words if membership else 2 * L
+        host_mm, host = _lazy_buffer(nbytes)        # (a ctypes array would be zero-filled here, by this one thread)
         _lib.check(lib.memo_dev_malloc(device, max(nbytes, 16), C.byref(d_out)))
         fn = lib.memo_query_membership_dev if membership else lib.memo_query_conservation_dev
         _lib.check(fn(ix, qs, qe, k, num_docs, d_out, None))        # (qe < qs: the reference's ValueError)
@@ -167,13 +179,13 @@ def try_query(in_file, region, k, num_docs, out_file, membership):
             need = lib.memo_emit_membership(host, L, num_docs, None, 0)
         else:
             need = lib.memo_emit_conservation(host, L, None, 0)
-        text = (C.c_char * max(need, 1))()
+        text_mm, text = _lazy_buffer(need)          # (its pages are first touched by the emitter's threads)
         if membership:
             lib.memo_emit_membership(host, L, num_docs, text, need)
         else:
             lib.memo_emit_conservation(host, L, text, need)
         with open(out_file, "wb") as fh:
-            fh.write(memoryview(text)[:need])
+            fh.write(memoryview(text_mm)[:need])
         t3 = time.perf_counter()
     finally:
         if d_out:

@@ -33,7 +33,7 @@ import time
 
 import numpy as np
 
-from ._lib import MemoUnpackable, check, lib
+from ._lib import MemoError, MemoUnpackable, check, lib
 from .index import DeviceIndex, dense_rows_can_answer
 
 VERSION = 3
@@ -136,10 +136,17 @@ def write(in_file, record, ix, k=None):
         # the k class's view as the DEVICE builds it (memo_index_prepare + memo_index_export_view: a few ms, and the rows' places
         # inside their groups chosen against LDS bank conflicts) -- rounds 3-4 rebuilt it here with whole-chromosome NumPy
         # temporaries, 30-40 bytes of host memory per row.  Groups of five rows: what memo_index_import_dense takes.
-        ix.set_option(4, 5)                           # MEMO_OPT_VIEW_ROWS
-        ix.prepare(k, int(min(max(inf["max_annot"] + 1, 2), 511)))
-        made = ix.export_view(k, 5)
-        ix.set_option(4, 0)
+        # The view is optional: whatever goes wrong building or fetching it (no room on the device, any HIP error) means "no
+        # view in the file", never a failed cache write; and the caller's index gets its own MEMO_OPT_VIEW_ROWS back.
+        made = None
+        before = ix.set_option(4, 5)                  # MEMO_OPT_VIEW_ROWS
+        try:
+            ix.prepare(k, int(min(max(inf["max_annot"] + 1, 2), 511)))
+            made = ix.export_view(k, 5)
+        except MemoError:
+            made = None
+        finally:
+            ix.set_option(4, before)
         if made is not None and made[3] == cap:
             pv, boffv, rows_v = made[0], made[1], made[2]
             view = {"cap": cap, "rows": rows_v}

@@ -137,6 +137,8 @@ struct memo_index {
         uint32_t *p3 = nullptr;
         int64_t *boff = nullptr;
         uint64_t rows = 0, padded = 0;
+        uint64_t bytes = 0;      // of the rows' allocation (set where a view is installed: a six-row view is (groups + 64) x 16 B, not
+                                 //   what its padded row count makes of five-row groups -- ADVICE r05: the budget charged it a fifth too much)
         float build_ms = 0.f;
         uint64_t stamp = 0;      // last use (view_clock): past the views' budget the least recently used one goes
     };
@@ -209,9 +211,11 @@ namespace memo {
 void drop_dense(memo_index *ix);       // frees the dense rows, their bucket table and the tile tables
 int dense_compact(memo_index *ix);     // memo_index.hip: leave the rows that can never write out of the dense rows (see boff3)
 // ... or a k-class view of them (memo_view.hip); window: the query's length (what a view would save this query decides when it is built);
-// allow_six: the caller reads views of six rows per group too (*rpg says which kind it got: 5 or 6)
+// allow_six: the caller reads views of six rows per group too (*rpg says which kind it got: 5 or 6); account = false: a query's
+// SECOND call (its six-row view found no tile table): hands back a five-row view that exists, adds nothing to the class's ledgers
+// and builds nothing -- the query has been counted once already
 int dense_rows_for(memo_index *ix, int km1, int64_t window, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows,
-                   int *view_cap = nullptr, bool allow_six = false, int *rpg = nullptr);
+                   int *view_cap = nullptr, bool allow_six = false, int *rpg = nullptr, bool account = true);
 extern thread_local int g_six_views;  // (AB library, memo_debug_six_views: -1 the library's choice, 0 five rows per group always, 1 six wherever they apply)
 constexpr int kNoRoom = 1;  // (internal) the device has no memory for a view / tile table: run without it
 constexpr size_t kMaxTileTables = 64;
@@ -230,6 +234,9 @@ hipError_t side_alloc(void **p, size_t bytes);
 void drop_dense_views(memo_index *ix);
 int packed_rows_for(memo_index *ix, int km1, int64_t window, bool membership, hipStream_t st, uint32_t **pk, int64_t **boff, uint64_t *rows);  // k-class view of the words (+ their order)
 void drop_packed_views(memo_index *ix);
+inline uint64_t dense_view_bytes(uint64_t padded, int rows_per_group) {  // what dense_view_build allocates for a view's rows
+    return (rows_per_group == 6 ? padded / 6 + 64 : (padded + 4) / 5 + 64) * 16;
+}
 inline uint64_t dense_groups_for(uint64_t padded) { return (padded + 4) / 5 + 64; }  // (+ one wave-load of slack: a wave reads its 64 groups whole)
 void drop_tile_tables(memo_index *ix);  // memo_sweep_cons3t.hip: the tables derive from the dense rows and the bucket table
 // memo_interleave.hip: reorder the 4-byte rows inside every bucket (mode 0: start order, 1: chunks of four dealt round-robin

@@ -853,15 +853,15 @@ static void fill_info(const memo_index *ix, memo_index_info_t *info) {
     info->row_order = ix->row_order;
     uint64_t side = ix->retired_bytes;
     for (const memo_index::DenseView &v : ix->views) {
-        side += v.p3 ? dense_groups_for(v.padded) * 16 + ix->nb * 8 : 0;
+        side += v.p3 ? v.bytes + ix->nb * 8 : 0;
         info->views_resident += v.p3 ? 1 : 0;
     }
     for (const memo_index::DenseView &v : ix->views6) {
-        side += v.p3 ? dense_groups_for(v.padded) * 16 + ix->nb * 8 : 0;
+        side += v.p3 ? v.bytes + ix->nb * 8 : 0;
         info->views_resident += v.p3 ? 1 : 0;
     }
     for (const memo_index::DenseView &v : ix->pviews) {
-        side += v.p3 ? v.padded * 4 + ix->nb * 8 : 0;
+        side += v.p3 ? v.bytes + ix->nb * 8 : 0;
         info->views_resident += v.p3 ? 1 : 0;
     }
     for (const memo_index::TileTable &t : ix->ttabs) side += (uint64_t)t.n * 32;
@@ -906,6 +906,7 @@ int memo_index_set_option(memo_index_t *ix, int32_t option, int64_t value) {
     if (!ix) return fail(MEMO_EINVAL, "index is NULL");
     if (option == MEMO_OPT_VIEWS) {
         if (value != 0 && value != 1) return fail(MEMO_EINVAL, "MEMO_OPT_VIEWS takes 0 or 1");
+        const int before = ix->views_on;
         ix->views_on = (int)value;
         if (!value) {
             DeviceGuard guard(ix->device);
@@ -925,27 +926,31 @@ int memo_index_set_option(memo_index_t *ix, int32_t option, int64_t value) {
             drop_packed_views(ix);
             flush_retired(ix);
         }
-        return MEMO_OK;
+        return before;
     }
     if (option == MEMO_OPT_VIEW_BUDGET_PCT) {
         if (value < 0 || value > 1600) return fail(MEMO_EINVAL, "MEMO_OPT_VIEW_BUDGET_PCT takes 0 .. 1600");
+        const int before = ix->view_budget_pct;
         ix->view_budget_pct = (int)value;
-        return MEMO_OK;
+        return before;
     }
     if (option == MEMO_OPT_BUILD_COST_PCT) {
         if (value < 0 || value > 100000) return fail(MEMO_EINVAL, "MEMO_OPT_BUILD_COST_PCT takes 0 .. 100000");
+        const int before = ix->build_cost_pct;
         ix->build_cost_pct = (int)value;
-        return MEMO_OK;
+        return before;
     }
     if (option == MEMO_OPT_VIEW_PLACES) {
         if (value != 0 && value != 1) return fail(MEMO_EINVAL, "MEMO_OPT_VIEW_PLACES takes 0 or 1");
+        const int before = ix->view_places;
         ix->view_places = (int)value;
-        return MEMO_OK;
+        return before;
     }
     if (option == MEMO_OPT_VIEW_ROWS) {
         if (value != 0 && value != 5 && value != 6) return fail(MEMO_EINVAL, "MEMO_OPT_VIEW_ROWS takes 0 (the library's choice), 5 or 6");
+        const int before = ix->view_rows;
         ix->view_rows = (int)value;
-        return MEMO_OK;
+        return before;
     }
     return fail(MEMO_EINVAL, "unknown index option %d", option);
 }

@@ -1429,7 +1429,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
                 uint32_t *vp3 = nullptr;
                 int64_t *vboff = nullptr;
                 uint64_t vrows = 0;
-                if ((rc = dense_rows_for(ix, k - 1, qe - qs, st, &vp3, &vboff, &vrows, &view_cap, can_six, &rpg))) return rc;
+                if ((rc = dense_rows_for(ix, k - 1, qe - qs, st, &vp3, &vboff, &vrows, &view_cap, can_six, &rpg, attempt == 0))) return rc;
                 A.p3 = vp3;
                 A.boff = vboff;
                 ix->last_rows_read = vrows;

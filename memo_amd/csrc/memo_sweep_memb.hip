@@ -196,7 +196,7 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 
 
 // One row of a planes kernel: the run of n = k - 1 - overlap bits that ends at bit d of plane row `col`; hand-written blocks,
-// EXEC narrowed by v_cmpx and restored at the end (every lane of the wave is active in the row loops).
+// EXEC narrowed by v_cmpx and put back at the end as the block found it (every lane of the wave is active in the row loops today).
 //   MW = 0 (k - 1 <= 31): the run fits two words.  12 vector instructions with the row's three fields and no scalar ones (the
 //   compiler's branchy form: 17 and 8): v_bfm_b32 for both masks, a saturating subtract for the bits that spill into the second
 //   word; a row that cannot write issues nothing (a zero or-ed into LDS costs what any atomic costs: the first version, without
@@ -219,7 +219,10 @@ __device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, 
     }
     if constexpr (MW == 0) {
         uint32_t n, first, wq, addr, lo;
+        // (EXEC is put back as the block found it -- s[38:39], declared clobbered -- not forced to -1: that would switch on lanes a future
+        // caller had off)
         asm volatile(
+            "s_mov_b64 s[38:39], exec\n\t"
             "v_sub_u32 %0, %6, %7\n\t"             // n = k - 1 - overlap
             "v_cmpx_lt_i32 vcc, 0, %0\n\t"         // the rest on the lanes whose row writes (the dead rows of a load that straddles
                                                    // an end of the slice too: two atomics that add nothing cost what any two cost)
@@ -233,10 +236,10 @@ __device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, 
             "ds_or_b32 %3, %4\n\t"
             "v_cmpx_ne_u32 vcc, 0, %2\n\t"         // (a run inside one word -- about half of them at k = 31 -- has no second ds_or)
             "ds_or_b32 %3, %2 offset:4\n\t"
-            "s_mov_b64 exec, -1"
+            "s_mov_b64 exec, s[38:39]"
             : "=&v"(n), "=&v"(first), "=&v"(wq), "=&v"(addr), "=&v"(lo)
             : "v"(t), "s"(km1), "v"(len), "v"(d)
-            : "memory", "vcc");
+            : "memory", "vcc", "s38", "s39");
     } else {
         // Runs of up to MW + 1 words (MW = the most words a run can reach past its first: (k - 1 + 30) / 32, rounded up to 2, 3, 4
         // or 8): the first word (with the last one's mask where the run ends in it), the last word on the lanes whose run has
@@ -248,6 +251,7 @@ __device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, 
 #define MEMO_PLANES_WORD(I) "v_cmpx_lt_u32 vcc, " #I ", %5\n\tds_write_b32 %9, %8 offset:" #I "*4\n\t"
 #define MEMO_PLANES_LONG(WORDS)                                                                                                     \
         asm volatile(                                                                                                               \
+            "s_mov_b64 s[38:39], exec\n\t"         /* EXEC as the block found it */                                                \
             "v_sub_u32 %0, %11, %12\n\t"           /* n = k - 1 - overlap */                                                       \
             "v_cmpx_lt_i32 vcc, 0, %0\n\t"         /* the lanes whose row writes */                                                \
             "v_sub_u32 %1, %13, %0\n\t"            /* first bit of the run */                                                      \
@@ -267,10 +271,10 @@ __device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, 
             "v_lshl_add_u32 %3, %4, 2, %10\n\t"                                                                                    \
             "ds_or_b32 %3, %7\n\t"                                                                                                 \
             WORDS                                  /* whole words: tests that only ever narrow EXEC */                             \
-            "s_mov_b64 exec, -1"                                                                                                   \
+            "s_mov_b64 exec, s[38:39]"                                                                                             \
             : "=&v"(n), "=&v"(first), "=&v"(last), "=&v"(w0), "=&v"(w1), "=&v"(more), "=&v"(head), "=&v"(tail), "=&v"(ones), "=&v"(a0) \
             : "v"(t), "s"(km1), "v"(len), "v"(d)                                                                                   \
-            : "memory", "vcc")
+            : "memory", "vcc", "s38", "s39")
         if constexpr (MW <= 2) MEMO_PLANES_LONG(MEMO_PLANES_WORD(1));
         else if constexpr (MW == 3) MEMO_PLANES_LONG(MEMO_PLANES_WORD(1) MEMO_PLANES_WORD(2));
         else if constexpr (MW == 4) MEMO_PLANES_LONG(MEMO_PLANES_WORD(1) MEMO_PLANES_WORD(2) MEMO_PLANES_WORD(3));

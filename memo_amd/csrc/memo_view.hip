@@ -804,7 +804,7 @@ static void retire_view(memo_index *ix, memo_index::DenseView &v, bool dense) {
             ++i;
         }
     }
-    retire(ix, v.p3, dense ? dense_groups_for(v.padded) * 16 : v.padded * 4);
+    retire(ix, v.p3, v.bytes);
     retire(ix, v.boff, ix->nb * 8);
     const int again = v.backoff < (1 << 16) ? v.backoff * 4 : v.backoff;  // back-off: see DenseView
     const int ask = v.ask_after ? (v.ask_after < (1 << 16) ? v.ask_after * 4 : v.ask_after) : 16;
@@ -843,7 +843,7 @@ void drop_packed_views(memo_index *ix) {
 // the index's retire list (memo_common.h) -- unless that list has itself grown past the budget: then the device is drained.
 static void keep_views_in_budget(memo_index *ix, const memo_index::DenseView *fresh, uint64_t base_bytes, bool dense) {
     auto bytes_of = [&](const memo_index::DenseView &v) -> uint64_t {
-        return v.p3 ? (dense ? dense_groups_for(v.padded) * 16 : v.padded * 4) + ix->nb * 8 : 0;
+        return v.p3 ? v.bytes + ix->nb * 8 : 0;
     };
     const uint64_t budget = base_bytes / 100 * (uint64_t)ix->view_budget_pct;
     constexpr int kDense = (int)(sizeof(ix->views) / sizeof(ix->views[0])), kPacked = (int)(sizeof(ix->pviews) / sizeof(ix->pviews[0]));
@@ -1105,6 +1105,7 @@ int packed_rows_for(memo_index *ix, int km1, int64_t window, bool membership, hi
         });
         if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)
         v.cap = cap;
+        v.bytes = v.padded * 4;
         v.state = v.p3 ? 1 : (rc == kNoRoom ? 0 : 2);
         if (rc == kNoRoom) {  // (the pressure may pass: look again, but not with every query)
             v.lost_ns = 0;
@@ -1138,7 +1139,7 @@ int packed_rows_for(memo_index *ix, int km1, int64_t window, bool membership, hi
 // library builds where it applies -- buckets of 32 positions, annots of eight bits, overlaps below 32 -- and where the padding of
 // every bucket to whole groups (2.5 rows on average) stays small against the bucket; *rpg says which kind was handed out.
 int dense_rows_for(memo_index *ix, int km1, int64_t window, hipStream_t st, uint32_t **p3, int64_t **boff, uint64_t *rows, int *view_cap,
-                   bool allow_six, int *rpg) {
+                   bool allow_six, int *rpg, bool account) {
     if (view_cap) *view_cap = 0;  // (the cap of the view handed out: its rows are exactly those with overlap < cap)
     if (rpg) *rpg = 5;
     ix->last_view_placed = 0;
@@ -1160,7 +1161,11 @@ int dense_rows_for(memo_index *ix, int km1, int64_t window, hipStream_t st, uint
         if (vp->state != 1 && ix->views[slot].state == 1) vp = &ix->views[slot], six = false;
     }
     memo_index::DenseView &v = *vp;
-    if (v.state == 0 && !view_due(ix, v, 0, src_rows, spared, window, km1)) return MEMO_OK;
+    if (!account) {  // (the same query asking again: what is there, no ledger, no build)
+        if (v.state != 1) return MEMO_OK;
+    } else if (v.state == 0 && !view_due(ix, v, 0, src_rows, spared, window, km1)) {
+        return MEMO_OK;
+    }
     const bool can_place = ix->view_places && g_view_colouring != 0;
     const uint32_t *src_p3 = *p3;
     const int64_t *src_boff = *boff;
@@ -1176,6 +1181,7 @@ int dense_rows_for(memo_index *ix, int km1, int64_t window, hipStream_t st, uint
         });
         if (rc && rc != kNoRoom) return rc;  // (no room on the device for a view: the sweep reads all the rows)
         v.cap = cap;
+        v.bytes = dense_view_bytes(v.padded, rpg_arg);
         v.state = v.p3 ? 1 : (rc == kNoRoom ? 0 : 2);
         if (rc == kNoRoom) {
             v.lost_ns = 0;
@@ -1191,7 +1197,7 @@ int dense_rows_for(memo_index *ix, int km1, int64_t window, hipStream_t st, uint
             view_built(ix, v.build_ms, place ? 2 : 0, src_rows);
             keep_views_in_budget(ix, &v, base_bytes, true);
         }
-    } else if (v.state == 1 && !v.placed && can_place && places_due(ix, v, src_rows, window, km1, six)) {
+    } else if (account && v.state == 1 && !v.placed && can_place && places_due(ix, v, src_rows, window, km1, six)) {
         // the same view again, its rows placed: built beside the one in use (sweeps queued on the caller's other streams may still
         // read that one), then the class switches over and the old copy waits on the retire list with its tile tables
         DeviceGuard guard(ix->device);
@@ -1208,6 +1214,7 @@ int dense_rows_for(memo_index *ix, int km1, int64_t window, hipStream_t st, uint
             retire_view(ix, v, true);
             v = nv;
             v.cap = cap;
+            v.bytes = dense_view_bytes(v.padded, rpg_arg);
             v.state = 1;
             v.placed = 1;
             v.backoff = backoff;

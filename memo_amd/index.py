@@ -137,9 +137,8 @@ class DeviceIndex:
 
     def set_option(self, option, value):
         """memo_index_set_option: 1 = MEMO_OPT_VIEWS (0 / 1), 2 = MEMO_OPT_VIEW_BUDGET_PCT, 3 = MEMO_OPT_BUILD_COST_PCT (100: ski rental; 0: the
-        first query of a class builds), 4 = MEMO_OPT_VIEW_ROWS (0 / 5 / 6), 5 = MEMO_OPT_VIEW_PLACES (0 / 1)"""
-        check(lib().memo_index_set_option(self._h, int(option), int(value)))
-        return self
+        first query of a class builds), 4 = MEMO_OPT_VIEW_ROWS (0 / 5 / 6), 5 = MEMO_OPT_VIEW_PLACES (0 / 1).  Returns the option's previous value."""
+        return check(lib().memo_index_set_option(self._h, int(option), int(value)))     # the option's previous value
 
     # ---- asynchronous launches on device buffers (torch tensors or raw addresses) ----
     def conservation_dev(self, qs, qe, k, num_docs, out, stream=None):
