@@ -204,6 +204,14 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 //   no second ds_or.
 //   MW = 2, 3, 4, 8: longer runs, see the block.
 //   base: the planes' LDS byte address in a VGPR; p4, s4: 4 * PITCH, 4 * SKEW; SK: SKEW != 0 (4, 8 or 16 result words).
+// (-DMEMO_EXEC_MINUS_ONE: rounds 2-5's ending, `s_mov_b64 exec, -1`, for A/B -- profiles/r06_membership.txt)
+#ifdef MEMO_EXEC_MINUS_ONE
+#define MEMO_PLANES_KEEP ""
+#define MEMO_PLANES_BACK "s_mov_b64 exec, -1"
+#else
+#define MEMO_PLANES_KEEP "s_mov_b64 s[38:39], exec\n\t"
+#define MEMO_PLANES_BACK "s_mov_b64 exec, s[38:39]"
+#endif
 template <int MW, bool SK>
 __device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, uint32_t p4, uint32_t s4, uint32_t len, uint32_t d,
                                            uint32_t col) {
@@ -222,7 +230,7 @@ __device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, 
         // (EXEC is put back as the block found it -- s[38:39], declared clobbered -- not forced to -1: that would switch on lanes a future
         // caller had off)
         asm volatile(
-            "s_mov_b64 s[38:39], exec\n\t"
+            MEMO_PLANES_KEEP
             "v_sub_u32 %0, %6, %7\n\t"             // n = k - 1 - overlap
             "v_cmpx_lt_i32 vcc, 0, %0\n\t"         // the rest on the lanes whose row writes (the dead rows of a load that straddles
                                                    // an end of the slice too: two atomics that add nothing cost what any two cost)
@@ -236,7 +244,7 @@ __device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, 
             "ds_or_b32 %3, %4\n\t"
             "v_cmpx_ne_u32 vcc, 0, %2\n\t"         // (a run inside one word -- about half of them at k = 31 -- has no second ds_or)
             "ds_or_b32 %3, %2 offset:4\n\t"
-            "s_mov_b64 exec, s[38:39]"
+            MEMO_PLANES_BACK
             : "=&v"(n), "=&v"(first), "=&v"(wq), "=&v"(addr), "=&v"(lo)
             : "v"(t), "s"(km1), "v"(len), "v"(d)
             : "memory", "vcc", "s38", "s39");
@@ -251,7 +259,7 @@ __device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, 
 #define MEMO_PLANES_WORD(I) "v_cmpx_lt_u32 vcc, " #I ", %5\n\tds_write_b32 %9, %8 offset:" #I "*4\n\t"
 #define MEMO_PLANES_LONG(WORDS)                                                                                                     \
         asm volatile(                                                                                                               \
-            "s_mov_b64 s[38:39], exec\n\t"         /* EXEC as the block found it */                                                \
+            MEMO_PLANES_KEEP                       /* EXEC as the block found it */                                                \
             "v_sub_u32 %0, %11, %12\n\t"           /* n = k - 1 - overlap */                                                       \
             "v_cmpx_lt_i32 vcc, 0, %0\n\t"         /* the lanes whose row writes */                                                \
             "v_sub_u32 %1, %13, %0\n\t"            /* first bit of the run */                                                      \
@@ -271,7 +279,7 @@ __device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, 
             "v_lshl_add_u32 %3, %4, 2, %10\n\t"                                                                                    \
             "ds_or_b32 %3, %7\n\t"                                                                                                 \
             WORDS                                  /* whole words: tests that only ever narrow EXEC */                             \
-            "s_mov_b64 exec, s[38:39]"                                                                                             \
+            MEMO_PLANES_BACK                                                                                                       \
             : "=&v"(n), "=&v"(first), "=&v"(last), "=&v"(w0), "=&v"(w1), "=&v"(more), "=&v"(head), "=&v"(tail), "=&v"(ones), "=&v"(a0) \
             : "v"(t), "s"(km1), "v"(len), "v"(d)                                                                                   \
             : "memory", "vcc", "s38", "s39")

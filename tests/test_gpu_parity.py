@@ -2379,10 +2379,10 @@ def test_dense_rows_of_256_to_511_genomes(memo, oracle, ab):
             ix.pack_dense()
 
 
-def test_six_row_views_experiment(memo, oracle, ab):
-    """memo_debug_six_views (A/B library only; round-4 experiment, off in the product): the dense k-class views as groups of SIX rows that
-    carry their bucket (memo_view.hip: view_build_kernel<6>; 2.67 B per row) on the table-driven kernel's form for them
-    (info.last_variant 3).  Ragged index with an empty stretch and a bucket above the builder's 96-row limit, every k class it takes
+def test_six_row_views_equal_five_row_views(memo, oracle, ab):
+    """The dense k-class views as groups of SIX rows that carry their bucket (memo_view.hip: view_build_kernel<6>; 2.67 B per row;
+    the library's own choice where they apply since round 5) on the table-driven kernel's form for them (info.last_variant 3),
+    forced on and off through memo_debug_six_views of the A/B library so that BOTH kinds answer every case.  Ragged index with an empty stretch and a bucket above the builder's 96-row limit, every k class it takes
     (k - 1 <= 31), windows that begin inside a bucket, both result types: equal to the oracle and to the five-row views."""
     rng = np.random.default_rng(61)
     n_docs, length, m = 120, 90_000, 260_000

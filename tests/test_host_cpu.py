@@ -517,7 +517,8 @@ def _device_disassembly(obj, tmp_path):
 @pytest.mark.parametrize("obj", ["memo_sweep_cons.o", "memo_sweep_cons3t.o", "memo_sweep_memb.o"])
 def test_row_blocks_run_with_every_lane_enabled(memo, tmp_path, obj):
     """The branch-free row blocks narrow EXEC themselves (v_cmpx) and restore it with `s_mov_b64 exec, -1` -- which is
-    only right when every lane was enabled on entry, something the compiler is never told (round-2 VERDICT, weak 6).
+    only right when every lane was enabled on entry, something the compiler is never told (round-2 VERDICT, weak 6) -- or,
+    the membership blocks since round 6, from the SGPR pair they saved it in.
     Scan the shipped gfx950 code: inside every kernel, no v_cmpx may sit between an `s_and_saveexec_b64` (or another
     instruction that narrows EXEC) and the `s_or_b64 exec, exec, ...` that restores it, and every v_cmpx region must
     end in `s_mov_b64 exec, -1` before the next instruction that reads EXEC as a mask."""
@@ -538,7 +539,7 @@ def test_row_blocks_run_with_every_lane_enabled(memo, tmp_path, obj):
         # EXEC is all ones at a kernel's entry (whole waves: every launch is a multiple of 64 threads); s_and_saveexec
         # opens a divergent region that the matching s_or_b64 exec, exec, <saved> closes; inside one, further narrowing
         # (s_and_b64 / s_andn2_b64 exec, exec, ...) is undone by that same s_or; outside any, it would be permanent
-        saved, narrowed, in_block = [], False, False
+        saved, narrowed, in_block, kept = [], False, False, None
         for op, args in ins:
             a = args.replace(" ", "")
             if op.startswith("s_and_saveexec") or op.startswith("s_or_saveexec") or op.startswith("s_andn2_saveexec"):
@@ -561,6 +562,10 @@ def test_row_blocks_run_with_every_lane_enabled(memo, tmp_path, obj):
                 in_block = True
             elif op == "s_mov_b64" and a == "exec,-1":
                 in_block = narrowed = False
+            elif op == "s_mov_b64" and re.fullmatch(r"s\[\d+:\d+\],exec", a) and not in_block:
+                kept = a.split(",")[0]          # (the membership row blocks: EXEC kept in an SGPR pair in front of the block ...)
+            elif op == "s_mov_b64" and kept and a == "exec," + kept:
+                in_block = narrowed = False     # (... and put back from it at the end: round 6)
             elif in_block:
                 assert not op.startswith("s_cbranch") and op not in ("s_barrier", "s_endpgm"), \
                     f"{name}: {op} inside a row block, before EXEC is restored"

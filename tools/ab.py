@@ -16,7 +16,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from memo_amd import _lib, synth  # noqa: E402
-from bench import WORKLOADS  # noqa: E402
+from memo_amd.bench_legs import WORKLOADS  # noqa: E402
 
 
 def main():
