@@ -100,8 +100,7 @@ typedef struct memo_index_info {
                                2 / 3 / 4 per query from k and the overlap lengths of the rows it sampled when the
                                packed rows were made; membership: 6 bit planes on the dense rows, 7 any other */
     int32_t last_variant;   /* of the dense-row sweep: 0 every wave worked its tile out, 2 the tile's rows from the index's tile table, 3 the same
-                               on a k-class view of SIX rows per group (last_view_rows_per_group); membership planes: 4 = with the word
-                               plane (long runs: first word, last word, one 64-bit run of word bits), 0 without */
+                               on a k-class view of SIX rows per group (last_view_rows_per_group) */
     uint64_t dense_row_count; /* rows the dense rows hold (0: none resident): fewer than `rows` when the rows that can never
                                write at k <= 64 (overlap >= 63, or end < start) were left out of them -- they are when more
                                than a tenth of the rows are such rows (none of the synthetic index, 40 % of one built from

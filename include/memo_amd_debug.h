@@ -31,8 +31,7 @@ extern "C" {
  *   level arrays with a halo, 3 = unclipped into radix-4 level arrays, 4 = unclipped into mixed level arrays
  *   (blocks of 1, 4, 16, then doubling; k - 1 >= 16) with every array a k - 1 of that size can need (rounds 2-3), 5 = the mixed
  *   arrays with the library's level plan (only the arrays some row of the index can write to) -- 2 .. 5 only when every annot of
- *   the index is inside the result matrix, else 1; membership planes: 6 = never with the word plane, 7 = with it wherever it
- *   fits (the library: where a run can have whole words in the middle, k - 1 >= 66). */
+ *   the index is inside the result matrix, else 1. */
 int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32_t membership_algo,
                           int32_t row_source, int32_t scatter);
 /* Order of the 4-byte rows inside a start bucket (memo_amd/csrc/memo_interleave.hip): 0 = the library's choice (3 for conservation, 4 for membership: whichever kind of query pays for the pass), 1 = start order (as the packers write them), 2 = chunks of four rows dealt round-robin

@@ -42,10 +42,9 @@ int memo_debug_set_tuning(memo_index_t *ix, int32_t tile_w, int32_t waves, int32
                                  "the 4- / 6-byte rows, else the int64 columns), 1 (int64 columns), 2 (same as 0), 3 (4- / 6-byte "
                                  "rows even where the dense rows could answer), 5 (dense rows, every wave works its tile out), 8, 9, 10 or 13 "
                                  "(include/memo_amd_debug.h; 4, 6, 7, 11, 12 were round 3's persistent sweeps: profiles/r03_persistent_sweep.txt)");
-    if (scatter < 0 || scatter > 7)
+    if (scatter < 0 || scatter > 5)
         return fail(MEMO_EINVAL, "scatter must be 0 (choose), 1 (clipped), 2 (unclipped, doubling levels), 3 (unclipped, radix-4 levels) "
-                                 "4 (unclipped, mixed levels, every array), 5 (mixed levels, the arrays of the library's level plan), "
-                                 "6 / 7 (membership planes: never / wherever it fits with the word plane)");
+                                 "4 (unclipped, mixed levels, every array) or 5 (mixed levels, the arrays of the library's level plan)");
     ix->tune.tile_w = tile_w;
     ix->tune.waves = waves;
     ix->tune.memb_algo = membership_algo;

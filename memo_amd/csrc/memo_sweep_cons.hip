@@ -1289,8 +1289,7 @@ static int query_conservation(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
     //    the k-1 halo: 1024 positions x 4 waves wins at k = 31 (20 KiB, 8 workgroups per CU) and at
     //    k = 101 (28 KiB) over 512 or 2048 positions.
     // Short windows want many small tiles either way.
-    memo_tuning tune = ix->tune;
-    if (tune.scatter > 5) tune.scatter = 0;  // (6 / 7 speak to the membership planes: memo_sweep_memb.hip)
+    const memo_tuning &tune = ix->tune;
     int w = tune.tile_w, waves = tune.waves == 1 || tune.waves == 4 ? tune.waves : 0;
     while (w & (w - 1)) w &= w - 1;  // (the clipped kernels and the doubling arrays come in powers of two)
     if (w > 4096) w = 4096;

@@ -212,45 +212,11 @@ __global__ __launch_bounds__(T) void sweep_membership_runs_kernel(const SweepArg
 #define MEMO_PLANES_KEEP "s_mov_b64 s[38:39], exec\n\t"
 #define MEMO_PLANES_BACK "s_mov_b64 exec, s[38:39]"
 #endif
-//   WP (MW >= 2, plane rows of at most 64 words): the WORD PLANE -- a second plane at word granularity, one 64-bit word per genome
-//   whose bit w says "word w of this genome's plane row is all absent".  A long run is then its first word, its last word and ONE
-//   ds_or_b64 of a run of word bits, whatever k: at k = 101 a run has 1.2-1.7 whole words in the middle (plain stores, one each,
-//   up to three; 3.2-3.5 LDS operations per row) -- now <= 3.  The rows' membership order (chunks dealt over annot mod 32,
-//   memo_interleave.hip) keeps the lanes of a half-wave on different genomes: the 64-bit atomics do not meet on one address.
-//   The word bits come back in the copy phase (planes_transpose_store).  wp: LDS byte address of the word plane.
-template <int MW, bool SK, bool WP = false>
+template <int MW, bool SK>
 __device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, uint32_t p4, uint32_t s4, uint32_t len, uint32_t d,
-                                           uint32_t col, uint32_t wp = 0) {
+                                           uint32_t col) {
     uint32_t t;
     MEMO_EXEC_ALL_ONES(status);  // (the row loops are wave-uniform: every lane of the wave is here)
-    if constexpr (WP) {
-        static_assert(MW >= 2, "the word plane is for runs of more than two words");
-        // the fields in plain code (the compiler schedules vector arithmetic well; what it must not do is branch or wait);
-        // the LDS operations behind v_cmpx tests that only ever narrow EXEC, as one block
-        const uint32_t colhi = col >> 5;
-        const uint32_t row = base + col * p4 + (SK ? colhi * s4 : 0u);
-        const int n = km1 - (int)len;                       // bits of the run (<= 0: the row does not write)
-        const uint32_t first = d - (uint32_t)n, last = d - 1u;
-        const uint32_t w0 = first >> 5, w1 = last >> 5, more = w1 - w0;
-        const uint32_t head = 0xFFFFFFFFu << (first & 31u), tail = 0xFFFFFFFFu >> (31u - (last & 31u));
-        const uint32_t m0 = more == 0 ? head & tail : head;
-        const uint32_t a0 = row + 4u * w0, a1 = row + 4u * w1;
-        const uint32_t cnt = (more - 1u) & 63u;             // whole words in the middle (used only where more > 1)
-        const uint64_t mid = (((uint64_t)1 << cnt) - 1u) << ((w0 + 1u) & 63u);
-        const uint32_t aw = wp + 8u * col;
-        asm volatile(MEMO_PLANES_KEEP
-                     "v_cmpx_lt_i32 vcc, 0, %0\n\t"          // the lanes whose row writes
-                     "ds_or_b32 %1, %2\n\t"
-                     "v_cmpx_lt_u32 vcc, 0, %3\n\t"          // runs of more than one word: the last one
-                     "ds_or_b32 %4, %5\n\t"
-                     "v_cmpx_lt_u32 vcc, 1, %3\n\t"          // ... of more than two: the words in between, as bits of the word plane
-                     "ds_or_b64 %6, %7\n\t"
-                     MEMO_PLANES_BACK
-                     :
-                     : "v"(n), "v"(a0), "v"(m0), "v"(more), "v"(a1), "v"(tail), "v"(aw), "v"(mid)
-                     : "memory", "vcc", "s38", "s39");
-        return;
-    }
     if constexpr (SK) {
         const uint32_t colhi = col >> 5;
         asm volatile("v_mad_u32_u24 %0, %1, %2, %3\n\t"
@@ -330,11 +296,8 @@ __device__ __forceinline__ void planes_put(int *status, uint32_t base, int km1, 
 
 // The second half of both planes kernels: the planes are complete (all scatters issued); transpose every 32 x 32 block
 // in registers, stage the tile position-major in LDS over the planes, copy it out in whole 16-byte pieces.
-// WP: the kernel keeps a word plane (planes_put): lanes that have no block of their own transpose ITS bits -- 32 genomes x 32
-// words per lane -- into one word per (position word, genome group), C[p][G], which the copy phase takes out of every result
-// word of position word p.  No barrier is added: the word plane is complete at the first one, C is read behind the third.
-template <int T, bool WP = false>
-__device__ __forceinline__ void planes_transpose_store(const SweepArgs &A, const Tile &t, uint32_t *lds, uint32_t wp_words = 0) {
+template <int T>
+__device__ __forceinline__ void planes_transpose_store(const SweepArgs &A, const Tile &t, uint32_t *lds) {
     const int tid = threadIdx.x;
     const int W = A.w, nw = A.nwords, PITCH = A.ls, SKEW = A.hl, HLW = A.nlev;
     __syncthreads();
@@ -343,20 +306,10 @@ __device__ __forceinline__ void planes_transpose_store(const SweepArgs &A, const
     const int PW = W / 32, blocks = nw * PW;
     const int G = tid % nw, p = tid / nw;
     uint32_t m[32];
-    uint32_t *const cwords = lds + wp_words + 64 * nw;  // C[p][G], behind the word plane (2 words x 32 nw genomes)
     if (tid < blocks) {
         const uint32_t *src = lds + (32 * G) * PITCH + G * SKEW + p + HLW;
 #pragma unroll
         for (int i = 0; i < 32; ++i) m[i] = src[i * PITCH];
-    } else if (WP && tid < blocks + nw * ((PW + 31) / 32)) {
-        const int e = tid - blocks, Ge = e % nw, c = e / nw;     // genome group, 32 position words from word 32 c
-        const uint64_t *rows = reinterpret_cast<const uint64_t *>(lds + wp_words) + 32 * Ge;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) m[i] = (uint32_t)(rows[i] >> (HLW + 32 * c));
-        transpose32(m);                                          // m[j] bit i: word HLW + 32 c + j of genome 32 Ge + i is all absent
-#pragma unroll
-        for (int j = 0; j < 32; ++j)
-            if (32 * c + j < PW) cwords[(32 * c + j) * nw + Ge] = m[j];
     }
     __syncthreads();  // the planes are dead: the staged result goes over them
     const int stride = 32 * nw + nw;  // staged words per position word (nw of padding)
@@ -374,24 +327,13 @@ __device__ __forceinline__ void planes_transpose_store(const SweepArgs &A, const
     const int64_t ob = (t.a - A.qs) * nw;  // output word of tile slot 0, word 0
     const int64_t o_lo = ob + (int64_t)t.x_lo * nw, o_hi = ob + (int64_t)t.x_hi * nw;
     // staged word of output word q of the tile: q + (q / (32 nw)) * nw; the quotient by v_mul_hi (q < 2^15)
-    // (WP: ... less the genomes whose whole position word is absent: C[q / (32 nw)][q mod nw])
-    auto staged = [&](int q) {
-        const int pq = (int)__umulhi((uint32_t)q, A.magic);
-        const uint32_t v = lds[q + pq * nw];
-        // (q mod nw: the same magic divides 32 q by 32 nw)
-        return WP ? v & ~cwords[pq * nw + (q - (int)__umulhi(32u * (uint32_t)q, A.magic) * nw)] : v;
-    };
+    auto staged = [&](int q) { return lds[q + (int)__umulhi((uint32_t)q, A.magic) * nw]; };
     for (int64_t g = (o_lo & ~(int64_t)3) + 4 * tid; g < o_hi; g += 4 * T) {
         const int q = (int)(g - ob);  // may be negative by up to 3 at the window's first piece
         if (g >= o_lo && g + 4 <= o_hi) {
             uint4 v;
             if ((nw & 3) == 0) {  // 4 | nw: a piece never straddles a position word, and is 16-byte aligned in LDS
-                const int pq = (int)__umulhi((uint32_t)q, A.magic);
-                v = *reinterpret_cast<const uint4 *>(lds + q + pq * nw);
-                if constexpr (WP) {
-                    const uint4 c4 = *reinterpret_cast<const uint4 *>(cwords + pq * nw + (q - (int)__umulhi(32u * (uint32_t)q, A.magic) * nw));
-                    v.x &= ~c4.x, v.y &= ~c4.y, v.z &= ~c4.z, v.w &= ~c4.w;
-                }
+                v = *reinterpret_cast<const uint4 *>(lds + q + (int)__umulhi((uint32_t)q, A.magic) * nw);
             } else {
                 v.x = staged(q);
                 v.y = staged(q + 1);
@@ -423,9 +365,7 @@ __device__ __forceinline__ void planes_transpose_store(const SweepArgs &A, const
 //   nw words of padding per position word: both chosen so that the lanes of a wave (nw groups x
 //   64/nw position words) fall on 64 different banks.
 // ------------------------------------------------------------------------------------------
-// WP: with a word plane (planes_put) at LDS word A.lvmask -- 2 words per genome, then the nw words per position word the copy
-// phase reads (planes_transpose_store): the launcher puts both behind the planes and the staged tile
-template <typename Rows, int U, int T, int MW, bool SK, bool WP = false>
+template <typename Rows, int U, int T, int MW, bool SK>
 __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
@@ -440,10 +380,6 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         uint4 *pz = reinterpret_cast<uint4 *>(lds);
         for (int i = tid; i < plane_pieces; i += T) pz[i] = z;
-        if constexpr (WP) {  // the word plane (64 nw words) and C (nw words per position word; read only where written, cleared all the same)
-            uint4 *pw4 = reinterpret_cast<uint4 *>(lds + A.lvmask);
-            for (int i = tid; i < (64 * nw + nw * (W / 32) + 3) / 4; i += T) pw4[i] = z;
-        }
         lds_barrier();
     }
 
@@ -452,16 +388,13 @@ __global__ __launch_bounds__(T) void sweep_membership_planes_kernel(const SweepA
     const uint32_t keym = pin_vgpr((int)Rows::tile_key(t.a - 32 * HLW));  // bit 32 * HLW of a plane row = tile slot 0
     const uint32_t base = pin_vgpr((int)(uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t *)lds);
     const uint32_t p4 = 4u * (uint32_t)PITCH, s4 = 4u * (uint32_t)SKEW;
-    const uint32_t wpa = WP ? pin_vgpr((int)(base + 4u * A.lvmask)) : 0u;
-    auto scatter = [&](uint32_t w, uint32_t col) {
-        planes_put<MW, SK, WP>(A.status, base, km1, p4, s4, (uint32_t)Rows::len(w), Rows::rel_start(w, keym), col, wpa);
-    };
+    auto scatter = [&](uint32_t w, uint32_t col) { planes_put<MW, SK>(A.status, base, km1, p4, s4, (uint32_t)Rows::len(w), Rows::rel_start(w, keym), col); };
     Rows::template consume<T, U>(A, t, 0, V, N, scatter);
     for (uint32_t b = 1, nb = Rows::template batches<T, U>(t); b < nb; ++b) {  // a dense tile: the rest
         Rows::template issue<T, U>(A, t, b, V, N);
         Rows::template consume<T, U>(A, t, b, V, N, scatter);
     }
-    planes_transpose_store<T, WP>(A, t, lds, A.lvmask);
+    planes_transpose_store<T>(A, t, lds);
 }
 
 // The same on the dense rows (PackedRows3: five rows per 16 bytes, a fifth fewer bytes to read; k - 1 <= 63, at most 255
@@ -522,14 +455,6 @@ SweepKernel planes_kernel_t(int mw, bool skewed) {
 template <typename Rows>
 SweepKernel planes_kernel(int T, int mw, bool skewed) {
     return T == 64 ? planes_kernel_t<Rows, 64>(mw, skewed) : planes_kernel_t<Rows, 256>(mw, skewed);
-}
-
-// ... with the word plane (runs of more than two words, T = 256: lanes without a block of their own transpose it); one row block
-// whatever the reach of a run
-template <typename Rows>
-SweepKernel planes_wp_kernel(bool skewed) {
-    return skewed ? (SweepKernel)sweep_membership_planes_kernel<Rows, 6, 256, 2, true, true>
-                  : (SweepKernel)sweep_membership_planes_kernel<Rows, 6, 256, 2, false, true>;
 }
 
 __global__ void fill_membership_kernel(uint32_t *out, int64_t n, int nw, int ncols) {
@@ -748,21 +673,8 @@ int memo_query_membership_dev(memo_index_t *ix, int64_t qs, int64_t qe, int32_t 
             SweepKernel kern = fmt == 4    ? planes_kernel<PackedRows<false, false>>(T, mw, skew != 0)
                                : fmt == 12 ? planes_kernel<PackedRows<false, false, true>>(T, mw, skew != 0)
                                            : planes_kernel<PackedRows<true, false>>(T, mw, skew != 0);
-            size_t lds_bytes = planes > staged ? planes : staged;
-            // The word plane (planes_put, WP) where a run can have whole words in the middle (reach >= 3: k - 1 >= 66 -- at reach 2 the one
-            // word in between is one plain store already), a plane row fits 64 word bits, and the workgroup has lanes without a block of
-            // their own to transpose it: config 4 (four result words, 1024-position tiles, 41-word plane rows at k = 101).
-            // tune.scatter 6 / 7 (A/B library): never / wherever it fits.
-            const bool wp_fits = T == 256 && (fmt == 4 || fmt == 12) && A.ls <= 64 && nw * pw + nw * ((pw + 31) / 32) <= 256 && mw >= 2;
-            const bool wp = wp_fits && tune.scatter != 6 && (reach >= 3 || tune.scatter == 7);
-            if (wp) {
-                A.lvmask = (uint32_t)((lds_bytes + 15) / 16 * 4);                       // LDS word of the word plane
-                lds_bytes = (size_t)A.lvmask * 4 + ((size_t)64 * nw + (size_t)nw * pw + 4) * 4;
-                kern = fmt == 4 ? planes_wp_kernel<PackedRows<false, false>>(skew != 0) : planes_wp_kernel<PackedRows<false, false, true>>(skew != 0);
-            }
             if ((rc = use_words())) return rc;
-            if ((rc = launch_tiles(kern, A, tw, T, lds_bytes, st))) return rc;
-            ix->last_variant = wp ? 4 : 0;  // (info.last_variant 4: the membership planes with their word plane)
+            if ((rc = launch_tiles(kern, A, tw, T, planes > staged ? planes : staged, st))) return rc;
             return long_rows_membership(ix, qs, qe, k, A.ncols, nw, d_out, st);
         }
     }
