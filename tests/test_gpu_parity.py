@@ -1729,6 +1729,20 @@ def test_bench_two_ranks_on_one_gpu(n_ranks, workload, extra):
             assert set(cands) == {"plain", "runs"} and cands["runs"]["wire_bytes"] < 0.3 * cands["plain"]["wire_bytes"]
             if "--coding" in extra:
                 assert j["config"]["gather_coding_choice"]["picked"] == "runs" and "2 byte(s) per change" in j["config"]["gather_payload"]
+    # round 6: next to every measured N > 1 value, what the step model makes of this run's own timings; and next to a headline that
+    # is not config 5, a short config-5 leg -- the configuration BASELINE's multi-GPU target is set on -- with its own parity sample
+    exp = j["expected_from_model"]
+    assert exp["value"] > 0 and exp["step_ms"] > 0 and exp["bound_by"] in ("peer_sweep_plus_encode_ms", "root_sweep_plus_decode_ms", "link_ms")
+    if workload == "c4":
+        assert "membership slices have no transport coding" in j["config"]["gather_payload"]
+    if workload != "c5":
+        c5 = j["config5"]
+        assert "error" not in c5, c5
+        assert c5["value"] > 0 and c5["x_one_gpu"] > 0 and c5["x_one_gpu_model"] > 0 and c5["coding"] in ("runs", "plain")
+        assert c5["gather_parity_sample"]["equal_to_oracle"] is True and c5["gather_parity_sample"].get("every_slice_complete", True) is True
+        assert c5["expected_from_model"]["coding"] == c5["coding"]
+    else:
+        assert "config5" not in j
     if n_ranks == 8:          # all seven peers' slices were received and decoded, and the choice was made for seven peers
         choice = j["config"]["gather_coding_choice"]
         assert choice["candidates"]["runs"]["decode_ms_all_slices_one_launch"] is not None

@@ -53,6 +53,53 @@ def test_library_exports_every_declared_symbol(memo):
     assert _exported(_lib.AB_SO_PATH) == declared | debug
 
 
+def test_host_threads_follow_the_cpu_budget(memo):
+    """memo_host_threads: the pool's size = min(CPUs allowed, cgroup CFS quota, 32), MEMO_HOST_THREADS overrides; the inputs come
+    back through the pointers.  (The GPU boxes of the pool show 256 CPUs and grant 16: round 6, profiles/r06_oneshot.txt.)"""
+    import ctypes as C
+    import subprocess
+    import sys
+    from memo_amd import _lib
+    allowed, quota = C.c_int32(-1), C.c_double(-1.0)
+    n = _lib.lib().memo_host_threads(C.byref(allowed), C.byref(quota))
+    assert 1 <= n <= 32 and allowed.value >= 1 and quota.value >= 0.0
+    assert n <= allowed.value and (quota.value == 0.0 or n <= max(1, int(quota.value)))
+    assert n == _lib.lib().memo_host_threads(None, None)
+    code = ("import sys; sys.path.insert(0, %r)\nfrom memo_amd import _lib\nprint(_lib.lib().memo_host_threads(None, None))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MEMO_HOST_THREADS="5"))
+    assert out.returncode == 0 and out.stdout.strip() == "5", out.stderr[-500:]
+
+
+def test_cgroup_quota_parser(tmp_path):
+    """memo_cpus.h against made-up cgroup trees: v2 `cpu.max` on the way up from the process's own group, v1 quota / period, `max`
+    = no quota, the smallest quota wins -- compiled into a tiny program with the file-system root redirected"""
+    import subprocess
+    src = tmp_path / "q.cpp"
+    hdr = open(os.path.join(ROOT, "memo_amd", "csrc", "memo_cpus.h")).read()
+    hdr = hdr.replace('"/sys/fs/cgroup', 'std::string(getenv("FAKE_ROOT")) + "/sys/fs/cgroup').replace('fopen("/proc/self/cgroup", "r")',
+                                                                                                      'fopen((std::string(getenv("FAKE_ROOT")) + "/proc/self/cgroup").c_str(), "r")')
+    src.write_text(hdr + '\nint main() { printf("%.3f\\n", memo::cgroup_cpu_quota()); return 0; }\n')
+    exe = str(tmp_path / "q")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", str(src), "-o", exe])
+
+    def run(files):
+        root = tmp_path / ("root%d" % len(os.listdir(tmp_path)))
+        for path, text in files.items():
+            f = root / path.lstrip("/")
+            f.parent.mkdir(parents=True, exist_ok=True)
+            f.write_text(text)
+        return float(subprocess.run([exe], capture_output=True, text=True, check=True, env=dict(os.environ, FAKE_ROOT=str(root))).stdout)
+    assert run({"/proc/self/cgroup": "0::/\n", "/sys/fs/cgroup/cpu.max": "1600000 100000\n"}) == 16.0        # the pool's GPU boxes
+    assert run({"/proc/self/cgroup": "0::/\n", "/sys/fs/cgroup/cpu.max": "max 100000\n"}) == 0.0
+    assert run({"/proc/self/cgroup": "0::/a/b\n", "/sys/fs/cgroup/cpu.max": "max 100000\n", "/sys/fs/cgroup/a/cpu.max": "400000 100000\n",
+                "/sys/fs/cgroup/a/b/cpu.max": "800000 100000\n"}) == 4.0                                       # an ancestor's is smaller
+    assert run({"/proc/self/cgroup": "4:cpu,cpuacct:/x\n1:name=systemd:/\n", "/sys/fs/cgroup/cpu/x/cpu.cfs_quota_us": "250000\n",
+                "/sys/fs/cgroup/cpu/x/cpu.cfs_period_us": "100000\n"}) == 2.5                                  # cgroup v1
+    assert run({"/proc/self/cgroup": "4:cpu,cpuacct:/x\n", "/sys/fs/cgroup/cpu/x/cpu.cfs_quota_us": "-1\n",
+                "/sys/fs/cgroup/cpu/x/cpu.cfs_period_us": "100000\n"}) == 0.0
+    assert run({}) == 0.0
+
+
 def test_index_info_layout_matches_the_header(memo, tmp_path):
     """memo_index_info_t as a C compiler lays it out (gcc on include/memo_amd.h) == the ctypes mirror the Python host binds:
     size, every field's offset; the struct starts with its own size and a version, and the call refuses a struct whose size
