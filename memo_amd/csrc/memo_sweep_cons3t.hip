@@ -61,7 +61,15 @@ __global__ void tile_table_kernel(const int64_t *boff, int64_t nb, int64_t bbase
 // AW: the row source is a k-class view whose cap is this k - 1 -- every row of it writes, the row blocks carry no test (memo_sweep_dense.h)
 // SIX: the row source is a k-class view in groups of six rows that carry their bucket (memo_view.hip: view_build_kernel<6>; the
 // library's choice of view where it applies: -2.3 % at k = 31 against five-row views, profiles/r05_view_pass.txt)
-template <int NLEV, typename OutT, int T, bool A9 = false, bool AW = false, bool SIX = false>
+// SP: a row source of few rows per tile (under ~3/4 of the 1024 groups a batch of loads covers: the k-class views of config 3, every
+// sequence-built index) -- a piece past the tile's slice issues NO load (a wave-uniform branch).  Rounds 3-5 issued all four loads of a
+// lane unconditionally, a dead piece fetching one group for its 64 lanes: one request to memory, but a full trip through the
+// vector memory pipeline and 1 KiB of registers written, nine to fourteen times per tile at k = 31 ... 9 -- and the sweep is
+// sensitive there (four MORE loads per lane, a later tile's rows prefetched into L2, cost it 8-15 %).  Skipping them: k = 31 -3 %,
+// k = 21 -3.4 %, k = 17 -4.5 %, k = 9 -6 % on config 3's views.  Not for tiles of several full batches (config 5: +2 ... +6 %:
+// behind the branches the compiler waits for ALL of a batch's loads before its first piece), hence a template flag the
+// launcher sets from the rows per tile (profiles/r06_headline.txt; masking the dead loads off with EXEC = 0 instead gained nothing).
+template <int NLEV, typename OutT, int T, bool A9 = false, bool AW = false, bool SIX = false, bool SP = false>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 : 4, 8)))
 void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     static_assert(!A9 || sizeof(OutT) == 2, "more than 255 genomes: uint16 results");
@@ -87,8 +95,8 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
         return;
     }
     const uint4 *src0 = reinterpret_cast<const uint4 *>(A.p3) + (((uint64_t)d0.y << 32) | d0.x);
-    // a lane's four groups of a batch of 1024 (group tid + 256 j): four loads in a row, none under a branch; a piece
-    // past the tile's groups loads ONE group for the whole wave (one request)
+    // a lane's four groups of a batch of 1024 (group tid + 256 j): four loads in a row, none under a branch, a piece past the
+    // tile's groups loading ONE group for the whole wave (one request) -- or, SP, no load at all for such a piece
     uint4 V[NL];
     auto issue = [&](uint32_t batch) {
 #pragma unroll
@@ -106,7 +114,11 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
 #ifdef MEMO_SLICE_CLAMP
             V[j] = src0[pg < g.ng ? (at < g.ng ? at : g.ng - 1u) : 0u];
 #else
-            V[j] = src0[pg < g.ng ? at : 0u];
+            if constexpr (SP) {
+                if (pg < g.ng) V[j] = src0[at];
+            } else {
+                V[j] = src0[pg < g.ng ? at : 0u];
+            }
 #endif
         }
     };
@@ -203,33 +215,33 @@ void sweep_conservation_halo3t_kernel(const SweepArgs A) {
     }
 }
 
-template <typename OutT, int T, bool A9, bool AW>
+template <typename OutT, int T, bool A9, bool AW, bool SP>
 SweepKernel kernel_for(int nlev) {
     switch (nlev) {
-        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, OutT, T, A9, AW>;
-        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, OutT, T, A9, AW>;
-        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, OutT, T, A9, AW>;
-        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, OutT, T, A9, AW>;
-        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, OutT, T, A9, AW>;
-        case 6: return (SweepKernel)sweep_conservation_halo3t_kernel<6, OutT, T, A9, AW>;
+        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, OutT, T, A9, AW, false, SP>;
+        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, OutT, T, A9, AW, false, SP>;
+        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, OutT, T, A9, AW, false, SP>;
+        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, OutT, T, A9, AW, false, SP>;
+        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, OutT, T, A9, AW, false, SP>;
+        case 6: return (SweepKernel)sweep_conservation_halo3t_kernel<6, OutT, T, A9, AW, false, SP>;
     }
     return nullptr;
 }
 
-template <bool AW>
+template <bool AW, bool SP>
 SweepKernel kernel_of(int nlev, int elem_bytes, bool annot9) {  // (256 .. 511 genomes: nine-bit orders, uint16 results)
-    return annot9 ? kernel_for<uint16_t, 256, true, AW>(nlev)
-                  : (elem_bytes == 1 ? kernel_for<uint8_t, 256, false, AW>(nlev) : kernel_for<uint16_t, 256, false, AW>(nlev));
+    return annot9 ? kernel_for<uint16_t, 256, true, AW, SP>(nlev)
+                  : (elem_bytes == 1 ? kernel_for<uint8_t, 256, false, AW, SP>(nlev) : kernel_for<uint16_t, 256, false, AW, SP>(nlev));
 }
 
-template <typename OutT, bool AW>
+template <typename OutT, bool AW, bool SP>
 SweepKernel kernel_six(int nlev) {
     switch (nlev) {
-        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, OutT, 256, false, AW, true>;
-        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, OutT, 256, false, AW, true>;
-        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, OutT, 256, false, AW, true>;
-        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, OutT, 256, false, AW, true>;
-        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, OutT, 256, false, AW, true>;
+        case 1: return (SweepKernel)sweep_conservation_halo3t_kernel<1, OutT, 256, false, AW, true, SP>;
+        case 2: return (SweepKernel)sweep_conservation_halo3t_kernel<2, OutT, 256, false, AW, true, SP>;
+        case 3: return (SweepKernel)sweep_conservation_halo3t_kernel<3, OutT, 256, false, AW, true, SP>;
+        case 4: return (SweepKernel)sweep_conservation_halo3t_kernel<4, OutT, 256, false, AW, true, SP>;
+        case 5: return (SweepKernel)sweep_conservation_halo3t_kernel<5, OutT, 256, false, AW, true, SP>;
     }
     return nullptr;
 }
@@ -321,10 +333,26 @@ int launch_halo3t(memo_index *ix, SweepArgs &A, int tw, int elem_bytes, hipStrea
     // what a wave does around its rows outweighs the rows: 7-9 % SLOWER on the k-class views of config 3 (0.217 against
     // 0.203 ms at k = 31, 0.168 against 0.154 at k = 17) and 1-4 % slower on all the rows; profiles/r03_views.txt.  Sixteen
     // waves per CU hide the scatter's LDS latency worse than thirty-two, whatever they save in instructions.)
-    SweepKernel kern = all_write ? kernel_of<true>(A.nlev, elem_bytes, annot9) : kernel_of<false>(A.nlev, elem_bytes, annot9);
-    if (six)
-        kern = elem_bytes == 1 ? (all_write ? kernel_six<uint8_t, true>(A.nlev) : kernel_six<uint8_t, false>(A.nlev))
-                               : (all_write ? kernel_six<uint16_t, true>(A.nlev) : kernel_six<uint16_t, false>(A.nlev));
+    // few rows per tile?  (the rows the sweep reads, spread over the index's span: groups per tile against the 1024 of a batch)
+    const double span = (double)(ix->max_s - ix->min_s) + 1.0;
+    const double groups_per_tile = (double)ix->last_rows_read / (six ? 6.0 : 5.0) * (double)tw / (span > 1.0 ? span : 1.0);
+#ifdef MEMO_SPARSE_NEVER   // (A/B builds: rounds 3-5's loads everywhere / the skipped loads everywhere)
+    const bool sp = false;
+#elif defined(MEMO_SPARSE_ALWAYS)
+    const bool sp = true;
+#else
+    const bool sp = groups_per_tile < 768.0;
+#endif
+    SweepKernel kern = sp ? (all_write ? kernel_of<true, true>(A.nlev, elem_bytes, annot9) : kernel_of<false, true>(A.nlev, elem_bytes, annot9))
+                          : (all_write ? kernel_of<true, false>(A.nlev, elem_bytes, annot9) : kernel_of<false, false>(A.nlev, elem_bytes, annot9));
+    if (six) {
+        if (sp)
+            kern = elem_bytes == 1 ? (all_write ? kernel_six<uint8_t, true, true>(A.nlev) : kernel_six<uint8_t, false, true>(A.nlev))
+                                   : (all_write ? kernel_six<uint16_t, true, true>(A.nlev) : kernel_six<uint16_t, false, true>(A.nlev));
+        else
+            kern = elem_bytes == 1 ? (all_write ? kernel_six<uint8_t, true, false>(A.nlev) : kernel_six<uint8_t, false, false>(A.nlev))
+                                   : (all_write ? kernel_six<uint16_t, true, false>(A.nlev) : kernel_six<uint16_t, false, false>(A.nlev));
+    }
     if (!kern) return 1;
     if (g_prepare_only) return MEMO_OK;  // memo_index_prepare: the table is built, nothing is launched
     if (int prc = refuse_plan_pointer(A.out)) return prc;
