@@ -1294,12 +1294,18 @@ def test_cli_sharded_path_single_rank(memo, tmp_path):
         argv = [sys.executable, exe, "query", "-b", os.path.join(G.GOLD, c["index"]), "-n", str(c["n"]), "-k", str(c["k"]),
                 "-r", c["region"], "-o", str(out)] + (["-m"] if c["membership"] else [])
         import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        r = subprocess.run(argv, capture_output=True,
-                           env=dict(os.environ, MEMO_FORCE_SHARDED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
-        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        for attempt in range(2):
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            r = subprocess.run(argv, capture_output=True,
+                               env=dict(os.environ, MEMO_FORCE_SHARDED="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+            err = r.stderr.decode(errors="replace")
+            # (one run of the round-6 tier failed here and passed on the next two boxes: a rendezvous that does not come up --
+            # the port taken between our bind and the child's, RCCL's bootstrap -- is tried once more; anything else fails at once)
+            if r.returncode == 0 or not any(w in err for w in ("NCCL", "RCCL", "Address already in use", "Connection", "rendezvous", "store")):
+                break
+        assert r.returncode == 0, (name, err[-3000:])
         assert G.sha(out.read_bytes()) == c["sha256"]
 
 
