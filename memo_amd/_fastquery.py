@@ -58,14 +58,10 @@ def _header_ok(head, file_bytes):       # (= memo_amd.cache.header_ok)
 
 
 def _lazy_buffer(nbytes):
-    """(mmap, address) of an anonymous mapping: pages appear when they are first written -- by the library's threads, not
-    by a zero-fill on this one (203 MB of text cost 0.2 s that way at BASELINE config 3: profiles/r06_cli_timing.txt) --
-    as huge pages where the kernel grants them"""
+    """(mmap, address) of an anonymous mapping: pages appear when they are first written -- by the library's threads, not by a
+    zero-fill on this one, which is what a ctypes array costs (203 MB of text + 200 MB of result at BASELINE config 3).  No
+    MADV_HUGEPAGE: with it the faults of the emitter's threads took longer, not shorter (profiles/r06_cli_timing.txt)."""
     mm = mmap.mmap(-1, max(nbytes, 1))
-    try:
-        mm.madvise(mmap.MADV_HUGEPAGE)
-    except (AttributeError, OSError, ValueError):
-        pass
     return mm, C.addressof(C.c_char.from_buffer(mm))
 
 

@@ -30,9 +30,6 @@
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
-#if defined(__linux__)
-#include <sys/mman.h>
-#endif
 
 namespace memo {
 
@@ -268,19 +265,6 @@ struct DeviceScope {  // the caller keeps its own notion of the current device
     }
 };
 
-// A result buffer the caller has just allocated (np.empty: untouched pages) is first written by the copy below: 200 MB
-// in 4 KiB pages are 49 000 page faults, more than half of the 7.5 ms the result of config 3 took to arrive.  The
-// whole 2 MiB pages inside it are offered to the kernel as huge pages (a hint, honoured where transparent huge
-// pages are set to madvise or always; contents and mapping are unchanged).
-void hint_huge_pages(void *p, size_t bytes) {
-#if defined(__linux__) && defined(MADV_HUGEPAGE)
-    const uintptr_t two = (uintptr_t)2 << 20, a = ((uintptr_t)p + two - 1) & ~(two - 1), e = ((uintptr_t)p + bytes) & ~(two - 1);
-    if (e > a) (void)madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);
-#else
-    (void)p, (void)bytes;
-#endif
-}
-
 void copy_tasks(HostPool &pool, char *dst, const char *src, size_t sz) {
     const int tasks = (int)((sz + ((size_t)1 << 20) - 1) >> 20);
     pool.run(tasks, [&](int t) {
@@ -303,7 +287,6 @@ int download_pipelined_core(int device, void *host, const void *dev, size_t byte
     PinnedRing *ring = nullptr;
     int rc = acquire_ring(device, &ring);
     if (rc) return rc;
-    hint_huge_pages(host, bytes);
     const size_t piece = PinnedRing::kSlotBytes;
     const size_t n = (bytes + piece - 1) / piece;
     HostPool &pool = HostPool::get();
