@@ -298,6 +298,9 @@ int memo_builder_create_rows(uint64_t max_rows, int32_t device, int32_t bucket_s
                              memo_builder_t **out);
 int memo_builder_push(memo_builder_t *b, const int64_t *start, const int64_t *end, const int64_t *annot,
                       uint64_t rows);
+/* the same from ROWS: rows3 = [rows][3] row-major (start, end, annot of a row side by side) -- the array filter_pq builds
+ * (memo_query.py:28-36: uint64; the same bits) -- read as it lies, no transposed copy on the host */
+int memo_builder_push_rows(memo_builder_t *b, const int64_t *rows3, uint64_t rows);
 /* hands the index over (destroy the builder afterwards; it cannot be used again) */
 int memo_builder_finish(memo_builder_t *b, memo_index_t **out);
 void memo_builder_destroy(memo_builder_t *b);
@@ -332,6 +335,15 @@ int memo_conservation(const int64_t *start, const int64_t *end, const int64_t *a
 int memo_membership(const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows,
                     int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint32_t *out_bits,
                     int32_t device);
+/* The same two, taking the reference's array AS IT IS: memo_init's first argument, filter_pq's result (memo_query.py:28-36, :100,
+ * :103) -- uint64 / int64 [rows][3] row-major, start / end / annot of a row side by side.  No argsort, no three contiguous copies
+ * in the caller (at BASELINE config 3 those cost a NumPy host a minute; this call ~50 ms): the host packer reads the rows as they
+ * lie (AVX-512: 48 consecutive qwords taken apart by two-source permutes).  Rows that cannot be packed (unsorted, wild annots,
+ * k > 256) are transposed into columns inside the call and take the int64 way in, as above. */
+int memo_conservation_rows(const int64_t *rows3, uint64_t rows, int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint16_t *out,
+                           int32_t device);
+int memo_membership_rows(const int64_t *rows3, uint64_t rows, int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint32_t *out_bits,
+                         int32_t device);
 
 /* ---- raw device buffers, for hosts that do not bring a device allocator (the CLI) ------ */
 int memo_dev_malloc(int32_t device, size_t bytes, void **out);

@@ -19,6 +19,7 @@ __version__ = "0.2.0"
 _LAZY = {
     "MemoError": "_lib", "MemoUnpackable": "_lib", "build": "_lib", "lib": "_lib",
     "DeviceIndex": "index", "IndexBuilder": "index", "conservation": "index", "membership": "index",
+    "conservation_rows": "index", "membership_rows": "index",
     "emit_conservation": "index", "emit_membership": "index",
 }
 

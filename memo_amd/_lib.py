@@ -81,6 +81,7 @@ SYMBOLS = {
     "memo_builder_create": (C.c_int, [_U64, _I32, _I32, C.POINTER(_P)]),
     "memo_builder_create_rows": (C.c_int, [_U64, _I32, _I32, _I32, C.POINTER(_P)]),
     "memo_builder_push": (C.c_int, [_P, _P, _P, _P, _U64]),
+    "memo_builder_push_rows": (C.c_int, [_P, _P, _U64]),
     "memo_builder_finish": (C.c_int, [_P, C.POINTER(_P)]),
     "memo_builder_destroy": (None, [_P]),
     "memo_query_conservation_dev": (C.c_int, [_P, _I64, _I64, _I32, _I32, _P, _P]),
@@ -89,6 +90,8 @@ SYMBOLS = {
     "memo_query_check": (C.c_int, [_P, _P]),
     "memo_conservation": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _I32]),
     "memo_membership": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _I32]),
+    "memo_conservation_rows": (C.c_int, [_P, _U64, _I64, _I64, _I32, _I32, _P, _I32]),
+    "memo_membership_rows": (C.c_int, [_P, _U64, _I64, _I64, _I32, _I32, _P, _I32]),
     "memo_split_window": (C.c_int, [_I64, _I64, _I32, _I32, C.c_double, _P]),
     "memo_conservation_multi": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _P, _I32]),
     "memo_membership_multi": (C.c_int, [_P, _P, _P, _U64, _I64, _I64, _I32, _I32, _P, _P, _I32]),

@@ -360,6 +360,12 @@ struct PackArgs {
     uint64_t global0;   // global row number of local row 0
     int64_t *boff;
     int64_t boff_size;
+    // 1: three columns (what the ABI's column forms hand over); 3: ROWS -- filter_pq's own [M, 3] array, row-major
+    // (memo_query.py:28-36): start = the array, end = start + 1, annot = start + 2, a row every three elements
+    int stride = 1;
+    int64_t s(uint64_t i) const { return start[i * (uint64_t)stride]; }
+    int64_t e(uint64_t i) const { return end[i * (uint64_t)stride]; }
+    int64_t a(uint64_t i) const { return annot[i * (uint64_t)stride]; }
 };
 
 // One row: the checks of memo_index_finalize, the bucket table, the rows with end < start.  Returns the row's fields
@@ -370,7 +376,7 @@ struct RowScan {
     int64_t ps, pb;
     RowScan(int64_t prev_start, int64_t prev_bucket) : ps(prev_start), pb(prev_bucket) {}
     inline void row(const PackArgs &A, uint64_t i, BlockResult &res, int64_t &s_out, int64_t &len_out, uint32_t &a12_out) {
-        const int64_t s = A.start[i], e = A.end[i], a = A.annot[i];
+        const int64_t s = A.s(i), e = A.e(i), a = A.a(i);
         bad |= (s < ps) ? 1 : 0;
         bad |= (s < 0) ? 2 : 0;
         bad |= ((uint64_t)a > 4095u) ? 4 : 0;
@@ -516,7 +522,13 @@ static void scan_block(const PackArgs &A, uint64_t i0, uint64_t i1, int64_t prev
     for (uint64_t i = i0; i < i1; i += kPiece) {
         const int n = (int)(i1 - i < (uint64_t)kPiece ? i1 - i : (uint64_t)kPiece);
         f.any_long = f.any_bucket = 0;
-        scan(A.start + i, A.end + i, A.annot + i, n, ps, A.shift, W, A8, mark, f);
+        if (A.stride == 1) {
+            scan(A.start + i, A.end + i, A.annot + i, n, ps, A.shift, W, A8, mark, f);
+        } else {  // rows: the piece's three columns first (7.5 KiB on the stack), then the same pass
+            alignas(64) int64_t tS[kPiece], tE[kPiece], tA[kPiece];
+            for (int j = 0; j < n; ++j) tS[j] = A.s(i + (uint64_t)j), tE[j] = A.e(i + (uint64_t)j), tA[j] = A.a(i + (uint64_t)j);
+            scan(tS, tE, tA, n, ps, A.shift, W, A8, mark, f);
+        }
         bad |= f.unsorted ? 1 : 0;
         bad |= (f.sign >> 63) ? 2 : 0;
         bad |= f.annot_or > 4095u ? 4 : 0;
@@ -525,11 +537,11 @@ static void scan_block(const PackArgs &A, uint64_t i0, uint64_t i1, int64_t prev
         if (f.any_bucket | f.any_long) {
             for (int j = 0; j < n; ++j) {
                 if (!mark[j]) continue;
-                const int64_t s = A.start[i + (uint64_t)j];
+                const int64_t s = A.s(i + (uint64_t)j);
                 if (mark[j] & 2) {
                     res.long_rows.push_back(s);
-                    res.long_rows.push_back(A.end[i + (uint64_t)j]);
-                    res.long_rows.push_back(A.annot[i + (uint64_t)j]);
+                    res.long_rows.push_back(A.e(i + (uint64_t)j));
+                    res.long_rows.push_back(A.a(i + (uint64_t)j));
                 }
                 const int64_t bk = s >> A.shift;
                 if (bk != pb) {  // first row of its bucket(s): boff[b] = lower_bound(start, b << shift)
@@ -541,7 +553,7 @@ static void scan_block(const PackArgs &A, uint64_t i0, uint64_t i1, int64_t prev
                 }
             }
         }
-        ps = A.start[i + (uint64_t)n - 1];
+        ps = A.s(i + (uint64_t)n - 1);
         emit(i, n, W, A8);
     }
     res.max_annot = top;
@@ -616,11 +628,11 @@ static inline void events16(const PackArgs &A, uint64_t row0, unsigned kb, unsig
         const int j = __builtin_ctz(m);
         m &= m - 1;
         const uint64_t i = row0 + (uint64_t)j;
-        const int64_t s = A.start[i];
+        const int64_t s = A.s(i);
         if ((kl >> j) & 1u) {
             res.long_rows.push_back(s);
-            res.long_rows.push_back(A.end[i]);
-            res.long_rows.push_back(A.annot[i]);
+            res.long_rows.push_back(A.e(i));
+            res.long_rows.push_back(A.a(i));
         }
         const int64_t bk = s >> A.shift;
         if (bk != pb) {
@@ -629,6 +641,32 @@ static inline void events16(const PackArgs &A, uint64_t row0, unsigned kb, unsig
             pb = bk;
         }
     }
+}
+
+// sixteen rows from row i on as two vectors each of starts, ends, annots: three columns (six loads), or ROWS -- 48 consecutive
+// qwords, start / end / annot of a row side by side -- taken apart by twelve two-source permutes
+template <bool ROWS>
+MEMO_T512 static inline void load16(const PackArgs &A, uint64_t i, __m512i &s0, __m512i &s1, __m512i &e0, __m512i &e1, __m512i &a0,
+                                    __m512i &a1) {
+    if (!ROWS) {
+        s0 = _mm512_loadu_si512(A.start + i), s1 = _mm512_loadu_si512(A.start + i + 8);
+        e0 = _mm512_loadu_si512(A.end + i), e1 = _mm512_loadu_si512(A.end + i + 8);
+        a0 = _mm512_loadu_si512(A.annot + i), a1 = _mm512_loadu_si512(A.annot + i + 8);
+        return;
+    }
+    const int64_t *r = A.start + 3 * i;
+    // row j of eight: start at qword 3 j, end at 3 j + 1, annot at 3 j + 2 of the 24; index 8 + x = qword x of the second source
+    const __m512i s_1 = _mm512_set_epi64(0, 0, 8 + 7, 8 + 4, 8 + 1, 6, 3, 0), s_2 = _mm512_set_epi64(8 + 5, 8 + 2, 5, 4, 3, 2, 1, 0);
+    const __m512i e_1 = _mm512_set_epi64(0, 0, 0, 8 + 5, 8 + 2, 7, 4, 1), e_2 = _mm512_set_epi64(8 + 6, 8 + 3, 8 + 0, 4, 3, 2, 1, 0);
+    const __m512i a_1 = _mm512_set_epi64(0, 0, 0, 8 + 6, 8 + 3, 8 + 0, 5, 2), a_2 = _mm512_set_epi64(8 + 7, 8 + 4, 8 + 1, 4, 3, 2, 1, 0);
+    const __m512i q0 = _mm512_loadu_si512(r), q1 = _mm512_loadu_si512(r + 8), q2 = _mm512_loadu_si512(r + 16);
+    const __m512i q3 = _mm512_loadu_si512(r + 24), q4 = _mm512_loadu_si512(r + 32), q5 = _mm512_loadu_si512(r + 40);
+    s0 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q0, s_1, q1), s_2, q2);
+    e0 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q0, e_1, q1), e_2, q2);
+    a0 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q0, a_1, q1), a_2, q2);
+    s1 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q3, s_1, q4), s_2, q5);
+    e1 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q3, e_1, q4), e_2, q5);
+    a1 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q3, a_1, q4), a_2, q5);
 }
 
 struct Perm512 {  // byte permutes of the dense groups: output vector j (four groups) from row vectors j and j + 1
@@ -651,6 +689,7 @@ struct Perm512 {  // byte permutes of the dense groups: output vector j (four gr
 };
 
 // rows [i0, i0 + 80 units) -> 16 units groups at out; returns the state after the last row
+template <bool ROWS>
 MEMO_T512 static void dense_units_512(const PackArgs &A, uint64_t i0, uint64_t units, int64_t prev_start, int64_t prev_bucket,
                                       uint32_t *out, BlockResult &res, Fast512 &st) {
     static const Perm512 P;
@@ -667,15 +706,13 @@ MEMO_T512 static void dense_units_512(const PackArgs &A, uint64_t i0, uint64_t u
     __m512i sprev = _mm512_set1_epi64(prev_start), acc_a = _mm512_setzero_si512(), top = _mm512_setzero_si512();
     unsigned uns = 0, neg = 0, coord = 0;
     int64_t pb = prev_bucket;
-    const int64_t *S = A.start, *E = A.end, *An = A.annot;
     for (uint64_t u = 0; u < units; ++u) {
         __m512i R[5];
         unsigned k9[5];
         for (int v = 0; v < 5; ++v) {
             const uint64_t i = i0 + 80 * u + 16 * (uint64_t)v;
-            const __m512i s0 = _mm512_loadu_si512(S + i), s1 = _mm512_loadu_si512(S + i + 8);
-            const __m512i e0 = _mm512_loadu_si512(E + i), e1 = _mm512_loadu_si512(E + i + 8);
-            const __m512i a0 = _mm512_loadu_si512(An + i), a1 = _mm512_loadu_si512(An + i + 8);
+            __m512i s0, s1, e0, e1, a0, a1;
+            load16<ROWS>(A, i, s0, s1, e0, e1, a0, a1);
             const __m512i p0 = _mm512_alignr_epi64(s0, sprev, 7), p1 = _mm512_alignr_epi64(s1, s0, 7);
             sprev = s1;
             uns |= (unsigned)_mm512_cmplt_epi64_mask(s0, p0) | (unsigned)_mm512_cmplt_epi64_mask(s1, p1);
@@ -717,7 +754,7 @@ MEMO_T512 static void dense_units_512(const PackArgs &A, uint64_t i0, uint64_t u
         }
     }
     if (nt) _mm_sfence();  // (the stores are weakly ordered: they are in memory before the task reports itself done)
-    st.ps = units ? S[i0 + 80 * units - 1] : prev_start;
+    st.ps = units ? A.s(i0 + 80 * units - 1) : prev_start;
     st.pb = pb;
     st.uns = uns, st.neg = neg, st.coord = coord;
     st.annot_or = (uint64_t)_mm512_reduce_or_epi64(acc_a);
@@ -725,7 +762,7 @@ MEMO_T512 static void dense_units_512(const PackArgs &A, uint64_t i0, uint64_t u
 }
 
 // rows [i0, i0 + 16 steps) -> one word each (format 4 or 12) at pk[i0 ...]
-template <int FMT>
+template <int FMT, bool ROWS>
 MEMO_T512 static void word_steps_512(const PackArgs &A, uint64_t i0, uint64_t steps, int64_t prev_start, int64_t prev_bucket,
                                      uint32_t *pk, BlockResult &res, Fast512 &st) {
     const __m512i lim = _mm512_set1_epi64(kHostCoordLimit), limm1 = _mm512_set1_epi64(kHostCoordLimit - 1),
@@ -736,13 +773,11 @@ MEMO_T512 static void word_steps_512(const PackArgs &A, uint64_t i0, uint64_t st
     __m512i sprev = _mm512_set1_epi64(prev_start), acc_a = _mm512_setzero_si512(), top = _mm512_setzero_si512();
     unsigned uns = 0, neg = 0, coord = 0;
     int64_t pb = prev_bucket;
-    const int64_t *S = A.start, *E = A.end, *An = A.annot;
     bool any_nt = false;
     for (uint64_t v = 0; v < steps; ++v) {
         const uint64_t i = i0 + 16 * v;
-        const __m512i s0 = _mm512_loadu_si512(S + i), s1 = _mm512_loadu_si512(S + i + 8);
-        const __m512i e0 = _mm512_loadu_si512(E + i), e1 = _mm512_loadu_si512(E + i + 8);
-        const __m512i a0 = _mm512_loadu_si512(An + i), a1 = _mm512_loadu_si512(An + i + 8);
+        __m512i s0, s1, e0, e1, a0, a1;
+        load16<ROWS>(A, i, s0, s1, e0, e1, a0, a1);
         const __m512i p0 = _mm512_alignr_epi64(s0, sprev, 7), p1 = _mm512_alignr_epi64(s1, s0, 7);
         sprev = s1;
         uns |= (unsigned)_mm512_cmplt_epi64_mask(s0, p0) | (unsigned)_mm512_cmplt_epi64_mask(s1, p1);
@@ -773,7 +808,7 @@ MEMO_T512 static void word_steps_512(const PackArgs &A, uint64_t i0, uint64_t st
         if (kb | kl) events16(A, i, kb, kl, (uns | neg | coord) != 0, pb, res);
     }
     if (any_nt) _mm_sfence();
-    st.ps = steps ? S[i0 + 16 * steps - 1] : prev_start;
+    st.ps = steps ? A.s(i0 + 16 * steps - 1) : prev_start;
     st.pb = pb;
     st.uns = uns, st.neg = neg, st.coord = coord;
     st.annot_or = (uint64_t)_mm512_reduce_or_epi64(acc_a);
@@ -808,9 +843,11 @@ void pack_words(const PackArgs &A, uint64_t i0, uint64_t i1, int64_t prev_start,
         Fast512 st;
         std::vector<int64_t> head_long;
         if (fmt == 12)
-            word_steps_512<12>(A, i0, steps, prev_start, prev_bucket, pk, res, st);
+            A.stride == 1 ? word_steps_512<12, false>(A, i0, steps, prev_start, prev_bucket, pk, res, st)
+                          : word_steps_512<12, true>(A, i0, steps, prev_start, prev_bucket, pk, res, st);
         else
-            word_steps_512<4>(A, i0, steps, prev_start, prev_bucket, pk, res, st);
+            A.stride == 1 ? word_steps_512<4, false>(A, i0, steps, prev_start, prev_bucket, pk, res, st)
+                          : word_steps_512<4, true>(A, i0, steps, prev_start, prev_bucket, pk, res, st);
         if (mid < i1) {
             head_long.swap(res.long_rows);  // (scan_block sets the other fields; the long rows of the fast part stay in front)
             if (fmt == 12)
@@ -845,7 +882,8 @@ void pack_dense(const PackArgs &A, uint64_t i0, uint64_t groups, int64_t prev_st
         const uint64_t units = groups / 16, mid = i0 + 80 * units;
         Fast512 st;
         std::vector<int64_t> head_long;
-        dense_units_512(A, i0, units, prev_start, prev_bucket, out, res, st);
+        A.stride == 1 ? dense_units_512<false>(A, i0, units, prev_start, prev_bucket, out, res, st)
+                      : dense_units_512<true>(A, i0, units, prev_start, prev_bucket, out, res, st);
         if (groups > 16 * units) {
             head_long.swap(res.long_rows);
             tail(mid, groups - 16 * units, st.ps, st.pb, out + 64 * units);
@@ -1010,16 +1048,15 @@ int refuse(memo_builder *b, int bad) {
 }
 
 // a sample of the annots decides the format the packing starts in (a wrong guess costs a restart of the push, below)
-bool sample_has_wide_annot(const int64_t *annot, uint64_t rows) {
+bool sample_has_wide_annot(const PackArgs &A, uint64_t rows) {
     const uint64_t step = rows / 2048 + 1;
     for (uint64_t i = 0; i < rows; i += step)
-        if ((uint64_t)annot[i] > 255u) return true;
-    return (uint64_t)annot[rows - 1] > 255u;
+        if ((uint64_t)A.a(i) > 255u) return true;
+    return (uint64_t)A.a(rows - 1) > 255u;
 }
 
 int push_words(memo_builder *b, const PackArgs &A, uint64_t rows) {
-    const int64_t *start = A.start;
-    if (b->fmt == 4 && sample_has_wide_annot(A.annot, rows)) {  // switch before anything of this push is on its way
+    if (b->fmt == 4 && sample_has_wide_annot(A, rows)) {  // switch before anything of this push is on its way
         int rc = hp::stream_sync(b->ring->stream);
         if (!rc && b->rows) rc = hp::widen_annots(b->d_pk, b->rows, b->ring->stream);
         if (rc) return builder_fail(b, rc, "rewriting the rows with 12-bit annots failed");
@@ -1032,8 +1069,8 @@ int push_words(memo_builder *b, const PackArgs &A, uint64_t rows) {
         auto pack = [&](uint64_t blk, uint64_t c, char *buf, BlockResult &r) {
             const uint64_t i0 = blk * kBlockRows, i1 = i0 + kBlockRows < rows ? i0 + kBlockRows : rows;
             const bool first = i0 == 0;
-            const int64_t prev_start = first ? (b->any ? b->last_start : INT64_MIN) : start[i0 - 1];
-            const int64_t prev_bucket = first ? b->last_bucket : (start[i0 - 1] >> b->bshift);
+            const int64_t prev_start = first ? (b->any ? b->last_start : INT64_MIN) : A.s(i0 - 1);
+            const int64_t prev_bucket = first ? b->last_bucket : (A.s(i0 - 1) >> b->bshift);
             pack_words(A, i0, i1, prev_start, prev_bucket, reinterpret_cast<uint32_t *>(buf) - c * kChunkRows, fmt, r);
             if (r.wide_annot && fmt == 4) pipe.stop.store(1, std::memory_order_relaxed);
         };
@@ -1065,8 +1102,8 @@ int push_words(memo_builder *b, const PackArgs &A, uint64_t rows) {
 int carry_rows(memo_builder *b, const PackArgs &A, uint64_t i0, uint64_t i1) {
     if (i0 >= i1) return MEMO_OK;
     const bool first = i0 == 0;
-    RowScan scan(first ? (b->any ? b->last_start : INT64_MIN) : A.start[i0 - 1],
-                 first ? b->last_bucket : (A.start[i0 - 1] >> b->bshift));
+    RowScan scan(first ? (b->any ? b->last_start : INT64_MIN) : A.s(i0 - 1),
+                 first ? b->last_bucket : (A.s(i0 - 1) >> b->bshift));
     std::vector<BlockResult> res(1);
     for (uint64_t i = i0; i < i1; ++i) {
         int64_t s, len;
@@ -1084,7 +1121,6 @@ int carry_rows(memo_builder *b, const PackArgs &A, uint64_t i0, uint64_t i1) {
 
 int push_dense(memo_builder *b, const PackArgs &A, uint64_t rows) {
     PinnedRing *ring = b->ring;
-    const int64_t *start = A.start;
     // rows that complete the group the last push left open
     const uint64_t head = b->carry_n ? ((uint64_t)(5 - b->carry_n) < rows ? (uint64_t)(5 - b->carry_n) : rows) : 0;
     int rc = carry_rows(b, A, 0, head);
@@ -1101,8 +1137,8 @@ int push_dense(memo_builder *b, const PackArgs &A, uint64_t rows) {
             if (ga >= gb) return;
             const uint64_t i0 = head + 5 * ga;
             const bool first = i0 == 0;
-            const int64_t prev_start = first ? (b->any ? b->last_start : INT64_MIN) : start[i0 - 1];
-            const int64_t prev_bucket = first ? b->last_bucket : (start[i0 - 1] >> b->bshift);
+            const int64_t prev_start = first ? (b->any ? b->last_start : INT64_MIN) : A.s(i0 - 1);
+            const int64_t prev_bucket = first ? b->last_bucket : (A.s(i0 - 1) >> b->bshift);
             uint32_t *out = reinterpret_cast<uint32_t *>(buf) + 4 * ((c == 0 ? pos : 0) + ga - c * kChunkGroups);
             pack_dense(A, i0, gb - ga, prev_start, prev_bucket, out, r);
         };
@@ -1137,9 +1173,9 @@ int builder_fail(memo_builder *b, int code, const char *what) {
     return fail(code, "%s", what);
 }
 
-int builder_push_core(memo_builder *b, const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows) {
+int builder_push_core(memo_builder *b, const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows, int stride) {
     // the bucket table has to reach the last row's bucket before the workers fill it
-    const int64_t s_last = start[rows - 1];
+    const int64_t s_last = start[(rows - 1) * (uint64_t)stride];
     if (s_last < 0 || s_last >= kHostCoordLimit || (b->any && start[0] < b->last_start))
     {
         b->why = 1;
@@ -1150,7 +1186,7 @@ int builder_push_core(memo_builder *b, const int64_t *start, const int64_t *end,
         if ((uint64_t)need > ((uint64_t)1 << 34)) return builder_fail(b, MEMO_EUNPACKABLE, "bucket table too large");
         b->boff.resize((size_t)need + (size_t)need / 4);
     }
-    PackArgs A{start, end, annot, b->bshift, b->rows, b->boff.data(), (int64_t)b->boff.size()};
+    PackArgs A{start, end, annot, b->bshift, b->rows, b->boff.data(), (int64_t)b->boff.size(), stride};
     const int rc = b->dense ? push_dense(b, A, rows) : push_words(b, A, rows);
     if (rc) return rc;
     if (!b->any) b->first_start = start[0];

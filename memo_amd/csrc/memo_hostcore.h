@@ -127,7 +127,9 @@ struct memo_builder {
 
 namespace memo {
 // the threaded part of memo_builder_push / memo_builder_finish (arguments already validated)
-int builder_push_core(memo_builder *b, const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows);
+// stride 1: three columns; 3: rows -- start / end / annot of a row side by side (start = the [M, 3] array, end = start + 1,
+// annot = start + 2): filter_pq's own array (memo_query.py:28-36)
+int builder_push_core(memo_builder *b, const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows, int stride = 1);
 int builder_flush_core(memo_builder *b);  // dense: the incomplete last group, padded with rows that never write
 int builder_fail(memo_builder *b, int code, const char *what);
 }  // namespace memo

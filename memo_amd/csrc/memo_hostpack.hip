@@ -169,6 +169,18 @@ int memo_builder_push(memo_builder_t *b, const int64_t *start, const int64_t *en
     return builder_push_core(b, start, end, annot, rows);  // (every error in there marks the builder failed)
 }
 
+int memo_builder_push_rows(memo_builder_t *b, const int64_t *rows3, uint64_t rows) {
+    if (!b) return fail(MEMO_EINVAL, "builder is NULL");
+    if (b->failed) return fail(b->failed, "the builder already failed");
+    if (!rows) return MEMO_OK;
+    if (!rows3) return fail(MEMO_EINVAL, "rows pointer is NULL");
+    if (rows > b->cap - b->rows)
+        return fail(MEMO_EINVAL, "%llu more rows do not fit a builder of %llu", (unsigned long long)rows,
+                    (unsigned long long)b->cap);
+    DeviceGuard guard(b->device);
+    return builder_push_core(b, rows3, rows3 + 1, rows3 + 2, rows, 3);
+}
+
 int memo_builder_finish(memo_builder_t *b, memo_index_t **out) {
     if (!b || !out) return fail(MEMO_EINVAL, "NULL argument");
     *out = nullptr;

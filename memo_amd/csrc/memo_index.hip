@@ -10,6 +10,7 @@
 #include <new>
 
 #include "memo_common.h"
+#include "memo_hostcore.h"
 
 using namespace memo;
 
@@ -995,10 +996,12 @@ int memo_index_prepare(memo_index_t *ix, int32_t k, int32_t num_docs, int32_t me
 // (start-sorted, start >= 0, annot in [0, 65535]: every index dap_to_bed.py writes) and k <= 256 take the
 // fast way in -- narrowed on the host into pinned memory, 4-6 B/row over PCIe, PackedRows kernels
 // (memo_hostpack.hip); anything else is uploaded as int64 columns and finalized on the device.
+// stride 1: three columns; 3: ROWS -- filter_pq's own [M, 3] array, row-major (start = the array, end = start + 1, annot = start + 2)
 static int one_shot(const int64_t *start, const int64_t *end, const int64_t *annot, uint64_t rows,
                     int64_t qs, int64_t qe, int32_t k, int32_t num_docs, void *out, int32_t device,
-                    bool membership) {
+                    bool membership, int stride = 1) {
     if (rows && (!start || !end || !annot)) return fail(MEMO_EINVAL, "column pointer is NULL");
+    const uint64_t st = (uint64_t)stride;
     memo_index_t *ix = nullptr;
     int rc = MEMO_OK;
     // MEMO_TIMING=1: phase times of the call on stderr (host clock; every phase ends synchronised)
@@ -1015,13 +1018,13 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
         // answer THIS query -- judged from the first and last start before the rows are touched, and again from the
         // largest annot once they have been packed; else (or when a row does not fit them) the 4-byte words
         const bool try_dense = g_one_shot_way != 2 &&
-                               memo_dense_rows_can_answer(rows, start[0], start[rows - 1], 0, k, num_docs, membership);
+                               memo_dense_rows_can_answer(rows, start[0], start[(rows - 1) * st], 0, k, num_docs, membership);
         for (int dense = try_dense ? 1 : 0; dense >= 0 && !ix; --dense) {
             memo_builder_t *b = nullptr;
             const auto ta = now();
             if ((rc = memo_builder_create_rows(rows, device, 0, dense ? MEMO_ROWS_DENSE : MEMO_ROWS_PACKED, &b))) return rc;
             const auto tb = now();
-            rc = memo_builder_push(b, start, end, annot, rows);
+            rc = stride == 1 ? memo_builder_push(b, start, end, annot, rows) : memo_builder_push_rows(b, start, rows);
             const auto tc = now();
             if (!rc) rc = memo_builder_finish(b, &ix);
             const int why = builder_why(b);
@@ -1042,6 +1045,22 @@ static int one_shot(const int64_t *start, const int64_t *end, const int64_t *ann
         }
     }
     if (!ix) {
+        // (rows that could not be packed on the host -- unsorted, wild annots, k > 256: the int64 columns go up and the device validates
+        // and sorts.  From ROWS the three columns are made here first: the rare way, one more pass over the host's memory)
+        std::vector<int64_t> cols;
+        if (stride != 1 && rows) {
+            try {
+                cols.resize(3 * rows);
+            } catch (const std::exception &) {
+                return fail(MEMO_EHIP, "out of host memory for the columns of %llu rows", (unsigned long long)rows);
+            }
+            int64_t *cs = cols.data(), *ce = cs + rows, *ca = ce + rows;
+            HostPool::get().run((int)((rows + 65535) / 65536), [&](int t) {
+                const uint64_t i0 = (uint64_t)t * 65536, i1 = i0 + 65536 < rows ? i0 + 65536 : rows;
+                for (uint64_t i = i0; i < i1; ++i) cs[i] = start[3 * i], ce[i] = start[3 * i + 1], ca[i] = start[3 * i + 2];
+            });
+            start = cs, end = ce, annot = ca;
+        }
         if ((rc = memo_index_create(rows, device, &ix))) return rc;
         rc = memo_index_upload(ix, start, end, annot, rows);
         if (!rc) rc = memo_index_finalize(ix, 0, 1);
@@ -1099,6 +1118,18 @@ int memo_membership(const int64_t *start, const int64_t *end, const int64_t *ann
                     int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint32_t *out_bits,
                     int32_t device) {
     return one_shot(start, end, annot, rows, qs, qe, k, num_docs, out_bits, device, true);
+}
+
+int memo_conservation_rows(const int64_t *rows3, uint64_t rows, int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint16_t *out,
+                           int32_t device) {
+    if (rows && !rows3) return fail(MEMO_EINVAL, "rows pointer is NULL");
+    return one_shot(rows3, rows3 + 1, rows3 + 2, rows, qs, qe, k, num_docs, out, device, false, 3);
+}
+
+int memo_membership_rows(const int64_t *rows3, uint64_t rows, int64_t qs, int64_t qe, int32_t k, int32_t num_docs, uint32_t *out_bits,
+                         int32_t device) {
+    if (rows && !rows3) return fail(MEMO_EINVAL, "rows pointer is NULL");
+    return one_shot(rows3, rows3 + 1, rows3 + 2, rows, qs, qe, k, num_docs, out_bits, device, true, 3);
 }
 
 int memo_synth_fill(memo_index_t *ix, uint64_t row_begin, uint64_t num, uint64_t den,

@@ -223,6 +223,12 @@ class IndexBuilder:
         check(lib().memo_builder_push(self._b, s.ctypes.data, e.ctypes.data, o.ctypes.data, len(s)))
         self.rows += len(s)
 
+    def push_rows(self, rows):
+        """memo_builder_push_rows: an [M, 3] row-major array (start, end, annot side by side) as it lies"""
+        r = _rows3(rows)
+        check(lib().memo_builder_push_rows(self._b, r.ctypes.data, len(r)))
+        self.rows += len(r)
+
     def finish(self):
         h = C.c_void_p()
         check(lib().memo_builder_finish(self._b, C.byref(h)))
@@ -260,6 +266,31 @@ def membership(start, end, annot, qs, qe, k, num_docs, device=0):
     out = np.empty((max(qe - qs, 0), words(num_docs)), np.uint32)
     check(lib().memo_membership(s.ctypes.data, e.ctypes.data, o.ctypes.data, len(s), qs, qe, k,
                                 num_docs, out.ctypes.data, device))
+    return out
+
+
+def _rows3(rows):
+    """filter_pq's array ([M, 3] uint64 / int64, row-major) as the ABI's rows3: no copy when it already is that"""
+    a = np.asarray(rows)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError("rows must be an [M, 3] array (start, end, annot)")
+    if a.dtype != np.int64:
+        a = a.view(np.int64) if a.dtype == np.uint64 else a.astype(np.int64)
+    return np.ascontiguousarray(a)
+
+
+def conservation_rows(rows, qs, qe, k, num_docs, device=0):
+    """memo_conservation_rows: memo_init's first argument as it is (memo_query.py:103) in, the conservation vector out"""
+    r = _rows3(rows)
+    out = np.empty(max(qe - qs, 0), np.uint16)
+    check(lib().memo_conservation_rows(r.ctypes.data, len(r), qs, qe, k, num_docs, out.ctypes.data, device))
+    return out
+
+
+def membership_rows(rows, qs, qe, k, num_docs, device=0):
+    r = _rows3(rows)
+    out = np.empty((max(qe - qs, 0), words(num_docs)), np.uint32)
+    check(lib().memo_membership_rows(r.ctypes.data, len(r), qs, qe, k, num_docs, out.ctypes.data, device))
     return out
 
 

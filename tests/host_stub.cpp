@@ -254,15 +254,26 @@ static void verify(const memo_builder *b, const Rows &r, uint64_t n) {
     for (size_t q = 0; q < boff.size(); ++q) CHECK(b->boff[q] == boff[q]);
 }
 
-static void run_builder(bool dense, uint64_t n, uint64_t seed, int late_wide_at, int long_every) {
+// the rows as filter_pq hands them over: [M, 3] row-major (stride 3 of builder_push_core)
+static std::vector<int64_t> interleaved(const Rows &r) {
+    std::vector<int64_t> v(3 * r.s.size());
+    for (size_t i = 0; i < r.s.size(); ++i) v[3 * i] = r.s[i], v[3 * i + 1] = r.e[i], v[3 * i + 2] = r.a[i];
+    return v;
+}
+
+static void run_builder(bool dense, uint64_t n, uint64_t seed, int late_wide_at, int long_every, bool as_rows = false) {
     Rows r = make_rows(n, seed, dense ? (seed % 2 ? 511 : 255) : 200, dense ? -1 : late_wide_at, long_every);   // (dense rows: annots of up to nine bits)
+    const std::vector<int64_t> rows = as_rows ? interleaved(r) : std::vector<int64_t>();
     memo_builder *b = new_builder(n, dense);
     std::mt19937_64 rng(seed ^ 0x55);
     uint64_t at = 0;
     while (at < n) {  // ragged pieces: 1 .. 300 000 rows, often not a multiple of five
         uint64_t piece = 1 + rng() % (rng() % 4 == 0 ? 300000 : 23);
         if (piece > n - at) piece = n - at;
-        CHECK(builder_push_core(b, r.s.data() + at, r.e.data() + at, r.a.data() + at, piece) == MEMO_OK);
+        if (as_rows)
+            CHECK(builder_push_core(b, rows.data() + 3 * at, rows.data() + 3 * at + 1, rows.data() + 3 * at + 2, piece, 3) == MEMO_OK);
+        else
+            CHECK(builder_push_core(b, r.s.data() + at, r.e.data() + at, r.a.data() + at, piece) == MEMO_OK);
         at += piece;
     }
     CHECK(builder_flush_core(b) == MEMO_OK);
@@ -281,6 +292,11 @@ int main() {
         t1.join();
         t2.join();
     }
+    // the same from ROWS ([M, 3] row-major, what filter_pq returns): both formats, the late switch to 12-bit annots, rows with end < start
+    run_builder(false, 700014, 2, 400000, 0, true);
+    run_builder(false, 500009, 3, -1, 1000, true);
+    run_builder(true, 612361, 13, -1, 777, true);
+    run_builder(true, 612354, 12, -1, 0, true);
     // one push of many chunks: more chunks than the ring has slots, so slots are reused while workers pack ahead
     // (dense: 1 047 744 groups = 5.2 M rows per chunk; words: 6.3 M rows), then the same rows with a row out of order
     // deep inside -- every worker has to stop, the caller has to come back
@@ -300,6 +316,10 @@ int main() {
         for (int dense = 0; dense < 2; ++dense) {
             memo_builder *b = new_builder(n, dense);
             CHECK(builder_push_core(b, r.s.data(), r.e.data(), r.a.data(), 3) == MEMO_OK);   // (a ragged start: carried rows, a leading group)
+            if (dense) {  // (the rest as ROWS: the many-chunk push with the interleaved loads)
+                const std::vector<int64_t> rows = interleaved(r);
+                CHECK(builder_push_core(b, rows.data() + 9, rows.data() + 10, rows.data() + 11, n - 3, 3) == MEMO_OK);
+            } else
             CHECK(builder_push_core(b, r.s.data() + 3, r.e.data() + 3, r.a.data() + 3, n - 3) == MEMO_OK);
             CHECK(builder_flush_core(b) == MEMO_OK);
             CHECK(b->ring->drain() == MEMO_OK);

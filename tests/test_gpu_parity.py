@@ -78,6 +78,57 @@ def test_golden_one_shot(c, memo, ab):
         assert G.sha(text) == c["sha256"]
 
 
+@pytest.mark.parametrize("c", G.cases(raises=False)[::2], ids=lambda c: c["name"])
+def test_golden_one_shot_rows(c, memo):
+    """memo_conservation_rows / memo_membership_rows: the goldens' `rows` -- filter_pq's own result, uint64 [M, 3] row-major, exactly
+    what memo_init is handed at memo_query.py:103 -- go in AS THEY ARE (no argsort, no column copies) and the reference's result
+    comes out."""
+    from memo_amd.index import bits_to_matrix
+    rec, qs, qe = G.region(c)
+    z = G.load(c)
+    rows = z["rows"].reshape(-1, 3)
+    assert rows.dtype == np.uint64
+    if c["membership"]:
+        got = memo.membership_rows(rows, qs, qe, c["k"], c["n"])
+        assert np.array_equal(bits_to_matrix(got, c["n"]), G.expected_matrix(c, z))
+        text = memo.emit_membership(got, c["n"])
+    else:
+        got = memo.conservation_rows(rows, qs, qe, c["k"], c["n"])
+        assert np.array_equal(got.astype(np.int64), z["vec"])
+        text = memo.emit_conservation(got)
+    assert G.sha(text) == c["sha256"]
+
+
+def test_rows_form_equals_column_form(memo, oracle):
+    """the [M, 3] way in at a size where the packer's vector code, several worker tasks and both row formats are in play: equal to
+    the column form and to the oracle; rows in the wrong order take the int64 way in (sorted on the device) with the same result;
+    a builder fed rows in ragged pieces equals one fed columns"""
+    from memo_amd import synth
+    n, L = 100, 3_000_000
+    num, den = synth.rows_per_position(n)
+    r0, r1 = synth.shard_rows(0, L, 101, num, den, L)
+    s, e, o = oracle.synth_rows(r0, r1 - r0, num, den, n)
+    rows = np.stack([s, e, o], axis=1).astype(np.uint64)
+    for k in (31, 101):                                   # dense rows; 4-byte words
+        want = oracle.conservation(*oracle.filter_rows(s, e, o, 5, L - 9, k), 5, L - 9, k, n, literal=False)
+        assert np.array_equal(memo.conservation_rows(rows, 5, L - 9, k, n), want)
+        assert np.array_equal(memo.conservation(s, e, o, 5, L - 9, k, n), want)
+    wantm = oracle.membership(*oracle.filter_rows(s, e, o, 1000, 90_000, 31), 1000, 90_000, 31, n, literal=False)
+    assert np.array_equal(memo.membership_rows(rows, 1000, 90_000, 31, n), wantm)
+    perm = np.random.default_rng(5).permutation(len(rows))
+    want = oracle.conservation(*oracle.filter_rows(s, e, o, 5, L - 9, 31), 5, L - 9, 31, n, literal=False)
+    assert np.array_equal(memo.conservation_rows(rows[perm], 5, L - 9, 31, n), want)
+    for dense in (True, False):
+        with memo.IndexBuilder(len(rows), dense=dense) as b:
+            at, step = 0, 1
+            while at < len(rows):
+                b.push_rows(rows[at:at + step])
+                at += step
+                step = step * 7 + 3
+            with b.finish() as ix:
+                assert np.array_equal(ix.conservation(5, L - 9, 31, n), want)
+
+
 def test_golden_one_shot_reached_the_benchmarked_kernel():
     """(runs after the cases above) a fair share of the reference's goldens was answered by halo3"""
     if not _ONE_SHOT_SWEEPS:

@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol(memo):
     declared = _declared("memo_amd.h", "memo_amd_multi.h", "memo_amd_dap.h", "memo_amd_transport.h")
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert len(_declared("memo_amd.h")) <= 41          # (round 6: + memo_host_threads)
+    assert len(_declared("memo_amd.h")) <= 44          # (round 6: + memo_host_threads, the three *_rows forms)
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name)

@@ -2,7 +2,8 @@
 """The reference's seam (memo_conservation: host int64 columns in, host uint16 result out) on BASELINE config 3, for one
 host thread count (MEMO_HOST_THREADS, read once per process): the columns first-touched by the library's pool threads
 (what bench.py's download gives) and by ONE thread (what a NumPy caller has), the calls' phases on stderr (MEMO_TIMING),
-the result compared with the resident path's.  GPU box.  usage: oneshot_sweep.py [calls]"""
+the result compared with the resident path's; then the same rows as the reference's own [M, 3] array through
+memo_conservation_rows.  GPU box.  usage: oneshot_sweep.py [calls]"""
 import ctypes as C
 import os
 import sys
@@ -42,3 +43,18 @@ for label, cols in (("pool-touched", pool_cols), ("one-thread-touched", None)):
     ok = bool(np.array_equal(out, want))
     print(f"{label}: calls {' '.join(f'{x:.1f}' for x in ms)} ms -> best {L / min(ms) * 1e3:.3g} positions/s, parity {ok}", flush=True)
     assert ok
+# the reference's own array: [M, 3] row-major (memo_conservation_rows) -- made here from the columns (one thread: NumPy)
+t = time.perf_counter()
+aos = np.empty((rows, 3), np.int64)
+for j in range(3):
+    aos[:, j] = cols[j]
+del cols
+print(f"[M, 3] array made in {time.perf_counter() - t:.1f} s (NumPy, strided; what the reference's concat of pandas frames gives for free)", flush=True)
+ms = []
+for _ in range(calls):
+    t = time.perf_counter()
+    out = memo_amd.conservation_rows(aos, 0, L, k, n)
+    ms.append((time.perf_counter() - t) * 1e3)
+ok = bool(np.array_equal(out, want))
+print(f"rows form: calls {' '.join(f'{x:.1f}' for x in ms)} ms -> best {L / min(ms) * 1e3:.3g} positions/s, parity {ok}", flush=True)
+assert ok
