@@ -462,6 +462,17 @@ def without_view_entry(R, other, kern_ms):
 
 
 # ---- the reference's seam ---------------------------------------------------------------------------------------
+def cgroup_throttled_us():
+    """microseconds this process's cgroup has spent frozen by its CFS quota so far (cgroup v2 cpu.stat), or None"""
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            if ln.startswith("throttled_usec"):
+                return int(ln.split()[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def pcie_rates(R, nbytes=256 << 20):
     """What this box's link gives a pinned buffer, both ways (HIP events around one copy of 256 MiB after an untimed
     one): the seam can be no faster than its packed rows over this -- boxes of the pool differ by a factor of three."""
@@ -506,6 +517,7 @@ def one_shot_seam(R, out):
                 ms.append((time.perf_counter() - t_s) * 1e3)
             return ms, seam
         pcie = pcie_rates(R)
+        thr0 = cgroup_throttled_us()
         first_ms, _ = calls(cols, 1)
         ms_pool, seam = calls(cols, 3)
         same = bool(np.array_equal(seam, R.result_as_host(out)))
@@ -513,6 +525,19 @@ def one_shot_seam(R, out):
         del cols
         ms_one, seam1 = calls(one, 3)
         same1 = bool(np.array_equal(seam1, seam))
+        # ... and as the stub of INTEGRATION.md section 2 calls it: filter_pq's own [M, 3] array, row-major, as it lies
+        # (memo_conservation_rows; the array is made here from the columns -- NumPy, strided, not timed)
+        aos = np.empty((rows, 3), np.int64)
+        for j_ in range(3):
+            aos[:, j_] = one[j_]
+        ms_rows, seam_r = [], None
+        for _ in range(3):
+            t_s = time.perf_counter()
+            seam_r = memo_amd.conservation_rows(aos, R.qs, R.qe, k, num_docs, device=R.local)
+            ms_rows.append((time.perf_counter() - t_s) * 1e3)
+        same_r = bool(np.array_equal(seam_r, seam))
+        del aos, seam_r
+        thr1 = cgroup_throttled_us()
         from memo_amd.index import dense_rows_can_answer
         dense_in = dense_rows_can_answer(rows, int(one[0][0]), int(one[0][-1]), 0, k, num_docs, False)
         allowed, quota = C.c_int32(), C.c_double()
@@ -527,11 +552,19 @@ def one_shot_seam(R, out):
                 "first_call_ms": float(first_ms[0]),
                 "columns_first_touched_by_one_thread": {"ms": float(np.median(ms_one)), "ms_calls": [float(x) for x in ms_one],
                                                         "value": L / (float(np.median(ms_one)) * 1e-3), "parity": same1},
+                "reference_array_form": {"what": "memo_conservation_rows: filter_pq's uint64 [M, 3] array, row-major, as it lies -- what the "
+                                                 "stub of INTEGRATION.md section 2 calls",
+                                         "ms": float(np.median(ms_rows)), "ms_calls": [float(x) for x in ms_rows],
+                                         "value": L / (float(np.median(ms_rows)) * 1e-3), "parity": same_r},
+                "box_note": "the host is shared by other tenants: the same call has taken 37 ... 113 ms across the pool's boxes and minutes with "
+                            "the link at 57 GB/s throughout (profiles/r06_oneshot.txt); pcie = this box's link now, "
+                            "cgroup_throttled_ms_during_the_calls = time the container was frozen by its CPU quota while the ten calls ran",
                 "note": "`ms` = median of three calls after one uncounted call (first_call_ms: it starts the worker pool and allocates "
                         "the pinned ring); the columns' pages were first touched by the library's pool threads (the download that "
                         "produced them) -- columns_first_touched_by_one_thread: the same on NumPy copies made by one thread",
                 "way_in": ("host packer -> dense rows (3.2 B per row over PCIe)" if dense_in else "host packer -> 4-byte words"),
                 "pcie": pcie,
+                "cgroup_throttled_ms_during_the_calls": (thr1 - thr0) / 1e3 if (thr0 is not None and thr1 is not None) else None,
                 "floor_ms_from_pcie": (bytes_up / (pcie["h2d_GBs"] * 1e9) + 2 * L / (pcie["d2h_GBs"] * 1e9)) * 1e3 if pcie.get("h2d_GBs") else None,
                 "host_threads": int(threads), "host_cpus_allowed": int(allowed.value),
                 "host_cgroup_cpu_quota": float(quota.value) or None,

@@ -643,8 +643,25 @@ static inline void events16(const PackArgs &A, uint64_t row0, unsigned kb, unsig
     }
 }
 
+// Eight ROWS (24 consecutive qwords: start at qword 3 j, end at 3 j + 1, annot at 3 j + 2 of row j) -> their starts, ends, annots.
+// A field's eight values sit in eight DIFFERENT lanes of the three vectors (3 j + c mod 8 runs through all of them), so two masked
+// blends collect them into one vector and one permute puts them in row order: six blends + three permutes per eight rows (twelve
+// two-source permutes at first: the rows form was 20 % behind the columns).
+MEMO_T512 static inline void rows8(const int64_t *q, __m512i &sv, __m512i &ev, __m512i &av) {
+    const __m512i s_ix = _mm512_set_epi64(5, 2, 7, 4, 1, 6, 3, 0), e_ix = _mm512_set_epi64(6, 3, 0, 5, 2, 7, 4, 1),
+                  a_ix = _mm512_set_epi64(7, 4, 1, 6, 3, 0, 5, 2);
+    const __m512i q0 = _mm512_loadu_si512(q), q1 = _mm512_loadu_si512(q + 8), q2 = _mm512_loadu_si512(q + 16);
+    // starts: q0 lanes 0 3 6, q1 lanes 1 4 7, q2 lanes 2 5;  ends: q0 1 4 7, q1 2 5, q2 0 3 6;  annots: q0 2 5, q1 0 3 6, q2 1 4 7
+    const __m512i sb = _mm512_mask_blend_epi64(0x24, _mm512_mask_blend_epi64(0x92, q0, q1), q2);
+    const __m512i eb = _mm512_mask_blend_epi64(0x49, _mm512_mask_blend_epi64(0x24, q0, q1), q2);
+    const __m512i ab = _mm512_mask_blend_epi64(0x92, _mm512_mask_blend_epi64(0x49, q0, q1), q2);
+    sv = _mm512_permutexvar_epi64(s_ix, sb);
+    ev = _mm512_permutexvar_epi64(e_ix, eb);
+    av = _mm512_permutexvar_epi64(a_ix, ab);
+}
+
 // sixteen rows from row i on as two vectors each of starts, ends, annots: three columns (six loads), or ROWS -- 48 consecutive
-// qwords, start / end / annot of a row side by side -- taken apart by twelve two-source permutes
+// qwords, start / end / annot of a row side by side -- taken apart by blends and permutes
 template <bool ROWS>
 MEMO_T512 static inline void load16(const PackArgs &A, uint64_t i, __m512i &s0, __m512i &s1, __m512i &e0, __m512i &e1, __m512i &a0,
                                     __m512i &a1) {
@@ -654,19 +671,8 @@ MEMO_T512 static inline void load16(const PackArgs &A, uint64_t i, __m512i &s0, 
         a0 = _mm512_loadu_si512(A.annot + i), a1 = _mm512_loadu_si512(A.annot + i + 8);
         return;
     }
-    const int64_t *r = A.start + 3 * i;
-    // row j of eight: start at qword 3 j, end at 3 j + 1, annot at 3 j + 2 of the 24; index 8 + x = qword x of the second source
-    const __m512i s_1 = _mm512_set_epi64(0, 0, 8 + 7, 8 + 4, 8 + 1, 6, 3, 0), s_2 = _mm512_set_epi64(8 + 5, 8 + 2, 5, 4, 3, 2, 1, 0);
-    const __m512i e_1 = _mm512_set_epi64(0, 0, 0, 8 + 5, 8 + 2, 7, 4, 1), e_2 = _mm512_set_epi64(8 + 6, 8 + 3, 8 + 0, 4, 3, 2, 1, 0);
-    const __m512i a_1 = _mm512_set_epi64(0, 0, 0, 8 + 6, 8 + 3, 8 + 0, 5, 2), a_2 = _mm512_set_epi64(8 + 7, 8 + 4, 8 + 1, 4, 3, 2, 1, 0);
-    const __m512i q0 = _mm512_loadu_si512(r), q1 = _mm512_loadu_si512(r + 8), q2 = _mm512_loadu_si512(r + 16);
-    const __m512i q3 = _mm512_loadu_si512(r + 24), q4 = _mm512_loadu_si512(r + 32), q5 = _mm512_loadu_si512(r + 40);
-    s0 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q0, s_1, q1), s_2, q2);
-    e0 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q0, e_1, q1), e_2, q2);
-    a0 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q0, a_1, q1), a_2, q2);
-    s1 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q3, s_1, q4), s_2, q5);
-    e1 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q3, e_1, q4), e_2, q5);
-    a1 = _mm512_permutex2var_epi64(_mm512_permutex2var_epi64(q3, a_1, q4), a_2, q5);
+    rows8(A.start + 3 * i, s0, e0, a0);
+    rows8(A.start + 3 * i + 24, s1, e1, a1);
 }
 
 struct Perm512 {  // byte permutes of the dense groups: output vector j (four groups) from row vectors j and j + 1
